@@ -1,0 +1,106 @@
+// Internal plumbing of libbzk: context, error handling, workspace, per-kernel event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bzk.h"
+
+struct bzk_prof_rec {
+    const char* name;
+    hipEvent_t a, b;
+};
+
+struct bzk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    bool prof = false;
+    std::vector<bzk_prof_rec> recs;
+    // grow-only scratch buffer reused across calls
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // pinned host staging (small results)
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // device-resident Poseidon constants per width t (index t), Montgomery, rc then mds
+    void* poseidon_dev[18] = {};
+    // MSM tuning overrides (0 = automatic); settable through env BZK_MSM_C / BZK_MSM_CHUNK
+    int msm_c_override = 0;
+    int msm_chunk_override = 0;
+    // NTT twiddle cache: per log_n, forward and inverse tables
+    void* ntt_tw[33][2] = {};
+};
+
+#define BZK_HIP(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);         \
+            return BZK_E_DEVICE;                                                            \
+        }                                                                                   \
+    } while (0)
+
+#define BZK_TRY(expr)                 \
+    do {                              \
+        int32_t s__ = (expr);         \
+        if (s__ != BZK_OK) return s__; \
+    } while (0)
+
+namespace bzk {
+
+int32_t ws_reserve(bzk_ctx* ctx, size_t bytes);           // ensures ctx->ws has >= bytes
+int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes);
+
+// bump allocator over ctx->ws
+struct WsCursor {
+    char* base;
+    size_t off = 0;
+    explicit WsCursor(void* b) : base((char*)b) {}
+    template <class T>
+    T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = (T*)(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};
+static inline size_t ws_pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+struct ProfScope {
+    bzk_ctx* ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char* name;
+    ProfScope(bzk_ctx* c, const char* n) : ctx(c), name(n) {
+        if (ctx->prof) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~ProfScope() {
+        if (a) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->recs.push_back({name, a, b});
+        }
+    }
+};
+
+// launch + error check; `name` must be a string literal (kept by pointer)
+#define BZK_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                      \
+    do {                                                                                            \
+        {                                                                                           \
+            bzk::ProfScope ps__(ctx, name);                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);              \
+        }                                                                                           \
+        hipError_t e__ = hipGetLastError();                                                         \
+        if (e__ != hipSuccess) {                                                                    \
+            (ctx)->last_error = std::string("launch ") + name + ": " + hipGetErrorString(e__);      \
+            return BZK_E_DEVICE;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+}  // namespace bzk

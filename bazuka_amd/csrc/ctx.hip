@@ -1,0 +1,216 @@
+// Context, memory plumbing and event-based per-kernel timing for libbzk.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+
+#include "bzk_internal.h"
+
+namespace bzk {
+
+void ntt_free_tables(bzk_ctx* ctx);  // ntt.hip
+
+int32_t ws_reserve(bzk_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return BZK_OK;
+    if (ctx->ws) {
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BZK_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 3);
+    hipError_t e = hipMalloc(&ctx->ws, want);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return BZK_E_ALLOC;
+    }
+    ctx->ws_bytes = want;
+    return BZK_OK;
+}
+
+int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes) return BZK_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    hipError_t e = hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return BZK_E_ALLOC;
+    }
+    ctx->pinned_bytes = bytes;
+    return BZK_OK;
+}
+
+}  // namespace bzk
+
+extern "C" {
+
+uint32_t bzk_abi_version(void) { return 1; }
+
+const char* bzk_strerror(int32_t s) {
+    switch (s) {
+        case BZK_OK: return "ok";
+        case BZK_E_ARG: return "bad argument";
+        case BZK_E_ALLOC: return "allocation failed";
+        case BZK_E_DEVICE: return "device error";
+        case BZK_E_UNSAT: return "constraint system not satisfied";
+        case BZK_E_INTERNAL: return "internal error";
+        default: return "unknown status";
+    }
+}
+
+int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
+    if (!out) return BZK_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return BZK_E_DEVICE;  // no CPU fallback by design
+    }
+    if (device_id < 0 || device_id >= count) return BZK_E_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return BZK_E_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "libbzk: device %d is %s, this library is built for gfx950 only\n", device_id, prop.gcnArchName);
+        return BZK_E_DEVICE;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) return BZK_E_DEVICE;
+    bzk_ctx* ctx = new (std::nothrow) bzk_ctx();
+    if (!ctx) return BZK_E_ALLOC;
+    ctx->device = device_id;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return BZK_E_DEVICE;
+        }
+        ctx->own_stream = true;
+    }
+    if (const char* e = getenv("BZK_MSM_C")) ctx->msm_c_override = atoi(e);
+    if (const char* e = getenv("BZK_MSM_CHUNK")) ctx->msm_chunk_override = atoi(e);
+    *out = ctx;
+    return BZK_OK;
+}
+
+void bzk_ctx_destroy(bzk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& p : ctx->poseidon_dev)
+        if (p) (void)hipFree(p);
+    bzk::ntt_free_tables(ctx);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t bzk_sync(bzk_ctx* ctx) {
+    if (!ctx) return BZK_E_ARG;
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+const char* bzk_last_error(bzk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+int32_t bzk_dev_alloc(bzk_ctx* ctx, uint64_t bytes, void** dptr) {
+    if (!ctx || !dptr) return BZK_E_ARG;
+    *dptr = nullptr;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return BZK_E_ALLOC;
+    }
+    return BZK_OK;
+}
+
+int32_t bzk_dev_free(bzk_ctx* ctx, void* dptr) {
+    if (!ctx) return BZK_E_ARG;
+    if (!dptr) return BZK_OK;
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BZK_HIP(ctx, hipFree(dptr));
+    return BZK_OK;
+}
+
+int32_t bzk_h2d(bzk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return BZK_E_ARG;
+    BZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+int32_t bzk_d2h(bzk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return BZK_E_ARG;
+    BZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+int32_t bzk_prof_enable(bzk_ctx* ctx, int32_t on) {
+    if (!ctx) return BZK_E_ARG;
+    ctx->prof = on != 0;
+    return BZK_OK;
+}
+
+int32_t bzk_prof_reset(bzk_ctx* ctx) {
+    if (!ctx) return BZK_E_ARG;
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ctx->recs.clear();
+    return BZK_OK;
+}
+
+int32_t bzk_prof_query(bzk_ctx* ctx, const char* name, uint64_t* launches, double* total_ms) {
+    if (!ctx || !name) return BZK_E_ARG;
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t n = 0;
+    double tot = 0;
+    for (auto& r : ctx->recs) {
+        if (strcmp(r.name, name) != 0) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            tot += ms;
+            ++n;
+        }
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = tot;
+    return BZK_OK;
+}
+
+int32_t bzk_prof_dump(bzk_ctx* ctx, char* buf, uint64_t cap) {
+    if (!ctx || !buf || !cap) return BZK_E_ARG;
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::map<std::string, std::pair<uint64_t, double>> agg;
+    for (auto& r : ctx->recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& e = agg[r.name];
+            e.first++;
+            e.second += ms;
+        }
+    }
+    std::string s;
+    for (auto& kv : agg) {
+        char line[256];
+        snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.first, kv.second.second);
+        s += line;
+    }
+    strncpy(buf, s.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+    return BZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// K4: G1 instantiation of the Pippenger pipeline (see msm_impl.cuh).  Fp products are inlined here:
+// msm_accumulate<G1> is the dominant kernel of a proof and benefits from cross-product scheduling.
+#include "msm_impl.cuh"
+using namespace bzk;
+
+extern "C" {
+
+uint32_t bzk_msm_window_count(uint64_t n) {
+    int c = msm_pick_c(n ? n : 1);
+    if (const char* e = getenv("BZK_MSM_C")) {
+        int v = atoi(e);
+        if (v >= 2 && v <= 20) c = v;
+    }
+    return (uint32_t)msm_windows_for(c);
+}
+int32_t bzk_msm_g1_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, uint8_t out[97]) {
+    return msm_entry_dev<FpOps>(ctx, bases, scalars, n, flags, 0, -1, out);
+}
+int32_t bzk_msm_g1_windows_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags,
+                               uint32_t w_begin, uint32_t w_end, uint8_t out[97]) {
+    return msm_entry_dev<FpOps>(ctx, bases, scalars, n, flags, (int)w_begin, (int)w_end, out);
+}
+int32_t bzk_msm_g1(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[97]) {
+    return msm_entry_host<FpOps>(ctx, bases, scalars, n, flags, out);
+}
+int32_t bzk_g1_sum(const uint8_t* pts, uint32_t count, uint8_t out[97]) { return sum_packed<FpOps>(pts, count, out); }
+int32_t bzk_g1_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev) {
+    if (!ctx || (n && !out_dev)) return BZK_E_ARG;
+    if (!n) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    auto k = synth_bases_kernel<FpOps>;
+    BZK_LAUNCH(ctx, "synth_bases_g1", k, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g1_generator_host(), seed, start, n,
+               (G1Affine*)out_dev);
+    return BZK_OK;
+}
+
+}  // extern "C"

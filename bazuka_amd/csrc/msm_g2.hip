@@ -1,0 +1,31 @@
+// K5: G2 instantiation of the Pippenger pipeline (see msm_impl.cuh).  An Fp2 product is three Fp
+// products; they are kept as real function calls here (BZK_FP_NOINLINE) so that the kernels stay
+// inside the instruction cache - a fully inlined XYZZ add over Fp2 is ~25k instructions.
+#define BZK_FP_NOINLINE 1
+#include "msm_impl.cuh"
+using namespace bzk;
+
+extern "C" {
+
+int32_t bzk_msm_g2_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, uint8_t out[193]) {
+    return msm_entry_dev<Fp2Ops>(ctx, bases, scalars, n, flags, 0, -1, out);
+}
+int32_t bzk_msm_g2_windows_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags,
+                               uint32_t w_begin, uint32_t w_end, uint8_t out[193]) {
+    return msm_entry_dev<Fp2Ops>(ctx, bases, scalars, n, flags, (int)w_begin, (int)w_end, out);
+}
+int32_t bzk_msm_g2(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[193]) {
+    return msm_entry_host<Fp2Ops>(ctx, bases, scalars, n, flags, out);
+}
+int32_t bzk_g2_sum(const uint8_t* pts, uint32_t count, uint8_t out[193]) { return sum_packed<Fp2Ops>(pts, count, out); }
+int32_t bzk_g2_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev) {
+    if (!ctx || (n && !out_dev)) return BZK_E_ARG;
+    if (!n) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    auto k = synth_bases_kernel<Fp2Ops>;
+    BZK_LAUNCH(ctx, "synth_bases_g2", k, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g2_generator_host(), seed, start, n,
+               (G2Affine*)out_dev);
+    return BZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,492 @@
+// K4 / K5: Pippenger multi-scalar multiplication over BLS12-381 G1 / G2 for gfx950.
+//
+// Replaces bellman 0.14 `multiexp` (third-party crate behind `create_random_proof`,
+// /root/reference/src/mpn/circuits/test.rs:135) - the h / l / a / b_g1 / b_g2 queries of a proof.
+//
+// Pipeline (all on the ctx stream, data stays in HBM):
+//   1. msm_digits      one lane per scalar: Montgomery -> canonical, signed c-bit window recoding,
+//                      emits (bucket key, point index | sign) pairs, window-major => coalesced stores
+//   2. radix sort      rocPRIM pair sort by bucket key (HBM-bound streaming passes)
+//   3. msm_offsets     bucket boundaries from the sorted keys
+//   4. size sort       buckets ordered by population (descending) so the 64 lanes of a wavefront
+//                      run equally long accumulation loops (no lane idles behind a long bucket)
+//   5. msm_accumulate  one lane per bucket: gathers its affine points (6 x 16 B loads each) and
+//                      folds them with XYZZ mixed adds                      <-- dominant kernel
+//   6. msm_reduce      per chunk of CH buckets: running-sum  sum (b+1) B_b  (+ chunk offset)
+//   7. msm_window_sum  per window: LDS tree over the chunk results
+//   8. host            Horner over <= 32 window sums, to affine, pack
+// MFMA is not used anywhere: the arithmetic is 32-bit integer carry chains.
+#pragma once
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+#include "bzk_curve.cuh"
+#include "bzk_internal.h"
+
+namespace bzk {
+
+// ------------------------------------------------------------------------------------------------
+// parameters
+// ------------------------------------------------------------------------------------------------
+static int msm_pick_c(uint64_t n) {
+    int lg = 0;
+    while (((uint64_t)1 << (lg + 1)) <= n) ++lg;
+    int c = lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return c;
+}
+static int msm_windows_for(int c) { return (256 + c - 1) / c; }  // signed digits need one spare bit
+
+struct alignas(16) U128 {
+    uint32_t x, y, z, w;
+};
+
+// ------------------------------------------------------------------------------------------------
+// 1. digits
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __restrict__ scalars, uint64_t n, int mont, int c,
+                                                         int w_total, int w_begin, int w_cnt,
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s;
+    {
+        U128 a = scalars[2 * i], b = scalars[2 * i + 1];
+        s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w;
+        s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
+    }
+    if (mont) s = fe_from_mont<FrParams>(s);
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    const uint32_t nb = (uint32_t)w_cnt * half;  // sentinel key (sorted behind every bucket)
+    uint64_t buf = 0;
+    int cnt = 0, w = 0;
+    uint32_t carry = 0;
+    auto emit = [&](uint32_t raw) {
+        uint32_t d = raw + carry;
+        uint32_t neg = 0;
+        if (d > half) {
+            d = (1u << c) - d;
+            neg = 1;
+            carry = 1;
+        } else {
+            carry = 0;
+        }
+        if (w >= w_begin && w < w_begin + w_cnt) {
+            const uint32_t lw = (uint32_t)(w - w_begin);
+            const uint64_t o = (uint64_t)lw * n + i;
+            keys[o] = d ? lw * half + (d - 1) : nb;
+            vals[o] = (uint32_t)i | (neg << 31);
+        }
+        ++w;
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        buf |= (uint64_t)s.l[j] << cnt;
+        cnt += 32;
+        while (cnt >= c && w < w_total) {
+            emit((uint32_t)buf & mask);
+            buf >>= c;
+            cnt -= c;
+        }
+    }
+    while (w < w_total) {
+        emit((uint32_t)buf & mask);
+        buf >>= c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. bucket boundaries
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) msm_offsets_kernel(const uint32_t* __restrict__ keys, uint64_t len, uint32_t nb,
+                                                          uint32_t* __restrict__ start, uint32_t* __restrict__ endx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const uint32_t k = keys[i];
+    if (k >= nb) return;
+    if (i == 0 || keys[i - 1] != k) start[k] = (uint32_t)i;
+    if (i + 1 == len || keys[i + 1] != k) endx[k] = (uint32_t)(i + 1);
+}
+
+// count[g] = end[g] - start[g] (in place over `endx`), iota[g] = g
+static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* __restrict__ start, uint32_t* __restrict__ endx_count,
+                                                        uint32_t* __restrict__ iota, uint32_t nb) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nb) return;
+    endx_count[g] = endx_count[g] - start[g];
+    iota[g] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// point loads
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ AffineT<F> load_affine(const void* bases, uint32_t idx);
+
+template <>
+__device__ __forceinline__ G1Affine load_affine<FpOps>(const void* bases, uint32_t idx) {
+    const U128* p = (const U128*)bases + (size_t)idx * 6;
+    G1Affine a;
+    U128 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.x.l[4 * k] = v[k].x; a.x.l[4 * k + 1] = v[k].y; a.x.l[4 * k + 2] = v[k].z; a.x.l[4 * k + 3] = v[k].w;
+        a.y.l[4 * k] = v[k + 3].x; a.y.l[4 * k + 1] = v[k + 3].y; a.y.l[4 * k + 2] = v[k + 3].z; a.y.l[4 * k + 3] = v[k + 3].w;
+    }
+    return a;
+}
+
+template <>
+__device__ __forceinline__ G2Affine load_affine<Fp2Ops>(const void* bases, uint32_t idx) {
+    const U128* p = (const U128*)bases + (size_t)idx * 12;
+    G2Affine a;
+    Fp* f[4] = {&a.x.c0, &a.x.c1, &a.y.c0, &a.y.c1};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            U128 v = p[3 * e + k];
+            f[e]->l[4 * k] = v.x; f[e]->l[4 * k + 1] = v.y; f[e]->l[4 * k + 2] = v.z; f[e]->l[4 * k + 3] = v.w;
+        }
+    }
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5. bucket accumulation (dominant kernel)
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(128) msm_accumulate_kernel(const void* __restrict__ bases, const uint32_t* __restrict__ vals,
+                                                             const uint32_t* __restrict__ start,
+                                                             const uint32_t* __restrict__ count,
+                                                             const uint32_t* __restrict__ order, uint32_t nb,
+                                                             XyzzT<F>* __restrict__ buckets) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    const uint32_t g = order[t];
+    const uint32_t s = start[g], cnt = count[g];
+    XyzzT<F> acc = xyzz_identity<F>();
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t v = vals[s + k];
+        AffineT<F> p = load_affine<F>(bases, v & 0x7fffffffu);
+        if (v >> 31) p.y = F::neg(p.y);
+        xyzz_add_mixed<F>(acc, p);
+    }
+    buckets[g] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 6. chunked running-sum reduction:  out[t] = sum_{j<CH} (lo + j + 1) * B[w][lo + j]
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) msm_reduce_kernel(const XyzzT<F>* __restrict__ buckets, uint32_t half, uint32_t ch,
+                                                        uint32_t n_chunks_total, XyzzT<F>* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chunks_total) return;
+    const uint32_t per_win = half / ch;
+    const uint32_t w = t / per_win, k = t % per_win;
+    const uint32_t lo = k * ch;
+    const XyzzT<F>* b = buckets + (size_t)w * half + lo;
+    XyzzT<F> run = xyzz_identity<F>(), acc = xyzz_identity<F>();
+    for (int j = (int)ch - 1; j >= 0; --j) {
+        XyzzT<F> p = b[j];
+        xyzz_add<F>(run, p);
+        xyzz_add<F>(acc, run);
+    }
+    if (lo) {
+        XyzzT<F> m = xyzz_mul_u32<F>(run, lo);
+        xyzz_add<F>(acc, m);
+    }
+    out[t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 7. per-window tree sum of the chunk results
+// ------------------------------------------------------------------------------------------------
+template <class F, int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const XyzzT<F>* __restrict__ chunk_out, uint32_t per_win,
+                                                                 XyzzT<F>* __restrict__ win_out) {
+    __shared__ XyzzT<F> sh[THREADS];
+    const uint32_t w = blockIdx.x;
+    const XyzzT<F>* src = chunk_out + (size_t)w * per_win;
+    XyzzT<F> acc = xyzz_identity<F>();
+    for (uint32_t i = threadIdx.x; i < per_win; i += THREADS) {
+        XyzzT<F> p = src[i];
+        xyzz_add<F>(acc, p);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            XyzzT<F> a = sh[threadIdx.x], b = sh[threadIdx.x + s];
+            xyzz_add<F>(a, b);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) win_out[w] = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic bases: out[i] = k_i * G
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix_first(uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) synth_bases_kernel(AffineT<F> gen, uint64_t seed, uint64_t start, uint64_t n,
+                                                         AffineT<F>* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = splitmix_first(seed + 0x632BE59BD9B4E019ull * (start + i)) | 1;
+    XyzzT<F> r = xyzz_identity<F>();
+    for (int b = 63; b >= 0; --b) {
+        r = xyzz_dbl<F>(r);
+        if ((k >> b) & 1) xyzz_add_mixed<F>(r, gen);
+    }
+    AffineT<F> a;
+    xyzz_to_affine<F>(r, a);
+    out[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static Fp fp_from_canon_be_hex(const char* hex) {  // 96 hex chars, big-endian
+    Fp c = Fp::zero();
+    for (int i = 0; i < 96; ++i) {
+        char ch = hex[i];
+        uint32_t v = ch <= '9' ? ch - '0' : (ch | 32) - 'a' + 10;
+        int nib = 95 - i;  // nibble index from LSB
+        c.l[nib / 8] |= v << ((nib % 8) * 4);
+    }
+    return fe_to_mont<FpParams>(c);
+}
+
+static G1Affine g1_generator_host() {
+    static const G1Affine g = {
+        fp_from_canon_be_hex("17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"),
+        fp_from_canon_be_hex("08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")};
+    return g;
+}
+static G2Affine g2_generator_host() {
+    static const G2Affine g = {
+        {fp_from_canon_be_hex("024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"),
+         fp_from_canon_be_hex("13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e")},
+        {fp_from_canon_be_hex("0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801"),
+         fp_from_canon_be_hex("0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be")}};
+    return g;
+}
+
+template <class F>
+struct PointIO;
+template <>
+struct PointIO<FpOps> {
+    static constexpr int RAW = 96, PACKED = 97;
+    static void pack(const XyzzT<FpOps>& p, uint8_t* out) {
+        G1Affine a;
+        bool fin = xyzz_to_affine<FpOps>(p, a);
+        memcpy(out, a.x.l, 48);
+        memcpy(out + 48, a.y.l, 48);
+        out[96] = fin ? 0 : 1;
+    }
+    static XyzzT<FpOps> unpack(const uint8_t* in) {
+        if (in[96]) return xyzz_identity<FpOps>();
+        G1Affine a;
+        memcpy(a.x.l, in, 48);
+        memcpy(a.y.l, in + 48, 48);
+        return xyzz_from_affine<FpOps>(a);
+    }
+};
+template <>
+struct PointIO<Fp2Ops> {
+    static constexpr int RAW = 192, PACKED = 193;
+    static void pack(const XyzzT<Fp2Ops>& p, uint8_t* out) {
+        G2Affine a;
+        bool fin = xyzz_to_affine<Fp2Ops>(p, a);
+        memcpy(out, a.x.c0.l, 48);
+        memcpy(out + 48, a.x.c1.l, 48);
+        memcpy(out + 96, a.y.c0.l, 48);
+        memcpy(out + 144, a.y.c1.l, 48);
+        out[192] = fin ? 0 : 1;
+    }
+    static XyzzT<Fp2Ops> unpack(const uint8_t* in) {
+        if (in[192]) return xyzz_identity<Fp2Ops>();
+        G2Affine a;
+        memcpy(a.x.c0.l, in, 48);
+        memcpy(a.x.c1.l, in + 48, 48);
+        memcpy(a.y.c0.l, in + 96, 48);
+        memcpy(a.y.c1.l, in + 144, 48);
+        return xyzz_from_affine<Fp2Ops>(a);
+    }
+};
+
+static int bits_for(uint64_t v) {
+    int b = 1;
+    while (b < 64 && ((uint64_t)1 << b) <= v) ++b;
+    return b;
+}
+
+// Computes sum over windows [w_begin, w_end) of 2^(c w) S_w into `result` (host XYZZ).
+template <class F>
+static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
+                       int w_end, XyzzT<F>& result) {
+    typedef XyzzT<F> Pt;
+    result = xyzz_identity<F>();
+    if (n == 0 || w_begin >= w_end) return BZK_OK;
+    if (n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
+    const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n);
+    const int w_total = msm_windows_for(c);
+    if (w_end > w_total) return BZK_E_ARG;
+    const uint32_t half = 1u << (c - 1);
+    uint32_t ch = ctx->msm_chunk_override > 0 ? (uint32_t)ctx->msm_chunk_override : 16u;
+    if (ch > half) ch = half;
+    while (half % ch) --ch;
+    const uint32_t per_win = half / ch;
+
+    // windows are processed in groups so that one group's pair list stays below 2^30 entries
+    int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w_end - w_begin), ((uint64_t)1 << 30) / n));
+    const uint64_t len_max = (uint64_t)group * n;
+    const uint32_t nb_max = (uint32_t)group * half;
+
+    // rocPRIM temp sizes
+    size_t tmp1 = 0, tmp2 = 0;
+    {
+        uint32_t* nul = nullptr;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp1, nul, nul, nul, nul, (size_t)len_max, 0, bits_for(nb_max), ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
+        e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_max, 0, bits_for(n), ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
+    }
+    const size_t tmp = std::max(tmp1, tmp2);
+    size_t total = 0;
+    total += 4 * ws_pad(len_max * 4);                 // keys, vals, keys_sorted, vals_sorted
+    total += 5 * ws_pad((size_t)nb_max * 4);          // start, count, count_sorted, iota, order
+    total += ws_pad((size_t)nb_max * sizeof(Pt));     // buckets
+    total += ws_pad((size_t)group * per_win * sizeof(Pt));
+    total += ws_pad((size_t)w_total * sizeof(Pt));
+    total += ws_pad(tmp) + 4096;
+    BZK_TRY(ws_reserve(ctx, total));
+    BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(Pt)));
+    WsCursor cur(ctx->ws);
+    uint32_t* keys = cur.take<uint32_t>(len_max);
+    uint32_t* vals = cur.take<uint32_t>(len_max);
+    uint32_t* keys_s = cur.take<uint32_t>(len_max);
+    uint32_t* vals_s = cur.take<uint32_t>(len_max);
+    uint32_t* start = cur.take<uint32_t>(nb_max);
+    uint32_t* count = cur.take<uint32_t>(nb_max);
+    uint32_t* count_s = cur.take<uint32_t>(nb_max);
+    uint32_t* iota = cur.take<uint32_t>(nb_max);
+    uint32_t* order = cur.take<uint32_t>(nb_max);
+    Pt* buckets = cur.take<Pt>(nb_max);
+    Pt* chunk_out = cur.take<Pt>((size_t)group * per_win);
+    Pt* win_out = cur.take<Pt>(w_total);
+    void* tmp_buf = cur.take<char>(tmp);
+
+    const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;
+    std::vector<Pt> wsum((size_t)(w_end - w_begin));
+    for (int wb = w_begin; wb < w_end; wb += group) {
+        const int wc = std::min(group, w_end - wb);
+        const uint64_t len = (uint64_t)wc * n;
+        const uint32_t nb = (uint32_t)wc * half;
+        BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                   (const U128*)scalars, n, mont, c, w_total, wb, wc, keys, vals);
+        {
+            ProfScope ps(ctx, "msm_sort_pairs");
+            size_t t = tmp;
+            hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, keys, keys_s, vals, vals_s, (size_t)len, 0, bits_for(nb), ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+        }
+        BZK_HIP(ctx, hipMemsetAsync(start, 0, (size_t)nb * 4, ctx->stream));
+        BZK_HIP(ctx, hipMemsetAsync(count, 0, (size_t)nb * 4, ctx->stream));
+        BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, start, count);
+        BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, start, count, iota, nb);
+        {
+            ProfScope ps(ctx, "msm_sort_buckets");
+            size_t t = tmp;
+            hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, count, count_s, iota, order, (size_t)nb, 0, bits_for(n), ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+        }
+        auto k_acc = msm_accumulate_kernel<F>;
+        auto k_red = msm_reduce_kernel<F>;
+        BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((nb + 127) / 128), dim3(128), 0, bases, vals_s, start, count, order, nb, buckets);
+        const uint32_t n_chunks = (uint32_t)wc * per_win;
+        BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);
+        constexpr int WT = F::LIMBS == 12 ? 256 : 128;
+        auto k_ws = msm_window_sum_kernel<F, WT>;
+        BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)wc), dim3(WT), 0, chunk_out, per_win, win_out);
+        BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)wc * sizeof(Pt), hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(&wsum[wb - w_begin], ctx->pinned, (size_t)wc * sizeof(Pt));
+    }
+    // Horner over the window sums (host): result = 2^(c*w_begin) * sum_k 2^(c k) S_{w_begin+k}
+    Pt acc = xyzz_identity<F>();
+    for (int k = (int)wsum.size() - 1; k >= 0; --k) {
+        for (int d = 0; d < c; ++d) acc = xyzz_dbl<F>(acc);
+        xyzz_add<F>(acc, wsum[k]);
+    }
+    for (int d = 0; d < c * w_begin; ++d) acc = xyzz_dbl<F>(acc);
+    result = acc;
+    return BZK_OK;
+}
+
+template <class F>
+static int32_t msm_entry_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
+                             int w_end, uint8_t* out) {
+    if (!ctx || !out || (n && (!bases || !scalars))) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    XyzzT<F> r;
+    if (w_end < 0) {
+        const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n ? n : 1);
+        w_end = msm_windows_for(c);
+    }
+    BZK_TRY(msm_run<F>(ctx, bases, scalars, n, flags, w_begin, w_end, r));
+    PointIO<F>::pack(r, out);
+    return BZK_OK;
+}
+
+template <class F>
+static int32_t msm_entry_host(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t* out) {
+    if (!ctx || !out || (n && (!bases || !scalars))) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    void *db = nullptr, *ds = nullptr;
+    if (n) {
+        BZK_HIP(ctx, hipMalloc(&db, n * PointIO<F>::RAW));
+        if (hipMalloc(&ds, n * 32) != hipSuccess) { (void)hipFree(db); return BZK_E_ALLOC; }
+        hipError_t e1 = hipMemcpyAsync(db, bases, n * PointIO<F>::RAW, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e2 = hipMemcpyAsync(ds, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(db); (void)hipFree(ds); return BZK_E_DEVICE; }
+    }
+    int32_t st = msm_entry_dev<F>(ctx, db, ds, n, flags, 0, -1, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (db) (void)hipFree(db);
+    if (ds) (void)hipFree(ds);
+    return st;
+}
+
+template <class F>
+static int32_t sum_packed(const uint8_t* pts, uint32_t count, uint8_t* out) {
+    if (!out || (count && !pts)) return BZK_E_ARG;
+    XyzzT<F> acc = xyzz_identity<F>();
+    for (uint32_t i = 0; i < count; ++i) {
+        XyzzT<F> p = PointIO<F>::unpack(pts + (size_t)i * PointIO<F>::PACKED);
+        xyzz_add<F>(acc, p);
+    }
+    PointIO<F>::pack(acc, out);
+    return BZK_OK;
+}
+
+}  // namespace bzk
+

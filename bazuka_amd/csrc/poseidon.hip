@@ -1,0 +1,375 @@
+// K1 (batched Poseidon) and K2 (dense 4-ary ZkState tree re-hash) for gfx950.
+//
+// Replaces, for bulk inputs, the reference's
+//   PoseidonHasher::hash -> poseidon::poseidon      /root/reference/src/zk/mod.rs:496-511,
+//                                                   /root/reference/src/zk/poseidon/mod.rs:24-84
+//   KvStoreStateManager::set_data level loop        /root/reference/src/zk/state/mod.rs:353-391
+// with identical outputs: state = [0, inputs...], R_F/2 full rounds, R_P partial rounds (S-box on
+// element 0 only), R_F/2 full rounds, dense MDS product every round, result = state[1].
+//
+// Parameters are NOT copied from the reference's params/*.txt: they are re-derived at first use
+// with the public hadeshash Grain-LFSR procedure (src/zk/poseidon/params/README.md names the
+// generator script and its arguments `1 0 255 t 5 128`); tests compare them with the files and the
+// 16 reference KATs (src/zk/poseidon/mod.rs:114-149) gate the result.
+//
+// Kernel shape: one lane per hash, state in VGPRs (t x 8 limbs), round constants and the MDS matrix
+// are wave-uniform and come through the scalar cache (SGPR operands of v_mad_u64_u32).  The MDS row
+// products are accumulated UNREDUCED in 17 limbs and Montgomery-reduced once per row: t*t half
+// products + t reductions per round instead of t*t full products.  The work is integer-ALU bound
+// (about 1.9k Fr products per arity-4 hash against 160 B of traffic), so coalescing matters little.
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "bzk_field.cuh"
+#include "bzk_internal.h"
+
+namespace bzk {
+
+// ------------------------------------------------------------------------------------------------
+// host: parameter generation (Grain LFSR, hadeshash)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct GrainLfsr {
+    uint8_t s[80];
+    int head = 0;
+    GrainLfsr(int t, int rf, int rp) {
+        int k = 0;
+        auto put = [&](int v, int w) {
+            for (int i = w - 1; i >= 0; --i) s[k++] = (uint8_t)((v >> i) & 1);
+        };
+        put(1, 2);     // field = GF(p)
+        put(0, 4);     // s-box = x^alpha
+        put(255, 12);  // n
+        put(t, 12);
+        put(rf, 10);
+        put(rp, 10);
+        while (k < 80) s[k++] = 1;
+        for (int i = 0; i < 160; ++i) clock();
+    }
+    int clock() {
+        auto at = [&](int i) { return s[(head + i) % 80]; };
+        uint8_t nb = at(62) ^ at(51) ^ at(38) ^ at(23) ^ at(13) ^ at(0);
+        s[head] = nb;
+        head = (head + 1) % 80;
+        return nb;
+    }
+    int next_bit() {  // shrinking: keep the 2nd bit of a pair iff the 1st is set
+        for (;;) {
+            int a = clock(), b = clock();
+            if (a) return b;
+        }
+    }
+    Fr next_raw(bool* below_modulus) {  // 255 bits, MSB first, canonical limbs (not reduced)
+        Fr v = Fr::zero();
+        for (int i = 254; i >= 0; --i)
+            if (next_bit()) v.l[i >> 5] |= 1u << (i & 31);
+        bool lt = false;
+        for (int i = 7; i >= 0; --i) {
+            if (v.l[i] != FrParams::MOD[i]) {
+                lt = v.l[i] < FrParams::MOD[i];
+                break;
+            }
+        }
+        *below_modulus = lt;
+        return v;
+    }
+};
+
+struct HostParams {
+    int t = 0, rf = 8, rp = 0;
+    std::vector<Fr> rc, mds;  // Montgomery
+};
+
+std::mutex g_mu;
+HostParams g_params[18];
+
+const HostParams& host_params(int t) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    HostParams& P = g_params[t];
+    if (P.t) return P;
+    P.rf = 8;
+    P.rp = t <= 5 ? 56 : 57;
+    GrainLfsr g(t, P.rf, P.rp);
+    while ((int)P.rc.size() < t * (P.rf + P.rp)) {
+        bool lt;
+        Fr v = g.next_raw(&lt);
+        if (lt) P.rc.push_back(fe_to_mont<FrParams>(v));  // rejection sampling
+    }
+    std::vector<Fr> xy;
+    for (int i = 0; i < 2 * t; ++i) {
+        bool lt;
+        Fr v = g.next_raw(&lt);
+        if (!lt) fe_reduce_once<FrParams>(v);  // MDS draws are reduced, not rejected
+        xy.push_back(fe_to_mont<FrParams>(v));
+    }
+    P.mds.resize((size_t)t * t);
+    for (int i = 0; i < t; ++i)
+        for (int j = 0; j < t; ++j) P.mds[(size_t)i * t + j] = fe_inv<FrParams>(fe_add<FrParams>(xy[i], xy[t + j]));
+    P.t = t;
+    return P;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// device
+// ------------------------------------------------------------------------------------------------
+__device__ __noinline__ Fr fr_mul_call(Fr a, Fr b) { return fe_mul<FrParams>(a, b); }
+
+__device__ __forceinline__ Fr fr_sbox(const Fr& x) {
+    Fr x2 = fr_mul_call(x, x);
+    Fr x4 = fr_mul_call(x2, x2);
+    return fr_mul_call(x4, x);
+}
+
+// acc(17 limbs) += a * b   (plain 8x8 limb product, no reduction)
+__device__ __forceinline__ void wide_mac(uint32_t (&acc)[17], const Fr& a, const uint32_t* __restrict__ b) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t bi = b[i];
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t s = (uint64_t)a.l[j] * bi + acc[i + j] + c;
+            acc[i + j] = (uint32_t)s;
+            c = (uint32_t)(s >> 32);
+        }
+        // propagate into the upper limbs
+#pragma unroll
+        for (int k = i + 8; k < 17; ++k) {
+            uint64_t s = (uint64_t)acc[k] + c;
+            acc[k] = (uint32_t)s;
+            c = (uint32_t)(s >> 32);
+        }
+    }
+}
+
+// Montgomery reduction of a 17-limb value v < t * r^2 (t <= 17, so v < 2^5 * 2^510 < 2^544) to
+// v * R^-1 mod r, fully reduced.
+__device__ __noinline__ Fr wide_reduce(const uint32_t* __restrict__ acc_in) {
+    uint32_t a[18];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) a[i] = acc_in[i];
+    a[17] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t m = a[i] * FrParams::INV;
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t s = (uint64_t)m * FrParams::MOD[j] + a[i + j] + c;
+            a[i + j] = (uint32_t)s;
+            c = (uint32_t)(s >> 32);
+        }
+#pragma unroll
+        for (int k = i + 8; k < 18; ++k) {
+            uint64_t s = (uint64_t)a[k] + c;
+            a[k] = (uint32_t)s;
+            c = (uint32_t)(s >> 32);
+        }
+    }
+    // value = a[8..17] (10 limbs), < (t r^2 + R r)/R < (t+1) * r  with t <= 17: subtract r while >= r.
+    // a[16], a[17] can be non-zero only transiently (value < 18 r < 2^260): fold by repeated subtraction.
+    uint32_t v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = a[8 + i];
+    // binary descent: subtract 16r, 8r, 4r, 2r, r when possible
+#pragma unroll
+    for (int sh = 4; sh >= 0; --sh) {
+        uint32_t t[9];
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            // limb i of (r << sh)
+            uint32_t lo = i < 8 ? FrParams::MOD[i] : 0u;
+            uint32_t prev = (i > 0 && i <= 8) ? FrParams::MOD[i - 1] : 0u;
+            uint32_t ri = sh ? ((lo << sh) | (prev >> (32 - sh))) : lo;
+            uint64_t d = (uint64_t)v[i] - ri - borrow;
+            t[i] = (uint32_t)d;
+            borrow = (d >> 63) & 1;
+        }
+        if (!borrow) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v[i] = t[i];
+        }
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = v[i];
+    return r;
+}
+
+template <int T>
+__global__ void __launch_bounds__(128) poseidon_kernel(const Fr* __restrict__ in, uint64_t n, const Fr* __restrict__ consts,
+                                                       int rf, int rp, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr st[T];
+    st[0] = Fr::zero();
+#pragma unroll
+    for (int k = 1; k < T; ++k) st[k] = in[i * (T - 1) + (k - 1)];
+    const Fr* rc = consts;
+    const Fr* mds = consts + (size_t)T * (rf + rp);
+    const int half_f = rf / 2;
+    for (int rnd = 0; rnd < rf + rp; ++rnd) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) st[k] = fe_add<FrParams>(st[k], rc[rnd * T + k]);
+        const bool full = rnd < half_f || rnd >= half_f + rp;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < T; ++k) st[k] = fr_sbox(st[k]);
+        } else {
+            st[0] = fr_sbox(st[0]);
+        }
+        Fr nw[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            uint32_t acc[17];
+#pragma unroll
+            for (int q = 0; q < 17; ++q) acc[q] = 0;
+#pragma unroll
+            for (int k = 0; k < T; ++k) wide_mac(acc, st[k], mds[j * T + k].l);
+            nw[j] = wide_reduce(acc);
+        }
+#pragma unroll
+        for (int k = 0; k < T; ++k) st[k] = nw[k];
+    }
+    out[i] = st[1];
+}
+
+typedef void (*poseidon_fn)(const Fr*, uint64_t, const Fr*, int, int, Fr*);
+static poseidon_fn poseidon_table(int t) {
+    switch (t) {
+        case 2: return poseidon_kernel<2>;
+        case 3: return poseidon_kernel<3>;
+        case 4: return poseidon_kernel<4>;
+        case 5: return poseidon_kernel<5>;
+        case 6: return poseidon_kernel<6>;
+        case 7: return poseidon_kernel<7>;
+        case 8: return poseidon_kernel<8>;
+        case 9: return poseidon_kernel<9>;
+        case 10: return poseidon_kernel<10>;
+        case 11: return poseidon_kernel<11>;
+        case 12: return poseidon_kernel<12>;
+        case 13: return poseidon_kernel<13>;
+        case 14: return poseidon_kernel<14>;
+        case 15: return poseidon_kernel<15>;
+        case 16: return poseidon_kernel<16>;
+        case 17: return poseidon_kernel<17>;
+        default: return nullptr;
+    }
+}
+
+static int32_t poseidon_consts_dev(bzk_ctx* ctx, int t, const Fr** out, int* rf, int* rp) {
+    const HostParams& P = host_params(t);
+    *rf = P.rf;
+    *rp = P.rp;
+    if (!ctx->poseidon_dev[t]) {
+        std::vector<Fr> flat(P.rc);
+        flat.insert(flat.end(), P.mds.begin(), P.mds.end());
+        void* d = nullptr;
+        BZK_HIP(ctx, hipMalloc(&d, flat.size() * sizeof(Fr)));
+        BZK_HIP(ctx, hipMemcpyAsync(d, flat.data(), flat.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->poseidon_dev[t] = d;
+    }
+    *out = (const Fr*)ctx->poseidon_dev[t];
+    return BZK_OK;
+}
+
+int32_t poseidon_launch(bzk_ctx* ctx, const void* in_dev, uint32_t arity, uint64_t n, void* out_dev) {
+    if (arity < 1 || arity > 16) return BZK_E_ARG;
+    if (n == 0) return BZK_OK;
+    const int t = (int)arity + 1;
+    const Fr* consts;
+    int rf, rp;
+    BZK_TRY(poseidon_consts_dev(ctx, t, &consts, &rf, &rp));
+    poseidon_fn k = poseidon_table(t);
+    const uint64_t blocks = (n + 127) / 128;
+    if (blocks > 0x7fffffffull) return BZK_E_ARG;
+    BZK_LAUNCH(ctx, "poseidon", k, dim3((unsigned)blocks), dim3(128), 0, (const Fr*)in_dev, n, consts, rf, rp, (Fr*)out_dev);
+    return BZK_OK;
+}
+
+}  // namespace bzk
+
+using namespace bzk;
+
+extern "C" {
+
+int32_t bzk_poseidon_batch_dev(bzk_ctx* ctx, const void* in_dev, uint32_t arity, uint64_t n, void* out_dev) {
+    if (!ctx || (n && (!in_dev || !out_dev))) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    return poseidon_launch(ctx, in_dev, arity, n, out_dev);
+}
+
+int32_t bzk_poseidon_batch(bzk_ctx* ctx, const uint8_t* in, uint32_t arity, uint64_t n, uint8_t* out) {
+    if (!ctx || arity < 1 || arity > 16 || (n && (!in || !out))) return BZK_E_ARG;
+    if (n == 0) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    const size_t in_b = (size_t)n * arity * 32, out_b = (size_t)n * 32;
+    BZK_TRY(ws_reserve(ctx, ws_pad(in_b) + ws_pad(out_b) + 512));
+    WsCursor cur(ctx->ws);
+    uint8_t* din = cur.take<uint8_t>(in_b);
+    uint8_t* dout = cur.take<uint8_t>(out_b);
+    BZK_HIP(ctx, hipMemcpyAsync(din, in, in_b, hipMemcpyHostToDevice, ctx->stream));
+    BZK_TRY(poseidon_launch(ctx, din, arity, n, dout));
+    BZK_HIP(ctx, hipMemcpyAsync(out, dout, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+// Dense tree: level k (k = log4-1 .. 0) has 4^k nodes, each the arity-4 hash of 4 consecutive
+// children of level k+1 - exactly the batched layout, so a level is one poseidon launch.
+int32_t bzk_merkle4_root_dev(bzk_ctx* ctx, const void* leaves_dev, uint32_t log4, uint8_t root[32], void* nodes_opt_dev) {
+    if (!ctx || !leaves_dev || !root || log4 > 15) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (log4 == 0) {
+        BZK_HIP(ctx, hipMemcpyAsync(root, leaves_dev, 32, hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return BZK_OK;
+    }
+    const uint64_t n_internal = ((((uint64_t)1) << (2 * log4)) - 1) / 3;
+    uint8_t* nodes = (uint8_t*)nodes_opt_dev;
+    if (!nodes) {
+        BZK_TRY(ws_reserve(ctx, ws_pad(n_internal * 32) + 512));
+        nodes = (uint8_t*)ctx->ws;
+    }
+    const uint8_t* child = (const uint8_t*)leaves_dev;
+    for (int k = (int)log4 - 1; k >= 0; --k) {
+        const uint64_t cnt = (uint64_t)1 << (2 * k);
+        uint8_t* dst = nodes + ((cnt - 1) / 3) * 32;  // heap offset (4^k - 1)/3
+        BZK_TRY(poseidon_launch(ctx, child, 4, cnt, dst));
+        child = dst;
+    }
+    BZK_HIP(ctx, hipMemcpyAsync(root, nodes, 32, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+int32_t bzk_merkle4_root(bzk_ctx* ctx, const uint8_t* leaves, uint32_t log4, uint8_t root[32], uint8_t* nodes_opt) {
+    if (!ctx || !leaves || !root || log4 > 15) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n_leaves = (uint64_t)1 << (2 * log4), n_internal = (n_leaves - 1) / 3;
+    void *dl = nullptr, *dn = nullptr;
+    BZK_HIP(ctx, hipMalloc(&dl, n_leaves * 32));
+    if (hipMalloc(&dn, n_internal ? n_internal * 32 : 32) != hipSuccess) {
+        (void)hipFree(dl);
+        return BZK_E_ALLOC;
+    }
+    int32_t st = BZK_OK;
+    if (hipMemcpyAsync(dl, leaves, n_leaves * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = BZK_E_DEVICE;
+    if (st == BZK_OK) st = bzk_merkle4_root_dev(ctx, dl, log4, root, dn);
+    if (st == BZK_OK && nodes_opt && n_internal) {
+        if (hipMemcpyAsync(nodes_opt, dn, n_internal * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = BZK_E_DEVICE;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dl);
+    (void)hipFree(dn);
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X-native Groth16 hot path (BASELINE.json metric).
+
+Step      = one complete BLS12-381 G1 Pippenger MSM over a synthetic batch whose bases and scalars are
+            already resident in HBM (BASELINE.json configs[1]: 2^20 points on one MI355X).
+N GPUs    = the north-star partition: ONE MSM over N * 2^20 points, sharded by scalar-window range
+            (rank r owns windows [W*r/N, W*(r+1)/N)), bases/scalars replicated; the only exchange is
+            an RCCL all-gather of the 97-byte partial sums (RCCL cannot add curve points), folded
+            locally.  Per-GPU work (window x point pairs) is constant in N  => "scaling": "weak".
+value     = points of the whole job / second (max over ranks of the timed region).
+roofline  = msm_accumulate (dominant kernel): algorithmic 128 B per (point, scalar) pair over its HIP
+            event time, against the 8 TB/s HBM peak.  The kernel is integer-ALU bound, so this
+            fraction is tiny by construction; int_ops/s is reported beside it.
+cpu_baseline = the C++ oracle Pippenger (bellman-equivalent algorithm, "port") on the host cores,
+            rank 0, N=1 only; its result doubles as the parity check of the timed GPU result.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_N = 20
+SEED = 0x42415A554B41
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=LOG_N, help="log2 points per GPU (default 20 = BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bazuka_amd import Bzk
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: libbzk has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    ctx = Bzk(local_rank, torch.cuda.current_stream().cuda_stream)
+    n = (1 << args.log_n) * world  # whole-job points; every rank holds all of them (CRS is replicated)
+    bases = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+    ctx.g1_synth_bases_dev(SEED, 0, n, bases)
+    g = torch.Generator(device=dev).manual_seed(SEED & 0x7FFFFFFF)
+    scalars = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    scalars[:, 31] &= 0x3F  # < 2^254 < r: valid Montgomery residues, uniform over that range
+    scalars = scalars.contiguous()
+    torch.cuda.synchronize()
+
+    W = ctx.msm_window_count(n)
+    w0, w1 = W * rank // world, W * (rank + 1) // world
+    gather_in = torch.zeros(104, dtype=torch.uint8, device=dev)
+    gather_out = torch.zeros(104 * world, dtype=torch.uint8, device=dev)
+
+    def step():
+        if world == 1:
+            return ctx.msm_g1_dev(bases, scalars, n)
+        part = ctx.msm_g1_windows_dev(bases, scalars, n, w0, w1)
+        gather_in[:97] = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev, non_blocking=True)
+        dist.all_gather_into_tensor(gather_out, gather_in)
+        parts = gather_out.cpu().numpy().reshape(world, 104)[:, :97].tobytes()
+        return ctx.g1_sum(parts)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = None
+    for _ in range(args.warmup):
+        result = step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # every rank must hold the same folded result
+        r = torch.frombuffer(bytearray(result), dtype=torch.uint8).to(dev)
+        r0 = r.clone()
+        dist.broadcast(r0, 0)
+        assert bool((r == r0).all()), "ranks disagree on the MSM result"
+
+    prof = ctx.prof_dump()
+    acc_n, acc_ms = prof.get("msm_accumulate", (0, 0.0))
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = n / (elapsed / args.steps) / 1e6
+    out = {
+        "metric": "G1-MSM throughput (BLS12-381 Pippenger, 2^20 points per GPU)",
+        "value": round(value, 3),
+        "unit": "Mpt/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: 2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU "
+                               f"(bases k_i*G, uniform scalars, resident in HBM)",
+                   "points_total": n, "windows": W, "window_range_this_rank": [w0, w1],
+                   "parallelism": "single-gpu" if world == 1 else f"window-sharded x{world} + RCCL all-gather of partial sums"},
+        "proofs_per_sec": None,
+    }
+    if rank == 0:
+        if acc_n:
+            per_launch_ms = acc_ms / acc_n
+            alg_bytes = 128.0 * n  # 96 B affine base + 32 B scalar per (point, scalar) pair
+            achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                               "traffic": None, "avg_launch_ms": round(per_launch_ms, 4),
+                               "note": "integer-ALU bound (381-bit Montgomery carry chains); HBM fraction is "
+                                       "structurally ~1e-3, see DESIGN.md"}
+        out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import coracle as co
+            cores = co.ncpu()
+            hb = bytes(bases.cpu().numpy().tobytes())
+            hs = bytes(scalars.cpu().numpy().tobytes())
+            t0 = time.perf_counter()
+            want = co.msm_g1(hb, hs, nthreads=cores)
+            dt = time.perf_counter() - t0
+            assert want == result, "GPU MSM result differs from the CPU oracle"
+            out["cpu_baseline"] = {"value": round(n / dt / 1e6, 4), "unit": "Mpt/s", "cores": cores, "kind": "port",
+                                   "sample": f"the full 2^{args.log_n}-point MSM of this run, 1 run, "
+                                             f"window-per-thread Pippenger (bellman-equivalent), {dt:.2f} s",
+                                   "parity": "bit-exact (97-byte affine result)"}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/* bzk.h - C ABI of the MI355X-native Groth16 hot path for Bazuka's MPN rollup (libbzk.so).
+ *
+ * This is the drop-in boundary a Rust host binds with `extern "C"`.  Each entry
+ * point names the reference interface it replaces; paths are relative to ziesha-network/bazuka.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every buffer; nothing allocated by the library
+ *    crosses the boundary except opaque handles (bzk_ctx, bzk_params) released by their destroy call;
+ *  - every function returns an int32 status: 0 = BZK_OK, negative = BZK_E_*; no exceptions, no abort;
+ *  - one ctx is bound to one GPU and one HIP stream and may be used from one thread at a time;
+ *    distinct ctxs are independent (one process per GPU is the intended deployment);
+ *  - scalars are 32-byte little-endian limbs.  Default = MONTGOMERY form, i.e. the in-memory
+ *    `ZkScalar` / `bls12_381::Scalar` (src/zk/mod.rs:202-206; transmute-compatible per
+ *    src/zk/groth16/mod.rs:7-17).  BZK_F_CANONICAL selects canonical integers (test drivers);
+ *  - Fp elements are 48-byte little-endian Montgomery limbs (R = 2^384), as `Fp([u64;6])` in
+ *    src/zk/groth16/mod.rs:19-20.  G1 affine = x|y (96 B, "raw", never the identity) or x|y|inf
+ *    (97 B, "packed", as `(Fp, Fp, bool)` at :33-38).  G2 = x.c0|x.c1|y.c0|y.c1 (192 B raw) or +inf
+ *    (193 B packed).  A Groth16 proof is a|b|c = 97+193+97 = 387 B (= bincode of `Groth16Proof`);
+ *  - `*_dev` variants take DEVICE pointers (HBM-resident data; what bench.py times).  The plain
+ *    variants take HOST pointers and stage through PCIe.
+ *  - There is NO CPU fallback: without a usable gfx950 device bzk_ctx_create fails with
+ *    BZK_E_DEVICE and nothing else can be called.
+ */
+#ifndef BZK_H
+#define BZK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BZK_OK 0
+#define BZK_E_ARG (-1)      /* bad argument (null pointer, size out of range, arity > 16 ...) */
+#define BZK_E_ALLOC (-2)    /* device or host allocation failed */
+#define BZK_E_DEVICE (-3)   /* HIP runtime / kernel launch error, or no gfx950 device */
+#define BZK_E_UNSAT (-4)    /* witness does not satisfy the constraint system */
+#define BZK_E_INTERNAL (-5) /* invariant violated (bug) */
+
+#define BZK_F_CANONICAL 1u  /* scalars are canonical integers instead of Montgomery limbs */
+
+typedef struct bzk_ctx bzk_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device_id: HIP ordinal.  stream: a hipStream_t the caller owns (e.g. torch's current stream), or
+ * NULL to let the ctx create its own non-blocking stream. */
+int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out);
+void bzk_ctx_destroy(bzk_ctx* ctx);
+int32_t bzk_sync(bzk_ctx* ctx); /* wait for the ctx stream */
+const char* bzk_strerror(int32_t status);
+const char* bzk_last_error(bzk_ctx* ctx); /* detail of the last BZK_E_DEVICE on this ctx */
+uint32_t bzk_abi_version(void);
+
+/* device-memory plumbing for hosts that want to keep inputs resident without a tensor library */
+int32_t bzk_dev_alloc(bzk_ctx* ctx, uint64_t bytes, void** dptr);
+int32_t bzk_dev_free(bzk_ctx* ctx, void* dptr);
+int32_t bzk_h2d(bzk_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int32_t bzk_d2h(bzk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+
+/* per-kernel timing with HIP events on the ctx stream (used by bench.py for `roofline.achieved`) */
+int32_t bzk_prof_enable(bzk_ctx* ctx, int32_t on);
+int32_t bzk_prof_reset(bzk_ctx* ctx);
+/* sums over launches whose kernel label == name; synchronises the stream */
+int32_t bzk_prof_query(bzk_ctx* ctx, const char* name, uint64_t* launches, double* total_ms);
+/* writes up to cap bytes of "name launches total_ms\n" lines */
+int32_t bzk_prof_dump(bzk_ctx* ctx, char* buf, uint64_t cap);
+
+/* ---- K1: batched Poseidon --------------------------------------------------------------------
+ * Replaces `ZkHasher::hash` = `PoseidonHasher::hash` -> `poseidon::poseidon`
+ * (src/zk/mod.rs:152-155, 496-511; src/zk/poseidon/mod.rs:24-84) for n independent inputs.
+ * in: n*arity scalars (hash i uses in[i*arity .. (i+1)*arity)), out: n scalars.  1 <= arity <= 16
+ * (MAX_ARITY, src/zk/poseidon/params/mod.rs:25); other arities -> BZK_E_ARG where the reference
+ * panics.  Always Montgomery form. */
+int32_t bzk_poseidon_batch(bzk_ctx* ctx, const uint8_t* in, uint32_t arity, uint64_t n, uint8_t* out);
+int32_t bzk_poseidon_batch_dev(bzk_ctx* ctx, const void* in_dev, uint32_t arity, uint64_t n, void* out_dev);
+
+/* ---- K2: dense 4-ary ZkState tree re-hash ----------------------------------------------------
+ * Root of `ZkStateModel::List{log4_size, Scalar}` with every leaf present, as
+ * `ZkStateBuilder::compress` / `KvStoreStateManager::root` would give (src/zk/state/mod.rs:66-90,
+ * 274-283, 310-420: node = H(c0,c1,c2,c3)).  leaves: 4^log4 scalars.  nodes_opt (may be NULL):
+ * receives all internal nodes in the reference's heap order, index (4^k-1)/3 + i for node i of
+ * depth k (src/zk/state/mod.rs:355,382-383), root at index 0; (4^log4-1)/3 scalars. */
+int32_t bzk_merkle4_root(bzk_ctx* ctx, const uint8_t* leaves, uint32_t log4_size, uint8_t root[32], uint8_t* nodes_opt);
+int32_t bzk_merkle4_root_dev(bzk_ctx* ctx, const void* leaves_dev, uint32_t log4_size, uint8_t root[32], void* nodes_opt_dev);
+
+/* ---- K3: radix-2 NTT over Fr -----------------------------------------------------------------
+ * bellman 0.14 `EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}` (third-party crate; reached
+ * from `create_random_proof`, src/mpn/circuits/test.rs:135,175,215).  In place, natural order in and
+ * out.  omega = 7^((r-1)/2^32)^(2^(32-log_n)); coset shift g = 7.
+ *   inverse=0,coset=0: a_k = sum_j a_j w^jk          inverse=1,coset=0: ... w^-jk / n
+ *   inverse=0,coset=1: scale a_j by g^j, then fft     inverse=1,coset=1: ifft, then scale by g^-j */
+int32_t bzk_ntt(bzk_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset);
+int32_t bzk_ntt_dev(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int32_t inverse, int32_t coset);
+
+/* ---- K4 / K5: Pippenger multi-scalar multiplication ------------------------------------------
+ * bellman 0.14 `multiexp` over G1 / G2 (third-party; the `h`, `l`, `a`, `b_g1`, `b_g2` queries of
+ * `create_proof`).  result = sum_i scalar_i * base_i, written packed (97 / 193 B).
+ * bases: raw affine, never the identity (bellman drops identity points from the CRS). */
+int32_t bzk_msm_g1(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[97]);
+int32_t bzk_msm_g1_dev(bzk_ctx* ctx, const void* bases_dev, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[97]);
+int32_t bzk_msm_g2(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[193]);
+int32_t bzk_msm_g2_dev(bzk_ctx* ctx, const void* bases_dev, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[193]);
+
+/* Sharded form for multi-GPU: this rank computes only windows
+ * [w_begin, w_end) of the W = bzk_msm_window_count(n) signed c-bit windows and returns their partial
+ * sum  sum_w 2^(c*w) * S_w  as a packed point; the partial sums of all ranks add up to the MSM.
+ * Ranks exchange the 97/193-byte partials as raw bytes (RCCL all-gather) and fold them with
+ * bzk_g1_sum / bzk_g2_sum - RCCL itself cannot add curve points. */
+uint32_t bzk_msm_window_count(uint64_t n);
+int32_t bzk_msm_g1_windows_dev(bzk_ctx* ctx, const void* bases_dev, const void* scalars_dev, uint64_t n, uint32_t flags,
+                               uint32_t w_begin, uint32_t w_end, uint8_t out[97]);
+int32_t bzk_msm_g2_windows_dev(bzk_ctx* ctx, const void* bases_dev, const void* scalars_dev, uint64_t n, uint32_t flags,
+                               uint32_t w_begin, uint32_t w_end, uint8_t out[193]);
+int32_t bzk_g1_sum(const uint8_t* packed_points, uint32_t count, uint8_t out[97]);   /* host, tiny */
+int32_t bzk_g2_sum(const uint8_t* packed_points, uint32_t count, uint8_t out[193]);
+
+/* synthetic-input helpers (device side, for benches and tests): base_i = k_i * G with
+ * k_i = SplitMix64(seed + 0x632BE59BD9B4E019 * (start+i)).next() | 1 ; raw affine out */
+int32_t bzk_g1_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev);
+int32_t bzk_g2_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BZK_H */

@@ -1,0 +1,82 @@
+// TEST HARNESS (not product): runs the __host__ __device__ field / curve code of libbzk on the CPU
+// so that limb-level logic is checked against the oracle in this GPU-less container.
+#include "../../bazuka_amd/csrc/bzk_curve.cuh"
+#include <string.h>
+using namespace bzk;
+
+template <class P> static Fe<P> ld(const uint8_t* p) { Fe<P> a; memcpy(a.l, p, 4 * P::N); return a; }
+template <class P> static void st(uint8_t* p, const Fe<P>& a) { memcpy(p, a.l, 4 * P::N); }
+
+template <class P> static int field_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    Fe<P> x = ld<P>(a), y = b ? ld<P>(b) : Fe<P>::zero(), r;
+    switch (op) {
+        case 0: r = fe_add<P>(x, y); break;
+        case 1: r = fe_sub<P>(x, y); break;
+        case 2: r = fe_mul<P>(x, y); break;
+        case 3: r = fe_inv<P>(x); break;
+        case 4: r = fe_from_mont<P>(x); break;
+        case 5: r = fe_to_mont<P>(x); break;
+        case 6: r = fe_neg<P>(x); break;
+        default: return -1;
+    }
+    st<P>(out, r);
+    return 0;
+}
+
+static G1Affine ld_g1(const uint8_t* p) { return {ld<FpParams>(p), ld<FpParams>(p + 48)}; }
+static G2Affine ld_g2(const uint8_t* p) {
+    return {{ld<FpParams>(p), ld<FpParams>(p + 48)}, {ld<FpParams>(p + 96), ld<FpParams>(p + 144)}};
+}
+static void st_g1(uint8_t* o, const G1Xyzz& p) {
+    G1Affine a; bool ok = xyzz_to_affine<FpOps>(p, a);
+    st<FpParams>(o, a.x); st<FpParams>(o + 48, a.y); o[96] = ok ? 0 : 1;
+}
+static void st_g2(uint8_t* o, const G2Xyzz& p) {
+    G2Affine a; bool ok = xyzz_to_affine<Fp2Ops>(p, a);
+    st<FpParams>(o, a.x.c0); st<FpParams>(o + 48, a.x.c1); st<FpParams>(o + 96, a.y.c0); st<FpParams>(o + 144, a.y.c1);
+    o[192] = ok ? 0 : 1;
+}
+
+extern "C" {
+int hc_fr_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) { return field_op<FrParams>(op, a, b, out); }
+int hc_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) { return field_op<FpParams>(op, a, b, out); }
+
+// computes sum_i k_i * P_i with the XYZZ ops only (mixed add, add, dbl); pts affine 96 B, k u32
+int hc_g1_lincomb(const uint8_t* pts, const uint32_t* k, int n, uint8_t* out97) {
+    G1Xyzz acc = xyzz_identity<FpOps>();
+    for (int i = 0; i < n; ++i) {
+        G1Affine a = ld_g1(pts + 96 * i);
+        G1Xyzz t = xyzz_identity<FpOps>();
+        xyzz_add_mixed<FpOps>(t, a);
+        G1Xyzz m = xyzz_mul_u32<FpOps>(t, k[i]);
+        xyzz_add<FpOps>(acc, m);
+    }
+    st_g1(out97, acc);
+    return 0;
+}
+int hc_g2_lincomb(const uint8_t* pts, const uint32_t* k, int n, uint8_t* out193) {
+    G2Xyzz acc = xyzz_identity<Fp2Ops>();
+    for (int i = 0; i < n; ++i) {
+        G2Affine a = ld_g2(pts + 192 * i);
+        G2Xyzz t = xyzz_identity<Fp2Ops>();
+        xyzz_add_mixed<Fp2Ops>(t, a);
+        G2Xyzz m = xyzz_mul_u32<Fp2Ops>(t, k[i]);
+        xyzz_add<Fp2Ops>(acc, m);
+    }
+    st_g2(out193, acc);
+    return 0;
+}
+// acc = sum of points via repeated mixed add (exercises add_mixed incl. doubling / cancellation)
+int hc_g1_sum_mixed(const uint8_t* pts, int n, uint8_t* out97) {
+    G1Xyzz acc = xyzz_identity<FpOps>();
+    for (int i = 0; i < n; ++i) xyzz_add_mixed<FpOps>(acc, ld_g1(pts + 96 * i));
+    st_g1(out97, acc);
+    return 0;
+}
+int hc_g2_sum_mixed(const uint8_t* pts, int n, uint8_t* out193) {
+    G2Xyzz acc = xyzz_identity<Fp2Ops>();
+    for (int i = 0; i < n; ++i) xyzz_add_mixed<Fp2Ops>(acc, ld_g2(pts + 192 * i));
+    st_g2(out193, acc);
+    return 0;
+}
+}

@@ -1,0 +1,122 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/bzk.h declares; the host-run of
+the __host__ __device__ field/curve headers (tests/host harness) matches the oracle limb for limb."""
+import ctypes as C
+import os
+import random
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_libbzk_exports_every_header_symbol():
+    from bazuka_amd import lib as L
+    hdr = open(os.path.join(ROOT, "include", "bzk.h")).read()
+    declared = set(re.findall(r"\b(bzk_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"bzk_ctx"}
+    assert len(declared) >= 30
+    so = C.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(so, name), f"{name} declared in bzk.h but not exported by libbzk.so"
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    L.load_library()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    from bazuka_amd import Bzk, BzkError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(BzkError):
+        Bzk(0)
+
+
+def test_status_strings():
+    from bazuka_amd import load_library
+    lib = load_library()
+    assert lib.bzk_strerror(0) == b"ok"
+    assert lib.bzk_strerror(-3) == b"device error"
+    assert lib.bzk_abi_version() == 1
+
+
+def test_host_g1_sum_matches_oracle(co):
+    """bzk_g1_sum / bzk_g2_sum are host-side (no GPU): fold packed points like the multi-GPU combine."""
+    from bazuka_amd import load_library
+    lib = load_library()
+    n = 5
+    b = co.g1_bases(11, 0, n)
+    packed = b"".join(b[96 * i:96 * i + 96] + b"\0" for i in range(n))
+    packed += b"\0" * 48 + co.g1_generator()[48:96] + b"\1"  # an identity entry (y ignored)
+    out = C.create_string_buffer(97)
+    assert lib.bzk_g1_sum(packed, n + 1, out) == 0
+    want = b[:96] + b"\0"
+    for i in range(1, n):
+        want = co.g1_add(want, b[96 * i:96 * i + 96] + b"\0")
+    assert out.raw == want
+    b2 = co.g2_bases(11, 0, n)
+    packed2 = b"".join(b2[192 * i:192 * i + 192] + b"\0" for i in range(n))
+    out2 = C.create_string_buffer(193)
+    assert lib.bzk_g2_sum(packed2, n, out2) == 0
+    want = b2[:192] + b"\0"
+    for i in range(1, n):
+        want = co.g2_add(want, b2[192 * i:192 * i + 192] + b"\0")
+    assert out2.raw == want
+    # P + (-P) = identity, packed as (0, R, inf=1)
+    P = b[:96]
+    from oracle import pyref as pr
+    negP = P[:48] + pr.fp_to_mont_bytes(-pr.fp_from_mont_bytes(P[48:96]))
+    assert lib.bzk_g1_sum(P + b"\0" + negP + b"\0", 2, out) == 0
+    assert out.raw == pr.g1_to_bytes(None)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(ROOT, "tests", "host", "_hostcheck.so")
+    if not os.path.exists(so):
+        pytest.skip("tests/host/_hostcheck.so not built (build() compiles it)")
+    return C.CDLL(so)
+
+
+def _op(fn, o, a, b, n):
+    out = C.create_string_buffer(n)
+    assert fn(o, a, b, out) == 0
+    return out.raw
+
+
+def test_device_field_code_on_host_matches_oracle(hc, co, pr):
+    rnd = random.Random(2)
+    cases_r = [(rnd.randrange(pr.R_MOD), rnd.randrange(pr.R_MOD)) for _ in range(100)]
+    cases_r += [(a, b) for a in (0, 1, pr.R_MOD - 1) for b in (0, 1, pr.R_MOD - 1)]
+    for a, b in cases_r:
+        A, B = pr.fr_to_mont_bytes(a), pr.fr_to_mont_bytes(b)
+        for o in (0, 1, 2, 3, 4, 5, 6):
+            assert _op(hc.hc_fr_op, o, A, B, 32) == co.fr_op(o, A, B), ("fr", o, a, b)
+    cases_p = [(rnd.randrange(pr.P_MOD), rnd.randrange(pr.P_MOD)) for _ in range(100)]
+    cases_p += [(a, b) for a in (0, 1, pr.P_MOD - 1) for b in (0, 1, pr.P_MOD - 1)]
+    for a, b in cases_p:
+        A, B = pr.fp_to_mont_bytes(a), pr.fp_to_mont_bytes(b)
+        for o in (0, 1, 2, 3, 4, 5, 6):
+            assert _op(hc.hc_fp_op, o, A, B, 48) == co.fp_op(o, A, B), ("fp", o, a, b)
+
+
+def test_device_curve_code_on_host_matches_oracle(hc, co, pr):
+    rnd = random.Random(3)
+    n = 10
+    bases = co.g1_bases(7, 0, n)
+    ks = [rnd.randrange(1, 2 ** 32) for _ in range(n)]
+    ks[0], ks[1] = 1, 0
+    sc = b"".join(k.to_bytes(32, "little") for k in ks)
+    out = C.create_string_buffer(97)
+    hc.hc_g1_lincomb(bases, (C.c_uint32 * n)(*ks), n, out)
+    assert out.raw == co.msm_g1(bases, sc, mont=False, naive=True)
+    b2 = co.g2_bases(7, 0, n)
+    out2 = C.create_string_buffer(193)
+    hc.hc_g2_lincomb(b2, (C.c_uint32 * n)(*ks), n, out2)
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    P, Q = bases[:96], bases[96:192]
+    negP = P[:48] + pr.fp_to_mont_bytes(-pr.fp_from_mont_bytes(P[48:96]))
+    hc.hc_g1_sum_mixed(P + P + Q + negP + negP + P, 6, out)  # doubling + cancellation paths
+    assert out.raw == co.g1_add(P + b"\0", Q + b"\0")
+    hc.hc_g1_sum_mixed(P + negP, 2, out)
+    assert out.raw[96] == 1

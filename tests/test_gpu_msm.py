@@ -1,0 +1,142 @@
+"""GPU parity: libbzk Pippenger (K4/K5) vs the CPU oracle, through the C ABI.  Bit-exact (integer)."""
+import pytest
+import torch
+
+from util import dev_bytes, fr_bytes, fr_list, rand_scalars_bytes, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _neg_y(pr, raw96):
+    return raw96[:48] + pr.fp_to_mont_bytes(-pr.fp_from_mont_bytes(raw96[48:96]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 100, 1000, 5000])
+def test_msm_g1_small_vs_oracle(bzk, co, n):
+    bases = co.g1_bases(21, 0, n, nthreads=co.ncpu())
+    sc = rand_scalars_bytes(n, n)
+    assert bzk.msm_g1(bases, sc) == co.msm_g1(bases, sc, nthreads=co.ncpu())
+
+
+def test_msm_g1_empty_and_zero(bzk, co, pr):
+    assert bzk.msm_g1(b"", b"") == pr.g1_to_bytes(None)
+    bases = co.g1_bases(1, 0, 8)
+    assert bzk.msm_g1(bases, fr_bytes([0] * 8)) == pr.g1_to_bytes(None)
+
+
+def test_msm_g1_edge_scalars_and_repeats(bzk, co, pr):
+    n = 64
+    bases = bytearray(co.g1_bases(31, 0, n))
+    # repeated points, P and -P with equal scalars (cancellation inside a bucket)
+    bases[96:192] = bases[0:96]
+    bases[192:288] = _neg_y(pr, bytes(bases[0:96]))
+    sc = fr_list(n, 5)
+    sc[0] = sc[1] = sc[2] = 12345          # same bucket: P + P + (-P)
+    sc[3], sc[4], sc[5] = 0, 1, pr.R_MOD - 1
+    sc[6] = 1 << 15                          # digit exactly half -> positive top bucket
+    sc[7] = (1 << 16) - 1                    # carries into the next window
+    sc[8] = pr.R_MOD - 2
+    for mont in (True, False):
+        scb = fr_bytes(sc, mont=mont)
+        assert bzk.msm_g1(bytes(bases), scb, canonical=not mont) == co.msm_g1(bytes(bases), scb, mont=mont)
+
+
+def test_msm_g1_all_same_scalar(bzk, co, pr):
+    """every point lands in the same buckets (one bucket per window): worst-case skew"""
+    n = 3000
+    bases = co.g1_bases(41, 0, n, nthreads=co.ncpu())
+    scb = fr_bytes([1] * n)
+    assert bzk.msm_g1(bases, scb) == co.msm_g1(bases, scb, nthreads=co.ncpu())
+    scb = fr_bytes([0x123456789ABCDEF0123456789ABCDEF] * n)
+    assert bzk.msm_g1(bases, scb) == co.msm_g1(bases, scb, nthreads=co.ncpu())
+
+
+def test_synth_bases_match_oracle(bzk, co):
+    n = 200
+    d = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(0x42415A554B41, 5, n, d)
+    torch.cuda.synchronize()
+    assert dev_bytes(d) == co.g1_bases(0x42415A554B41, 5, n, nthreads=co.ncpu())
+    d2 = torch.empty(n * 192, dtype=torch.uint8, device="cuda")
+    bzk.g2_synth_bases_dev(0x42415A554B41, 5, n, d2)
+    torch.cuda.synchronize()
+    assert dev_bytes(d2) == co.g2_bases(0x42415A554B41, 5, n, nthreads=co.ncpu())
+
+
+def test_msm_g1_windows_partition(bzk, co):
+    """window-range shards fold (bzk_g1_sum) to the full MSM - the multi-GPU combine on one GPU"""
+    n = 4096
+    bases, sc = to_dev(co.g1_bases(51, 0, n, nthreads=co.ncpu())), to_dev(rand_scalars_bytes(n, 3))
+    full = bzk.msm_g1_dev(bases, sc, n)
+    W = bzk.msm_window_count(n)
+    for parts in (2, 3, W):
+        cuts = [W * i // parts for i in range(parts + 1)]
+        shards = b"".join(bzk.msm_g1_windows_dev(bases, sc, n, cuts[i], cuts[i + 1]) for i in range(parts))
+        assert bzk.g1_sum(shards) == full
+    assert full == co.msm_g1(dev_bytes(bases), dev_bytes(sc), nthreads=co.ncpu())
+
+
+def test_msm_g1_full_size_2p20_vs_oracle(bzk, co):
+    """BASELINE config[1]: 2^20 points, uniform scalars; oracle = 8-thread CPU Pippenger (seconds)"""
+    n = 1 << 20
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(0x42415A554B41, 0, n, bases)
+    scb = rand_scalars_bytes(n, 2020)
+    sc = to_dev(scb)
+    got = bzk.msm_g1_dev(bases, sc, n)
+    assert got == co.msm_g1(dev_bytes(bases), scb, nthreads=co.ncpu())
+    # witness-like scalars: 10 % ones, 5 % zeros, small values (skewed buckets)
+    import numpy as np
+    a = np.frombuffer(scb, dtype=np.uint8).reshape(n, 32).copy()
+    rs = np.random.RandomState(7)
+    sel = rs.rand(n)
+    one = np.frombuffer(fr_bytes([1]), dtype=np.uint8)
+    a[sel < 0.10] = one
+    a[(sel >= 0.10) & (sel < 0.15)] = 0
+    wb = a.tobytes()
+    got = bzk.msm_g1_dev(bases, to_dev(wb), n)
+    assert got == co.msm_g1(dev_bytes(bases), wb, nthreads=co.ncpu())
+
+
+def test_msm_g1_linearity_2p20(bzk, pr):
+    """size-independent property at full size: MSM(s) + MSM(t) == MSM(s + t)"""
+    import numpy as np
+    n = 1 << 20
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(99, 0, n, bases)
+    rs = np.random.RandomState(5)
+    s = rs.randint(0, 2 ** 62, size=(n, 4), dtype=np.uint64)
+    t = rs.randint(0, 2 ** 62, size=(n, 4), dtype=np.uint64)
+    u = s + t  # limb-wise, no carries (each limb < 2^63), value < 2^255 < ... canonical form
+    s[:, 3] &= (1 << 60) - 1
+    t[:, 3] &= (1 << 60) - 1
+    u = s + t
+    ms = bzk.msm_g1_dev(bases, to_dev(s.tobytes()), n, canonical=True)
+    mt = bzk.msm_g1_dev(bases, to_dev(t.tobytes()), n, canonical=True)
+    mu = bzk.msm_g1_dev(bases, to_dev(u.tobytes()), n, canonical=True)
+    assert bzk.g1_sum(ms + mt) == mu
+
+
+@pytest.mark.parametrize("n", [1, 2, 50, 1500])
+def test_msm_g2_small_vs_oracle(bzk, co, n):
+    bases = co.g2_bases(23, 0, n, nthreads=co.ncpu())
+    sc = rand_scalars_bytes(n, 100 + n)
+    assert bzk.msm_g2(bases, sc) == co.msm_g2(bases, sc, nthreads=co.ncpu())
+
+
+def test_msm_g2_edges(bzk, co, pr):
+    n = 16
+    bases = co.g2_bases(29, 0, n)
+    sc = fr_list(n, 9)
+    sc[0], sc[1], sc[2] = 0, 1, pr.R_MOD - 1
+    scb = fr_bytes(sc)
+    assert bzk.msm_g2(bases, scb) == co.msm_g2(bases, scb)
+    assert bzk.msm_g2(b"", b"") == pr.g2_to_bytes(None)
+
+
+def test_msm_g2_2p16_vs_oracle(bzk, co):
+    n = 1 << 16
+    bases = torch.empty(n * 192, dtype=torch.uint8, device="cuda")
+    bzk.g2_synth_bases_dev(77, 0, n, bases)
+    scb = rand_scalars_bytes(n, 16)
+    assert bzk.msm_g2_dev(bases, to_dev(scb), n) == co.msm_g2(dev_bytes(bases), scb, nthreads=co.ncpu())

@@ -1,0 +1,94 @@
+"""GPU parity: Poseidon batch / 4-ary tree (K1, K2) and NTT (K3) vs the CPU oracle, bit-exact."""
+import pytest
+import torch
+
+from test_oracle_cpu import POSEIDON_KAT
+from util import dev_bytes, fr_bytes, fr_list, rand_scalars_bytes, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_poseidon_reference_kats(bzk, pr):
+    # /root/reference/src/zk/poseidon/mod.rs:114-149
+    for k in range(1, 17):
+        out = bzk.poseidon_batch(fr_bytes(range(k)), k)
+        assert pr.fr_from_mont_bytes(out) == POSEIDON_KAT[k - 1], k
+
+
+@pytest.mark.parametrize("arity", [1, 2, 4, 5, 7, 16])
+def test_poseidon_batch_vs_oracle(bzk, co, arity):
+    n = 1000 if arity < 10 else 200
+    inp = rand_scalars_bytes(n * arity, arity)
+    assert bzk.poseidon_batch(inp, arity) == co.poseidon_batch(inp, arity, nthreads=co.ncpu())
+
+
+def test_poseidon_bad_arity(bzk):
+    from bazuka_amd import BzkError
+    for arity in (0, 17):
+        with pytest.raises(BzkError):
+            bzk.poseidon_batch(b"\0" * 32 * max(arity, 1), arity)
+    assert bzk.poseidon_batch(b"", 4) == b""
+
+
+@pytest.mark.parametrize("log4", [0, 1, 2, 5])
+def test_merkle4_vs_oracle(bzk, co, log4):
+    leaves = rand_scalars_bytes(4 ** log4, log4)
+    root, nodes = bzk.merkle4_root(leaves, log4, want_nodes=True)
+    oroot, onodes = co.merkle4_root(leaves, log4, True, nthreads=co.ncpu())
+    assert root == oroot and nodes == onodes
+
+
+def test_merkle4_empty_tree_is_default_chain(bzk, pr):
+    d = 0
+    for _ in range(4):
+        d = pr.poseidon([d] * 4)
+    assert bzk.merkle4_root(fr_bytes([0] * 256), 4) == pr.fr_to_mont_bytes(d)
+
+
+def test_merkle4_log8_vs_oracle_and_composition(bzk, co):
+    """65536 leaves vs oracle; and root(log4=8) == root over the 16 roots of its log4=6 subtrees"""
+    leaves = rand_scalars_bytes(4 ** 8, 88)
+    root = bzk.merkle4_root(leaves, 8)
+    assert root == co.merkle4_root(leaves, 8, nthreads=co.ncpu())
+    sub = 4 ** 6 * 32
+    subs = b"".join(bzk.merkle4_root(leaves[i * sub:(i + 1) * sub], 6) for i in range(16))
+    assert bzk.merkle4_root(subs, 2) == root
+
+
+def test_merkle4_full_size_2p24_composition(bzk):
+    """BASELINE config[4] size: 2^24 leaves resident in HBM; checked through the composition
+    property against 16 independent 2^20-leaf sub-trees (the oracle would need ~30 s here)."""
+    n = 1 << 24
+    g = torch.Generator(device="cuda").manual_seed(24)
+    leaves = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    leaves[:, 31] &= 0x3F
+    leaves = leaves.contiguous()
+    root = bzk.merkle4_root_dev(leaves, 12)
+    sub = n // 16
+    subs = b"".join(bzk.merkle4_root_dev(leaves[i * sub:(i + 1) * sub], 10) for i in range(16))
+    assert bzk.merkle4_root(subs, 2) == root
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 7, 10, 11, 13])
+def test_ntt_vs_oracle(bzk, co, log_n):
+    data = rand_scalars_bytes(1 << log_n, log_n)
+    for inv in (False, True):
+        for cs in (False, True):
+            assert bzk.ntt(data, log_n, inv, cs) == co.ntt(data, log_n, inv, cs, nthreads=co.ncpu()), (inv, cs)
+
+
+def test_ntt_2p20_vs_oracle_and_roundtrip(bzk, co):
+    log_n = 20
+    data = rand_scalars_bytes(1 << log_n, 20)
+    d = to_dev(data)
+    bzk.ntt_dev(d, log_n, False, True)
+    torch.cuda.synchronize()
+    assert dev_bytes(d) == co.ntt(data, log_n, False, True, nthreads=co.ncpu())
+    bzk.ntt_dev(d, log_n, True, True)
+    torch.cuda.synchronize()
+    assert dev_bytes(d) == data
+
+
+def test_ntt_log0_is_identity(bzk):
+    x = rand_scalars_bytes(1, 1)
+    assert bzk.ntt(x, 0) == x

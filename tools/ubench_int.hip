@@ -1,0 +1,181 @@
+// Integer-ALU micro-benchmark for gfx950: measures the issue rate of the instructions a 381-bit
+// Montgomery product is made of, and the product itself.  This is the "binding roofline" of the MSM /
+// Poseidon kernels (not in the local guides - measure it).  Standalone tool:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/ubench_int tools/ubench_int.hip && ./tools/ubench_int
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include "../bazuka_amd/csrc/bzk_field.cuh"
+using namespace bzk;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int ILP>
+__global__ void k_mad64(uint64_t* out, uint32_t a, uint32_t b, int iters) {
+    uint64_t acc[ILP];
+    uint32_t x = a + threadIdx.x, y = b + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc[i] = i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc[i] = (uint64_t)x * (uint32_t)(y + i) + acc[i];   // v_mad_u64_u32
+        x = (uint32_t)acc[0];
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ILP>
+__global__ void k_mullo(uint32_t* out, uint32_t a, int iters) {
+    uint32_t acc[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc[i] = acc[i] * (acc[i] | 1);   // v_mul_lo_u32
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ILP>
+__global__ void k_mulhi(uint32_t* out, uint32_t a, int iters) {
+    uint32_t acc[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc[i] = __umulhi(acc[i], acc[i] | 0x80000001u);   // v_mul_hi_u32
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ILP>
+__global__ void k_add64(uint64_t* out, uint64_t a, int iters) {
+    uint64_t acc[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc[i] += (acc[i] >> 7) ^ a;   // shift + xor + 64-bit add (2 adds)
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ILP>
+__global__ void k_mad24(uint32_t* out, uint32_t a, int iters) {
+    uint32_t acc[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc[i] = (acc[i] & 0xffffffu) * (a & 0xffffffu) + acc[i];  // v_mad_u32_u24
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ILP>
+__global__ void k_fma64(double* out, double a, int iters) {
+    double acc[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc[i] = a + i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc[i] = __builtin_fma(acc[i], a, 1.0);   // v_fma_f64
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <class P, int ILP>
+__global__ void k_femul(uint32_t* out, int iters) {
+    Fe<P> x[ILP], y;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) y.l[i] = P::R2[i] ^ threadIdx.x;
+    y.l[P::N - 1] &= 0x0fffffff;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+#pragma unroll
+        for (int i = 0; i < P::N; ++i) x[k].l[i] = P::ONE[i] + k;
+        x[k].l[P::N - 1] &= 0x0fffffff;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) x[k] = fe_mul<P>(x[k], y);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) s ^= x[k].l[0] ^ x[k].l[P::N - 1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <class F>
+static double time_kernel(F launch, int reps = 3) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    launch();  // warm
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(a);
+        launch();
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    return best * 1e-3;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s, CUs %d, clock %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
+    void* buf; CK(hipMalloc(&buf, 256 << 20));
+    const int blocks = prop.multiProcessorCount * 8, threads = 256, iters = 4096;
+    const double lanes = (double)blocks * threads;
+    {
+        auto run = [&](const char* nm, auto kern, auto arg, int ilp) {
+            double t = time_kernel([&] { kern(arg); });
+            printf("%-30s ILP=%-2d %10.2f Gop/s   (%.3f ms)\n", nm, ilp, lanes * iters * ilp / t / 1e9, t * 1e3);
+        };
+        run("v_mad_u64_u32", [&](int) { hipLaunchKernelGGL(k_mad64<1>, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)buf, 3u, 5u, iters); }, 0, 1);
+        run("v_mad_u64_u32", [&](int) { hipLaunchKernelGGL(k_mad64<4>, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)buf, 3u, 5u, iters); }, 0, 4);
+        run("v_mad_u64_u32", [&](int) { hipLaunchKernelGGL(k_mad64<12>, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)buf, 3u, 5u, iters); }, 0, 12);
+        run("v_mul_lo_u32", [&](int) { hipLaunchKernelGGL(k_mullo<8>, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, 3u, iters); }, 0, 8);
+        run("v_mul_hi_u32", [&](int) { hipLaunchKernelGGL(k_mulhi<8>, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, 3u, iters); }, 0, 8);
+        run("v_mad_u32_u24", [&](int) { hipLaunchKernelGGL(k_mad24<8>, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, 3u, iters); }, 0, 8);
+        run("add64+shift+xor (4 valu)", [&](int) { hipLaunchKernelGGL(k_add64<8>, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)buf, (uint64_t)3, iters); }, 0, 8);
+        run("v_fma_f64", [&](int) { hipLaunchKernelGGL(k_fma64<8>, dim3(blocks), dim3(threads), 0, 0, (double*)buf, 1.0000001, iters); }, 0, 8);
+    }
+    {
+        const int it2 = 512;
+        auto run = [&](const char* nm, auto kern, int ilp, int bl, int th) {
+            double t = time_kernel([&] { kern(bl, th); });
+            printf("%-30s ILP=%-2d blocks/CU=%-2d %10.3f Gmul/s (%.3f ms)\n", nm, ilp, bl / prop.multiProcessorCount, (double)bl * th * it2 * ilp / t / 1e9, t * 1e3);
+        };
+        for (int bpc : {1, 2, 4, 8}) {
+            int bl = prop.multiProcessorCount * bpc;
+            run("Fp mul (12x32 CIOS)", [&](int b, int t) { hipLaunchKernelGGL((k_femul<FpParams, 1>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
+            run("Fp mul (12x32 CIOS)", [&](int b, int t) { hipLaunchKernelGGL((k_femul<FpParams, 2>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
+            run("Fr mul (8x32 CIOS)", [&](int b, int t) { hipLaunchKernelGGL((k_femul<FrParams, 2>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
+        }
+    }
+    CK(hipFree(buf));
+    return 0;
+}
