@@ -155,8 +155,61 @@ BZK_HD Fe<P> fe_dbl(const Fe<P>& a) {
 // Montgomery product a*b*R^-1 mod p.  CIOS, multiplication and reduction rows interleaved,
 // no-carry variant (top bit of the modulus is clear, so the running value stays below 2^(32N+1)
 // and the two row carries can simply be summed into the top limb).
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host build of the same product on 64-bit limbs (the byte layout is identical): used by the few
+// host-side point operations (window Horner, proof assembly), ~5x faster than the 32-bit form.
+template <class P>
+inline Fe<P> fe_mul_host64(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int M = P::N / 2;
+    typedef unsigned __int128 u128;
+    uint64_t A[M], B[M], Q[M], t[M + 2];
+    for (int i = 0; i < M; ++i) {
+        A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+        Q[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
+    }
+    // -p^-1 mod 2^64 from the 32-bit constant by one Newton step
+    const uint64_t x32 = (uint64_t)(uint32_t)(0u - P::INV);  // p^-1 mod 2^32
+    const uint64_t x64 = x32 * (2 - Q[0] * x32);
+    const uint64_t inv = (uint64_t)0 - x64;
+    for (int i = 0; i < M + 2; ++i) t[i] = 0;
+    for (int i = 0; i < M; ++i) {
+        uint64_t c = 0;
+        for (int j = 0; j < M; ++j) {
+            u128 s = (u128)A[j] * B[i] + t[j] + c;
+            t[j] = (uint64_t)s;
+            c = (uint64_t)(s >> 64);
+        }
+        u128 s = (u128)t[M] + c;
+        t[M] = (uint64_t)s;
+        t[M + 1] = (uint64_t)(s >> 64);
+        const uint64_t m = t[0] * inv;
+        s = (u128)m * Q[0] + t[0];
+        c = (uint64_t)(s >> 64);
+        for (int j = 1; j < M; ++j) {
+            s = (u128)m * Q[j] + t[j] + c;
+            t[j - 1] = (uint64_t)s;
+            c = (uint64_t)(s >> 64);
+        }
+        s = (u128)t[M] + c;
+        t[M - 1] = (uint64_t)s;
+        t[M] = t[M + 1] + (uint64_t)(s >> 64);
+    }
+    Fe<P> r;
+    for (int i = 0; i < M; ++i) {
+        r.l[2 * i] = (uint32_t)t[i];
+        r.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    fe_reduce_once<P>(r);
+    return r;
+}
+#endif
+
 template <class P>
 BZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return fe_mul_host64<P>(a, b);
+#else
     constexpr int N = P::N;
     uint32_t t[N];
 #pragma unroll
@@ -184,6 +237,7 @@ BZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     for (int i = 0; i < N; ++i) r.l[i] = t[i];
     fe_reduce_once<P>(r);
     return r;
+#endif
 }
 
 template <class P>

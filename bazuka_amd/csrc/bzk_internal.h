@@ -68,6 +68,7 @@ struct WsCursor {
         return p;
     }
 };
+int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int coset);  // ntt.hip
 static inline size_t ws_pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
 struct ProfScope {

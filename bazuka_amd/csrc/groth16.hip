@@ -1,0 +1,243 @@
+// a4-a7: Groth16 prove after witness synthesis, on gfx950.
+//
+// Replaces bellman 0.14 `groth16::create_proof` (third-party crate; reference call sites
+// /root/reference/src/mpn/circuits/test.rs:135,175,215) from the point where the assignment
+// (z, A.z, B.z, C.z) exists.  Layout of the computation follows SURVEY.md Appendix D:
+//   a,b,c <- iNTT ; <- coset NTT (shift 7) ; a <- (a*b - c) / (7^m - 1) ; a <- inverse coset NTT
+//   H = MSM(h, a[0..m-1)) ; L = MSM(l, aux) ; A = MSM(a, z|a_density) ; B1, B2 = MSM(b, z|b_density)
+//   g_a = r*delta1 + alpha1 + A ;  g_b = s*delta2 + beta2 + B2
+//   g_c = rs*delta1 + s*alpha1 + r*beta1 + s*A + r*B1 + H + L
+// The NTTs and MSMs are the HIP kernels of ntt.hip / msm_g1.hip / msm_g2.hip; the last three lines
+// are ~10 point operations done on the host.  Proof bytes = Groth16Proof layout
+// (/root/reference/src/zk/groth16/mod.rs:33-38).
+#include <string.h>
+
+#include <vector>
+
+#include "bzk_curve.cuh"
+#include "bzk_internal.h"
+
+struct bzk_params {
+    uint32_t n_in, n_aux, log_m, n_a, n_b;
+    uint8_t vk[870];
+    void *h, *l, *a, *b_g1, *b_g2;      // device CRS
+    uint32_t *a_idx, *b_idx;            // device: variable index of each dense entry
+    void *d_z, *d_a, *d_b, *d_c, *d_sa, *d_sb;  // device scratch sized for this circuit
+};
+
+namespace bzk {
+
+__global__ void __launch_bounds__(256) g16_pointwise_kernel(Fr* __restrict__ a, const Fr* __restrict__ b,
+                                                            const Fr* __restrict__ c, uint64_t m, Fr zinv) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fr v = fe_mul<FrParams>(a[i], b[i]);
+    v = fe_sub<FrParams>(v, c[i]);
+    a[i] = fe_mul<FrParams>(v, zinv);
+}
+
+__global__ void __launch_bounds__(256) g16_gather_kernel(const Fr* __restrict__ z, const uint32_t* __restrict__ idx, uint32_t n,
+                                                         Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = z[idx[i]];
+}
+
+static Fr host_fr_pow(Fr b, uint64_t e) {
+    Fr r = Fr::one();
+    while (e) {
+        if (e & 1) r = fe_mul<FrParams>(r, b);
+        b = fe_sqr<FrParams>(b);
+        e >>= 1;
+    }
+    return r;
+}
+
+int32_t groth16_h(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m) {
+    if (log_m > 28) return BZK_E_ARG;
+    const uint64_t m = (uint64_t)1 << log_m;
+    void* v[3] = {a, b, c};
+    for (int k = 0; k < 3; ++k) {
+        BZK_TRY(ntt_run(ctx, v[k], log_m, 1, 0));
+        BZK_TRY(ntt_run(ctx, v[k], log_m, 0, 1));
+    }
+    Fr seven = Fr::zero();
+    seven.l[0] = 7;
+    seven = fe_to_mont<FrParams>(seven);
+    Fr zinv = fe_inv<FrParams>(fe_sub<FrParams>(host_fr_pow(seven, m), Fr::one()));
+    BZK_LAUNCH(ctx, "g16_pointwise", g16_pointwise_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (Fr*)a, (const Fr*)b,
+               (const Fr*)c, m, zinv);
+    BZK_TRY(ntt_run(ctx, a, log_m, 1, 1));
+    return BZK_OK;
+}
+
+template <class F>
+static XyzzT<F> host_mul_fr(const XyzzT<F>& p, const Fr& k_mont) {
+    Fr k = fe_from_mont<FrParams>(k_mont);
+    XyzzT<F> r = xyzz_identity<F>();
+    for (int i = 254; i >= 0; --i) {
+        r = xyzz_dbl<F>(r);
+        if ((k.l[i >> 5] >> (i & 31)) & 1) xyzz_add<F>(r, p);
+    }
+    return r;
+}
+
+static G1Xyzz unpack_g1(const uint8_t* in) {
+    if (in[96]) return xyzz_identity<FpOps>();
+    G1Affine a;
+    memcpy(a.x.l, in, 48);
+    memcpy(a.y.l, in + 48, 48);
+    return xyzz_from_affine<FpOps>(a);
+}
+static G2Xyzz unpack_g2(const uint8_t* in) {
+    if (in[192]) return xyzz_identity<Fp2Ops>();
+    G2Affine a;
+    memcpy(a.x.c0.l, in, 48);
+    memcpy(a.x.c1.l, in + 48, 48);
+    memcpy(a.y.c0.l, in + 96, 48);
+    memcpy(a.y.c1.l, in + 144, 48);
+    return xyzz_from_affine<Fp2Ops>(a);
+}
+static void pack_g1(const G1Xyzz& p, uint8_t* out) {
+    G1Affine a;
+    bool fin = xyzz_to_affine<FpOps>(p, a);
+    memcpy(out, a.x.l, 48);
+    memcpy(out + 48, a.y.l, 48);
+    out[96] = fin ? 0 : 1;
+}
+static void pack_g2(const G2Xyzz& p, uint8_t* out) {
+    G2Affine a;
+    bool fin = xyzz_to_affine<Fp2Ops>(p, a);
+    memcpy(out, a.x.c0.l, 48);
+    memcpy(out + 48, a.x.c1.l, 48);
+    memcpy(out + 96, a.y.c0.l, 48);
+    memcpy(out + 144, a.y.c1.l, 48);
+    out[192] = fin ? 0 : 1;
+}
+
+}  // namespace bzk
+
+using namespace bzk;
+
+extern "C" {
+
+void bzk_params_free(bzk_ctx* ctx, bzk_params* p) {
+    if (!p) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    void* bufs[] = {p->h, p->l, p->a, p->b_g1, p->b_g2, p->a_idx, p->b_idx, p->d_z, p->d_a, p->d_b, p->d_c, p->d_sa, p->d_sb};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete p;
+}
+
+int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out) {
+    if (!ctx || !d || !out || !d->vk || !d->a_density || !d->b_density) return BZK_E_ARG;
+    if (d->log_m > 28 || d->n_in == 0) return BZK_E_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t m = (uint64_t)1 << d->log_m, nv = (uint64_t)d->n_in + d->n_aux;
+    std::vector<uint32_t> ia, ib;
+    for (uint64_t v = 0; v < nv; ++v) {
+        if (d->a_density[v]) ia.push_back((uint32_t)v);
+        if (d->b_density[v]) ib.push_back((uint32_t)v);
+    }
+    if (ia.size() != d->n_a || ib.size() != d->n_b) return BZK_E_ARG;
+    if ((m > 1 && !d->h) || (d->n_aux && !d->l) || (d->n_a && !d->a) || (d->n_b && (!d->b_g1 || !d->b_g2))) return BZK_E_ARG;
+    bzk_params* p = new (std::nothrow) bzk_params();
+    if (!p) return BZK_E_ALLOC;
+    memset(p, 0, sizeof(*p));
+    p->n_in = d->n_in; p->n_aux = d->n_aux; p->log_m = d->log_m; p->n_a = d->n_a; p->n_b = d->n_b;
+    memcpy(p->vk, d->vk, 870);
+    struct Up { void** dst; const void* src; size_t bytes; };
+    Up ups[] = {
+        {&p->h, d->h, (size_t)(m - 1) * 96}, {&p->l, d->l, (size_t)d->n_aux * 96}, {&p->a, d->a, (size_t)d->n_a * 96},
+        {&p->b_g1, d->b_g1, (size_t)d->n_b * 96}, {&p->b_g2, d->b_g2, (size_t)d->n_b * 192},
+        {(void**)&p->a_idx, ia.data(), ia.size() * 4}, {(void**)&p->b_idx, ib.data(), ib.size() * 4},
+        {&p->d_z, nullptr, (size_t)nv * 32}, {&p->d_a, nullptr, (size_t)m * 32}, {&p->d_b, nullptr, (size_t)m * 32},
+        {&p->d_c, nullptr, (size_t)m * 32}, {&p->d_sa, nullptr, (size_t)d->n_a * 32}, {&p->d_sb, nullptr, (size_t)d->n_b * 32},
+    };
+    for (auto& u : ups) {
+        hipError_t e = hipMalloc(u.dst, u.bytes ? u.bytes : 32);
+        if (e == hipSuccess && u.src && u.bytes) e = hipMemcpyAsync(*u.dst, u.src, u.bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("params_load: ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            bzk_params_free(ctx, p);
+            return BZK_E_ALLOC;
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        bzk_params_free(ctx, p);
+        return BZK_E_DEVICE;
+    }
+    *out = p;
+    return BZK_OK;
+}
+
+int32_t bzk_groth16_h_dev(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m) {
+    if (!ctx || !a || !b || !c) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    return groth16_h(ctx, a, b, c, log_m);
+}
+
+int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
+                          uint8_t proof[387]) {
+    if (!ctx || !p || !asg || !r32 || !s32 || !proof || !asg->z || !asg->az || !asg->bz || !asg->cz) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t m = (uint64_t)1 << p->log_m, nv = (uint64_t)p->n_in + p->n_aux;
+    if (asg->n_rows > m) return BZK_E_ARG;
+    // stage the assignment
+    void* ev[3] = {p->d_a, p->d_b, p->d_c};
+    const uint8_t* hv[3] = {asg->az, asg->bz, asg->cz};
+    for (int k = 0; k < 3; ++k) {
+        BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+        if (m > asg->n_rows)
+            BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
+    }
+    BZK_HIP(ctx, hipMemcpyAsync(p->d_z, asg->z, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    // h polynomial
+    BZK_TRY(groth16_h(ctx, p->d_a, p->d_b, p->d_c, p->log_m));
+    // density-filtered scalar vectors
+    if (p->n_a)
+        BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_a + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->a_idx, p->n_a, (Fr*)p->d_sa);
+    if (p->n_b)
+        BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_b + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->b_idx, p->n_b, (Fr*)p->d_sb);
+    uint8_t pH[97], pL[97], pA[97], pB1[97], pB2[193];
+    BZK_TRY(bzk_msm_g1_dev(ctx, p->h, p->d_a, m - 1, 0, pH));
+    BZK_TRY(bzk_msm_g1_dev(ctx, p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, 0, pL));
+    BZK_TRY(bzk_msm_g1_dev(ctx, p->a, p->d_sa, p->n_a, 0, pA));
+    BZK_TRY(bzk_msm_g1_dev(ctx, p->b_g1, p->d_sb, p->n_b, 0, pB1));
+    BZK_TRY(bzk_msm_g2_dev(ctx, p->b_g2, p->d_sb, p->n_b, 0, pB2));
+    // assembly (host)
+    Fr r, s;
+    memcpy(r.l, r32, 32);
+    memcpy(s.l, s32, 32);
+    Fr rs = fe_mul<FrParams>(r, s);
+    const uint8_t* vk = p->vk;
+    G1Xyzz alpha = unpack_g1(vk), beta1 = unpack_g1(vk + 97), delta1 = unpack_g1(vk + 580);
+    G2Xyzz beta2 = unpack_g2(vk + 194), delta2 = unpack_g2(vk + 677);
+    G1Xyzz H = unpack_g1(pH), L = unpack_g1(pL), A = unpack_g1(pA), B1 = unpack_g1(pB1);
+    G2Xyzz B2 = unpack_g2(pB2);
+    G1Xyzz ga = host_mul_fr<FpOps>(delta1, r);
+    xyzz_add<FpOps>(ga, alpha);
+    xyzz_add<FpOps>(ga, A);
+    G2Xyzz gb = host_mul_fr<Fp2Ops>(delta2, s);
+    xyzz_add<Fp2Ops>(gb, beta2);
+    xyzz_add<Fp2Ops>(gb, B2);
+    G1Xyzz gc = host_mul_fr<FpOps>(delta1, rs);
+    G1Xyzz t;
+    t = host_mul_fr<FpOps>(alpha, s);  xyzz_add<FpOps>(gc, t);
+    t = host_mul_fr<FpOps>(beta1, r);  xyzz_add<FpOps>(gc, t);
+    t = host_mul_fr<FpOps>(A, s);      xyzz_add<FpOps>(gc, t);
+    t = host_mul_fr<FpOps>(B1, r);     xyzz_add<FpOps>(gc, t);
+    xyzz_add<FpOps>(gc, H);
+    xyzz_add<FpOps>(gc, L);
+    pack_g1(ga, proof);
+    pack_g2(gb, proof + 97);
+    pack_g1(gc, proof + 290);
+    return BZK_OK;
+}
+
+}  // extern "C"

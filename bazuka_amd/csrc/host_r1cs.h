@@ -1,0 +1,579 @@
+// Host-side R1CS builder + the reference's gadget library, restated in C++ (product code).
+//
+// Mirrors, in allocation and constraint ORDER, what the reference builds on bellman 0.14's
+// `ConstraintSystem<Fr>`:
+//   Number / UnsignedInteger / mux / boolean helpers   src/zk/groth16/gadgets/common/{number,uint,mux,boolean}.rs
+//   Poseidon gadget                                   src/zk/groth16/gadgets/poseidon/mod.rs:8-95
+//   4-ary Merkle gadget                               src/zk/groth16/gadgets/merkle/mod.rs:21-78
+//   EdDSA-on-Jubjub gadget                            src/zk/groth16/gadgets/eddsa/mod.rs:14-280
+// and the bellman primitives they call (third-party, restated from the crate's published behaviour,
+// SURVEY.md Appendix B): AllocatedNum::{alloc, mul, inputize, to_bits_le_strict},
+// AllocatedBit::{alloc, and, and_not, nor, alloc_conditionally}, Boolean::and.
+//
+// One object serves both bellman roles: with `record_matrices` it is the KeypairAssembly (CSR of A, B,
+// C for CRS generation), and it always is the ProvingAssignment (z, A.z, B.z, C.z, densities).
+// Linear combinations merge duplicate variables (bellman appends; the evaluations are identical).
+#pragma once
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include "host_zk.h"
+
+namespace bzk {
+
+typedef uint32_t Var;  // bit 31 set => aux variable, else input variable (0 = ONE)
+static constexpr Var VAR_AUX = 0x80000000u;
+static constexpr Var VAR_ONE = 0;
+
+struct LC {
+    std::vector<std::pair<Var, Fr>> t;
+    LC() {}
+    LC& add(Var v, const Fr& c) {
+        for (auto& e : t)
+            if (e.first == v) {
+                e.second = fe_add<FrParams>(e.second, c);
+                return *this;
+            }
+        t.emplace_back(v, c);
+        return *this;
+    }
+    LC& add_var(Var v) { return add(v, Fr::one()); }
+    LC& sub_var(Var v) { return add(v, fe_neg<FrParams>(Fr::one())); }
+    LC& add_scaled(const LC& o, const Fr& k) {
+        for (auto& e : o.t) add(e.first, fe_mul<FrParams>(e.second, k));
+        return *this;
+    }
+    LC& add_lc(const LC& o) {
+        for (auto& e : o.t) add(e.first, e.second);
+        return *this;
+    }
+    LC& sub_lc(const LC& o) {
+        for (auto& e : o.t) add(e.first, fe_neg<FrParams>(e.second));
+        return *this;
+    }
+    static LC of(Var v) { return LC().add_var(v); }
+    static LC one() { return LC().add_var(VAR_ONE); }
+};
+
+struct CsrBuilder {
+    std::vector<uint32_t> row_ptr{0}, col;
+    std::vector<Fr> val;
+};
+
+class ConstraintSystem {
+   public:
+    bool record_matrices;
+    std::vector<Fr> inputs, aux;   // assignment; inputs[0] = 1
+    std::vector<Fr> az, bz, cz;    // per-constraint evaluations
+    CsrBuilder A, B, C;            // only when record_matrices (columns still Var-encoded until finalize)
+    std::vector<uint8_t> a_in_d, a_aux_d, b_in_d, b_aux_d;  // densities by appearance
+    bool finalized = false;
+
+    explicit ConstraintSystem(bool record) : record_matrices(record) { inputs.push_back(Fr::one()); }
+
+    Var alloc(const Fr& v) {
+        aux.push_back(v);
+        return VAR_AUX | (Var)(aux.size() - 1);
+    }
+    Var alloc_input(const Fr& v) {
+        inputs.push_back(v);
+        return (Var)(inputs.size() - 1);
+    }
+    const Fr& value(Var v) const { return (v & VAR_AUX) ? aux[v & ~VAR_AUX] : inputs[v]; }
+    Fr eval(const LC& lc) const {
+        Fr acc = Fr::zero();
+        for (auto& e : lc.t) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(e.second, value(e.first)));
+        return acc;
+    }
+    size_t num_constraints() const { return az.size(); }
+
+    void enforce(const LC& a, const LC& b, const LC& c) {
+        az.push_back(eval(a));
+        bz.push_back(eval(b));
+        cz.push_back(eval(c));
+        mark(a, a_in_d, a_aux_d);
+        mark(b, b_in_d, b_aux_d);
+        if (record_matrices) {
+            push_row(A, a);
+            push_row(B, b);
+            push_row(C, c);
+        }
+    }
+
+    // bellman appends `input_i * 0 = 0` for every input after synthesis (makes every input's A
+    // polynomial non-zero); call exactly once.
+    void finalize() {
+        if (finalized) return;
+        for (size_t i = 0; i < inputs.size(); ++i) enforce(LC::of((Var)i), LC(), LC());
+        finalized = true;
+    }
+
+    bool is_satisfied() const {
+        for (size_t k = 0; k < az.size(); ++k)
+            if (!fe_mul<FrParams>(az[k], bz[k]).equals(cz[k])) return false;
+        return true;
+    }
+    // first violated constraint or -1
+    long first_unsatisfied() const {
+        for (size_t k = 0; k < az.size(); ++k)
+            if (!fe_mul<FrParams>(az[k], bz[k]).equals(cz[k])) return (long)k;
+        return -1;
+    }
+    uint32_t flat_index(Var v) const { return (v & VAR_AUX) ? (uint32_t)inputs.size() + (v & ~VAR_AUX) : v; }
+
+   private:
+    static void mark(const LC& lc, std::vector<uint8_t>& din, std::vector<uint8_t>& daux) {
+        for (auto& e : lc.t) {
+            if (e.second.is_zero()) continue;
+            std::vector<uint8_t>& d = (e.first & VAR_AUX) ? daux : din;
+            const uint32_t i = e.first & ~VAR_AUX;
+            if (d.size() <= i) d.resize(i + 1, 0);
+            d[i] = 1;
+        }
+    }
+    static void push_row(CsrBuilder& m, const LC& lc) {
+        for (auto& e : lc.t) {
+            if (e.second.is_zero()) continue;
+            m.col.push_back(e.first);
+            m.val.push_back(e.second);
+        }
+        m.row_ptr.push_back((uint32_t)m.col.size());
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// bellman primitives
+// ------------------------------------------------------------------------------------------------
+struct Num {  // AllocatedNum
+    Var var;
+    Fr val;
+};
+struct Bit {  // AllocatedBit
+    Var var;
+    bool val;
+};
+struct Bool {  // Boolean
+    enum Kind { IS, NOT, CONST } kind;
+    Bit bit;
+    bool cval;
+    static Bool is(const Bit& b) { return {IS, b, false}; }
+    static Bool not_(const Bit& b) { return {NOT, b, false}; }
+    static Bool constant(bool v) { return {CONST, {0, false}, v}; }
+    bool value() const { return kind == IS ? bit.val : kind == NOT ? !bit.val : cval; }
+    Bool negate() const {
+        if (kind == IS) return not_(bit);
+        if (kind == NOT) return is(bit);
+        return constant(!cval);
+    }
+};
+
+static inline Fr fr_from_bool(bool b) { return b ? Fr::one() : Fr::zero(); }
+static inline Fr fr_from_u64(uint64_t x) { return ZkScalar::from_u64(x).v; }
+
+static inline Num num_alloc(ConstraintSystem& cs, const Fr& v) { return {cs.alloc(v), v}; }
+
+static inline void num_inputize(ConstraintSystem& cs, const Num& n) {
+    Var in = cs.alloc_input(n.val);
+    cs.enforce(LC::of(in), LC::one(), LC::of(n.var));
+}
+
+static inline Num num_mul(ConstraintSystem& cs, const Num& a, const Num& b) {  // AllocatedNum::mul
+    Num r = num_alloc(cs, fe_mul<FrParams>(a.val, b.val));
+    cs.enforce(LC::of(a.var), LC::of(b.var), LC::of(r.var));
+    return r;
+}
+
+static inline Bit bit_alloc(ConstraintSystem& cs, bool v) {
+    Bit b = {cs.alloc(fr_from_bool(v)), v};
+    cs.enforce(LC::one().sub_var(b.var), LC::of(b.var), LC());  // (1 - a) * a = 0
+    return b;
+}
+static inline Bit bit_alloc_conditionally(ConstraintSystem& cs, bool v, const Bit& must_be_false) {
+    Bit b = {cs.alloc(fr_from_bool(v)), v};
+    cs.enforce(LC::one().sub_var(must_be_false.var).sub_var(b.var), LC::of(b.var), LC());
+    return b;
+}
+static inline Bit bit_and(ConstraintSystem& cs, const Bit& a, const Bit& b) {
+    Bit r = {cs.alloc(fr_from_bool(a.val && b.val)), a.val && b.val};
+    cs.enforce(LC::of(a.var), LC::of(b.var), LC::of(r.var));
+    return r;
+}
+static inline Bit bit_and_not(ConstraintSystem& cs, const Bit& a, const Bit& b) {  // a AND (NOT b)
+    Bit r = {cs.alloc(fr_from_bool(a.val && !b.val)), a.val && !b.val};
+    cs.enforce(LC::of(a.var), LC::one().sub_var(b.var), LC::of(r.var));
+    return r;
+}
+static inline Bit bit_nor(ConstraintSystem& cs, const Bit& a, const Bit& b) {  // (NOT a) AND (NOT b)
+    Bit r = {cs.alloc(fr_from_bool(!a.val && !b.val)), !a.val && !b.val};
+    cs.enforce(LC::one().sub_var(a.var), LC::one().sub_var(b.var), LC::of(r.var));
+    return r;
+}
+static inline Bool bool_and(ConstraintSystem& cs, const Bool& a, const Bool& b) {  // Boolean::and
+    if (a.kind == Bool::CONST) return a.cval ? b : Bool::constant(false);
+    if (b.kind == Bool::CONST) return b.cval ? a : Bool::constant(false);
+    if (a.kind == Bool::IS && b.kind == Bool::IS) return Bool::is(bit_and(cs, a.bit, b.bit));
+    if (a.kind == Bool::IS && b.kind == Bool::NOT) return Bool::is(bit_and_not(cs, a.bit, b.bit));
+    if (a.kind == Bool::NOT && b.kind == Bool::IS) return Bool::is(bit_and_not(cs, b.bit, a.bit));
+    return Bool::is(bit_nor(cs, a.bit, b.bit));
+}
+
+// AllocatedNum::to_bits_le_strict: bits of the canonical value, constrained to be <= r - 1.
+// Returned little-endian (bit 0 first); every entry is an allocated bit.
+static inline std::vector<Bit> num_to_bits_le_strict(ConstraintSystem& cs, const Num& n) {
+    uint32_t a[8], rm1[8];
+    ZkScalar(n.val).to_canonical(a);
+    {
+        uint64_t borrow = 1;
+        for (int i = 0; i < 8; ++i) {
+            uint64_t d = (uint64_t)FrParams::MOD[i] - borrow;
+            rm1[i] = (uint32_t)d;
+            borrow = (d >> 63) & 1;
+        }
+    }
+    std::vector<Bit> result;  // big-endian while building
+    std::vector<Bit> current_run;
+    bool have_last_run = false, found_one = false;
+    Bit last_run = {0, false};
+    for (int i = 255; i >= 0; --i) {
+        const bool b = (rm1[i >> 5] >> (i & 31)) & 1;
+        const bool abit = (a[i >> 5] >> (i & 31)) & 1;
+        found_one |= b;
+        if (!found_one) continue;  // leading zero bit of r - 1 (bit 255): a's bit is zero as well
+        if (b) {
+            Bit ab = bit_alloc(cs, abit);
+            current_run.push_back(ab);
+            result.push_back(ab);
+        } else {
+            if (!current_run.empty()) {
+                if (have_last_run) current_run.push_back(last_run);
+                Bit cur = current_run[0];  // k-ary AND, left to right
+                for (size_t k = 1; k < current_run.size(); ++k) cur = bit_and(cs, cur, current_run[k]);
+                last_run = cur;
+                have_last_run = true;
+                current_run.clear();
+            }
+            result.push_back(bit_alloc_conditionally(cs, abit, last_run));
+        }
+    }
+    LC lc;
+    Fr coeff = Fr::one();
+    for (size_t k = result.size(); k-- > 0;) {
+        lc.add(result[k].var, coeff);
+        coeff = fe_dbl<FrParams>(coeff);
+    }
+    lc.sub_var(n.var);
+    cs.enforce(LC(), LC(), lc);  // unpacking constraint: 0 * 0 = sum(bits) - value
+    std::vector<Bit> le(result.rbegin(), result.rend());
+    return le;
+}
+
+// ------------------------------------------------------------------------------------------------
+// common/number.rs
+// ------------------------------------------------------------------------------------------------
+struct Number {
+    LC lc;
+    Fr val;
+    static Number zero() { return {LC(), Fr::zero()}; }
+    static Number one() { return {LC::one(), Fr::one()}; }
+    static Number constant(const Fr& v) { return {LC().add(VAR_ONE, v), v}; }
+    static Number from(const Num& n) { return {LC::of(n.var), n.val}; }
+    static Number from_scaled(const Fr& k, const Num& n) { return {LC().add(n.var, k), fe_mul<FrParams>(n.val, k)}; }
+    static Number from(const Bit& b) { return {LC::of(b.var), fr_from_bool(b.val)}; }
+    void add_constant(const Fr& c) {
+        lc.add(VAR_ONE, c);
+        val = fe_add<FrParams>(val, c);
+    }
+    void add_num(const Fr& coeff, const Num& n) {
+        lc.add(n.var, coeff);
+        val = fe_add<FrParams>(val, fe_mul<FrParams>(n.val, coeff));
+    }
+    Number plus(const Number& o) const {
+        Number r = *this;
+        r.lc.add_lc(o.lc);
+        r.val = fe_add<FrParams>(val, o.val);
+        return r;
+    }
+    Number plus_scaled(const Fr& k, const Number& o) const {
+        Number r = *this;
+        r.lc.add_scaled(o.lc, k);
+        r.val = fe_add<FrParams>(val, fe_mul<FrParams>(k, o.val));
+        return r;
+    }
+    Number minus(const Number& o) const {
+        Number r = *this;
+        r.lc.sub_lc(o.lc);
+        r.val = fe_sub<FrParams>(val, o.val);
+        return r;
+    }
+    Num mul(ConstraintSystem& cs, const Number& o) const {  // number.rs:48-65
+        Num r = num_alloc(cs, fe_mul<FrParams>(val, o.val));
+        cs.enforce(lc, o.lc, LC::of(r.var));
+        return r;
+    }
+    Num compress(ConstraintSystem& cs) const { return mul(cs, one()); }  // :66-72
+    Bool is_zero(ConstraintSystem& cs) const {                            // :75-111
+        const bool z = val.is_zero();
+        Bit isz = bit_alloc(cs, z);
+        Num inv = num_alloc(cs, z ? Fr::zero() : fe_inv<FrParams>(val));
+        cs.enforce(LC().sub_lc(lc), LC::of(inv.var), LC::of(isz.var).sub_var(VAR_ONE));
+        cs.enforce(LC::of(isz.var), lc, LC());
+        return Bool::is(isz);
+    }
+    Bool is_equal(ConstraintSystem& cs, const Number& o) const { return minus(o).is_zero(cs); }  // :113-119
+    void assert_equal(ConstraintSystem& cs, const Number& o) const { cs.enforce(lc, LC::one(), o.lc); }  // :121-128
+    void assert_equal_if_enabled(ConstraintSystem& cs, const Bool& enabled, const Number& o) const {  // :130-177
+        if (enabled.kind == Bool::IS) {
+            Var eis = cs.alloc(enabled.bit.val ? val : Fr::zero());
+            cs.enforce(LC::of(enabled.bit.var), lc, LC::of(eis));
+            cs.enforce(LC::of(enabled.bit.var), o.lc, LC::of(eis));
+        } else if (enabled.kind == Bool::CONST) {
+            if (enabled.cval) assert_equal(cs, o);
+        } else {
+            throw std::logic_error("assert_equal_if_enabled(Boolean::Not) is unimplemented in the reference");
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// common/boolean.rs, common/mux.rs
+// ------------------------------------------------------------------------------------------------
+static inline Number extract_bool(const Bool& b) {
+    if (b.kind == Bool::IS) return Number::from(b.bit);
+    if (b.kind == Bool::NOT) return Number::one().minus(Number::from(b.bit));
+    return b.cval ? Number::one() : Number::zero();
+}
+static inline void assert_true(ConstraintSystem& cs, const Bool& b) { extract_bool(b).assert_equal(cs, Number::one()); }
+static inline Bool boolean_or(ConstraintSystem& cs, const Bool& a, const Bool& b) {
+    return bool_and(cs, a.negate(), b.negate()).negate();
+}
+// select ? b : a      (mux.rs:7-47)
+static inline Num mux(ConstraintSystem& cs, const Bool& select, const Number& a, const Number& b) {
+    if (select.kind == Bool::IS) {
+        Num ret = num_alloc(cs, select.bit.val ? b.val : a.val);
+        cs.enforce(LC().add_lc(a.lc).sub_lc(b.lc), LC::of(select.bit.var), LC().add_lc(a.lc).sub_var(ret.var));
+        return ret;
+    }
+    if (select.kind == Bool::NOT) {
+        Num ret = num_alloc(cs, select.bit.val ? a.val : b.val);
+        cs.enforce(LC().add_lc(b.lc).sub_lc(a.lc), LC::of(select.bit.var), LC().add_lc(b.lc).sub_var(ret.var));
+        return ret;
+    }
+    throw std::logic_error("mux(Boolean::Constant) is unimplemented in the reference");
+}
+
+// ------------------------------------------------------------------------------------------------
+// common/uint.rs
+// ------------------------------------------------------------------------------------------------
+struct UInt {
+    std::vector<Bit> bits;
+    Number num;
+    static UInt constrain(ConstraintSystem& cs, const Number& num, int num_bits) {  // :66-91
+        UInt u;
+        u.num = num;
+        const ZkScalar v(num.val);
+        LC all;
+        Fr coeff = Fr::one();
+        for (int i = 0; i < num_bits; ++i) {
+            Bit b = bit_alloc(cs, v.bit(i));
+            all.add(b.var, coeff);
+            u.bits.push_back(b);
+            coeff = fe_dbl<FrParams>(coeff);
+        }
+        cs.enforce(all, LC::one(), num.lc);
+        return u;
+    }
+    static UInt alloc(ConstraintSystem& cs, const Fr& val, int bits) {  // :34-41
+        Num a = num_alloc(cs, val);
+        return constrain(cs, Number::from(a), bits);
+    }
+    static UInt alloc_64(ConstraintSystem& cs, uint64_t v) { return alloc(cs, fr_from_u64(v), 64); }
+    Bool lt(ConstraintSystem& cs, const UInt& other) const {  // :94-109
+        const int nb = (int)bits.size();
+        if ((int)other.bits.size() != nb) throw std::logic_error("UnsignedInteger::lt: width mismatch");
+        Fr two_bits = Fr::one();
+        for (int i = 0; i < nb + 1; ++i) two_bits = fe_dbl<FrParams>(two_bits);  // 2^(nb+1)
+        Number sub = num.minus(other.num);
+        sub.add_constant(two_bits);
+        UInt sb = constrain(cs, sub, nb + 2);
+        return Bool::is(sb.bits[nb]);
+    }
+    Bool gt(ConstraintSystem& cs, const UInt& other) const { return other.lt(cs, *this); }
+    Bool lte(ConstraintSystem& cs, const UInt& other) const { return gt(cs, other).negate(); }
+    Bool gte(ConstraintSystem& cs, const UInt& other) const { return lt(cs, other).negate(); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// poseidon/mod.rs
+// ------------------------------------------------------------------------------------------------
+static inline Num g_sbox(ConstraintSystem& cs, const Number& a) {
+    Num a2 = a.mul(cs, a);
+    Num a4 = num_mul(cs, a2, a2);
+    return a.mul(cs, Number::from(a4));
+}
+static inline std::vector<Number> g_product_mds(const std::vector<Number>& vals, const PoseidonHostParams& P) {
+    const int t = (int)vals.size();
+    std::vector<Number> res(t, Number::zero());
+    for (int j = 0; j < t; ++j)
+        for (int k = 0; k < t; ++k) res[j] = res[j].plus_scaled(P.mds[j * t + k], vals[k]);
+    return res;
+}
+static inline Number g_poseidon(ConstraintSystem& cs, const std::vector<Number>& vals) {
+    std::vector<Number> e;
+    e.push_back(Number::zero());
+    for (auto& v : vals) e.push_back(v);
+    const int t = (int)e.size();
+    PoseidonHostParams P = poseidon_host_params(t);
+    int off = 0;
+    for (int rnd = 0; rnd < P.rf + P.rp; ++rnd) {
+        for (int i = 0; i < t; ++i) e[i].add_constant(P.rc[off + i]);
+        off += t;
+        const bool full = rnd < P.rf / 2 || rnd >= P.rf / 2 + P.rp;
+        if (full) {
+            for (int i = 0; i < t; ++i) e[i] = Number::from(g_sbox(cs, e[i]));
+        } else {
+            e[0] = Number::from(g_sbox(cs, e[0]));
+            for (int i = 1; i < t; ++i) e[i] = Number::from(e[i].compress(cs));
+        }
+        e = g_product_mds(e, P);
+    }
+    return e[1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// merkle/mod.rs
+// ------------------------------------------------------------------------------------------------
+typedef Num ProofTriple[3];
+static inline Number g_merge_hash4(ConstraintSystem& cs, const Bit& s0b, const Bit& s1b, const Number& v, const Num* p) {
+    Bool s0 = Bool::is(s0b), s1 = Bool::is(s1b);
+    Bool andb = bool_and(cs, s0, s1);
+    Bool orb = boolean_or(cs, s0, s1);
+    Number p0 = Number::from(p[0]), p1 = Number::from(p[1]), p2 = Number::from(p[2]);
+    Num v0 = mux(cs, orb, v, p0);
+    Num v1p = mux(cs, s0, p0, v);
+    Num v1 = mux(cs, s1, Number::from(v1p), p1);
+    Num v2p = mux(cs, s0, v, p2);
+    Num v2 = mux(cs, s1, p1, Number::from(v2p));
+    Num v3 = mux(cs, andb, p2, v);
+    return g_poseidon(cs, {Number::from(v0), Number::from(v1), Number::from(v2), Number::from(v3)});
+}
+struct MerkleProofWit {
+    std::vector<Num> sib;  // 3 per level
+};
+static inline Number g_calc_root4(ConstraintSystem& cs, const UInt& index, const Number& val, const MerkleProofWit& proof) {
+    if (index.bits.size() != proof.sib.size() / 3 * 2) throw std::logic_error("calc_root: index width != 2 * depth");
+    Number cur = val;
+    for (size_t lvl = 0; lvl < proof.sib.size() / 3; ++lvl)
+        cur = g_merge_hash4(cs, index.bits[2 * lvl], index.bits[2 * lvl + 1], cur, &proof.sib[3 * lvl]);
+    return cur;
+}
+static inline void g_check_proof4(ConstraintSystem& cs, const Bool& enabled, const UInt& index, const Number& val,
+                                  const MerkleProofWit& proof, const Number& root) {
+    Number nr = g_calc_root4(cs, index, val, proof);
+    root.assert_equal_if_enabled(cs, enabled, nr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// eddsa/mod.rs
+// ------------------------------------------------------------------------------------------------
+struct APoint {
+    Num x, y;
+    PointAffine value() const { return {ZkScalar(x.val), ZkScalar(y.val)}; }
+    static APoint alloc(ConstraintSystem& cs, const PointAffine& p) { return {num_alloc(cs, p.x.v), num_alloc(cs, p.y.v)}; }
+    Bool is_null(ConstraintSystem& cs) const {
+        Bool xz = Number::from(x).is_zero(cs);
+        Bool yz = Number::from(y).is_zero(cs);
+        return bool_and(cs, xz, yz);
+    }
+    Bool is_equal(ConstraintSystem& cs, const APoint& o) const {
+        Bool xe = Number::from(x).is_equal(cs, Number::from(o.x));
+        Bool ye = Number::from(y).is_equal(cs, Number::from(o.y));
+        return bool_and(cs, xe, ye);
+    }
+    void assert_on_curve(ConstraintSystem& cs, const Bool& enabled) const {  // :64-75
+        Num x2 = num_mul(cs, x, x), y2 = num_mul(cs, y, y), x2y2 = num_mul(cs, x2, y2);
+        Number lhs = Number::from(y2).minus(Number::from(x2));
+        Number rhs = Number::from_scaled(jubjub_d().v, x2y2).plus(Number::one());
+        lhs.assert_equal_if_enabled(cs, enabled, rhs);
+    }
+    APoint add_const(ConstraintSystem& cs, const PointAffine& b) const {  // :77-123
+        PointAffine a = value(), sumv;  // default (0,0) when either operand is off-curve
+        if (a.is_on_curve() && b.is_on_curve()) {
+            sumv = a;
+            sumv.add_assign(b);
+        }
+        APoint sum = alloc(cs, sumv);
+        const Fr bx = b.x.v, by = b.y.v;
+        const Fr dbb = fe_mul<FrParams>(fe_mul<FrParams>(jubjub_d().v, bx), by);
+        Num common = num_mul(cs, x, y);
+        cs.enforce(LC::one().add(common.var, dbb), LC::of(sum.x.var), LC().add(x.var, by).add(y.var, bx));
+        // y_1 - y_2: by*y - (A*bx)*x with A = -1
+        cs.enforce(LC::one().add(common.var, fe_neg<FrParams>(dbb)), LC::of(sum.y.var), LC().add(y.var, by).add(x.var, bx));
+        return sum;
+    }
+    APoint add(ConstraintSystem& cs, const APoint& o) const {  // :125-172
+        PointAffine a = value(), b = o.value(), sumv;
+        if (a.is_on_curve() && b.is_on_curve()) {
+            sumv = a;
+            sumv.add_assign(b);
+        }
+        APoint sum = alloc(cs, sumv);
+        const Fr d = jubjub_d().v;
+        Num common = num_mul(cs, num_mul(cs, num_mul(cs, x, o.x), y), o.y);
+        Num x1 = num_mul(cs, x, o.y), x2 = num_mul(cs, y, o.x);
+        cs.enforce(LC::one().add(common.var, d), LC::of(sum.x.var), LC::of(x1.var).add_var(x2.var));
+        Num y1 = num_mul(cs, y, o.y), y2 = num_mul(cs, x, o.x);
+        // y_1 - A*y_2 with A = -1  =>  y_1 + y_2
+        cs.enforce(LC::one().add(common.var, fe_neg<FrParams>(d)), LC::of(sum.y.var), LC::of(y1.var).add_var(y2.var));
+        return sum;
+    }
+    APoint mul(ConstraintSystem& cs, const Num& b) const {  // :174-202
+        std::vector<Bit> le = num_to_bits_le_strict(cs, b);
+        std::vector<Bit> bits(le.rbegin(), le.rend());  // MSB first
+        APoint result = {mux(cs, Bool::is(bits[0]), Number::zero(), Number::from(x)),
+                         mux(cs, Bool::is(bits[0]), Number::constant(Fr::one()), Number::from(y))};
+        for (size_t i = 1; i < bits.size(); ++i) {
+            result = result.add(cs, result);
+            APoint rpb = result.add(cs, *this);
+            Num rx = mux(cs, Bool::is(bits[i]), Number::from(result.x), Number::from(rpb.x));
+            Num ry = mux(cs, Bool::is(bits[i]), Number::from(result.y), Number::from(rpb.y));
+            result = {rx, ry};
+        }
+        return result;
+    }
+};
+
+static inline APoint g_base_mul(ConstraintSystem& cs, const PointAffine& base, const Num& b) {  // :205-236
+    std::vector<Bit> le = num_to_bits_le_strict(cs, b);
+    std::vector<Bit> bits(le.rbegin(), le.rend());
+    APoint result = {mux(cs, Bool::is(bits[0]), Number::zero(), Number::constant(base.x.v)),
+                     mux(cs, Bool::is(bits[0]), Number::constant(Fr::one()), Number::constant(base.y.v))};
+    for (size_t i = 1; i < bits.size(); ++i) {
+        result = result.add(cs, result);
+        APoint rpb = result.add_const(cs, base);
+        Num rx = mux(cs, Bool::is(bits[i]), Number::from(result.x), Number::from(rpb.x));
+        Num ry = mux(cs, Bool::is(bits[i]), Number::from(result.y), Number::from(rpb.y));
+        result = {rx, ry};
+    }
+    return result;
+}
+
+static inline APoint g_mul_cofactor(ConstraintSystem& cs, const APoint& p) {  // :238-247
+    APoint q = p.add(cs, p);
+    q = q.add(cs, q);
+    q = q.add(cs, q);
+    return q;
+}
+
+static inline void g_verify_eddsa(ConstraintSystem& cs, const Bool& enabled, const APoint& pk, const Number& msg,
+                                  const APoint& sig_r, const Num& sig_s) {  // :249-280
+    Num h = g_poseidon(cs, {Number::from(sig_r.x), Number::from(sig_r.y), Number::from(pk.x), Number::from(pk.y), msg}).compress(cs);
+    APoint sb = g_base_mul(cs, jubjub_base_cofactor(), sig_s);
+    APoint rpha = pk.mul(cs, h);
+    rpha = rpha.add(cs, sig_r);
+    rpha = g_mul_cofactor(cs, rpha);
+    Number::from(rpha.x).assert_equal_if_enabled(cs, enabled, Number::from(sb.x));
+    Number::from(rpha.y).assert_equal_if_enabled(cs, enabled, Number::from(sb.y));
+}
+
+}  // namespace bzk

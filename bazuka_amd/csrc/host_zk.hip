@@ -1,0 +1,325 @@
+// Host-side ZkScalar helpers, Poseidon, SHA3-256 and Jubjub/EdDSA (see host_zk.h for the mapping to
+// the reference's src/zk and src/crypto/jubjub).
+#include "host_zk.h"
+
+#include <mutex>
+
+namespace bzk {
+
+// ------------------------------------------------------------------------------------------------
+// ZkScalar
+// ------------------------------------------------------------------------------------------------
+ZkScalar ZkScalar::from_le_bytes_mod(const uint8_t* b, size_t len) {
+    const ZkScalar k256 = ZkScalar::from_u64(256);
+    ZkScalar acc;
+    for (size_t i = len; i-- > 0;) acc = acc * k256 + ZkScalar::from_u64(b[i]);
+    return acc;
+}
+
+ZkScalar ZkScalar::from_dec(const char* s) {
+    const ZkScalar ten = ZkScalar::from_u64(10);
+    ZkScalar acc;
+    for (; *s; ++s) acc = acc * ten + ZkScalar::from_u64((uint64_t)(*s - '0'));
+    return acc;
+}
+
+ZkScalar ZkScalar::pow(const uint32_t* e, int nlimbs) const {
+    ZkScalar r = ZkScalar::one();
+    for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+        r = r.square();
+        if ((e[i >> 5] >> (i & 31)) & 1) r = r * *this;
+    }
+    return r;
+}
+
+// Tonelli-Shanks with r - 1 = 2^32 * t, non-residue generator 7 (src/zk/mod.rs:204)
+bool ZkScalar::sqrt(ZkScalar* out) const {
+    if (is_zero()) {
+        *out = ZkScalar::zero();
+        return true;
+    }
+    uint32_t rm1[8];
+    {
+        uint64_t borrow = 1;
+        for (int i = 0; i < 8; ++i) {
+            uint64_t d = (uint64_t)FrParams::MOD[i] - borrow;
+            rm1[i] = (uint32_t)d;
+            borrow = (d >> 63) & 1;
+        }
+    }
+    uint32_t t[8] = {0}, th[8] = {0};  // t = (r-1) >> 32 ; th = (t+1)/2 = (t >> 1) + 1 (t odd)
+    for (int i = 0; i < 7; ++i) t[i] = rm1[i + 1];
+    for (int i = 0; i < 8; ++i) th[i] = (t[i] >> 1) | (i < 7 ? t[i + 1] << 31 : 0);
+    {
+        uint64_t c = 1;
+        for (int i = 0; i < 8; ++i) {
+            c += th[i];
+            th[i] = (uint32_t)c;
+            c >>= 32;
+        }
+    }
+    ZkScalar z = ZkScalar::from_u64(7).pow(t, 8);  // 2^32-th root of unity
+    ZkScalar x = pow(th, 8);                       // a^((t+1)/2)
+    ZkScalar b = pow(t, 8);                        // a^t
+    int m = 32;
+    while (b != ZkScalar::one()) {
+        int k = 0;
+        ZkScalar b2 = b;
+        while (b2 != ZkScalar::one()) {
+            b2 = b2.square();
+            if (++k >= m) return false;  // non-residue
+        }
+        ZkScalar w = z;
+        for (int i = 0; i < m - k - 1; ++i) w = w.square();
+        z = w.square();
+        b = b * z;
+        x = x * w;
+        m = k;
+    }
+    *out = x;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Poseidon (host)
+// ------------------------------------------------------------------------------------------------
+ZkScalar poseidon_hash(const ZkScalar* vals, int arity) {
+    const int t = arity + 1;
+    PoseidonHostParams P = poseidon_host_params(t);
+    Fr st[17], nw[17];
+    st[0] = Fr::zero();
+    for (int i = 0; i < arity; ++i) st[i + 1] = vals[i].v;
+    int off = 0;
+    for (int rnd = 0; rnd < P.rf + P.rp; ++rnd) {
+        for (int i = 0; i < t; ++i) st[i] = fe_add<FrParams>(st[i], P.rc[off + i]);
+        off += t;
+        const bool full = rnd < P.rf / 2 || rnd >= P.rf / 2 + P.rp;
+        const int ns = full ? t : 1;
+        for (int i = 0; i < ns; ++i) {
+            Fr x2 = fe_sqr<FrParams>(st[i]);
+            st[i] = fe_mul<FrParams>(fe_sqr<FrParams>(x2), st[i]);
+        }
+        for (int j = 0; j < t; ++j) {
+            Fr acc = Fr::zero();
+            for (int k = 0; k < t; ++k) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(P.mds[j * t + k], st[k]));
+            nw[j] = acc;
+        }
+        for (int i = 0; i < t; ++i) st[i] = nw[i];
+    }
+    return ZkScalar(st[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SHA3-256 (FIPS 202)
+// ------------------------------------------------------------------------------------------------
+static void keccak_f(uint64_t s[25]) {
+    static const uint64_t RC[24] = {
+        0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+        0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+        0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+        0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    auto rol = [](uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; };
+    for (int rnd = 0; rnd < 24; ++rnd) {
+        uint64_t c[5], d[5], b[25];
+        for (int x = 0; x < 5; ++x) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+        for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; ++i) s[i] ^= d[i % 5];
+        for (int x = 0; x < 5; ++x)
+            for (int y = 0; y < 5; ++y) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(s[x + 5 * y], ROT[x + 5 * y]);
+        for (int y = 0; y < 5; ++y)
+            for (int x = 0; x < 5; ++x) s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        s[0] ^= RC[rnd];
+    }
+}
+
+void sha3_256(const uint8_t* data, size_t len, uint8_t out[32]) {
+    const size_t rate = 136;
+    uint64_t s[25] = {0};
+    uint8_t block[136];
+    size_t off = 0;
+    auto absorb = [&](const uint8_t* blk) {
+        for (size_t i = 0; i < rate / 8; ++i) {
+            uint64_t w = 0;
+            for (int j = 7; j >= 0; --j) w = (w << 8) | blk[8 * i + j];
+            s[i] ^= w;
+        }
+        keccak_f(s);
+    };
+    while (len - off >= rate) {
+        absorb(data + off);
+        off += rate;
+    }
+    memset(block, 0, rate);
+    memcpy(block, data + off, len - off);
+    block[len - off] ^= 0x06;
+    block[rate - 1] ^= 0x80;
+    absorb(block);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)(s[i] >> (8 * j));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Jubjub
+// ------------------------------------------------------------------------------------------------
+const ZkScalar& jubjub_d() {
+    static const ZkScalar d = ZkScalar::from_dec("19257038036680949359750312669786877991949435402254120286184196891950884077233");
+    return d;
+}
+const PointAffine& jubjub_base() {
+    static const PointAffine b = {ZkScalar::from_dec("28867639725710769449342053336011988556061781325688749245863888315629457631946"),
+                                  ZkScalar::from_u64(18)};
+    return b;
+}
+const PointAffine& jubjub_base_cofactor() {
+    static const PointAffine b = jubjub_base().multiply(ZkScalar::from_u64(8));
+    return b;
+}
+
+bool PointAffine::is_on_curve() const {
+    ZkScalar xx = x.square(), yy = y.square();
+    return yy - xx == ZkScalar::one() + jubjub_d() * xx * yy;
+}
+
+PointAffine PointAffine::dbl() const {  // curve.rs:48-57 (A = -1)
+    ZkScalar xx = x.square(), yy = y.square();
+    ZkScalar dx = (yy - xx).invert();                                   // (A x^2 + y^2)^-1
+    ZkScalar dy = (ZkScalar::one() + ZkScalar::one() + xx - yy).invert();  // (2 - A x^2 - y^2)^-1
+    return {((x * y) * dx).dbl(), (yy + xx) * dy};
+}
+
+void PointAffine::add_assign(const PointAffine& o) {  // curve.rs:19-36
+    if (*this == o) {
+        *this = dbl();
+        return;
+    }
+    ZkScalar dxy = jubjub_d() * x * o.x * y * o.y;
+    ZkScalar xi = (ZkScalar::one() + dxy).invert(), yi = (ZkScalar::one() - dxy).invert();
+    ZkScalar nx = (x * o.y + y * o.x) * xi, ny = (y * o.y + x * o.x) * yi;
+    x = nx;
+    y = ny;
+}
+
+namespace {
+struct Proj {
+    ZkScalar X, Y, Z;
+    static Proj zero() { return {ZkScalar::zero(), ZkScalar::one(), ZkScalar::zero()}; }
+    bool is_zero() const { return Z.is_zero(); }
+    Proj dbl() const {  // curve.rs:127-138
+        if (is_zero()) return zero();
+        ZkScalar b = (X + Y).square(), c = X.square(), d = Y.square();
+        ZkScalar e = -c, f = e + d, h = Z.square(), j = f - h.dbl();
+        return {(b - c - d) * j, f * (e - d), f * j};
+    }
+    void add_assign(const Proj& o) {  // curve.rs:91-117; the unified formula is complete on Jubjub
+        if (is_zero()) { *this = o; return; }   // (d is a non-square), so the reference's
+        if (o.is_zero()) return;                 // equal-points detour to double() is not needed
+        ZkScalar a = Z * o.Z, b = a.square(), c = X * o.X, d = Y * o.Y;
+        ZkScalar e = jubjub_d() * c * d, f = b - e, g = b + e;
+        ZkScalar nx = a * f * ((X + Y) * (o.X + o.Y) - c - d), ny = a * g * (d + c);
+        X = nx; Y = ny; Z = f * g;
+    }
+    PointAffine to_affine() const {
+        if (is_zero()) return PointAffine::zero();
+        ZkScalar zi = Z.invert();
+        return {X * zi, Y * zi};
+    }
+};
+}  // namespace
+
+PointAffine PointAffine::multiply(const ZkScalar& k) const {  // curve.rs:58-68
+    Proj r = Proj::zero(), self = {x, y, ZkScalar::one()};
+    uint32_t c[8];
+    k.to_canonical(c);
+    for (int i = 255; i >= 0; --i) {
+        r = r.dbl();
+        if ((c[i >> 5] >> (i & 31)) & 1) r.add_assign(self);
+    }
+    return r.to_affine();
+}
+
+// ---- EdDSA (src/crypto/jubjub/mod.rs:112-167)
+static void order_limbs(uint32_t out[8]) {
+    static uint32_t ord[8];
+    static std::once_flag f;
+    std::call_once(f, [] { ZkScalar::from_dec("6554484396890773809930967563523245729705921265872317281365359162392183254199").to_canonical(ord); });
+    memcpy(out, ord, 32);
+}
+
+JubjubPrivateKey jubjub_generate_keys(const uint8_t* seed, size_t len) {
+    JubjubPrivateKey k;
+    k.randomness = hash_to_scalar(seed, len);
+    uint8_t repr[32];
+    uint32_t c[8];
+    k.randomness.to_canonical(c);
+    memcpy(repr, c, 32);  // to_repr() = canonical little-endian bytes
+    k.scalar = hash_to_scalar(repr, 32);
+    k.public_key = jubjub_base().multiply(k.scalar);
+    return k;
+}
+
+JubjubSignature jubjub_sign(const JubjubPrivateKey& sk, const ZkScalar& msg) {
+    ZkScalar rr[2] = {sk.randomness, msg};
+    ZkScalar r = poseidon_hash(rr, 2);
+    PointAffine R = jubjub_base().multiply(r);
+    ZkScalar hin[5] = {R.x, R.y, sk.public_key.x, sk.public_key.y, msg};
+    ZkScalar h = poseidon_hash(hin, 5);
+    // s = (r + h * a) mod ORDER over the integers
+    uint32_t rc[8], hc[8], ac[8], ord[8];
+    r.to_canonical(rc);
+    h.to_canonical(hc);
+    sk.scalar.to_canonical(ac);
+    order_limbs(ord);
+    uint32_t prod[17] = {0};
+    for (int i = 0; i < 8; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 8; ++j) {
+            uint64_t t = (uint64_t)hc[i] * ac[j] + prod[i + j] + carry;
+            prod[i + j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        prod[i + 8] = (uint32_t)carry;
+    }
+    uint64_t carry = 0;
+    for (int i = 0; i < 17; ++i) {
+        uint64_t t = (uint64_t)prod[i] + (i < 8 ? rc[i] : 0) + carry;
+        prod[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    // binary long division: rem = prod mod ORDER
+    uint32_t rem[9] = {0};
+    for (int bit = 17 * 32 - 1; bit >= 0; --bit) {
+        for (int i = 8; i > 0; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
+        rem[0] = (rem[0] << 1) | ((prod[bit >> 5] >> (bit & 31)) & 1);
+        // if rem >= ord: rem -= ord
+        bool ge = rem[8] != 0;
+        if (!ge) {
+            ge = true;
+            for (int i = 7; i >= 0; --i) {
+                if (rem[i] != ord[i]) { ge = rem[i] > ord[i]; break; }
+            }
+        }
+        if (ge) {
+            uint64_t borrow = 0;
+            for (int i = 0; i < 9; ++i) {
+                uint64_t d = (uint64_t)rem[i] - (i < 8 ? ord[i] : 0) - borrow;
+                rem[i] = (uint32_t)d;
+                borrow = (d >> 63) & 1;
+            }
+        }
+    }
+    return {R, ZkScalar::from_canonical_limbs(rem)};
+}
+
+bool jubjub_verify(const PointAffine& pk, const ZkScalar& msg, const JubjubSignature& sig) {
+    if (!pk.is_on_curve() || !sig.r.is_on_curve()) return false;
+    ZkScalar hin[5] = {sig.r.x, sig.r.y, pk.x, pk.y, msg};
+    ZkScalar h = poseidon_hash(hin, 5);
+    PointAffine sb = jubjub_base().multiply(sig.s);
+    PointAffine q = pk.multiply(h);
+    q.add_assign(sig.r);
+    return q == sb;
+}
+
+}  // namespace bzk

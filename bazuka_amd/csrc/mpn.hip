@@ -1,0 +1,606 @@
+// a3 / a9: host-side MPN witness + R1CS generator (C++), the CPU half of the prover.
+//
+// Restates, for the Update function of the Main Payment Network:
+//   * the sparse 4-ary account / token state (KvStoreStateManager semantics)   src/zk/state/mod.rs:218-420,
+//     MpnConfig::state_model                                                   src/mpn/mod.rs:218-241,
+//     MpnAccount::{tokens_hash, find_token_index}                              src/zk/mod.rs:68-118
+//   * the witness builder `update::update`                                     src/mpn/update.rs:8-299
+//   * `UpdateTransition` / `UpdateTransition::null`                            src/mpn/mod.rs:491-537
+//   * `impl Circuit for UpdateCircuit` (allocation + constraint order)         src/mpn/circuits/update_circuit.rs:49-494
+//   * MpnTransaction::{hash, sign}                                             src/zk/mod.rs:609-627
+//   * wallet `create_mpn_transaction` semantics for the synthetic batch        src/wallet/tx_builder.rs:287-306
+// Output: the Groth16 assignment (z, A.z, B.z, C.z, densities) and, on request, the CSR matrices for
+// CRS generation.  The storage engine (KvStore / LevelDB keys) is out of scope: state lives in RAM.
+#include <array>
+#include <map>
+#include <memory>
+#include <unordered_map>
+
+#include "bzk_internal.h"
+#include "host_r1cs.h"
+
+namespace bzk {
+
+// ------------------------------------------------------------------------------------------------
+// sparse 4-ary Poseidon tree
+// ------------------------------------------------------------------------------------------------
+struct SparseTree4 {
+    int depth;
+    std::vector<ZkScalar> defaults;                              // [0] = leaf default ... [depth] = empty root
+    std::vector<std::unordered_map<uint64_t, ZkScalar>> level;   // level[0] = leaves
+    SparseTree4(int d, const ZkScalar& leaf_default) : depth(d), level(d + 1) {
+        defaults.push_back(leaf_default);
+        for (int i = 0; i < d; ++i) {
+            ZkScalar c[4] = {defaults.back(), defaults.back(), defaults.back(), defaults.back()};
+            defaults.push_back(poseidon_hash(c, 4));
+        }
+    }
+    ZkScalar get(int lv, uint64_t i) const {
+        auto it = level[lv].find(i);
+        return it == level[lv].end() ? defaults[lv] : it->second;
+    }
+    ZkScalar root() const { return get(depth, 0); }
+    void set_leaf(uint64_t i, const ZkScalar& v) {
+        level[0][i] = v;
+        for (int lv = 0; lv < depth; ++lv) {
+            const uint64_t base = i & ~(uint64_t)3;
+            ZkScalar c[4] = {get(lv, base), get(lv, base + 1), get(lv, base + 2), get(lv, base + 3)};
+            i >>= 2;
+            level[lv + 1][i] = poseidon_hash(c, 4);
+        }
+    }
+    // sibling triples, leaf level first (src/zk/state/mod.rs:218-264)
+    std::vector<std::array<ZkScalar, 3>> prove(uint64_t i) const {
+        std::vector<std::array<ZkScalar, 3>> out;
+        for (int lv = 0; lv < depth; ++lv) {
+            const uint64_t base = i & ~(uint64_t)3;
+            std::array<ZkScalar, 3> t;
+            int k = 0;
+            for (uint64_t j = 0; j < 4; ++j)
+                if (base + j != i) t[k++] = get(lv, base + j);
+            out.push_back(t);
+            i >>= 2;
+        }
+        return out;
+    }
+};
+
+struct Money {
+    ZkScalar token_id;  // ContractId as scalar: Null -> 0, Ziesha -> 1, Custom(x) -> x (src/zk/mod.rs:280-288)
+    uint64_t amount = 0;
+};
+
+struct MpnAccount {
+    uint32_t tx_nonce = 0, withdraw_nonce = 0;
+    PointAffine address;  // default (0, 0) = empty slot
+    std::map<uint64_t, Money> tokens;
+    long find_token_index(int log4_cap, const ZkScalar& token, bool empty_allowed) const {
+        for (auto& kv : tokens)
+            if (kv.second.token_id == token) return (long)kv.first;
+        if (empty_allowed)
+            for (uint64_t i = 0; i < ((uint64_t)1 << (2 * log4_cap)); ++i)
+                if (!tokens.count(i)) return (long)i;
+        return -1;
+    }
+};
+
+static ZkScalar token_leaf(const Money& m) {
+    ZkScalar v[2] = {m.token_id, ZkScalar::from_u64(m.amount)};
+    return poseidon_hash(v, 2);
+}
+
+struct MpnTx {  // MpnTransaction with decompressed keys
+    uint32_t nonce = 0;
+    PointAffine src_pub, dst_pub;
+    Money amount, fee;
+    JubjubSignature sig;
+    ZkScalar hash() const {
+        ZkScalar v[7] = {ZkScalar::from_u64(nonce), dst_pub.x, dst_pub.y, amount.token_id, ZkScalar::from_u64(amount.amount),
+                         fee.token_id, ZkScalar::from_u64(fee.amount)};
+        return poseidon_hash(v, 7);
+    }
+};
+
+typedef std::vector<std::array<ZkScalar, 3>> Proof4;
+
+struct UpdateTransition {
+    bool enabled = false;
+    MpnTx tx;
+    MpnAccount src_before, dst_before;
+    ZkScalar src_before_balances_hash, dst_before_balances_hash;
+    Money src_before_balance, src_before_fee_balance, dst_before_balance;
+    Proof4 src_proof, src_balance_proof, src_fee_balance_proof, dst_proof, dst_balance_proof;
+    uint64_t src_index = 0, src_token_index = 0, src_fee_token_index = 0, dst_index = 0, dst_token_index = 0;
+    static UpdateTransition null(int L, int T) {
+        UpdateTransition t;
+        std::array<ZkScalar, 3> z = {ZkScalar(), ZkScalar(), ZkScalar()};
+        t.src_proof.assign(L, z);
+        t.dst_proof.assign(L, z);
+        t.src_balance_proof.assign(T, z);
+        t.src_fee_balance_proof.assign(T, z);
+        t.dst_balance_proof.assign(T, z);
+        return t;
+    }
+};
+
+}  // namespace bzk
+
+using namespace bzk;
+
+// ------------------------------------------------------------------------------------------------
+// the MPN world (RAM state) - opaque handle of the C ABI
+// ------------------------------------------------------------------------------------------------
+struct bzk_mpn {
+    int L, T;
+    ZkScalar token_default, tokens_tree_default, account_default;
+    std::unique_ptr<SparseTree4> accounts;
+    std::map<uint64_t, MpnAccount> acct;
+    std::map<uint64_t, JubjubPrivateKey> keys;
+    std::vector<MpnTx> mempool;
+    uint64_t height = 0;
+
+    bzk_mpn(int l, int t) : L(l), T(t) {
+        token_default = token_leaf(Money());
+        SparseTree4 tt(T, token_default);
+        tokens_tree_default = tt.root();
+        account_default = account_hash(MpnAccount());
+        accounts.reset(new SparseTree4(L, account_default));
+    }
+    SparseTree4 tokens_tree(const MpnAccount& a) const {
+        SparseTree4 t(T, token_default);
+        for (auto& kv : a.tokens) t.set_leaf(kv.first, token_leaf(kv.second));
+        return t;
+    }
+    ZkScalar tokens_hash(const MpnAccount& a) const { return a.tokens.empty() ? tokens_tree_default : tokens_tree(a).root(); }
+    ZkScalar account_hash(const MpnAccount& a) const {
+        ZkScalar v[5] = {ZkScalar::from_u64(a.tx_nonce), ZkScalar::from_u64(a.withdraw_nonce), a.address.x, a.address.y, tokens_hash(a)};
+        return poseidon_hash(v, 5);
+    }
+    MpnAccount get(uint64_t i) const {
+        auto it = acct.find(i);
+        return it == acct.end() ? MpnAccount() : it->second;
+    }
+    void set(uint64_t i, const MpnAccount& a) {
+        acct[i] = a;
+        accounts->set_leaf(i, account_hash(a));
+    }
+};
+
+struct bzk_r1cs {
+    ConstraintSystem cs;
+    std::vector<uint8_t> z_bytes, a_density, b_density;
+    std::vector<uint32_t> colA, colB, colC;  // flat variable indices (after finalize)
+    uint64_t accepted = 0, rejected = 0;
+    explicit bzk_r1cs(bool rec) : cs(rec) {}
+};
+
+namespace bzk {
+
+// update::update for the queued transactions (src/mpn/update.rs:8-299); mutates the world.
+static void build_transitions(bzk_mpn& w, int log4_batch, const ZkScalar& fee_token, std::vector<UpdateTransition>& out,
+                              uint64_t& fee_sum, uint64_t& rejected) {
+    const size_t cap = (size_t)1 << (2 * log4_batch);
+    fee_sum = 0;
+    rejected = 0;
+    std::vector<MpnTx> rest;
+    for (const MpnTx& tx : w.mempool) {
+        if (out.size() == cap) {
+            rest.push_back(tx);
+            continue;
+        }
+        if (tx.fee.token_id != fee_token || !tx.src_pub.is_on_curve() || !tx.dst_pub.is_on_curve()) { ++rejected; continue; }
+        long src_index = -1, dst_index = -1;
+        for (auto& kv : w.acct) {
+            if (kv.second.address == tx.src_pub && src_index < 0) src_index = (long)kv.first;
+            if (kv.second.address == tx.dst_pub && dst_index < 0) dst_index = (long)kv.first;
+        }
+        if (src_index < 0) { ++rejected; continue; }
+        if (dst_index < 0) dst_index = w.acct.empty() ? 0 : (long)(w.acct.rbegin()->first + 1);  // next free slot
+        MpnAccount src_before = w.get(src_index), dst_before0 = w.get(dst_index);
+        // (the reference passes the ACCOUNT-tree log4 size here; harmless, kept)
+        long sti = src_before.find_token_index(w.L, tx.amount.token_id, false);
+        long dti = dst_before0.find_token_index(w.L, tx.amount.token_id, true);
+        long sfi = src_before.find_token_index(w.L, tx.fee.token_id, false);
+        if (sti < 0 || dti < 0 || sfi < 0) { ++rejected; continue; }
+        Money src_token = src_before.tokens[sti];
+        const bool dst_has = dst_before0.tokens.count(dti) != 0;
+        if (tx.nonce != src_before.tx_nonce + 1 || !(src_before.address == tx.src_pub) ||
+            (dst_before0.address.is_on_curve() && !(dst_before0.address == tx.dst_pub)) ||
+            (dst_has && src_token.token_id != dst_before0.tokens[dti].token_id) || src_token.token_id != tx.amount.token_id ||
+            src_token.amount < tx.amount.amount) {
+            ++rejected;
+            continue;
+        }
+        // work on a copy ("isolated" mirror); commit at the end
+        bzk_mpn iso_view = bzk_mpn(w.L, w.T);  // cheap shell; share state by copying the sparse tree
+        *iso_view.accounts = *w.accounts;
+        iso_view.acct = w.acct;
+        UpdateTransition t;
+        t.enabled = true;
+        t.tx = tx;
+        t.src_index = src_index; t.dst_index = dst_index;
+        t.src_token_index = sti; t.dst_token_index = dti; t.src_fee_token_index = sfi;
+        t.src_before = src_before;
+        t.src_before_balance = src_token;
+        t.src_before_balances_hash = w.tokens_hash(src_before);
+        t.src_proof = iso_view.accounts->prove(src_index);
+        MpnAccount src_after = src_before;
+        src_after.tx_nonce += 1;
+        t.src_balance_proof = w.tokens_tree(src_before).prove(sti);
+        src_after.tokens[sti].amount -= tx.amount.amount;
+        iso_view.set(src_index, src_after);
+        if (!src_after.tokens.count(sfi)) { ++rejected; continue; }
+        Money src_fee_token = src_after.tokens[sfi];
+        if (src_fee_token.token_id != tx.fee.token_id || src_fee_token.amount < tx.fee.amount) { ++rejected; continue; }
+        t.src_before_fee_balance = src_fee_token;
+        t.src_fee_balance_proof = w.tokens_tree(src_after).prove(sfi);
+        src_after.tokens[sfi].amount -= tx.fee.amount;
+        iso_view.set(src_index, src_after);
+        t.dst_proof = iso_view.accounts->prove(dst_index);
+        MpnAccount dst_before = iso_view.get(dst_index);
+        t.dst_balance_proof = w.tokens_tree(dst_before).prove(dti);
+        t.dst_before = dst_before;
+        t.dst_before_balances_hash = w.tokens_hash(dst_before);
+        t.dst_before_balance = dst_before.tokens.count(dti) ? dst_before.tokens[dti] : Money();
+        MpnAccount dst_after = dst_before;
+        dst_after.address = tx.dst_pub;
+        if (!dst_after.tokens.count(dti)) dst_after.tokens[dti] = Money{tx.amount.token_id, 0};
+        dst_after.tokens[dti].amount += tx.amount.amount;
+        iso_view.set(dst_index, dst_after);
+        // commit
+        *w.accounts = *iso_view.accounts;
+        w.acct = iso_view.acct;
+        fee_sum += tx.fee.amount;
+        out.push_back(std::move(t));
+    }
+    w.mempool.swap(rest);
+}
+
+static MerkleProofWit alloc_proof(ConstraintSystem& cs, const Proof4& p) {
+    MerkleProofWit w;
+    for (auto& tr : p)
+        for (int k = 0; k < 3; ++k) w.sib.push_back(num_alloc(cs, tr[k].v));
+    return w;
+}
+
+// impl Circuit for UpdateCircuit (src/mpn/circuits/update_circuit.rs:49-494); steps = SURVEY App. F
+static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
+                              const ZkScalar& aux_data, const ZkScalar& next_state, const ZkScalar& fee_token,
+                              const std::vector<UpdateTransition>& transitions) {
+    Num commitment_wit = num_alloc(cs, commitment.v);
+    num_inputize(cs, commitment_wit);
+    Num height_wit = num_alloc(cs, fr_from_u64(height));
+    num_inputize(cs, height_wit);
+    Num state_wit = num_alloc(cs, state.v);
+    num_inputize(cs, state_wit);
+    Num accepted_fee_token = num_alloc(cs, fee_token.v);
+    Num aux_wit = num_alloc(cs, aux_data.v);
+    num_inputize(cs, aux_wit);
+    Num claimed_next = num_alloc(cs, next_state.v);
+    num_inputize(cs, claimed_next);
+    Number fee_sum = Number::zero();
+
+    for (const UpdateTransition& tr : transitions) {
+        Bool enabled = Bool::is(bit_alloc(cs, tr.enabled));                                                  // 1
+        UInt src_token_index = UInt::alloc(cs, fr_from_u64(tr.src_token_index), 2 * T);                      // 2
+        UInt src_fee_token_index = UInt::alloc(cs, fr_from_u64(tr.src_fee_token_index), 2 * T);
+        UInt dst_token_index = UInt::alloc(cs, fr_from_u64(tr.dst_token_index), 2 * T);
+        Num src_tx_nonce = num_alloc(cs, fr_from_u64(tr.src_before.tx_nonce));                               // 3
+        Num src_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.src_before.withdraw_nonce));
+        APoint src_addr = APoint::alloc(cs, tr.src_before.address);
+        src_addr.assert_on_curve(cs, enabled);
+        Num src_before_bh = num_alloc(cs, tr.src_before_balances_hash.v);                                    // 4
+        Num dst_before_bh = num_alloc(cs, tr.dst_before_balances_hash.v);
+        Num src_token_id = num_alloc(cs, tr.src_before_balance.token_id.v);                                  // 5
+        UInt src_balance = UInt::alloc_64(cs, tr.src_before_balance.amount);
+        Number src_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), src_balance.num});
+        Num src_fee_token_id = num_alloc(cs, tr.src_before_fee_balance.token_id.v);                          // 6
+        UInt src_fee_balance = UInt::alloc_64(cs, tr.src_before_fee_balance.amount);
+        Number src_fee_token_balance_hash = g_poseidon(cs, {Number::from(src_fee_token_id), src_fee_balance.num});
+        MerkleProofWit src_balance_proof = alloc_proof(cs, tr.src_balance_proof);                            // 7
+        g_check_proof4(cs, enabled, src_token_index, src_token_balance_hash, src_balance_proof, Number::from(src_before_bh));
+        UInt tx_amount = UInt::alloc_64(cs, tr.tx.amount.amount);                                            // 8
+        UInt tx_fee = UInt::alloc_64(cs, tr.tx.fee.amount);
+        Number new_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), src_balance.num.minus(tx_amount.num)});  // 9
+        Number balance_middle_root = g_calc_root4(cs, src_token_index, new_token_balance_hash, src_balance_proof);
+        MerkleProofWit src_fee_balance_proof = alloc_proof(cs, tr.src_fee_balance_proof);                    // 10
+        g_check_proof4(cs, enabled, src_fee_token_index, src_fee_token_balance_hash, src_fee_balance_proof, balance_middle_root);
+        Number new_fee_token_balance_hash =
+            g_poseidon(cs, {Number::from(src_fee_token_id), src_fee_balance.num.minus(tx_fee.num)});        // 11
+        Number src_balance_final_root = g_calc_root4(cs, src_fee_token_index, new_fee_token_balance_hash, src_fee_balance_proof);
+        Num tx_nonce = num_alloc(cs, fr_from_u64(tr.tx.nonce));                                              // 12
+        UInt tx_src_index = UInt::alloc(cs, fr_from_u64(tr.src_index), 2 * L);
+        Num tx_amount_token_id = num_alloc(cs, tr.tx.amount.token_id.v);
+        Num tx_fee_token_id = num_alloc(cs, tr.tx.fee.token_id.v);
+        Number::from(accepted_fee_token).assert_equal_if_enabled(cs, enabled, Number::from(tx_fee_token_id));  // 13
+        Number::from(src_token_id).assert_equal(cs, Number::from(tx_amount_token_id));
+        Number::from(src_fee_token_id).assert_equal(cs, Number::from(tx_fee_token_id));
+        Number src_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce), Number::from(src_addr.x),
+                                          Number::from(src_addr.y), Number::from(src_before_bh)});         // 14
+        Num dst_token_id = num_alloc(cs, tr.dst_before_balance.token_id.v);                                  // 15
+        Num dst_balance = num_alloc(cs, fr_from_u64(tr.dst_before_balance.amount));
+        Number dst_token_balance_hash = g_poseidon(cs, {Number::from(dst_token_id), Number::from(dst_balance)});
+        Number new_dst_token_balance_hash =
+            g_poseidon(cs, {Number::from(tx_amount_token_id), Number::from(dst_balance).plus(tx_amount.num)});
+        MerkleProofWit dst_balance_proof = alloc_proof(cs, tr.dst_balance_proof);                            // 16
+        g_check_proof4(cs, enabled, dst_token_index, dst_token_balance_hash, dst_balance_proof, Number::from(dst_before_bh));
+        Number dst_balance_final_root = g_calc_root4(cs, dst_token_index, new_dst_token_balance_hash, dst_balance_proof);
+        MerkleProofWit src_proof = alloc_proof(cs, tr.src_proof);                                            // 17
+        g_check_proof4(cs, enabled, tx_src_index, src_hash, src_proof, Number::from(state_wit));
+        Number new_src_tx_nonce = Number::from(src_tx_nonce).plus(Number::constant(Fr::one()));              // 18
+        Number new_src_hash = g_poseidon(cs, {new_src_tx_nonce, Number::from(src_withdraw_nonce), Number::from(src_addr.x),
+                                              Number::from(src_addr.y), src_balance_final_root});
+        Number middle_root = g_calc_root4(cs, tx_src_index, new_src_hash, src_proof);
+        APoint tx_dst_addr = APoint::alloc(cs, tr.tx.dst_pub);                                               // 19
+        tx_dst_addr.assert_on_curve(cs, enabled);
+        UInt tx_dst_index = UInt::alloc(cs, fr_from_u64(tr.dst_index), 2 * L);
+        Num dst_tx_nonce = num_alloc(cs, fr_from_u64(tr.dst_before.tx_nonce));
+        Num dst_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.dst_before.withdraw_nonce));
+        APoint dst_addr = APoint::alloc(cs, tr.dst_before.address);
+        Number dst_hash = g_poseidon(cs, {Number::from(dst_tx_nonce), Number::from(dst_withdraw_nonce), Number::from(dst_addr.x),
+                                          Number::from(dst_addr.y), Number::from(dst_before_bh)});         // 20
+        MerkleProofWit dst_proof = alloc_proof(cs, tr.dst_proof);
+        Bool is_dst_null = dst_addr.is_null(cs);
+        Bool is_dst_eq = dst_addr.is_equal(cs, tx_dst_addr);
+        Bool addr_valid = boolean_or(cs, is_dst_null, is_dst_eq);
+        assert_true(cs, addr_valid);
+        g_check_proof4(cs, enabled, tx_dst_index, dst_hash, dst_proof, middle_root);                         // 21
+        Number new_dst_hash = g_poseidon(cs, {Number::from(dst_tx_nonce), Number::from(dst_withdraw_nonce), Number::from(tx_dst_addr.x),
+                                              Number::from(tx_dst_addr.y), dst_balance_final_root});
+        Number next_state_wit = g_calc_root4(cs, tx_dst_index, new_dst_hash, dst_proof);
+        state_wit = mux(cs, enabled, Number::from(state_wit), next_state_wit);                               // 22
+        UInt amount_plus_fee = UInt::constrain(cs, tx_amount.num.plus(tx_fee.num), 64);                      // 23
+        Bool is_lte = amount_plus_fee.lte(cs, src_balance);
+        assert_true(cs, is_lte);
+        Number::from(tx_nonce).assert_equal_if_enabled(cs, enabled, Number::from(src_tx_nonce).plus(Number::constant(Fr::one())));  // 24
+        Num final_fee = mux(cs, enabled, Number::zero(), tx_fee.num);
+        fee_sum.add_num(Fr::one(), final_fee);
+        Number tx_hash = g_poseidon(cs, {Number::from(tx_nonce), Number::from(tx_dst_addr.x), Number::from(tx_dst_addr.y),
+                                         Number::from(tx_amount_token_id), tx_amount.num, Number::from(tx_fee_token_id), tx_fee.num});  // 25
+        APoint sig_r = APoint::alloc(cs, tr.tx.sig.r);
+        sig_r.assert_on_curve(cs, enabled);
+        Num sig_s = num_alloc(cs, tr.tx.sig.s.v);
+        g_verify_eddsa(cs, enabled, src_addr, tx_hash, sig_r, sig_s);
+    }
+    Number fee_hash = g_poseidon(cs, {Number::from(accepted_fee_token), fee_sum});
+    cs.enforce(LC::of(aux_wit.var), LC::one(), fee_hash.lc);
+    cs.enforce(LC::of(state_wit.var), LC::one(), LC::of(claimed_next.var));
+    cs.finalize();
+}
+
+static void finish_r1cs(bzk_r1cs* r) {
+    ConstraintSystem& cs = r->cs;
+    const size_t n_in = cs.inputs.size(), n_aux = cs.aux.size();
+    r->z_bytes.resize((n_in + n_aux) * 32);
+    for (size_t i = 0; i < n_in; ++i) memcpy(&r->z_bytes[32 * i], cs.inputs[i].l, 32);
+    for (size_t i = 0; i < n_aux; ++i) memcpy(&r->z_bytes[32 * (n_in + i)], cs.aux[i].l, 32);
+    auto dens = [&](const std::vector<uint8_t>& din, const std::vector<uint8_t>& daux, std::vector<uint8_t>& out) {
+        out.assign(n_in + n_aux, 0);
+        for (size_t i = 0; i < din.size() && i < n_in; ++i) out[i] = din[i];
+        for (size_t i = 0; i < daux.size() && i < n_aux; ++i) out[n_in + i] = daux[i];
+    };
+    dens(cs.a_in_d, cs.a_aux_d, r->a_density);
+    dens(cs.b_in_d, cs.b_aux_d, r->b_density);
+    if (cs.record_matrices) {
+        auto flat = [&](const CsrBuilder& m, std::vector<uint32_t>& out) {
+            out.resize(m.col.size());
+            for (size_t k = 0; k < m.col.size(); ++k) out[k] = cs.flat_index(m.col[k]);
+        };
+        flat(cs.A, r->colA);
+        flat(cs.B, r->colB);
+        flat(cs.C, r->colC);
+    }
+}
+
+}  // namespace bzk
+
+extern "C" {
+
+int32_t bzk_mpn_create(uint32_t log4_tree, uint32_t log4_token_tree, bzk_mpn** out) {
+    if (!out || log4_tree == 0 || log4_tree > 30 || log4_token_tree == 0 || log4_token_tree > 8) return BZK_E_ARG;
+    *out = new (std::nothrow) bzk_mpn((int)log4_tree, (int)log4_token_tree);
+    return *out ? BZK_OK : BZK_E_ALLOC;
+}
+
+void bzk_mpn_destroy(bzk_mpn* w) { delete w; }
+
+int32_t bzk_mpn_set_height(bzk_mpn* w, uint64_t height) {
+    if (!w) return BZK_E_ARG;
+    w->height = height;
+    return BZK_OK;
+}
+
+int32_t bzk_mpn_add_account(bzk_mpn* w, uint64_t index, const uint8_t* seed, uint32_t seed_len, const uint8_t token_id[32],
+                            uint64_t balance, uint8_t pub_xy_out[64]) {
+    if (!w || !seed || !token_id || index >= ((uint64_t)1 << (2 * w->L))) return BZK_E_ARG;
+    JubjubPrivateKey k = jubjub_generate_keys(seed, seed_len);
+    MpnAccount a;
+    a.address = k.public_key;
+    a.tokens[0] = Money{ZkScalar::from_bytes(token_id), balance};
+    w->keys[index] = k;
+    w->set(index, a);
+    if (pub_xy_out) {
+        k.public_key.x.to_bytes(pub_xy_out);
+        k.public_key.y.to_bytes(pub_xy_out + 32);
+    }
+    return BZK_OK;
+}
+
+int32_t bzk_mpn_root(bzk_mpn* w, uint8_t root[32]) {
+    if (!w || !root) return BZK_E_ARG;
+    w->accounts->root().to_bytes(root);
+    return BZK_OK;
+}
+
+// create_mpn_transaction semantics (src/wallet/tx_builder.rs:287-306): nonce = sender nonce + 1 (+ txs
+// already queued from that sender), signed with the sender's key.  dst may be a not-yet-existing
+// account index whose key seed was registered with bzk_mpn_add_key.
+int32_t bzk_mpn_push_tx(bzk_mpn* w, uint64_t src_index, uint64_t dst_index, const uint8_t token_id[32], uint64_t amount,
+                        const uint8_t fee_token[32], uint64_t fee) {
+    if (!w || !token_id || !fee_token) return BZK_E_ARG;
+    if (!w->keys.count(src_index) || !w->keys.count(dst_index)) return BZK_E_ARG;
+    MpnTx tx;
+    tx.src_pub = w->keys[src_index].public_key;
+    tx.dst_pub = w->keys[dst_index].public_key;
+    uint32_t queued = 0;
+    for (auto& q : w->mempool)
+        if (q.src_pub == tx.src_pub) ++queued;
+    tx.nonce = w->get(src_index).tx_nonce + 1 + queued;
+    tx.amount = Money{ZkScalar::from_bytes(token_id), amount};
+    tx.fee = Money{ZkScalar::from_bytes(fee_token), fee};
+    tx.sig = jubjub_sign(w->keys[src_index], tx.hash());
+    w->mempool.push_back(tx);
+    return BZK_OK;
+}
+
+int32_t bzk_mpn_add_key(bzk_mpn* w, uint64_t index, const uint8_t* seed, uint32_t seed_len) {
+    if (!w || !seed) return BZK_E_ARG;
+    w->keys[index] = jubjub_generate_keys(seed, seed_len);
+    return BZK_OK;
+}
+
+void bzk_r1cs_free(bzk_r1cs* r) { delete r; }
+
+int32_t bzk_mpn_update_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], const uint8_t fee_token[32],
+                                  int32_t record_matrices, bzk_r1cs** out) {
+    if (!w || !commitment || !fee_token || !out || log4_batch > 6) return BZK_E_ARG;
+    *out = nullptr;
+    try {
+        const ZkScalar ft = ZkScalar::from_bytes(fee_token);
+        const ZkScalar state = w->accounts->root();
+        std::vector<UpdateTransition> trs;
+        uint64_t fee_sum = 0, rejected = 0;
+        build_transitions(*w, (int)log4_batch, ft, trs, fee_sum, rejected);
+        const uint64_t accepted = trs.size();
+        while (trs.size() < ((size_t)1 << (2 * log4_batch))) trs.push_back(UpdateTransition::null(w->L, w->T));
+        ZkScalar auxin[2] = {ft, ZkScalar::from_u64(fee_sum)};
+        const ZkScalar aux = poseidon_hash(auxin, 2);
+        const ZkScalar next_state = w->accounts->root();
+        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
+        synthesize_update(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, next_state, ft, trs);
+        r->accepted = accepted;
+        r->rejected = rejected;
+        finish_r1cs(r.get());
+        *out = r.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception&) {
+        return BZK_E_INTERNAL;
+    }
+}
+
+// The all-disabled instance `MpnCircuit::empty(L, T, B)` with explicit public inputs - the circuit the
+// reference uses for setup (src/config/blockchain.rs:373-399) and in its own test
+// (src/mpn/circuits/test.rs:117-149).
+int32_t bzk_mpn_update_empty(uint32_t log4_tree, uint32_t log4_token_tree, uint32_t log4_batch, const uint8_t commitment[32],
+                             uint64_t height, const uint8_t state[32], const uint8_t aux_data[32], const uint8_t next_state[32],
+                             const uint8_t fee_token[32], int32_t record_matrices, bzk_r1cs** out) {
+    if (!commitment || !state || !aux_data || !next_state || !fee_token || !out || log4_batch > 6 || log4_tree == 0 ||
+        log4_tree > 30 || log4_token_tree == 0 || log4_token_tree > 8)
+        return BZK_E_ARG;
+    *out = nullptr;
+    try {
+        std::vector<UpdateTransition> trs((size_t)1 << (2 * log4_batch), UpdateTransition::null((int)log4_tree, (int)log4_token_tree));
+        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
+        synthesize_update(r->cs, (int)log4_tree, (int)log4_token_tree, ZkScalar::from_bytes(commitment), height,
+                          ZkScalar::from_bytes(state), ZkScalar::from_bytes(aux_data), ZkScalar::from_bytes(next_state),
+                          ZkScalar::from_bytes(fee_token), trs);
+        finish_r1cs(r.get());
+        *out = r.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception&) {
+        return BZK_E_INTERNAL;
+    }
+}
+
+// info[0..8) = n_in, n_aux, n_constraints, nnz(A), nnz(B), nnz(C), first unsatisfied constraint + 1 (0 = ok),
+//              accepted txs, rejected txs  (9 entries)
+int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]) {
+    if (!r || !info) return BZK_E_ARG;
+    const ConstraintSystem& cs = r->cs;
+    info[0] = cs.inputs.size();
+    info[1] = cs.aux.size();
+    info[2] = cs.num_constraints();
+    info[3] = cs.A.col.size();
+    info[4] = cs.B.col.size();
+    info[5] = cs.C.col.size();
+    info[6] = (uint64_t)(cs.first_unsatisfied() + 1);
+    info[7] = r->accepted;
+    info[8] = r->rejected;
+    return BZK_OK;
+}
+
+// which: 0 z, 1 az, 2 bz, 3 cz, 4 a_density, 5 b_density, 6/7/8 val of A/B/C, 9/10/11 col of A/B/C (u32, flat variable
+// index), 12/13/14 row_ptr of A/B/C (u32).  Returns a borrowed pointer valid until bzk_r1cs_free; *bytes = length.
+const void* bzk_r1cs_data(const bzk_r1cs* r, int32_t which, uint64_t* bytes) {
+    if (!r || !bytes) return nullptr;
+    const ConstraintSystem& cs = r->cs;
+    auto ret = [&](const void* p, size_t n) { *bytes = n; return p; };
+    switch (which) {
+        case 0: return ret(r->z_bytes.data(), r->z_bytes.size());
+        case 1: return ret(cs.az.data(), cs.az.size() * 32);
+        case 2: return ret(cs.bz.data(), cs.bz.size() * 32);
+        case 3: return ret(cs.cz.data(), cs.cz.size() * 32);
+        case 4: return ret(r->a_density.data(), r->a_density.size());
+        case 5: return ret(r->b_density.data(), r->b_density.size());
+        case 6: return ret(cs.A.val.data(), cs.A.val.size() * 32);
+        case 7: return ret(cs.B.val.data(), cs.B.val.size() * 32);
+        case 8: return ret(cs.C.val.data(), cs.C.val.size() * 32);
+        case 9: return ret(r->colA.data(), r->colA.size() * 4);
+        case 10: return ret(r->colB.data(), r->colB.size() * 4);
+        case 11: return ret(r->colC.data(), r->colC.size() * 4);
+        case 12: return ret(cs.A.row_ptr.data(), cs.A.row_ptr.size() * 4);
+        case 13: return ret(cs.B.row_ptr.data(), cs.B.row_ptr.size() * 4);
+        case 14: return ret(cs.C.row_ptr.data(), cs.C.row_ptr.size() * 4);
+        default: *bytes = 0; return nullptr;
+    }
+}
+
+// host-side mirrors of the reference's ZkHasher / jubjub entry points (CPU; for wallets and tests)
+int32_t bzk_host_poseidon(const uint8_t* in, uint32_t arity, uint8_t out[32]) {
+    if (!in || !out || arity < 1 || arity > 16) return BZK_E_ARG;
+    ZkScalar v[16];
+    for (uint32_t i = 0; i < arity; ++i) v[i] = ZkScalar::from_bytes(in + 32 * i);
+    poseidon_hash(v, (int)arity).to_bytes(out);
+    return BZK_OK;
+}
+int32_t bzk_host_sha3_256(const uint8_t* in, uint64_t len, uint8_t out[32]) {
+    if ((!in && len) || !out) return BZK_E_ARG;
+    sha3_256(in, len, out);
+    return BZK_OK;
+}
+// keys from seed: out = pub.x | pub.y | randomness | scalar (4 x 32 B Montgomery)
+int32_t bzk_host_jubjub_keys(const uint8_t* seed, uint32_t len, uint8_t out[128]) {
+    if (!seed || !out) return BZK_E_ARG;
+    JubjubPrivateKey k = jubjub_generate_keys(seed, len);
+    k.public_key.x.to_bytes(out);
+    k.public_key.y.to_bytes(out + 32);
+    k.randomness.to_bytes(out + 64);
+    k.scalar.to_bytes(out + 96);
+    return BZK_OK;
+}
+// sig = r.x | r.y | s
+int32_t bzk_host_jubjub_sign(const uint8_t key[128], const uint8_t msg[32], uint8_t sig_out[96]) {
+    if (!key || !msg || !sig_out) return BZK_E_ARG;
+    JubjubPrivateKey k;
+    k.public_key = {ZkScalar::from_bytes(key), ZkScalar::from_bytes(key + 32)};
+    k.randomness = ZkScalar::from_bytes(key + 64);
+    k.scalar = ZkScalar::from_bytes(key + 96);
+    JubjubSignature s = jubjub_sign(k, ZkScalar::from_bytes(msg));
+    s.r.x.to_bytes(sig_out);
+    s.r.y.to_bytes(sig_out + 32);
+    s.s.to_bytes(sig_out + 64);
+    return BZK_OK;
+}
+// returns 1 valid, 0 invalid, negative on bad arguments
+int32_t bzk_host_jubjub_verify(const uint8_t pub_xy[64], const uint8_t msg[32], const uint8_t sig[96]) {
+    if (!pub_xy || !msg || !sig) return BZK_E_ARG;
+    PointAffine pk = {ZkScalar::from_bytes(pub_xy), ZkScalar::from_bytes(pub_xy + 32)};
+    JubjubSignature s = {{ZkScalar::from_bytes(sig), ZkScalar::from_bytes(sig + 32)}, ZkScalar::from_bytes(sig + 64)};
+    return jubjub_verify(pk, ZkScalar::from_bytes(msg), s) ? 1 : 0;
+}
+
+}  // extern "C"

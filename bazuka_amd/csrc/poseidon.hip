@@ -24,6 +24,7 @@
 
 #include "bzk_field.cuh"
 #include "bzk_internal.h"
+#include "host_zk.h"
 
 namespace bzk {
 
@@ -113,6 +114,11 @@ const HostParams& host_params(int t) {
 }
 
 }  // namespace
+
+PoseidonHostParams poseidon_host_params(int t) {
+    const HostParams& P = host_params(t);
+    return {P.t, P.rf, P.rp, P.rc.data(), P.mds.data()};
+}
 
 // ------------------------------------------------------------------------------------------------
 // device

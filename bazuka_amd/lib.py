@@ -42,9 +42,39 @@ SIGNATURES = {
     "bzk_msm_g2_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "bzk_g1_sum": (_i32, [_vp, _u32, _vp]),
     "bzk_g2_sum": (_i32, [_vp, _u32, _vp]),
+    "bzk_params_load": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "bzk_params_free": (None, [_vp, _vp]),
+    "bzk_groth16_prove": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "bzk_groth16_h_dev": (_i32, [_vp, _vp, _vp, _vp, _u32]),
+    "bzk_mpn_create": (_i32, [_u32, _u32, C.POINTER(_vp)]),
+    "bzk_mpn_destroy": (None, [_vp]),
+    "bzk_mpn_set_height": (_i32, [_vp, _u64]),
+    "bzk_mpn_add_account": (_i32, [_vp, _u64, _vp, _u32, _vp, _u64, _vp]),
+    "bzk_mpn_add_key": (_i32, [_vp, _u64, _vp, _u32]),
+    "bzk_mpn_root": (_i32, [_vp, _vp]),
+    "bzk_mpn_push_tx": (_i32, [_vp, _u64, _u64, _vp, _u64, _vp, _u64]),
+    "bzk_mpn_update_synthesize": (_i32, [_vp, _u32, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "bzk_mpn_update_empty": (_i32, [_u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "bzk_r1cs_info": (_i32, [_vp, C.POINTER(_u64)]),
+    "bzk_r1cs_data": (_vp, [_vp, _i32, C.POINTER(_u64)]),
+    "bzk_r1cs_free": (None, [_vp]),
+    "bzk_host_poseidon": (_i32, [_vp, _u32, _vp]),
+    "bzk_host_sha3_256": (_i32, [_vp, _u64, _vp]),
+    "bzk_host_jubjub_keys": (_i32, [_vp, _u32, _vp]),
+    "bzk_host_jubjub_sign": (_i32, [_vp, _vp, _vp]),
+    "bzk_host_jubjub_verify": (_i32, [_vp, _vp, _vp]),
     "bzk_g1_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
     "bzk_g2_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
 }
+
+
+class ParamsDesc(C.Structure):
+    _fields_ = [("n_in", _u32), ("n_aux", _u32), ("log_m", _u32), ("n_a", _u32), ("n_b", _u32), ("vk", _vp), ("h", _vp),
+                ("l", _vp), ("a", _vp), ("b_g1", _vp), ("b_g2", _vp), ("a_density", _vp), ("b_density", _vp)]
+
+
+class Assignment(C.Structure):
+    _fields_ = [("z", _vp), ("az", _vp), ("bz", _vp), ("cz", _vp), ("n_rows", _u64)]
 
 
 class BzkError(RuntimeError):
@@ -205,8 +235,155 @@ class Bzk:
         self._ck(self.lib.bzk_g2_sum(_ptr(packed), len(packed) // 193, out), "g2_sum")
         return out.raw
 
+    # ---- Groth16
+    def params_load(self, params: dict):
+        """params: dict with n_in, n_aux, log_m, n_a, n_b and byte strings vk(870), h, l, a, b_g1, b_g2,
+        a_density, b_density (the layout oracle.coracle.groth16_setup produces)."""
+        keep = {k: C.create_string_buffer(bytes(params[k]), max(1, len(params[k])))
+                for k in ("vk", "h", "l", "a", "b_g1", "b_g2", "a_density", "b_density")}
+        d = ParamsDesc(params["n_in"], params["n_aux"], params["log_m"], params["n_a"], params["n_b"],
+                       *[C.cast(keep[k], C.c_void_p) for k in ("vk", "h", "l", "a", "b_g1", "b_g2", "a_density", "b_density")])
+        h = C.c_void_p()
+        self._ck(self.lib.bzk_params_load(self.h, C.byref(d), C.byref(h)), "params_load")
+        return h
+
+    def params_free(self, ph):
+        self.lib.bzk_params_free(self.h, ph)
+
+    def groth16_prove(self, ph, z: bytes, az: bytes, bz: bytes, cz: bytes, r: bytes, s: bytes) -> bytes:
+        bufs = [C.create_string_buffer(bytes(x), max(1, len(x))) for x in (z, az, bz, cz)]
+        asg = Assignment(*[C.cast(b, C.c_void_p) for b in bufs], len(az) // 32)
+        out = C.create_string_buffer(387)
+        self._ck(self.lib.bzk_groth16_prove(self.h, ph, C.byref(asg), _ptr(r), _ptr(s), out), "groth16_prove")
+        return out.raw
+
+    def groth16_h_dev(self, a, b, c, log_m: int):
+        self._ck(self.lib.bzk_groth16_h_dev(self.h, _ptr(a), _ptr(b), _ptr(c), log_m), "groth16_h_dev")
+
     def g1_synth_bases_dev(self, seed: int, start: int, n: int, out):
         self._ck(self.lib.bzk_g1_synth_bases_dev(self.h, seed, start, n, _ptr(out)), "g1_synth_bases_dev")
 
     def g2_synth_bases_dev(self, seed: int, start: int, n: int, out):
         self._ck(self.lib.bzk_g2_synth_bases_dev(self.h, seed, start, n, _ptr(out)), "g2_synth_bases_dev")
+
+
+# --------------------------------------------------------------------------------------------------
+# host-side (CPU, C++) MPN witness / R1CS generator - no GPU needed
+# --------------------------------------------------------------------------------------------------
+def _st(st, what):
+    if st != 0:
+        raise BzkError(f"{what}: {load_library().bzk_strerror(st).decode()}")
+
+
+class R1cs:
+    """A synthesized circuit instance (assignment + optional CSR matrices)."""
+    VIEWS = {"z": 0, "az": 1, "bz": 2, "cz": 3, "a_density": 4, "b_density": 5, "valA": 6, "valB": 7, "valC": 8,
+             "colA": 9, "colB": 10, "colC": 11, "rpA": 12, "rpB": 13, "rpC": 14}
+
+    def __init__(self, handle):
+        self.lib = load_library()
+        self.h = handle
+        info = (_u64 * 9)()
+        _st(self.lib.bzk_r1cs_info(self.h, info), "r1cs_info")
+        (self.n_in, self.n_aux, self.n_constraints, self.nnzA, self.nnzB, self.nnzC, first_bad, self.accepted,
+         self.rejected) = [int(x) for x in info]
+        self.first_unsatisfied = first_bad - 1
+        self.satisfied = first_bad == 0
+
+    def view(self, name: str) -> bytes:
+        n = _u64()
+        p = self.lib.bzk_r1cs_data(self.h, self.VIEWS[name], C.byref(n))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def free(self):
+        if self.h:
+            self.lib.bzk_r1cs_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MpnWorld:
+    def __init__(self, log4_tree: int, log4_token_tree: int):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _st(self.lib.bzk_mpn_create(log4_tree, log4_token_tree, C.byref(h)), "mpn_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.bzk_mpn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_height(self, height: int):
+        _st(self.lib.bzk_mpn_set_height(self.h, height), "set_height")
+
+    def add_account(self, index: int, seed: bytes, token_id: bytes, balance: int) -> bytes:
+        out = C.create_string_buffer(64)
+        _st(self.lib.bzk_mpn_add_account(self.h, index, _ptr(seed), len(seed), _ptr(token_id), balance, out), "add_account")
+        return out.raw
+
+    def add_key(self, index: int, seed: bytes):
+        _st(self.lib.bzk_mpn_add_key(self.h, index, _ptr(seed), len(seed)), "add_key")
+
+    def root(self) -> bytes:
+        out = C.create_string_buffer(32)
+        _st(self.lib.bzk_mpn_root(self.h, out), "root")
+        return out.raw
+
+    def push_tx(self, src: int, dst: int, token_id: bytes, amount: int, fee_token: bytes, fee: int):
+        _st(self.lib.bzk_mpn_push_tx(self.h, src, dst, _ptr(token_id), amount, _ptr(fee_token), fee), "push_tx")
+
+    def update_synthesize(self, log4_batch: int, commitment: bytes, fee_token: bytes, record_matrices=False) -> R1cs:
+        h = C.c_void_p()
+        _st(self.lib.bzk_mpn_update_synthesize(self.h, log4_batch, _ptr(commitment), _ptr(fee_token), int(record_matrices),
+                                               C.byref(h)), "update_synthesize")
+        return R1cs(h)
+
+
+def mpn_update_empty(L, T, B, commitment, height, state, aux, next_state, fee_token, record_matrices=False) -> R1cs:
+    h = C.c_void_p()
+    _st(load_library().bzk_mpn_update_empty(L, T, B, _ptr(commitment), height, _ptr(state), _ptr(aux), _ptr(next_state),
+                                            _ptr(fee_token), int(record_matrices), C.byref(h)), "update_empty")
+    return R1cs(h)
+
+
+def host_poseidon(inp: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    _st(load_library().bzk_host_poseidon(_ptr(inp), len(inp) // 32, out), "host_poseidon")
+    return out.raw
+
+
+def host_sha3_256(b: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    _st(load_library().bzk_host_sha3_256(_ptr(b) if b else None, len(b), out), "host_sha3")
+    return out.raw
+
+
+def host_jubjub_keys(seed: bytes) -> bytes:
+    out = C.create_string_buffer(128)
+    _st(load_library().bzk_host_jubjub_keys(_ptr(seed), len(seed), out), "jubjub_keys")
+    return out.raw
+
+
+def host_jubjub_sign(key: bytes, msg: bytes) -> bytes:
+    out = C.create_string_buffer(96)
+    _st(load_library().bzk_host_jubjub_sign(_ptr(key), _ptr(msg), out), "jubjub_sign")
+    return out.raw
+
+
+def host_jubjub_verify(pub_xy: bytes, msg: bytes, sig: bytes) -> bool:
+    r = load_library().bzk_host_jubjub_verify(_ptr(pub_xy), _ptr(msg), _ptr(sig))
+    if r < 0:
+        raise BzkError("jubjub_verify: bad argument")
+    return bool(r)

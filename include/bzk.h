@@ -114,6 +114,90 @@ int32_t bzk_msm_g2_windows_dev(bzk_ctx* ctx, const void* bases_dev, const void* 
 int32_t bzk_g1_sum(const uint8_t* packed_points, uint32_t count, uint8_t out[97]);   /* host, tiny */
 int32_t bzk_g2_sum(const uint8_t* packed_points, uint32_t count, uint8_t out[193]);
 
+/* ---- Groth16 prove (a4-a7) --------------------------------------------------------------------
+ * bellman 0.14 `groth16::create_proof(circuit, params, r, s)` after synthesis (third-party; call
+ * sites src/mpn/circuits/test.rs:135,175,215): 3 iNTT + 3 coset NTT + pointwise (a*b-c)/Z + 1 inverse
+ * coset NTT -> h; MSMs over the h / l / a / b_g1 / b_g2 queries; assembly of (A, B, C).
+ * Output = the 387 bytes of `Groth16Proof` (src/zk/groth16/mod.rs:33-38), i.e. the payload of
+ * `ZkProof::Groth16` (src/zk/mod.rs:646-651) that `groth16_verify` (src/zk/groth16/mod.rs:67-121)
+ * accepts.
+ *
+ * CRS layout (= bellman `Parameters`, identity points dropped): variables are numbered inputs first
+ * (index 0 = ONE) then aux.  a / b_g1 / b_g2 hold ONLY the variables whose density flag is set, in
+ * variable order (a_density[v] = v occurs in some A row; b_density likewise). */
+typedef struct bzk_params bzk_params;
+typedef struct {
+    uint32_t n_in, n_aux, log_m; /* m = 2^log_m >= number of constraints */
+    uint32_t n_a, n_b;           /* popcount of a_density / b_density */
+    const uint8_t* vk;           /* 870 B: alpha_g1|beta_g1|beta_g2|gamma_g2|delta_g1|delta_g2, packed */
+    const uint8_t* h;            /* (m-1) raw G1 */
+    const uint8_t* l;            /* n_aux raw G1 */
+    const uint8_t* a;            /* n_a raw G1 */
+    const uint8_t* b_g1;         /* n_b raw G1 */
+    const uint8_t* b_g2;         /* n_b raw G2 */
+    const uint8_t* a_density;    /* n_in + n_aux bytes, 0/1 */
+    const uint8_t* b_density;    /* n_in + n_aux bytes, 0/1 */
+} bzk_params_desc;
+typedef struct {
+    const uint8_t* z;            /* (n_in + n_aux) scalars: inputs (z[0] = 1) then aux, Montgomery */
+    const uint8_t* az;           /* n_rows scalars: <A_k, z> per constraint */
+    const uint8_t* bz;
+    const uint8_t* cz;
+    uint64_t n_rows;             /* number of constraints incl. bellman's n_in trailing `input*0=0` rows */
+} bzk_assignment;
+/* uploads the CRS to HBM once (host pointers in the descriptor are not retained) */
+int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* desc, bzk_params** out);
+void bzk_params_free(bzk_ctx* ctx, bzk_params* params);
+/* r, s: Montgomery scalars (the prover's blinding factors; bellman draws them from the rng) */
+int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* params, const bzk_assignment* asg, const uint8_t r[32],
+                          const uint8_t s[32], uint8_t proof_out[387]);
+/* h-polynomial stage alone (7 NTTs + pointwise), device resident: a,b,c hold az,bz,cz zero-padded to
+ * m scalars on entry; on return a[0 .. m-1) holds the h coefficients.  Exposed for parity tests. */
+int32_t bzk_groth16_h_dev(bzk_ctx* ctx, void* a_dev, void* b_dev, void* c_dev, uint32_t log_m);
+
+/* ---- a3 / a9: host-side MPN witness + R1CS generator (CPU, C++) --------------------------------
+ * The part of the prover that bellman runs through `Circuit::synthesize`: restates
+ * `impl Circuit for UpdateCircuit` (src/mpn/circuits/update_circuit.rs:49-494), the gadgets under
+ * src/zk/groth16/gadgets/, the witness builder `update::update` (src/mpn/update.rs:8-299) over a
+ * RAM-resident sparse account tree (src/zk/state/mod.rs semantics, MpnConfig::state_model
+ * src/mpn/mod.rs:218-241) and the wallet's `create_mpn_transaction` (src/wallet/tx_builder.rs:287-306).
+ * No GPU involved; the result feeds bzk_groth16_prove. */
+typedef struct bzk_mpn bzk_mpn;   /* an MPN state: accounts, keys, mempool */
+typedef struct bzk_r1cs bzk_r1cs; /* a synthesized circuit instance: assignment (+ matrices) */
+int32_t bzk_mpn_create(uint32_t log4_tree, uint32_t log4_token_tree, bzk_mpn** out);
+void bzk_mpn_destroy(bzk_mpn* w);
+int32_t bzk_mpn_set_height(bzk_mpn* w, uint64_t height);
+/* account `index` := keys from `JubJub::generate_keys(seed)` (src/crypto/jubjub/mod.rs:112-124), token
+ * slot 0 = (token_id, balance); pub_xy_out (optional) receives address x|y */
+int32_t bzk_mpn_add_account(bzk_mpn* w, uint64_t index, const uint8_t* seed, uint32_t seed_len, const uint8_t token_id[32],
+                            uint64_t balance, uint8_t pub_xy_out[64]);
+int32_t bzk_mpn_add_key(bzk_mpn* w, uint64_t index, const uint8_t* seed, uint32_t seed_len); /* key for a future account */
+int32_t bzk_mpn_root(bzk_mpn* w, uint8_t root[32]);
+/* queue a signed MpnTransaction src -> dst (nonce = sender nonce + 1 + already queued from that sender) */
+int32_t bzk_mpn_push_tx(bzk_mpn* w, uint64_t src_index, uint64_t dst_index, const uint8_t token_id[32], uint64_t amount,
+                        const uint8_t fee_token[32], uint64_t fee);
+/* applies up to 4^log4_batch queued txs (update::update), pads with UpdateTransition::null, synthesizes the
+ * circuit.  Public inputs = [commitment, height, state, aux_data, next_state]. */
+int32_t bzk_mpn_update_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], const uint8_t fee_token[32],
+                                  int32_t record_matrices, bzk_r1cs** out);
+/* `MpnCircuit::empty(L, T, B)` with explicit public inputs (src/mpn/circuits/test.rs:117-132) */
+int32_t bzk_mpn_update_empty(uint32_t log4_tree, uint32_t log4_token_tree, uint32_t log4_batch, const uint8_t commitment[32],
+                             uint64_t height, const uint8_t state[32], const uint8_t aux_data[32], const uint8_t next_state[32],
+                             const uint8_t fee_token[32], int32_t record_matrices, bzk_r1cs** out);
+/* info: n_in, n_aux, n_constraints, nnz(A), nnz(B), nnz(C), first unsatisfied constraint + 1 (0 = satisfied),
+ * accepted txs, rejected txs */
+int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]);
+/* borrowed views: 0 z, 1 az, 2 bz, 3 cz, 4 a_density, 5 b_density, 6-8 val(A/B/C), 9-11 col(A/B/C) u32 flat
+ * variable index, 12-14 row_ptr(A/B/C) u32 */
+const void* bzk_r1cs_data(const bzk_r1cs* r, int32_t which, uint64_t* bytes);
+void bzk_r1cs_free(bzk_r1cs* r);
+/* CPU mirrors of `ZkHasher::hash`, `hash_to_scalar`'s SHA3 and `JubJub::{generate_keys, sign, verify}` */
+int32_t bzk_host_poseidon(const uint8_t* in, uint32_t arity, uint8_t out[32]);
+int32_t bzk_host_sha3_256(const uint8_t* in, uint64_t len, uint8_t out[32]);
+int32_t bzk_host_jubjub_keys(const uint8_t* seed, uint32_t len, uint8_t out[128]); /* pub.x|pub.y|randomness|scalar */
+int32_t bzk_host_jubjub_sign(const uint8_t key[128], const uint8_t msg[32], uint8_t sig_out[96]); /* r.x|r.y|s */
+int32_t bzk_host_jubjub_verify(const uint8_t pub_xy[64], const uint8_t msg[32], const uint8_t sig[96]); /* 1 / 0 */
+
 /* synthetic-input helpers (device side, for benches and tests): base_i = k_i * G with
  * k_i = SplitMix64(seed + 0x632BE59BD9B4E019 * (start+i)).next() | 1 ; raw affine out */
 int32_t bzk_g1_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev);

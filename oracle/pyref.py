@@ -655,3 +655,60 @@ class SplitMix64:
             v &= (1 << 255) - 1
             if v < R_MOD:
                 return v
+
+
+# --------------------------------------------------------------------------------------------------
+# Jubjub + EdDSA (src/crypto/jubjub/curve.rs:19-164, mod.rs:112-167) - independent check of the host code
+# --------------------------------------------------------------------------------------------------
+JJ_D = 19257038036680949359750312669786877991949435402254120286184196891950884077233
+JJ_BASE = (28867639725710769449342053336011988556061781325688749245863888315629457631946, 18)
+JJ_ORDER = 6554484396890773809930967563523245729705921265872317281365359162392183254199
+
+
+def jj_on_curve(p):
+    x, y = p
+    return (y * y - x * x - 1 - JJ_D * x * x % R_MOD * y * y) % R_MOD == 0
+
+
+def jj_add(p, q):
+    (x1, y1), (x2, y2) = p, q
+    k = JJ_D * x1 * x2 * y1 * y2 % R_MOD
+    x3 = (x1 * y2 + y1 * x2) * inv_mod((1 + k) % R_MOD, R_MOD) % R_MOD
+    y3 = (y1 * y2 + x1 * x2) * inv_mod((1 - k) % R_MOD, R_MOD) % R_MOD
+    return (x3, y3)
+
+
+def jj_mul(p, k):
+    r = (0, 1)
+    for bit in bin(k)[2:] if k else "":
+        r = jj_add(r, r)
+        if bit == "1":
+            r = jj_add(r, p)
+    return r
+
+
+def sha3_scalar(b: bytes) -> int:
+    import hashlib
+    return int.from_bytes(hashlib.sha3_256(b).digest(), "little") % R_MOD
+
+
+def jj_generate_keys(seed: bytes):
+    randomness = sha3_scalar(seed)
+    scalar = sha3_scalar(randomness.to_bytes(32, "little"))
+    return {"pub": jj_mul(JJ_BASE, scalar), "randomness": randomness, "scalar": scalar}
+
+
+def jj_sign(sk, msg: int):
+    r = poseidon([sk["randomness"], msg])
+    rr = jj_mul(JJ_BASE, r)
+    h = poseidon([rr[0], rr[1], sk["pub"][0], sk["pub"][1], msg])
+    s = (r + h * sk["scalar"]) % JJ_ORDER
+    return rr, s
+
+
+def jj_verify(pub, msg: int, sig) -> bool:
+    rr, s = sig
+    if not (jj_on_curve(pub) and jj_on_curve(rr)):
+        return False
+    h = poseidon([rr[0], rr[1], pub[0], pub[1], msg])
+    return jj_add(jj_mul(pub, h), rr) == jj_mul(JJ_BASE, s)

@@ -1,0 +1,50 @@
+"""GPU parity: Groth16 prove (a4-a7) - proof bytes bit-exact vs the CPU oracle on the same
+(CRS, witness, r, s); the oracle verifier (pairing check) accepts them.  Proof bytes are unpinned by
+the reference (OsRng everywhere), so the oracle on identical inputs is the parity anchor."""
+import pytest
+import torch
+
+from util import dev_bytes, fr_bytes, fr_list, log2_ceil, r1cs_to_csr, rand_scalars_bytes, synth_r1cs, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(co, pr, n_mul, seed):
+    r1 = synth_r1cs(n_mul, seed=seed)
+    A, B, Cm = r1cs_to_csr(co, r1)
+    log_m = log2_ceil(len(r1["rows"]))
+    tox = fr_bytes(fr_list(5, seed + 1))
+    params = co.groth16_setup(A, B, Cm, r1["n_in"], r1["n_aux"], log_m, tox, nthreads=co.ncpu())
+    zb = fr_bytes(r1["z"])
+    az, bz, cz = co.r1cs_eval(A, B, Cm, zb, nthreads=co.ncpu())
+    return r1, params, zb, az, bz, cz
+
+
+@pytest.mark.parametrize("n_mul", [5, 100, 2000])
+def test_groth16_prove_bytes_vs_oracle(bzk, co, pr, n_mul):
+    r1, params, zb, az, bz, cz = _setup(co, pr, n_mul, 1000 + n_mul)
+    r, s = fr_bytes(fr_list(2, 5))[:32], fr_bytes(fr_list(2, 5))[32:]
+    want = co.groth16_prove(params, zb, az, bz, cz, r, s, nthreads=co.ncpu())
+    ph = bzk.params_load(params)
+    got = bzk.groth16_prove(ph, zb, az, bz, cz, r, s)
+    bzk.params_free(ph)
+    assert got == want
+    if n_mul <= 100:
+        vk = {"alpha_g1": pr.g1_from_bytes(params["vk"][0:97]), "beta_g2": pr.g2_from_bytes(params["vk"][194:387]),
+              "gamma_g2": pr.g2_from_bytes(params["vk"][387:580]), "delta_g2": pr.g2_from_bytes(params["vk"][677:870]),
+              "ic": [pr.g1_from_bytes(params["ic"][97 * i:97 * i + 97]) for i in range(r1["n_in"])]}
+        pub = r1["z"][1:r1["n_in"]]
+        assert pr.groth16_verify(vk, pub, pr.proof_from_bytes(got))
+        assert not pr.groth16_verify(vk, [pub[0] + 1] + pub[1:], pr.proof_from_bytes(got))
+
+
+def test_groth16_h_stage_vs_oracle_2p16(bzk, co):
+    log_m = 16
+    m = 1 << log_m
+    n_rows = m - 1000
+    az, bz, cz = (rand_scalars_bytes(n_rows, k) for k in (1, 2, 3))
+    pad = b"\0" * (32 * (m - n_rows))
+    da, db, dc = to_dev(az + pad), to_dev(bz + pad), to_dev(cz + pad)
+    bzk.groth16_h_dev(da, db, dc, log_m)
+    torch.cuda.synchronize()
+    assert dev_bytes(da)[: 32 * (m - 1)] == co.groth16_h(az, bz, cz, log_m, nthreads=co.ncpu())

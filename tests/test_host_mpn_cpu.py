@@ -1,0 +1,136 @@
+"""CPU suite: host-side (C++) mirror of src/zk + src/mpn (witness / R1CS generator, a3 + a9) and the
+reference's C1 configuration - the 4-slot Update circuit proved and verified on the CPU."""
+import array
+import hashlib
+
+import pytest
+
+from bazuka_amd import lib as L
+from oracle import pyref as pr
+
+F, U = pr.fr_to_mont_bytes, pr.fr_from_mont_bytes
+ZIESHA = F(1)  # ContractId::Ziesha -> 1 (src/zk/mod.rs:280-288)
+
+
+def test_sha3_256_matches_hashlib():
+    for m in (b"", b"abc", b"x" * 135, b"y" * 136, b"z" * 300):
+        assert L.host_sha3_256(m) == hashlib.sha3_256(m).digest()
+
+
+def test_host_poseidon_kats():
+    from test_oracle_cpu import POSEIDON_KAT
+    for k in range(1, 17):
+        assert U(L.host_poseidon(b"".join(F(i) for i in range(k)))) == POSEIDON_KAT[k - 1]
+
+
+def test_jubjub_constants_and_group_law():
+    # mirrors src/crypto/jubjub/curve.rs:166-198 at the level the C ABI exposes
+    assert pr.jj_on_curve(pr.JJ_BASE)
+    assert pr.jj_mul(pr.JJ_BASE, pr.JJ_ORDER) == (0, 1)
+    assert (pr.JJ_D * 10241 + 10240) % pr.R_MOD == 0  # d = -10240/10241
+
+
+def test_jubjub_keys_sign_verify_vs_python():
+    # mirrors test_jubjub_signature_verification (src/crypto/jubjub/mod.rs:180-192): seed b"ABC", msg 123456
+    key = L.host_jubjub_keys(b"ABC")
+    sk = pr.jj_generate_keys(b"ABC")
+    assert (U(key[:32]), U(key[32:64])) == sk["pub"]
+    assert U(key[64:96]) == sk["randomness"] and U(key[96:]) == sk["scalar"]
+    sig = L.host_jubjub_sign(key, F(123456))
+    rr, s = pr.jj_sign(sk, 123456)
+    assert (U(sig[:32]), U(sig[32:64])) == rr and U(sig[64:]) == s
+    assert L.host_jubjub_verify(key[:64], F(123456), sig)
+    assert not L.host_jubjub_verify(key[:64], F(123457), sig)
+    assert pr.jj_verify(sk["pub"], 123456, (rr, s))
+
+
+def _world(lg, t, n_acc):
+    w = L.MpnWorld(lg, t)
+    for i in range(n_acc):
+        w.add_account(i, b"acct%d" % i, ZIESHA, 10 ** 12)
+    return w
+
+
+def test_update_circuit_sizes_match_survey_model():
+    """R1CS sizes of the restated gadgets == the tally of the in-tree gadget code."""
+    r = L.mpn_update_empty(3, 3, 1, F(456), 0, F(123), F(pr.poseidon([1, 0])), F(123), ZIESHA)
+    assert (r.n_in, r.n_aux, r.n_constraints) == (6, 126166, 126001)
+    assert r.satisfied
+
+
+def test_update_circuit_production_class_16tx():
+    """(L=15, T=3, B=2): the 2^20 class of BASELINE.json - 16 signed txs, every constraint satisfied."""
+    w = _world(15, 3, 32)
+    for i in range(16):
+        w.push_tx(i, 16 + i, ZIESHA, 100 + i, ZIESHA, i)
+    r = w.update_synthesize(2, F(99), ZIESHA)
+    assert (r.n_in, r.n_aux, r.n_constraints) == (6, 904870, 903037)
+    assert r.accepted == 16 and r.rejected == 0 and r.satisfied
+
+
+def test_update_batch_public_inputs_and_state_transition():
+    w = _world(3, 3, 4)
+    r0 = w.root()
+    w.push_tx(0, 1, ZIESHA, 1000, ZIESHA, 7)
+    w.push_tx(1, 2, ZIESHA, 500, ZIESHA, 3)
+    w.push_tx(2, 0, ZIESHA, 1, ZIESHA, 0)
+    w.push_tx(0, 3, ZIESHA, 999, ZIESHA, 11)  # second tx of account 0: nonce 2
+    w.set_height(5)
+    r = w.update_synthesize(1, F(456), ZIESHA)
+    assert r.accepted == 4 and r.satisfied
+    z = r.view("z")
+    pub = [U(z[32 * i:32 * i + 32]) for i in range(6)]
+    assert pub == [1, 456, 5, U(r0), pr.poseidon([1, 7 + 3 + 0 + 11]), U(w.root())]
+    assert w.root() != r0
+
+
+def test_update_batch_new_destination_partial_batch_and_rejects():
+    w = _world(3, 3, 4)
+    w.add_key(9, b"newacct")
+    w.push_tx(3, 9, ZIESHA, 5, ZIESHA, 1)          # destination slot is empty: allowed (null address)
+    r = w.update_synthesize(1, F(1), ZIESHA)
+    assert r.accepted == 1 and r.satisfied          # 3 padded null transitions
+    before = w.root()
+    w.push_tx(0, 1, ZIESHA, 10 ** 13, ZIESHA, 0)   # overspend: rejected by the witness builder
+    w.push_tx(0, 1, F(7), 1, ZIESHA, 0)            # unknown token: rejected
+    r = w.update_synthesize(1, F(1), ZIESHA)
+    assert r.accepted == 0 and r.rejected == 2 and r.satisfied and w.root() == before
+
+
+def test_witness_evaluations_match_matrices(co):
+    """A.z, B.z, C.z emitted by the generator == CSR matrices x z evaluated by the oracle."""
+    w = _world(3, 3, 2)
+    w.push_tx(0, 1, ZIESHA, 42, ZIESHA, 1)
+    r = w.update_synthesize(1, F(3), ZIESHA, record_matrices=True)
+    hold = []
+    for which in "ABC":
+        rp, col = array.array("I"), array.array("I")
+        rp.frombytes(r.view("rp" + which))
+        col.frombytes(r.view("col" + which))
+        hold.append(co.CsrHolder(r.n_constraints, rp, col, r.view("val" + which)))
+    az, bz, cz = co.r1cs_eval(*hold, r.view("z"), nthreads=co.ncpu())
+    assert (az, bz, cz) == (r.view("az"), r.view("bz"), r.view("cz"))
+    assert co.r1cs_density(hold[0], r.n_in + r.n_aux) == r.view("a_density")
+    assert co.r1cs_density(hold[1], r.n_in + r.n_aux) == r.view("b_density")
+
+
+def test_c1_empty_update_circuit_cpu_prove_verify(co):
+    """BASELINE configs[0] (plumbing, no GPU): the reference's own test instance
+    (src/mpn/circuits/test.rs:117-149) - 4 disabled slots, L=T=3, public inputs [456, 0, 123, aux, 123] with
+    aux = H2(1, 0) - set up, proved and verified (3-pairing check) with the CPU oracle."""
+    aux = pr.poseidon([1, 0])
+    r = L.mpn_update_empty(3, 3, 1, F(456), 0, F(123), F(aux), F(123), ZIESHA, record_matrices=True)
+    hold = []
+    for which in "ABC":
+        rp, col = array.array("I"), array.array("I")
+        rp.frombytes(r.view("rp" + which))
+        col.frombytes(r.view("col" + which))
+        hold.append(co.CsrHolder(r.n_constraints, rp, col, r.view("val" + which)))
+    tox = b"".join(F(x) for x in (11, 22, 33, 44, 55))
+    params = co.groth16_setup(*hold, r.n_in, r.n_aux, 17, tox, nthreads=co.ncpu())
+    proof = co.groth16_prove(params, r.view("z"), r.view("az"), r.view("bz"), r.view("cz"), F(7), F(9), nthreads=co.ncpu())
+    vk = {"alpha_g1": pr.g1_from_bytes(params["vk"][0:97]), "beta_g2": pr.g2_from_bytes(params["vk"][194:387]),
+          "gamma_g2": pr.g2_from_bytes(params["vk"][387:580]), "delta_g2": pr.g2_from_bytes(params["vk"][677:870]),
+          "ic": [pr.g1_from_bytes(params["ic"][97 * i:97 * i + 97]) for i in range(6)]}
+    assert pr.groth16_verify(vk, [456, 0, 123, aux, 123], pr.proof_from_bytes(proof))
+    assert not pr.groth16_verify(vk, [457, 0, 123, aux, 123], pr.proof_from_bytes(proof))
