@@ -121,7 +121,7 @@ BZK_HD XyzzT<F> xyzz_neg(const XyzzT<F>& p) {
 
 // affine (x, y); returns false for the identity
 template <class F>
-__host__ __device__ inline bool xyzz_to_affine(const XyzzT<F>& p, AffineT<F>& out) {
+BZK_HD bool xyzz_to_affine(const XyzzT<F>& p, AffineT<F>& out) {
     typedef typename F::T T;
     if (xyzz_is_identity<F>(p)) {
         out.x = F::zero();
@@ -138,7 +138,7 @@ __host__ __device__ inline bool xyzz_to_affine(const XyzzT<F>& p, AffineT<F>& ou
 
 // k * p for a small scalar k (< 2^32), double-and-add, used in bucket-chunk recombination
 template <class F>
-__host__ __device__ inline XyzzT<F> xyzz_mul_u32(const XyzzT<F>& p, uint32_t k) {
+BZK_HD XyzzT<F> xyzz_mul_u32(const XyzzT<F>& p, uint32_t k) {
     XyzzT<F> r = xyzz_identity<F>();
     for (int i = 31; i >= 0; --i) {
         r = xyzz_dbl<F>(r);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <string>
 #include <vector>
@@ -31,6 +32,7 @@ struct bzk_ctx {
     // MSM tuning overrides (0 = automatic); settable through env BZK_MSM_C / BZK_MSM_CHUNK
     int msm_c_override = 0;
     int msm_chunk_override = 0;
+    bool debug = false;  // env BZK_DEBUG=1: synchronise + log after every launch (hang localisation)
     // NTT twiddle cache: per log_n, forward and inverse tables
     void* ntt_tw[33][2] = {};
 };
@@ -98,6 +100,13 @@ struct ProfScope {
             hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);              \
         }                                                                                           \
         hipError_t e__ = hipGetLastError();                                                         \
+        if (e__ == hipSuccess && (ctx)->debug) {                                                    \
+            fprintf(stderr, "[bzk] launched %s ...", name);                                         \
+            fflush(stderr);                                                                         \
+            e__ = hipStreamSynchronize((ctx)->stream);                                              \
+            fprintf(stderr, " %s\n", e__ == hipSuccess ? "done" : hipGetErrorString(e__));          \
+            fflush(stderr);                                                                         \
+        }                                                                                           \
         if (e__ != hipSuccess) {                                                                    \
             (ctx)->last_error = std::string("launch ") + name + ": " + hipGetErrorString(e__);      \
             return BZK_E_DEVICE;                                                                    \

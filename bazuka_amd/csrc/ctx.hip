@@ -92,6 +92,7 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     }
     if (const char* e = getenv("BZK_MSM_C")) ctx->msm_c_override = atoi(e);
     if (const char* e = getenv("BZK_MSM_CHUNK")) ctx->msm_chunk_override = atoi(e);
+    if (const char* e = getenv("BZK_DEBUG")) ctx->debug = atoi(e) != 0;
     *out = ctx;
     return BZK_OK;
 }

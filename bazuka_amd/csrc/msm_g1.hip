@@ -1,5 +1,8 @@
-// K4: G1 instantiation of the Pippenger pipeline (see msm_impl.cuh).  Fp products are inlined here:
-// msm_accumulate<G1> is the dominant kernel of a proof and benefits from cross-product scheduling.
+// K4: G1 instantiation of the Pippenger pipeline (see msm_impl.cuh).  The Fp product is a real
+// function (BZK_FP_NOINLINE): one inlined product is ~11 KB of code, an XYZZ mixed add ten of them -
+// more than the 64 KB instruction cache - and the first GPU measurements showed the fully inlined
+// kernels fetch-bound (200 us per mixed add at low occupancy).  As a call the hot loop stays resident.
+#define BZK_FP_NOINLINE 1
 #include "msm_impl.cuh"
 using namespace bzk;
 

@@ -64,19 +64,15 @@ def main():
     scalars = scalars.contiguous()
     torch.cuda.synchronize()
 
+    from bazuka_amd.dist import allgather_fold, window_range
     W = ctx.msm_window_count(n)
-    w0, w1 = W * rank // world, W * (rank + 1) // world
-    gather_in = torch.zeros(104, dtype=torch.uint8, device=dev)
-    gather_out = torch.zeros(104 * world, dtype=torch.uint8, device=dev)
+    w0, w1 = window_range(W, rank, world)
 
     def step():
         if world == 1:
             return ctx.msm_g1_dev(bases, scalars, n)
         part = ctx.msm_g1_windows_dev(bases, scalars, n, w0, w1)
-        gather_in[:97] = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev, non_blocking=True)
-        dist.all_gather_into_tensor(gather_out, gather_in)
-        parts = gather_out.cpu().numpy().reshape(world, 104)[:, :97].tobytes()
-        return ctx.g1_sum(parts)
+        return allgather_fold(part, device=dev)  # RCCL all-gather of 97-byte partials + local fold
 
     def fence():
         if world > 1:

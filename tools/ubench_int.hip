@@ -124,6 +124,81 @@ __global__ void k_femul(uint32_t* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// same product through a real function call (by-value args travel in VGPRs)
+__device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fe_mul<FpParams>(a, b); }
+template <int ILP>
+__global__ void k_femul_call(uint32_t* out, int iters) {
+    Fp x[ILP], y;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) y.l[i] = FpParams::R2[i] ^ threadIdx.x;
+    y.l[11] &= 0x0fffffff;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) x[k].l[i] = FpParams::ONE[i] + k;
+        x[k].l[11] &= 0x0fffffff;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) x[k] = fp_mul_call(x[k], y);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) s ^= x[k].l[0] ^ x[k].l[11];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// reduced-radix prototype: 14 x 28-bit limbs, column accumulators in 64 bits, no carry chains
+struct Fp28 { uint32_t l[14]; };
+__device__ constexpr uint32_t P28[14] = {0xfffaaab, 0xffeffff, 0x53ffffb, 0x3fffeb1, 0xf6241ea, 0x0a0f6b0, 0x12bf673,
+                                         0x084f385, 0x764774b, 0x034bacd, 0xba7b643, 0x069a4b1, 0xea397fe, 0x01a0111};
+template <bool CALL>
+__device__ __forceinline__ Fp28 mul28_body(const Fp28& a, const Fp28& b) {
+    constexpr int N = 14, W = 28;
+    constexpr uint32_t MASK = (1u << W) - 1, PINV = 0xffcfffd;
+    uint64_t c[2 * N];
+#pragma unroll
+    for (int k = 0; k < 2 * N; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P28[j];
+        c[i + 1] += c[i] >> W;
+    }
+    Fp28 r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+        c[k + 1] += c[k] >> W;
+        r.l[k - N] = (uint32_t)c[k] & MASK;
+    }
+    r.l[N - 1] = (uint32_t)c[2 * N - 1] & MASK;
+    return r;
+}
+__device__ __noinline__ Fp28 mul28_call(Fp28 a, Fp28 b) { return mul28_body<true>(a, b); }
+template <int ILP, bool CALL>
+__global__ void k_mul28(uint32_t* out, int iters) {
+    Fp28 x[ILP], y;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) y.l[i] = (P28[i] ^ threadIdx.x) & 0xfffffff;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k)
+#pragma unroll
+        for (int i = 0; i < 14; ++i) x[k].l[i] = (P28[13 - i] + k) & 0xfffffff;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) x[k] = CALL ? mul28_call(x[k], y) : mul28_body<false>(x[k], y);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) s ^= x[k].l[0] ^ x[k].l[13];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <class F>
 static double time_kernel(F launch, int reps = 3) {
     hipEvent_t a, b;
@@ -145,6 +220,7 @@ static double time_kernel(F launch, int reps = 3) {
 int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
+    setvbuf(stdout, nullptr, _IONBF, 0);
     printf("device: %s, CUs %d, clock %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
     void* buf; CK(hipMalloc(&buf, 256 << 20));
     const int blocks = prop.multiProcessorCount * 8, threads = 256, iters = 4096;
@@ -174,6 +250,10 @@ int main() {
             run("Fp mul (12x32 CIOS)", [&](int b, int t) { hipLaunchKernelGGL((k_femul<FpParams, 1>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
             run("Fp mul (12x32 CIOS)", [&](int b, int t) { hipLaunchKernelGGL((k_femul<FpParams, 2>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
             run("Fr mul (8x32 CIOS)", [&](int b, int t) { hipLaunchKernelGGL((k_femul<FrParams, 2>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
+            run("Fp mul 12x32 via CALL", [&](int b, int t) { hipLaunchKernelGGL((k_femul_call<1>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
+            run("Fp mul 14x28 inline", [&](int b, int t) { hipLaunchKernelGGL((k_mul28<1, false>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
+            run("Fp mul 14x28 inline", [&](int b, int t) { hipLaunchKernelGGL((k_mul28<2, false>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
+            run("Fp mul 14x28 via CALL", [&](int b, int t) { hipLaunchKernelGGL((k_mul28<1, true>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
         }
     }
     CK(hipFree(buf));
