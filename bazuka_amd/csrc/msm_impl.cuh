@@ -162,25 +162,85 @@ __device__ __forceinline__ G2Affine load_affine<Fp2Ops>(const void* bases, uint3
 
 // ------------------------------------------------------------------------------------------------
 // 5. bucket accumulation (dominant kernel)
+//
+// Work unit = a TASK: a run of at most MSM_SEG consecutive entries of one bucket.  Buckets are taken in
+// population order (largest first), so (a) the 64 lanes of a wavefront run equally long loops and
+// (b) a heavily populated bucket - real witnesses put ~10 % of the scalars on the value 1, and a short
+// top window concentrates n points on a handful of buckets - is spread over many lanes instead of
+// serialising on one.  Multi-task buckets write per-task partial sums, folded by msm_fold_kernel.
 // ------------------------------------------------------------------------------------------------
+static constexpr uint32_t MSM_SEG = 256;
+
+static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* __restrict__ count_sorted, uint32_t nb,
+                                                               uint32_t* __restrict__ ntask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const uint32_t c = count_sorted[i];
+    ntask[i] = c <= MSM_SEG ? 1u : (c + MSM_SEG - 1) / MSM_SEG;  // empty buckets keep one task (writes the identity)
+}
+
 template <class F>
 __global__ void __launch_bounds__(128) msm_accumulate_kernel(const void* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                              const uint32_t* __restrict__ start,
-                                                             const uint32_t* __restrict__ count,
-                                                             const uint32_t* __restrict__ order, uint32_t nb,
-                                                             XyzzT<F>* __restrict__ buckets) {
+                                                             const uint32_t* __restrict__ count_sorted,
+                                                             const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t t_max,
+                                                             XyzzT<F>* __restrict__ buckets, XyzzT<F>* __restrict__ partial) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nb) return;
-    const uint32_t g = order[t];
-    const uint32_t s = start[g], cnt = count[g];
+    if (t >= t_max) return;
+    // last sorted position i with tbase[i] <= t
+    uint32_t lo = 0, hi = nb;
+    while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tbase[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t i = lo;
+    const uint32_t cnt = count_sorted[i];
+    const uint32_t k = t - tbase[i];
+    if (k * MSM_SEG >= cnt && !(cnt == 0 && k == 0)) return;  // beyond the last task
+    const uint32_t g = order[i];
+    const uint32_t s = start[g] + k * MSM_SEG;
+    const uint32_t len = cnt - k * MSM_SEG < MSM_SEG ? cnt - k * MSM_SEG : MSM_SEG;
     XyzzT<F> acc = xyzz_identity<F>();
-    for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t v = vals[s + k];
+    for (uint32_t j = 0; j < len; ++j) {
+        const uint32_t v = vals[s + j];
         AffineT<F> p = load_affine<F>(bases, v & 0x7fffffffu);
         if (v >> 31) p.y = F::neg(p.y);
         xyzz_add_mixed<F>(acc, p);
     }
-    buckets[g] = acc;
+    if (cnt <= MSM_SEG) buckets[g] = acc;
+    else partial[t] = acc;
+}
+
+// one 64-lane workgroup per multi-task bucket: lanes stride over the partial sums, LDS tree, lane 0 stores
+template <class F>
+__global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ tbase, uint32_t nb,
+                                                      const XyzzT<F>* __restrict__ partial, XyzzT<F>* __restrict__ buckets) {
+    __shared__ XyzzT<F> sh[64];
+    const uint32_t i = blockIdx.x;
+    if (i >= nb) return;
+    const uint32_t cnt = count_sorted[i];
+    if (cnt <= MSM_SEG) return;  // wave-uniform: whole workgroup leaves
+    const uint32_t nt = (cnt + MSM_SEG - 1) / MSM_SEG;
+    const XyzzT<F>* src = partial + tbase[i];
+    XyzzT<F> acc = xyzz_identity<F>();
+    for (uint32_t j = threadIdx.x; j < nt; j += 64) {
+        XyzzT<F> p = src[j];
+        xyzz_add<F>(acc, p);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            XyzzT<F> a = sh[threadIdx.x], b = sh[threadIdx.x + s];
+            xyzz_add<F>(a, b);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) buckets[order[i]] = sh[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,18 +422,22 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
     const uint32_t nb_max = (uint32_t)group * half;
 
     // rocPRIM temp sizes
-    size_t tmp1 = 0, tmp2 = 0;
+    size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
     {
         uint32_t* nul = nullptr;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp1, nul, nul, nul, nul, (size_t)len_max, 0, bits_for(nb_max), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_max, 0, bits_for(n), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
+        e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)nb_max, rocprim::plus<uint32_t>(), ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
     }
-    const size_t tmp = std::max(tmp1, tmp2);
+    const size_t tmp = std::max(std::max(tmp1, tmp2), tmp3);
+    const uint64_t t_cap = (uint64_t)nb_max + len_max / MSM_SEG + 1;  // upper bound on the number of tasks
     size_t total = 0;
     total += 4 * ws_pad(len_max * 4);                 // keys, vals, keys_sorted, vals_sorted
-    total += 5 * ws_pad((size_t)nb_max * 4);          // start, count, count_sorted, iota, order
+    total += 7 * ws_pad((size_t)nb_max * 4);          // start, count, count_sorted, iota, order, ntask, tbase
+    total += ws_pad((size_t)t_cap * sizeof(Pt));      // per-task partial sums (multi-task buckets only)
     total += ws_pad((size_t)nb_max * sizeof(Pt));     // buckets
     total += ws_pad((size_t)group * per_win * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(Pt));
@@ -390,6 +454,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
     uint32_t* count_s = cur.take<uint32_t>(nb_max);
     uint32_t* iota = cur.take<uint32_t>(nb_max);
     uint32_t* order = cur.take<uint32_t>(nb_max);
+    uint32_t* ntask = cur.take<uint32_t>(nb_max);
+    uint32_t* tbase = cur.take<uint32_t>(nb_max);
+    Pt* partial = cur.take<Pt>(t_cap);
     Pt* buckets = cur.take<Pt>(nb_max);
     Pt* chunk_out = cur.take<Pt>((size_t)group * per_win);
     Pt* win_out = cur.take<Pt>(w_total);
@@ -419,9 +486,24 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
             hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, count, count_s, iota, order, (size_t)nb, 0, bits_for(n), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
+        BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, count_s, nb, ntask);
+        {
+            ProfScope ps(ctx, "msm_scan_tasks");
+            size_t t = tmp;
+            hipError_t e = rocprim::exclusive_scan(tmp_buf, t, ntask, tbase, 0u, (size_t)nb, rocprim::plus<uint32_t>(), ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+        }
+        const uint32_t t_max = (uint32_t)((uint64_t)nb + len / MSM_SEG + 1);
         auto k_acc = msm_accumulate_kernel<F>;
+        auto k_fold = msm_fold_kernel<F>;
         auto k_red = msm_reduce_kernel<F>;
-        BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((nb + 127) / 128), dim3(128), 0, bases, vals_s, start, count, order, nb, buckets);
+        BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, start, count_s, order, tbase, nb,
+                   t_max, buckets, partial);
+        {
+            // only sorted positions < len / MSM_SEG can hold a multi-task bucket
+            const uint32_t n_fold = (uint32_t)std::min<uint64_t>(nb, len / MSM_SEG + 1);
+            BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_fold), dim3(64), 0, count_s, order, tbase, nb, partial, buckets);
+        }
         const uint32_t n_chunks = (uint32_t)wc * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);
         constexpr int WT = F::LIMBS == 12 ? 256 : 128;

@@ -155,10 +155,15 @@ __device__ __forceinline__ void wide_mac(uint32_t (&acc)[17], const Fr& a, const
 
 // Montgomery reduction of a 17-limb value v < t * r^2 (t <= 17, so v < 2^5 * 2^510 < 2^544) to
 // v * R^-1 mod r, fully reduced.
-__device__ __noinline__ Fr wide_reduce(const uint32_t* __restrict__ acc_in) {
+struct Wide17 {
+    uint32_t v[17];
+};
+// by-value argument (17 VGPRs): never hand a noinline device function a pointer into the caller's
+// private arrays - that form hung on gfx950 / ROCm 7.2 in the first GPU session
+__device__ __noinline__ Fr wide_reduce(Wide17 acc_in) {
     uint32_t a[18];
 #pragma unroll
-    for (int i = 0; i < 17; ++i) a[i] = acc_in[i];
+    for (int i = 0; i < 17; ++i) a[i] = acc_in.v[i];
     a[17] = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -233,11 +238,11 @@ __global__ void __launch_bounds__(128) poseidon_kernel(const Fr* __restrict__ in
         Fr nw[T];
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            uint32_t acc[17];
+            Wide17 acc;
 #pragma unroll
-            for (int q = 0; q < 17; ++q) acc[q] = 0;
+            for (int q = 0; q < 17; ++q) acc.v[q] = 0;
 #pragma unroll
-            for (int k = 0; k < T; ++k) wide_mac(acc, st[k], mds[j * T + k].l);
+            for (int k = 0; k < T; ++k) wide_mac(acc.v, st[k], mds[j * T + k].l);
             nw[j] = wide_reduce(acc);
         }
 #pragma unroll
