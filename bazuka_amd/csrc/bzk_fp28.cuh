@@ -1,0 +1,343 @@
+// Fp in reduced radix for the gfx950 integer pipe: 14 limbs of 28 bits, Montgomery factor R' = 2^392.
+//
+// Why: CDNA4's multiplier is v_mad_u64_u32 (32x32 + 64 -> 64, measured 31.4 Top/s).  With saturated
+// 32-bit limbs every partial product needs a carry (v_addc + VCC hazards) or, as hipcc lowers the
+// textbook CIOS, ~2.6 v_mov per mad to build even-aligned 64-bit addend pairs (1419 instructions per
+// product, 41.6 G products/s measured).  With 28-bit limbs a column accumulator is a plain u64 that
+// absorbs all 2 x 14 partial products of a Montgomery product without overflow:
+//       c[i+j] = a[i] * b[j] + c[i+j]        <- one v_mad_u64_u32, destination == addend
+// 394 mads + ~125 other instructions per product (519 total, measured 71.5 G products/s as a function
+// call).  Additions are 14 independent v_add_u32 (no carry chain); subtraction adds a multiple of p
+// laid out so that no limb can underflow.  Values are kept only WEAKLY reduced (below a small multiple
+// of p) with per-operation bounds documented below and checked by the host harness
+// (tests/host/hostcheck.hip runs this very header on the CPU with bound assertions).
+//
+// Bounds (k = value < k*p, L = every limb < 2^L):
+//   mul(a, b)   needs  14 * 2^(La+Lb) + 14 * 2^56 < 2^64 (La + Lb <= 59.2 suffices) and ka * kb <= 2048
+//               gives  k = 2, L = 28 (normalised; top limb < 2^18)
+//   add(a, b)   gives  k = ka + kb, limbs add
+//   sub<K>(a,b) needs  b normalised (L = 28) and kb < K ; gives k = ka + K, limbs < 2^La + 2^29
+//   norm(a)     carry propagation only: same value, L = 28 (value must be < 2^392)
+// The memory/ABI form stays 12 x 32-bit Montgomery (R = 2^384); to28 / from28 convert (one product each).
+#pragma once
+#include "bzk_curve.cuh"
+#if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+#include <assert.h>
+#endif
+
+namespace bzk {
+
+struct alignas(8) Fp28 {
+    uint32_t l[14];
+};
+
+namespace fp28 {
+
+static constexpr int N = 14;
+static constexpr int W = 28;
+static constexpr uint32_t MASK = (1u << W) - 1;
+static constexpr uint32_t PINV = 0xffcfffdu;  // -p^-1 mod 2^28
+
+struct Consts {
+    uint32_t v[14];
+};
+// p
+static constexpr Consts P = {{0xfffaaabu, 0xfefffffu, 0x3ffffb9u, 0xfffeb15u, 0x6241eabu, 0xa0f6b0fu, 0xf6730d2u,
+                              0xf38512bu, 0x4774b84u, 0x4bacd76u, 0xba7b643u, 0xe69a4b1u, 0x1ea397fu, 0x001a011u}};
+// K*p with limb i (i < 13) raised by 2^28 (-1 for i > 0) and the top limb lowered by 1: same value, every
+// limb below the top is >= 2^28 - 1, so `D[i] - b[i]` cannot underflow for a normalised b.
+static constexpr Consts D3 = {{0x1fff0001u, 0x1fcffffeu, 0x1bffff2cu, 0x1fffc13eu, 0x126c5c02u, 0x1e2e412du, 0x1e359276u,
+                               0x1da8f382u, 0x1d65e28du, 0x1e306861u, 0x12f722c8u, 0x1b3cee14u, 0x15beac7eu, 0x004e032u}};
+static constexpr Consts D6 = {{0x1ffe0002u, 0x1f9ffffeu, 0x17fffe5au, 0x1fff827eu, 0x14d8b806u, 0x1c5c825bu, 0x1c6b24eeu,
+                               0x1b51e706u, 0x1acbc51cu, 0x1c60d0c4u, 0x15ee4592u, 0x1679dc29u, 0x1b7d58feu, 0x009c065u}};
+static constexpr Consts D12 = {{0x1ffc0004u, 0x1f3ffffeu, 0x1ffffcb6u, 0x1fff04fdu, 0x19b1700eu, 0x18b904b7u, 0x18d649deu,
+                                0x16a3ce0eu, 0x15978a3au, 0x18c1a18au, 0x1bdc8b26u, 0x1cf3b853u, 0x16fab1fdu, 0x01380ccu}};
+// 2^400 mod p and 2^384 mod p as plain integers (conversion multipliers), 2^392 mod p (Montgomery one)
+static constexpr Consts C_IN = {{0x80e6299u, 0x3500034u, 0xeb12856u, 0xdeb2699u, 0xc988670u, 0x4ef6697u, 0x70983e8u,
+                                 0xa4e6fe9u, 0x3e8a053u, 0xecf271eu, 0xc20d323u, 0x6eb6385u, 0x47f1286u, 0x00156dau}};
+static constexpr Consts C_OUT = {{0x002fffdu, 0x0900000u, 0xc000276u, 0x000bc40u, 0x8baebf4u, 0x5753c75u, 0x55f4898u,
+                                  0x7052574u, 0x7ce5853u, 0x56ec6d7u, 0x71a97a2u, 0xe4935c0u, 0xec3fa80u, 0x0015f65u}};
+static constexpr Consts ONE = {{0x347fcb8u, 0xd800000u, 0x002b119u, 0x0cde6d2u, 0xc7212e0u, 0x83a2090u, 0x037669fu,
+                                0xda0f73eu, 0x9b09b42u, 0x1297bb0u, 0x515d98fu, 0x012ca7cu, 0x659fcfau, 0x000577au}};
+
+BZK_HD Fp28 zero() {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = 0;
+    return r;
+}
+BZK_HD Fp28 one() {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = ONE.v[i];
+    return r;
+}
+BZK_HD bool limbs_all_zero(const Fp28& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o |= a.l[i];
+    return o == 0;
+}
+
+// ---- the product (see bounds in the header comment)
+BZK_HD Fp28 mul_body(const Fp28& a, const Fp28& b) {
+#if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    {  // host harness: the 64-bit column accumulators must never wrap
+        unsigned __int128 worst = 0;
+        uint32_t ma = 0, mb = 0;
+        for (int i = 0; i < N; ++i) { if (a.l[i] > ma) ma = a.l[i]; if (b.l[i] > mb) mb = b.l[i]; }
+        worst = (unsigned __int128)14 * ma * mb + (unsigned __int128)14 * MASK * MASK + ((unsigned __int128)1 << 40);
+        assert(worst < ((unsigned __int128)1 << 64));
+    }
+#endif
+    uint64_t c[2 * N];
+#pragma unroll
+    for (int k = 0; k < 2 * N; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P.v[j];
+        c[i + 1] += c[i] >> W;
+    }
+    Fp28 r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+        c[k + 1] += c[k] >> W;
+        r.l[k - N] = (uint32_t)c[k] & MASK;
+    }
+    r.l[N - 1] = (uint32_t)c[2 * N - 1];
+    return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// one resident copy of the product per kernel image: by-value arguments travel in VGPRs
+__device__ __noinline__ static Fp28 mul_call(Fp28 a, Fp28 b) { return mul_body(a, b); }
+BZK_HD Fp28 mul(const Fp28& a, const Fp28& b) { return mul_call(a, b); }
+BZK_HD Fp28 sqr(const Fp28& a) { return mul_call(a, a); }
+#else
+BZK_HD Fp28 mul(const Fp28& a, const Fp28& b) { return mul_body(a, b); }
+BZK_HD Fp28 sqr(const Fp28& a) { return mul_body(a, a); }
+#endif
+
+BZK_HD Fp28 add(const Fp28& a, const Fp28& b) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+
+// a + K*p - b ; b normalised, value(b) < K*p
+template <int K>
+BZK_HD Fp28 sub(const Fp28& a, const Fp28& b) {
+    static_assert(K == 3 || K == 6 || K == 12, "no table for this multiple of p");
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t d = K == 3 ? D3.v[i] : K == 6 ? D6.v[i] : D12.v[i];
+#if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+        assert(d >= b.l[i]);                                 // no limb underflow
+        assert((uint64_t)a.l[i] + d - b.l[i] < (1ull << 32));  // no u32 overflow
+#endif
+        r.l[i] = a.l[i] + d - b.l[i];
+    }
+    return r;
+}
+
+// carry propagation: limbs -> [0, 2^28), value unchanged (value < 2^392 required)
+BZK_HD Fp28 norm(const Fp28& a) {
+    Fp28 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        const uint32_t t = a.l[i] + c;
+        r.l[i] = t & MASK;
+        c = t >> W;
+    }
+    r.l[N - 1] = a.l[N - 1] + c;
+    return r;
+}
+
+// for a product output (normalised, value in [0, 2p)): is it 0 mod p ?
+BZK_HD bool mulout_is_zero(const Fp28& a) {
+    uint32_t o0 = 0, op = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        o0 |= a.l[i];
+        op |= a.l[i] ^ P.v[i];
+    }
+    return o0 == 0 || op == 0;
+}
+
+// ---- conversions with the 12 x 32-bit, R = 2^384 memory form
+BZK_HD Fp28 repack_from32(const Fp& a) {  // same integer, 28-bit limbs
+    Fp28 r;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int bit = W * k, w = bit >> 5, sh = bit & 31;
+        uint32_t v = a.l[w] >> sh;
+        if (sh + W > 32 && w + 1 < 12) v |= a.l[w + 1] << (32 - sh);
+        r.l[k] = v & MASK;
+    }
+    return r;
+}
+BZK_HD Fp repack_to32(const Fp28& a) {  // a normalised and < 2^384
+    Fp r;
+#pragma unroll
+    for (int w = 0; w < 12; ++w) {
+        // bits [32w, 32w+32)
+        const int lo = (32 * w) / W, sh = 32 * w - W * lo;
+        uint64_t v = (uint64_t)a.l[lo] >> sh;
+        v |= (uint64_t)a.l[lo + 1] << (W - sh);
+        if (2 * W - sh < 32 && lo + 2 < N) v |= (uint64_t)a.l[lo + 2] << (2 * W - sh);
+        r.l[w] = (uint32_t)v;
+    }
+    return r;
+}
+BZK_HD Fp28 consts_as_fp28(const Consts& c) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = c.v[i];
+    return r;
+}
+// x * 2^384 (12x32)  ->  x * 2^392 (14x28), k = 2, normalised
+BZK_HD Fp28 to28(const Fp& a) { return mul(repack_from32(a), consts_as_fp28(C_IN)); }
+// any k <= 1024 value -> canonical 12x32 Montgomery-384 limbs
+BZK_HD Fp from28(const Fp28& a) {
+    Fp28 t = mul(a, consts_as_fp28(C_OUT));  // in [0, 2p), normalised
+    // conditional subtraction of p (borrow chain over 28-bit limbs)
+    Fp28 s;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t d = t.l[i] - P.v[i] - borrow;
+        borrow = d >> 31;  // limbs < 2^28, so a negative difference sets bit 31
+        s.l[i] = d & MASK;
+    }
+    if (!borrow) t = s;
+    return repack_to32(t);
+}
+
+}  // namespace fp28
+
+// ------------------------------------------------------------------------------------------------
+// G1 in XYZZ over Fp28.  Invariants of a stored point: X normalised k <= 11, Y normalised k <= 5,
+// ZZ / ZZZ product outputs (normalised, k = 2); identity <=> all ZZ limbs zero.
+// Affine bases: x, y product outputs of to28 (normalised, k = 2).
+// ------------------------------------------------------------------------------------------------
+struct G1A28 {
+    Fp28 x, y;
+};
+struct G1X28 {
+    Fp28 X, Y, ZZ, ZZZ;
+};
+
+namespace g1x28 {
+using namespace fp28;
+
+BZK_HD G1X28 identity() { return {zero(), one(), zero(), zero()}; }
+BZK_HD bool is_identity(const G1X28& p) { return limbs_all_zero(p.ZZ); }
+
+BZK_HD G1X28 dbl_affine(const G1A28& a) {  // mdbl-2008-s-1
+    Fp28 U = add(a.y, a.y);                 // k 4, L 29
+    Fp28 V = sqr(U), Wv = mul(U, V), S = mul(a.x, V);
+    Fp28 xx = sqr(a.x);
+    Fp28 M = add(add(xx, xx), xx);          // k 6, L < 29.6
+    G1X28 r;
+    r.X = norm(sub<3>(sub<3>(sqr(M), S), S));                 // k 8
+    r.Y = norm(sub<3>(mul(M, sub<12>(S, r.X)), mul(Wv, a.y)));  // k 5
+    r.ZZ = V;
+    r.ZZZ = Wv;
+    return r;
+}
+
+BZK_HD G1X28 dbl(const G1X28& p) {  // dbl-2008-s-1
+    if (is_identity(p)) return p;
+    Fp28 U = add(p.Y, p.Y);                 // k 10, L 29
+    Fp28 V = sqr(U), Wv = mul(U, V), S = mul(p.X, V);
+    Fp28 xx = sqr(p.X);
+    Fp28 M = add(add(xx, xx), xx);
+    G1X28 r;
+    r.X = norm(sub<3>(sub<3>(sqr(M), S), S));
+    r.Y = norm(sub<3>(mul(M, sub<12>(S, r.X)), mul(Wv, p.Y)));
+    r.ZZ = mul(V, p.ZZ);
+    r.ZZZ = mul(Wv, p.ZZZ);
+    return r;
+}
+
+// acc += q  (q affine, never the identity); neg_q: add -q instead
+BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q) {
+    G1A28 q = q_in;
+    if (neg_q) q.y = norm(sub<3>(zero(), q.y));  // 3p - y, k 3
+    if (is_identity(acc)) {
+        acc = {q.x, q.y, one(), one()};
+        return;
+    }
+    Fp28 U2 = mul(q.x, acc.ZZ), S2 = mul(q.y, acc.ZZZ);
+    Fp28 Pp = sub<12>(U2, acc.X);  // k 14
+    Fp28 R = sub<6>(S2, acc.Y);    // k 8
+    Fp28 PP = sqr(Pp);
+    if (mulout_is_zero(PP)) {  // same x: doubling or cancellation (rare)
+        Fp28 RR = sqr(R);
+        if (mulout_is_zero(RR)) acc = dbl_affine(q);
+        else acc = identity();
+        return;
+    }
+    Fp28 PPP = mul(Pp, PP), Q = mul(acc.X, PP), RR = sqr(R);
+    Fp28 X3 = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));             // k 11
+    Fp28 Y3 = norm(sub<3>(mul(R, sub<12>(Q, X3)), mul(acc.Y, PPP)));   // k 5
+    acc.X = X3;
+    acc.Y = Y3;
+    acc.ZZ = mul(acc.ZZ, PP);
+    acc.ZZZ = mul(acc.ZZZ, PPP);
+}
+
+BZK_HD void add_full(G1X28& acc, const G1X28& q) {  // add-2008-s
+    if (is_identity(q)) return;
+    if (is_identity(acc)) {
+        acc = q;
+        return;
+    }
+    Fp28 U1 = mul(acc.X, q.ZZ), U2 = mul(q.X, acc.ZZ);
+    Fp28 S1 = mul(acc.Y, q.ZZZ), S2 = mul(q.Y, acc.ZZZ);
+    Fp28 Pp = sub<3>(U2, U1), R = sub<3>(S2, S1);  // k 5
+    Fp28 PP = sqr(Pp);
+    if (mulout_is_zero(PP)) {
+        Fp28 RR = sqr(R);
+        if (mulout_is_zero(RR)) acc = dbl(acc);
+        else acc = identity();
+        return;
+    }
+    Fp28 PPP = mul(Pp, PP), Q = mul(U1, PP), RR = sqr(R);
+    Fp28 X3 = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));
+    Fp28 Y3 = norm(sub<3>(mul(R, sub<12>(Q, X3)), mul(S1, PPP)));
+    acc.X = X3;
+    acc.Y = Y3;
+    acc.ZZ = mul(mul(acc.ZZ, q.ZZ), PP);
+    acc.ZZZ = mul(mul(acc.ZZZ, q.ZZZ), PPP);
+}
+
+BZK_HD G1X28 mul_u32(const G1X28& p, uint32_t k) {
+    G1X28 r = identity();
+    for (int i = 31; i >= 0; --i) {
+        r = dbl(r);
+        if ((k >> i) & 1) add_full(r, p);
+    }
+    return r;
+}
+
+BZK_HD G1A28 affine_to28(const G1Affine& a) { return {to28(a.x), to28(a.y)}; }
+
+// -> standard XYZZ over 12x32 limbs (canonical field elements) for the host-side Horner / packing
+BZK_HD G1Xyzz to_std(const G1X28& p) {
+    if (is_identity(p)) return xyzz_identity<FpOps>();
+    return {from28(p.X), from28(p.Y), from28(p.ZZ), from28(p.ZZZ)};
+}
+
+}  // namespace g1x28
+}  // namespace bzk

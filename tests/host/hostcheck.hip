@@ -1,6 +1,7 @@
 // TEST HARNESS (not product): runs the __host__ __device__ field / curve code of libbzk on the CPU
 // so that limb-level logic is checked against the oracle in this GPU-less container.
-#include "../../bazuka_amd/csrc/bzk_curve.cuh"
+#define BZK_FP28_CHECK 1
+#include "../../bazuka_amd/csrc/bzk_fp28.cuh"
 #include <string.h>
 using namespace bzk;
 
@@ -38,6 +39,36 @@ static void st_g2(uint8_t* o, const G2Xyzz& p) {
 }
 
 extern "C" {
+// radix-2^28 field (device header run on the CPU with bound assertions)
+int hc_fp28_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    Fp x = ld<FpParams>(a), y = ld<FpParams>(b);
+    st<FpParams>(out, fp28::from28(fp28::mul(fp28::to28(x), fp28::to28(y))));
+    return 0;
+}
+int hc_fp28_roundtrip(const uint8_t* a, uint8_t* out) {
+    st<FpParams>(out, fp28::from28(fp28::to28(ld<FpParams>(a))));
+    return 0;
+}
+// sum_i (+/-) k_i * P_i through the XYZZ/Fp28 ops: mixed add (with negation), full add, doubling
+int hc_g1x28_lincomb(const uint8_t* pts, const uint32_t* k, const uint8_t* neg, int n, uint8_t* out97) {
+    G1X28 acc = g1x28::identity();
+    for (int i = 0; i < n; ++i) {
+        G1A28 a = g1x28::affine_to28(ld_g1(pts + 96 * i));
+        G1X28 t = g1x28::identity();
+        g1x28::add_mixed(t, a, neg[i] != 0);
+        G1X28 m = g1x28::mul_u32(t, k[i]);
+        g1x28::add_full(acc, m);
+    }
+    st_g1(out97, g1x28::to_std(acc));
+    return 0;
+}
+// acc = sum of (+/-) points via repeated mixed add; long chains exercise the weak-reduction bounds
+int hc_g1x28_sum_mixed(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* out97) {
+    G1X28 acc = g1x28::identity();
+    for (int i = 0; i < n; ++i) g1x28::add_mixed(acc, g1x28::affine_to28(ld_g1(pts + 96 * i)), neg[i] != 0);
+    st_g1(out97, g1x28::to_std(acc));
+    return 0;
+}
 int hc_fr_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) { return field_op<FrParams>(op, a, b, out); }
 int hc_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) { return field_op<FpParams>(op, a, b, out); }
 
