@@ -17,14 +17,14 @@ uint32_t bzk_msm_window_count(uint64_t n) {
     return (uint32_t)msm_windows_for(c);
 }
 int32_t bzk_msm_g1_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, uint8_t out[97]) {
-    return msm_entry_dev<FpOps>(ctx, bases, scalars, n, flags, 0, -1, out);
+    return msm_entry_dev<G1Fast>(ctx, bases, scalars, n, flags, 0, -1, out);
 }
 int32_t bzk_msm_g1_windows_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags,
                                uint32_t w_begin, uint32_t w_end, uint8_t out[97]) {
-    return msm_entry_dev<FpOps>(ctx, bases, scalars, n, flags, (int)w_begin, (int)w_end, out);
+    return msm_entry_dev<G1Fast>(ctx, bases, scalars, n, flags, (int)w_begin, (int)w_end, out);
 }
 int32_t bzk_msm_g1(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[97]) {
-    return msm_entry_host<FpOps>(ctx, bases, scalars, n, flags, out);
+    return msm_entry_host<G1Fast>(ctx, bases, scalars, n, flags, out);
 }
 int32_t bzk_g1_sum(const uint8_t* pts, uint32_t count, uint8_t out[97]) { return sum_packed<FpOps>(pts, count, out); }
 int32_t bzk_g1_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev) {

@@ -24,8 +24,8 @@
 #include <algorithm>
 #include <cstring>
 
-#include "bzk_curve.cuh"
 #include "bzk_internal.h"
+#include "msm_policy.cuh"
 
 namespace bzk {
 
@@ -41,10 +41,6 @@ static int msm_pick_c(uint64_t n) {
     return c;
 }
 static int msm_windows_for(int c) { return (256 + c - 1) / c; }  // signed digits need one spare bit
-
-struct alignas(16) U128 {
-    uint32_t x, y, z, w;
-};
 
 // ------------------------------------------------------------------------------------------------
 // 1. digits
@@ -124,40 +120,13 @@ static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// point loads
+// 4b. base conversion to the policy's internal form (G1: 14 x 28-bit limbs); one pass per call
 // ------------------------------------------------------------------------------------------------
-template <class F>
-__device__ __forceinline__ AffineT<F> load_affine(const void* bases, uint32_t idx);
-
-template <>
-__device__ __forceinline__ G1Affine load_affine<FpOps>(const void* bases, uint32_t idx) {
-    const U128* p = (const U128*)bases + (size_t)idx * 6;
-    G1Affine a;
-    U128 v[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = p[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        a.x.l[4 * k] = v[k].x; a.x.l[4 * k + 1] = v[k].y; a.x.l[4 * k + 2] = v[k].z; a.x.l[4 * k + 3] = v[k].w;
-        a.y.l[4 * k] = v[k + 3].x; a.y.l[4 * k + 1] = v[k + 3].y; a.y.l[4 * k + 2] = v[k + 3].z; a.y.l[4 * k + 3] = v[k + 3].w;
-    }
-    return a;
-}
-
-template <>
-__device__ __forceinline__ G2Affine load_affine<Fp2Ops>(const void* bases, uint32_t idx) {
-    const U128* p = (const U128*)bases + (size_t)idx * 12;
-    G2Affine a;
-    Fp* f[4] = {&a.x.c0, &a.x.c1, &a.y.c0, &a.y.c1};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            U128 v = p[3 * e + k];
-            f[e]->l[4 * k] = v.x; f[e]->l[4 * k + 1] = v.y; f[e]->l[4 * k + 2] = v.z; f[e]->l[4 * k + 3] = v.w;
-        }
-    }
-    return a;
+template <class C>
+__global__ void __launch_bounds__(128) msm_convert_bases_kernel(const void* __restrict__ raw, uint64_t n,
+                                                                typename C::DevAff* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = C::convert(raw, i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -179,13 +148,14 @@ static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* _
     ntask[i] = c <= MSM_SEG ? 1u : (c + MSM_SEG - 1) / MSM_SEG;  // empty buckets keep one task (writes the identity)
 }
 
-template <class F>
+template <class C>
 __global__ void __launch_bounds__(128) msm_accumulate_kernel(const void* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                              const uint32_t* __restrict__ start,
                                                              const uint32_t* __restrict__ count_sorted,
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t t_max,
-                                                             XyzzT<F>* __restrict__ buckets, XyzzT<F>* __restrict__ partial) {
+                                                             typename C::Pt* __restrict__ buckets,
+                                                             typename C::Pt* __restrict__ partial) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= t_max) return;
     // last sorted position i with tbase[i] <= t
@@ -202,40 +172,41 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const void* __restr
     const uint32_t g = order[i];
     const uint32_t s = start[g] + k * MSM_SEG;
     const uint32_t len = cnt - k * MSM_SEG < MSM_SEG ? cnt - k * MSM_SEG : MSM_SEG;
-    XyzzT<F> acc = xyzz_identity<F>();
+    typename C::Pt acc = C::identity();
     for (uint32_t j = 0; j < len; ++j) {
         const uint32_t v = vals[s + j];
-        AffineT<F> p = load_affine<F>(bases, v & 0x7fffffffu);
-        if (v >> 31) p.y = F::neg(p.y);
-        xyzz_add_mixed<F>(acc, p);
+        typename C::DevAff p = C::load(bases, v & 0x7fffffffu);
+        C::add_mixed(acc, p, (v >> 31) != 0);
     }
     if (cnt <= MSM_SEG) buckets[g] = acc;
     else partial[t] = acc;
 }
 
 // one 64-lane workgroup per multi-task bucket: lanes stride over the partial sums, LDS tree, lane 0 stores
-template <class F>
+template <class C>
 __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ order,
                                                       const uint32_t* __restrict__ tbase, uint32_t nb,
-                                                      const XyzzT<F>* __restrict__ partial, XyzzT<F>* __restrict__ buckets) {
-    __shared__ XyzzT<F> sh[64];
+                                                      const typename C::Pt* __restrict__ partial,
+                                                      typename C::Pt* __restrict__ buckets) {
+    typedef typename C::Pt Pt;
+    __shared__ Pt sh[64];
     const uint32_t i = blockIdx.x;
     if (i >= nb) return;
     const uint32_t cnt = count_sorted[i];
     if (cnt <= MSM_SEG) return;  // wave-uniform: whole workgroup leaves
     const uint32_t nt = (cnt + MSM_SEG - 1) / MSM_SEG;
-    const XyzzT<F>* src = partial + tbase[i];
-    XyzzT<F> acc = xyzz_identity<F>();
+    const Pt* src = partial + tbase[i];
+    Pt acc = C::identity();
     for (uint32_t j = threadIdx.x; j < nt; j += 64) {
-        XyzzT<F> p = src[j];
-        xyzz_add<F>(acc, p);
+        Pt p = src[j];
+        C::add(acc, p);
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 32; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
-            XyzzT<F> a = sh[threadIdx.x], b = sh[threadIdx.x + s];
-            xyzz_add<F>(a, b);
+            Pt a = sh[threadIdx.x], b = sh[threadIdx.x + s];
+            C::add(a, b);
             sh[threadIdx.x] = a;
         }
         __syncthreads();
@@ -246,24 +217,25 @@ __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // 6. chunked running-sum reduction:  out[t] = sum_{j<CH} (lo + j + 1) * B[w][lo + j]
 // ------------------------------------------------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(64) msm_reduce_kernel(const XyzzT<F>* __restrict__ buckets, uint32_t half, uint32_t ch,
-                                                        uint32_t n_chunks_total, XyzzT<F>* __restrict__ out) {
+template <class C>
+__global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __restrict__ buckets, uint32_t half, uint32_t ch,
+                                                        uint32_t n_chunks_total, typename C::Pt* __restrict__ out) {
+    typedef typename C::Pt Pt;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_chunks_total) return;
     const uint32_t per_win = half / ch;
     const uint32_t w = t / per_win, k = t % per_win;
     const uint32_t lo = k * ch;
-    const XyzzT<F>* b = buckets + (size_t)w * half + lo;
-    XyzzT<F> run = xyzz_identity<F>(), acc = xyzz_identity<F>();
+    const Pt* b = buckets + (size_t)w * half + lo;
+    Pt run = C::identity(), acc = C::identity();
     for (int j = (int)ch - 1; j >= 0; --j) {
-        XyzzT<F> p = b[j];
-        xyzz_add<F>(run, p);
-        xyzz_add<F>(acc, run);
+        Pt p = b[j];
+        C::add(run, p);
+        C::add(acc, run);
     }
     if (lo) {
-        XyzzT<F> m = xyzz_mul_u32<F>(run, lo);
-        xyzz_add<F>(acc, m);
+        Pt m = C::mul_u32(run, lo);
+        C::add(acc, m);
     }
     out[t] = acc;
 }
@@ -271,28 +243,29 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const XyzzT<F>* __restri
 // ------------------------------------------------------------------------------------------------
 // 7. per-window tree sum of the chunk results
 // ------------------------------------------------------------------------------------------------
-template <class F, int THREADS>
-__global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const XyzzT<F>* __restrict__ chunk_out, uint32_t per_win,
-                                                                 XyzzT<F>* __restrict__ win_out) {
-    __shared__ XyzzT<F> sh[THREADS];
+template <class C, int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const typename C::Pt* __restrict__ chunk_out, uint32_t per_win,
+                                                                 XyzzT<typename C::HostF>* __restrict__ win_out) {
+    typedef typename C::Pt Pt;
+    __shared__ Pt sh[THREADS];
     const uint32_t w = blockIdx.x;
-    const XyzzT<F>* src = chunk_out + (size_t)w * per_win;
-    XyzzT<F> acc = xyzz_identity<F>();
+    const Pt* src = chunk_out + (size_t)w * per_win;
+    Pt acc = C::identity();
     for (uint32_t i = threadIdx.x; i < per_win; i += THREADS) {
-        XyzzT<F> p = src[i];
-        xyzz_add<F>(acc, p);
+        Pt p = src[i];
+        C::add(acc, p);
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = THREADS / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
-            XyzzT<F> a = sh[threadIdx.x], b = sh[threadIdx.x + s];
-            xyzz_add<F>(a, b);
+            Pt a = sh[threadIdx.x], b = sh[threadIdx.x + s];
+            C::add(a, b);
             sh[threadIdx.x] = a;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) win_out[w] = sh[0];
+    if (threadIdx.x == 0) win_out[w] = C::to_std(sh[0]);  // standard 12 x 32-bit XYZZ for the host-side Horner
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -399,11 +372,13 @@ static int bits_for(uint64_t v) {
     return b;
 }
 
-// Computes sum over windows [w_begin, w_end) of 2^(c w) S_w into `result` (host XYZZ).
-template <class F>
-static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
-                       int w_end, XyzzT<F>& result) {
-    typedef XyzzT<F> Pt;
+// Computes sum over windows [w_begin, w_end) of 2^(c w) S_w into `result` (host XYZZ, standard limbs).
+template <class C>
+static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
+                       int w_end, XyzzT<typename C::HostF>& result) {
+    typedef typename C::HostF F;
+    typedef typename C::Pt Pt;
+    typedef XyzzT<F> StdPt;
     result = xyzz_identity<F>();
     if (n == 0 || w_begin >= w_end) return BZK_OK;
     if (n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
@@ -440,10 +415,11 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
     total += ws_pad((size_t)t_cap * sizeof(Pt));      // per-task partial sums (multi-task buckets only)
     total += ws_pad((size_t)nb_max * sizeof(Pt));     // buckets
     total += ws_pad((size_t)group * per_win * sizeof(Pt));
-    total += ws_pad((size_t)w_total * sizeof(Pt));
+    total += ws_pad((size_t)w_total * sizeof(StdPt));
+    if (C::CONVERT_BASES) total += ws_pad((size_t)n * sizeof(typename C::DevAff));
     total += ws_pad(tmp) + 4096;
     BZK_TRY(ws_reserve(ctx, total));
-    BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(Pt)));
+    BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(StdPt)));
     WsCursor cur(ctx->ws);
     uint32_t* keys = cur.take<uint32_t>(len_max);
     uint32_t* vals = cur.take<uint32_t>(len_max);
@@ -459,11 +435,18 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
     Pt* partial = cur.take<Pt>(t_cap);
     Pt* buckets = cur.take<Pt>(nb_max);
     Pt* chunk_out = cur.take<Pt>((size_t)group * per_win);
-    Pt* win_out = cur.take<Pt>(w_total);
+    StdPt* win_out = cur.take<StdPt>(w_total);
+    const void* bases = bases_raw;
+    if (C::CONVERT_BASES) {
+        typename C::DevAff* conv = cur.take<typename C::DevAff>(n);
+        auto k_conv = msm_convert_bases_kernel<C>;
+        BZK_LAUNCH(ctx, "msm_convert_bases", k_conv, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, bases_raw, n, conv);
+        bases = conv;
+    }
     void* tmp_buf = cur.take<char>(tmp);
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;
-    std::vector<Pt> wsum((size_t)(w_end - w_begin));
+    std::vector<StdPt> wsum((size_t)(w_end - w_begin));
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
         const uint64_t len = (uint64_t)wc * n;
@@ -494,9 +477,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
             if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         const uint32_t t_max = (uint32_t)((uint64_t)nb + len / MSM_SEG + 1);
-        auto k_acc = msm_accumulate_kernel<F>;
-        auto k_fold = msm_fold_kernel<F>;
-        auto k_red = msm_reduce_kernel<F>;
+        auto k_acc = msm_accumulate_kernel<C>;
+        auto k_fold = msm_fold_kernel<C>;
+        auto k_red = msm_reduce_kernel<C>;
         BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, start, count_s, order, tbase, nb,
                    t_max, buckets, partial);
         {
@@ -506,15 +489,15 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
         }
         const uint32_t n_chunks = (uint32_t)wc * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);
-        constexpr int WT = F::LIMBS == 12 ? 256 : 128;
-        auto k_ws = msm_window_sum_kernel<F, WT>;
+        constexpr int WT = C::WSUM_THREADS;
+        auto k_ws = msm_window_sum_kernel<C, WT>;
         BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)wc), dim3(WT), 0, chunk_out, per_win, win_out);
-        BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)wc * sizeof(Pt), hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)wc * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy(&wsum[wb - w_begin], ctx->pinned, (size_t)wc * sizeof(Pt));
+        memcpy(&wsum[wb - w_begin], ctx->pinned, (size_t)wc * sizeof(StdPt));
     }
     // Horner over the window sums (host): result = 2^(c*w_begin) * sum_k 2^(c k) S_{w_begin+k}
-    Pt acc = xyzz_identity<F>();
+    StdPt acc = xyzz_identity<F>();
     for (int k = (int)wsum.size() - 1; k >= 0; --k) {
         for (int d = 0; d < c; ++d) acc = xyzz_dbl<F>(acc);
         xyzz_add<F>(acc, wsum[k]);
@@ -524,9 +507,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases, const void* scalars, uin
     return BZK_OK;
 }
 
-template <class F>
+template <class C>
 static int32_t msm_entry_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
                              int w_end, uint8_t* out) {
+    typedef typename C::HostF F;
     if (!ctx || !out || (n && (!bases || !scalars))) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     XyzzT<F> r;
@@ -534,24 +518,24 @@ static int32_t msm_entry_dev(bzk_ctx* ctx, const void* bases, const void* scalar
         const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n ? n : 1);
         w_end = msm_windows_for(c);
     }
-    BZK_TRY(msm_run<F>(ctx, bases, scalars, n, flags, w_begin, w_end, r));
+    BZK_TRY(msm_run<C>(ctx, bases, scalars, n, flags, w_begin, w_end, r));
     PointIO<F>::pack(r, out);
     return BZK_OK;
 }
 
-template <class F>
+template <class C>
 static int32_t msm_entry_host(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t* out) {
     if (!ctx || !out || (n && (!bases || !scalars))) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     void *db = nullptr, *ds = nullptr;
     if (n) {
-        BZK_HIP(ctx, hipMalloc(&db, n * PointIO<F>::RAW));
+        BZK_HIP(ctx, hipMalloc(&db, n * C::RAW));
         if (hipMalloc(&ds, n * 32) != hipSuccess) { (void)hipFree(db); return BZK_E_ALLOC; }
-        hipError_t e1 = hipMemcpyAsync(db, bases, n * PointIO<F>::RAW, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e1 = hipMemcpyAsync(db, bases, n * C::RAW, hipMemcpyHostToDevice, ctx->stream);
         hipError_t e2 = hipMemcpyAsync(ds, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream);
         if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(db); (void)hipFree(ds); return BZK_E_DEVICE; }
     }
-    int32_t st = msm_entry_dev<F>(ctx, db, ds, n, flags, 0, -1, out);
+    int32_t st = msm_entry_dev<C>(ctx, db, ds, n, flags, 0, -1, out);
     (void)hipStreamSynchronize(ctx->stream);
     if (db) (void)hipFree(db);
     if (ds) (void)hipFree(ds);

@@ -1,0 +1,89 @@
+// Curve policies for the Pippenger pipeline (msm_impl.cuh): what a bucket is made of and how points are
+// loaded, added and handed back to the host.
+//   G1Fast  - Fp in reduced radix (bzk_fp28.cuh): buckets are G1X28 (224 B), bases are converted once per
+//             call to the internal 112-byte form (x, y in 14 x 28-bit limbs, Montgomery 2^392)
+//   G2Plain - Fp2 over the 12 x 32-bit field code (generic XYZZ), bases used in their raw 192-byte form
+#pragma once
+#include "bzk_fp28.cuh"
+
+namespace bzk {
+
+struct alignas(16) U128 {
+    uint32_t x, y, z, w;
+};
+
+struct G1Fast {
+    typedef FpOps HostF;
+    typedef G1X28 Pt;
+    typedef G1A28 DevAff;
+    static constexpr int RAW = 96, PACKED = 97;
+    static constexpr bool CONVERT_BASES = true;
+    static constexpr int WSUM_THREADS = 256;  // 256 x 224 B = 56 KiB LDS
+    __device__ static __forceinline__ Pt identity() { return g1x28::identity(); }
+    __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p, bool neg) { g1x28::add_mixed(acc, p, neg); }
+    __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { g1x28::add_full(acc, q); }
+    __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return g1x28::mul_u32(p, k); }
+    __device__ static __forceinline__ XyzzT<FpOps> to_std(const Pt& p) { return g1x28::to_std(p); }
+    // raw 96-byte affine (12 x 32-bit Montgomery-384) -> internal
+    __device__ static __forceinline__ DevAff convert(const void* raw, uint64_t i) {
+        const U128* p = (const U128*)raw + i * 6;
+        G1Affine a;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            U128 v = p[k], w = p[k + 3];
+            a.x.l[4 * k] = v.x; a.x.l[4 * k + 1] = v.y; a.x.l[4 * k + 2] = v.z; a.x.l[4 * k + 3] = v.w;
+            a.y.l[4 * k] = w.x; a.y.l[4 * k + 1] = w.y; a.y.l[4 * k + 2] = w.z; a.y.l[4 * k + 3] = w.w;
+        }
+        return g1x28::affine_to28(a);
+    }
+    // gather of one internal base: 112 B = 7 x 16 B
+    __device__ static __forceinline__ DevAff load(const void* internal, uint32_t idx) {
+        const U128* p = (const U128*)internal + (size_t)idx * 7;
+        U128 v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = p[k];
+        DevAff a;
+        uint32_t* dst = a.x.l;  // x.l[0..13] then y.l[0..13] are contiguous (2 x 56 B)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            dst[4 * k] = v[k].x; dst[4 * k + 1] = v[k].y; dst[4 * k + 2] = v[k].z; dst[4 * k + 3] = v[k].w;
+        }
+        return a;
+    }
+};
+static_assert(sizeof(G1A28) == 112 && sizeof(G1X28) == 224, "internal G1 layouts");
+
+struct G2Plain {
+    typedef Fp2Ops HostF;
+    typedef XyzzT<Fp2Ops> Pt;
+    typedef AffineT<Fp2Ops> DevAff;
+    static constexpr int RAW = 192, PACKED = 193;
+    static constexpr bool CONVERT_BASES = false;
+    static constexpr int WSUM_THREADS = 128;  // 128 x 384 B = 48 KiB LDS
+    __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2Ops>(); }
+    __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p_in, bool neg) {
+        DevAff p = p_in;
+        if (neg) p.y = Fp2Ops::neg(p.y);
+        xyzz_add_mixed<Fp2Ops>(acc, p);
+    }
+    __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2Ops>(acc, q); }
+    __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return xyzz_mul_u32<Fp2Ops>(p, k); }
+    __device__ static __forceinline__ XyzzT<Fp2Ops> to_std(const Pt& p) { return p; }
+    __device__ static __forceinline__ DevAff convert(const void*, uint64_t) { return DevAff(); }
+    __device__ static __forceinline__ DevAff load(const void* bases, uint32_t idx) {
+        const U128* p = (const U128*)bases + (size_t)idx * 12;
+        DevAff a;
+        Fp* f[4] = {&a.x.c0, &a.x.c1, &a.y.c0, &a.y.c1};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                U128 v = p[3 * e + k];
+                f[e]->l[4 * k] = v.x; f[e]->l[4 * k + 1] = v.y; f[e]->l[4 * k + 2] = v.z; f[e]->l[4 * k + 3] = v.w;
+            }
+        }
+        return a;
+    }
+};
+
+}  // namespace bzk
