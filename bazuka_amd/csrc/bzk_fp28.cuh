@@ -223,7 +223,105 @@ BZK_HD Fp from28(const Fp28& a) {
     return repack_to32(t);
 }
 
+// ---- strong reduction: any value < 2048 p with limbs < 2^31  ->  normalised, value < 3p
+// Quotient estimate from the top limb (p / 2^364 = 0x1a011.ea39...): q = floor(top / 0x1a012) never exceeds
+// floor(a / p) and falls short by less than 1.03, so a - q p lies in [0, 2.03 p).
+BZK_HD Fp28 reduce(const Fp28& a) {
+    Fp28 r = norm(a);
+    const uint32_t q = r.l[N - 1] / 0x1a012u;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        const int64_t t = (int64_t)r.l[i] - (int64_t)((uint64_t)q * P.v[i]) + carry;
+        r.l[i] = (uint32_t)t & MASK;
+        carry = t >> W;
+    }
+    r.l[N - 1] = (uint32_t)((int64_t)r.l[N - 1] - (int64_t)((uint64_t)q * P.v[N - 1]) + carry);
+    return r;
+}
+
+// for a reduced value (normalised, < 3p): is it 0 mod p ?
+BZK_HD bool reduced_is_zero(const Fp28& a) {
+    uint32_t o0 = 0, o1 = 0, o2 = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        o0 |= a.l[i];
+        o1 |= a.l[i] ^ P.v[i];
+    }
+    // 2p in normalised limbs
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t t = 2 * P.v[i] + c;
+        const uint32_t limb = i < N - 1 ? (t & MASK) : t;
+        c = t >> W;
+        o2 |= a.l[i] ^ limb;
+    }
+    return o0 == 0 || o1 == 0 || o2 == 0;
+}
+
+// a^(p-2) ; inv(0) = 0.  Input k <= 45, output a product output (k 2).
+BZK_HD Fp28 inv(const Fp28& a) {
+    uint32_t e[12];
+    {
+        uint64_t borrow = 2;
+#pragma unroll 1
+        for (int i = 0; i < 12; ++i) {
+            uint64_t d = (uint64_t)FpParams::MOD[i] - borrow;
+            e[i] = (uint32_t)d;
+            borrow = (d >> 63) & 1;
+        }
+    }
+    Fp28 r = one();
+#pragma unroll 1
+    for (int i = 383; i >= 0; --i) {
+        r = sqr(r);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = mul(r, a);
+    }
+    return r;
+}
+
 }  // namespace fp28
+
+// ------------------------------------------------------------------------------------------------
+// Fp2 = Fp[u]/(u^2+1) over the reduced-radix field, with one uniform discipline so that the generic
+// XYZZ code (bzk_curve.cuh) can run on it unchanged: every component handed out by these operations is
+// normalised with value < 3p (`reduce`), or a product output (< 2p).
+// ------------------------------------------------------------------------------------------------
+struct Fp2x28 {
+    Fp28 c0, c1;
+};
+
+struct Fp2x28Ops {
+    typedef Fp2x28 T;
+    static constexpr int LIMBS = 28;
+    BZK_HD static T zero() { return {fp28::zero(), fp28::zero()}; }
+    BZK_HD static T one() { return {fp28::one(), fp28::zero()}; }
+    BZK_HD static bool is_zero(const T& a) { return fp28::reduced_is_zero(a.c0) && fp28::reduced_is_zero(a.c1); }
+    BZK_HD static T add(const T& a, const T& b) { return {fp28::reduce(fp28::add(a.c0, b.c0)), fp28::reduce(fp28::add(a.c1, b.c1))}; }
+    BZK_HD static T sub(const T& a, const T& b) {
+        return {fp28::reduce(fp28::sub<6>(a.c0, b.c0)), fp28::reduce(fp28::sub<6>(a.c1, b.c1))};
+    }
+    BZK_HD static T neg(const T& a) { return sub(zero(), a); }
+    BZK_HD static T dbl(const T& a) { return add(a, a); }
+    BZK_HD static T mul(const T& a, const T& b) {  // Karatsuba: 3 base-field products
+        using namespace fp28;
+        Fp28 aa = fp28::mul(a.c0, b.c0), bb = fp28::mul(a.c1, b.c1);
+        Fp28 s = fp28::mul(fp28::add(a.c0, a.c1), fp28::add(b.c0, b.c1));
+        return {reduce(fp28::sub<3>(aa, bb)), reduce(fp28::sub<3>(fp28::sub<3>(s, aa), bb))};
+    }
+    BZK_HD static T sqr(const T& a) {  // (c0 + c1)(c0 - c1), 2 c0 c1 : 2 base-field products
+        using namespace fp28;
+        Fp28 m = fp28::mul(a.c0, a.c1);
+        return {fp28::mul(fp28::add(a.c0, a.c1), fp28::sub<6>(a.c0, a.c1)), reduce(fp28::add(m, m))};
+    }
+    BZK_HD static T inv(const T& a) {
+        using namespace fp28;
+        Fp28 d = fp28::inv(reduce(fp28::add(fp28::sqr(a.c0), fp28::sqr(a.c1))));
+        return {fp28::mul(a.c0, d), fp28::mul(reduce(fp28::sub<6>(fp28::zero(), a.c1)), d)};
+    }
+    BZK_HD static bool eq(const T& a, const T& b) { return is_zero(sub(a, b)); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // G1 in XYZZ over Fp28.  Invariants of a stored point: X normalised k <= 11, Y normalised k <= 5,
@@ -340,4 +438,17 @@ BZK_HD G1Xyzz to_std(const G1X28& p) {
 }
 
 }  // namespace g1x28
+
+// G2 over Fp2x28: generic XYZZ code, plus conversions with the 12 x 32-bit memory form
+typedef AffineT<Fp2x28Ops> G2A28;  // 224 B
+typedef XyzzT<Fp2x28Ops> G2X28;    // 448 B
+namespace g2x28 {
+BZK_HD Fp2x28 fp2_to28(const Fp2& a) { return {fp28::to28(a.c0), fp28::to28(a.c1)}; }
+BZK_HD Fp2 fp2_from28(const Fp2x28& a) { return {fp28::from28(a.c0), fp28::from28(a.c1)}; }
+BZK_HD G2A28 affine_to28(const G2Affine& a) { return {fp2_to28(a.x), fp2_to28(a.y)}; }
+BZK_HD G2Xyzz to_std(const G2X28& p) {
+    if (xyzz_is_identity<Fp2x28Ops>(p)) return xyzz_identity<Fp2Ops>();
+    return {fp2_from28(p.X), fp2_from28(p.Y), fp2_from28(p.ZZ), fp2_from28(p.ZZZ)};
+}
+}  // namespace g2x28
 }  // namespace bzk

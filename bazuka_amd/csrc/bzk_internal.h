@@ -52,6 +52,11 @@ struct bzk_ctx {
         if (s__ != BZK_OK) return s__; \
     } while (0)
 
+// groth16.hip hooks used by setup.hip
+int32_t bzk_params_alloc_internal(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out);
+void bzk_params_buffers_internal(bzk_params* p, void** h, void** l, void** a, void** b_g1, void** b_g2);
+void bzk_params_set_vk_internal(bzk_params* p, const uint8_t vk[870]);
+
 namespace bzk {
 
 int32_t ws_reserve(bzk_ctx* ctx, size_t bytes);           // ensures ctx->ws has >= bytes

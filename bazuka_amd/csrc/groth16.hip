@@ -132,7 +132,7 @@ void bzk_params_free(bzk_ctx* ctx, bzk_params* p) {
     delete p;
 }
 
-int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out) {
+static int32_t params_build(bzk_ctx* ctx, const bzk_params_desc* d, bool upload_crs, bzk_params** out) {
     if (!ctx || !d || !out || !d->vk || !d->a_density || !d->b_density) return BZK_E_ARG;
     if (d->log_m > 28 || d->n_in == 0) return BZK_E_ARG;
     *out = nullptr;
@@ -144,7 +144,8 @@ int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out
         if (d->b_density[v]) ib.push_back((uint32_t)v);
     }
     if (ia.size() != d->n_a || ib.size() != d->n_b) return BZK_E_ARG;
-    if ((m > 1 && !d->h) || (d->n_aux && !d->l) || (d->n_a && !d->a) || (d->n_b && (!d->b_g1 || !d->b_g2))) return BZK_E_ARG;
+    if (upload_crs && ((m > 1 && !d->h) || (d->n_aux && !d->l) || (d->n_a && !d->a) || (d->n_b && (!d->b_g1 || !d->b_g2))))
+        return BZK_E_ARG;
     bzk_params* p = new (std::nothrow) bzk_params();
     if (!p) return BZK_E_ALLOC;
     memset(p, 0, sizeof(*p));
@@ -152,8 +153,9 @@ int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out
     memcpy(p->vk, d->vk, 870);
     struct Up { void** dst; const void* src; size_t bytes; };
     Up ups[] = {
-        {&p->h, d->h, (size_t)(m - 1) * 96}, {&p->l, d->l, (size_t)d->n_aux * 96}, {&p->a, d->a, (size_t)d->n_a * 96},
-        {&p->b_g1, d->b_g1, (size_t)d->n_b * 96}, {&p->b_g2, d->b_g2, (size_t)d->n_b * 192},
+        {&p->h, upload_crs ? d->h : nullptr, (size_t)(m - 1) * 96}, {&p->l, upload_crs ? d->l : nullptr, (size_t)d->n_aux * 96},
+        {&p->a, upload_crs ? d->a : nullptr, (size_t)d->n_a * 96}, {&p->b_g1, upload_crs ? d->b_g1 : nullptr, (size_t)d->n_b * 96},
+        {&p->b_g2, upload_crs ? d->b_g2 : nullptr, (size_t)d->n_b * 192},
         {(void**)&p->a_idx, ia.data(), ia.size() * 4}, {(void**)&p->b_idx, ib.data(), ib.size() * 4},
         {&p->d_z, nullptr, (size_t)nv * 32}, {&p->d_a, nullptr, (size_t)m * 32}, {&p->d_b, nullptr, (size_t)m * 32},
         {&p->d_c, nullptr, (size_t)m * 32}, {&p->d_sa, nullptr, (size_t)d->n_a * 32}, {&p->d_sb, nullptr, (size_t)d->n_b * 32},
@@ -173,6 +175,36 @@ int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out
         return BZK_E_DEVICE;
     }
     *out = p;
+    return BZK_OK;
+}
+
+int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out) { return params_build(ctx, d, true, out); }
+
+// which: 0 vk (870 B), 1 h, 2 l, 3 a, 4 b_g1, 5 b_g2 ; copies min(cap, size) bytes, *size_out = full size
+int32_t bzk_params_read(bzk_ctx* ctx, const bzk_params* p, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out) {
+    if (!ctx || !p || (cap && !out)) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t m = (uint64_t)1 << p->log_m;
+    const void* src = nullptr;
+    uint64_t size = 0;
+    switch (which) {
+        case 0: size = 870; break;
+        case 1: src = p->h; size = (m - 1) * 96; break;
+        case 2: src = p->l; size = (uint64_t)p->n_aux * 96; break;
+        case 3: src = p->a; size = (uint64_t)p->n_a * 96; break;
+        case 4: src = p->b_g1; size = (uint64_t)p->n_b * 96; break;
+        case 5: src = p->b_g2; size = (uint64_t)p->n_b * 192; break;
+        default: return BZK_E_ARG;
+    }
+    if (size_out) *size_out = size;
+    const uint64_t nbytes = cap < size ? cap : size;
+    if (!nbytes) return BZK_OK;
+    if (which == 0) {
+        memcpy(out, p->vk, nbytes);
+        return BZK_OK;
+    }
+    BZK_HIP(ctx, hipMemcpyAsync(out, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BZK_OK;
 }
 
@@ -241,3 +273,10 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
 }
 
 }  // extern "C"
+
+// internal hooks for setup.hip (CRS generated in place on the device)
+int32_t bzk_params_alloc_internal(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out) { return params_build(ctx, d, false, out); }
+void bzk_params_buffers_internal(bzk_params* p, void** h, void** l, void** a, void** b_g1, void** b_g2) {
+    *h = p->h; *l = p->l; *a = p->a; *b_g1 = p->b_g1; *b_g2 = p->b_g2;
+}
+void bzk_params_set_vk_internal(bzk_params* p, const uint8_t vk[870]) { memcpy(p->vk, vk, 870); }

@@ -1,6 +1,6 @@
-// K5: G2 instantiation of the Pippenger pipeline (see msm_impl.cuh).  An Fp2 product is three Fp
-// products; they are kept as real function calls here (BZK_FP_NOINLINE) so that the kernels stay
-// inside the instruction cache - a fully inlined XYZZ add over Fp2 is ~25k instructions.
+// K5: G2 instantiation of the Pippenger pipeline (see msm_impl.cuh) on the reduced-radix field
+// (Fp2x28Ops, bzk_fp28.cuh): an Fp2 product is three 14 x 28-bit base-field products, each a call to the
+// one resident copy of fp28::mul, so the kernels stay inside the instruction cache.
 #define BZK_FP_NOINLINE 1
 #include "msm_impl.cuh"
 using namespace bzk;
@@ -8,14 +8,14 @@ using namespace bzk;
 extern "C" {
 
 int32_t bzk_msm_g2_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, uint8_t out[193]) {
-    return msm_entry_dev<G2Plain>(ctx, bases, scalars, n, flags, 0, -1, out);
+    return msm_entry_dev<G2Fast>(ctx, bases, scalars, n, flags, 0, -1, out);
 }
 int32_t bzk_msm_g2_windows_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags,
                                uint32_t w_begin, uint32_t w_end, uint8_t out[193]) {
-    return msm_entry_dev<G2Plain>(ctx, bases, scalars, n, flags, (int)w_begin, (int)w_end, out);
+    return msm_entry_dev<G2Fast>(ctx, bases, scalars, n, flags, (int)w_begin, (int)w_end, out);
 }
 int32_t bzk_msm_g2(bzk_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[193]) {
-    return msm_entry_host<G2Plain>(ctx, bases, scalars, n, flags, out);
+    return msm_entry_host<G2Fast>(ctx, bases, scalars, n, flags, out);
 }
 int32_t bzk_g2_sum(const uint8_t* pts, uint32_t count, uint8_t out[193]) { return sum_packed<Fp2Ops>(pts, count, out); }
 int32_t bzk_g2_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev) {

@@ -138,14 +138,14 @@ __global__ void __launch_bounds__(128) msm_convert_bases_kernel(const void* __re
 // top window concentrates n points on a handful of buckets - is spread over many lanes instead of
 // serialising on one.  Multi-task buckets write per-task partial sums, folded by msm_fold_kernel.
 // ------------------------------------------------------------------------------------------------
-static constexpr uint32_t MSM_SEG = 256;
+static constexpr uint32_t MSM_SEG_MAX = 256;  // longest serial run of mixed adds one lane executes
 
-static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* __restrict__ count_sorted, uint32_t nb,
+static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* __restrict__ count_sorted, uint32_t nb, uint32_t seg,
                                                                uint32_t* __restrict__ ntask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     const uint32_t c = count_sorted[i];
-    ntask[i] = c <= MSM_SEG ? 1u : (c + MSM_SEG - 1) / MSM_SEG;  // empty buckets keep one task (writes the identity)
+    ntask[i] = c <= seg ? 1u : (c + seg - 1) / seg;  // empty buckets keep one task (writes the identity)
 }
 
 template <class C>
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const void* __restr
                                                              const uint32_t* __restrict__ count_sorted,
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t t_max,
-                                                             typename C::Pt* __restrict__ buckets,
+                                                             uint32_t seg, typename C::Pt* __restrict__ buckets,
                                                              typename C::Pt* __restrict__ partial) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= t_max) return;
@@ -168,24 +168,48 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const void* __restr
     const uint32_t i = lo;
     const uint32_t cnt = count_sorted[i];
     const uint32_t k = t - tbase[i];
-    if (k * MSM_SEG >= cnt && !(cnt == 0 && k == 0)) return;  // beyond the last task
+    if (k * seg >= cnt && !(cnt == 0 && k == 0)) return;  // beyond the last task
     const uint32_t g = order[i];
-    const uint32_t s = start[g] + k * MSM_SEG;
-    const uint32_t len = cnt - k * MSM_SEG < MSM_SEG ? cnt - k * MSM_SEG : MSM_SEG;
+    const uint32_t s = start[g] + k * seg;
+    const uint32_t len = cnt - k * seg < seg ? cnt - k * seg : seg;
     typename C::Pt acc = C::identity();
     for (uint32_t j = 0; j < len; ++j) {
         const uint32_t v = vals[s + j];
         typename C::DevAff p = C::load(bases, v & 0x7fffffffu);
         C::add_mixed(acc, p, (v >> 31) != 0);
     }
-    if (cnt <= MSM_SEG) buckets[g] = acc;
+    if (cnt <= seg) buckets[g] = acc;
     else partial[t] = acc;
 }
 
-// one 64-lane workgroup per multi-task bucket: lanes stride over the partial sums, LDS tree, lane 0 stores
+static constexpr uint32_t MSM_FOLD_SMALL = 16;  // buckets with at most this many tasks are folded by one lane
+
+// multi-task buckets with few tasks: one lane per bucket (sorted position), serial fold
+template <class C>
+__global__ void __launch_bounds__(64) msm_fold_small_kernel(const uint32_t* __restrict__ count_sorted,
+                                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ tbase,
+                                                            uint32_t n_pos, uint32_t seg, const typename C::Pt* __restrict__ partial,
+                                                            typename C::Pt* __restrict__ buckets) {
+    typedef typename C::Pt Pt;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos) return;
+    const uint32_t cnt = count_sorted[i];
+    if (cnt <= seg) return;
+    const uint32_t nt = (cnt + seg - 1) / seg;
+    if (nt > MSM_FOLD_SMALL) return;
+    const Pt* src = partial + tbase[i];
+    Pt acc = src[0];
+    for (uint32_t j = 1; j < nt; ++j) {
+        Pt p = src[j];
+        C::add(acc, p);
+    }
+    buckets[order[i]] = acc;
+}
+
+// heavily populated buckets: one 64-lane workgroup per bucket: lanes stride over the partial sums, LDS tree
 template <class C>
 __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ order,
-                                                      const uint32_t* __restrict__ tbase, uint32_t nb,
+                                                      const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t seg,
                                                       const typename C::Pt* __restrict__ partial,
                                                       typename C::Pt* __restrict__ buckets) {
     typedef typename C::Pt Pt;
@@ -193,8 +217,9 @@ __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict
     const uint32_t i = blockIdx.x;
     if (i >= nb) return;
     const uint32_t cnt = count_sorted[i];
-    if (cnt <= MSM_SEG) return;  // wave-uniform: whole workgroup leaves
-    const uint32_t nt = (cnt + MSM_SEG - 1) / MSM_SEG;
+    if (cnt <= seg) return;  // wave-uniform: whole workgroup leaves
+    const uint32_t nt = (cnt + seg - 1) / seg;
+    if (nt <= MSM_FOLD_SMALL) return;
     const Pt* src = partial + tbase[i];
     Pt acc = C::identity();
     for (uint32_t j = threadIdx.x; j < nt; j += 64) {
@@ -408,7 +433,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
     }
     const size_t tmp = std::max(std::max(tmp1, tmp2), tmp3);
-    const uint64_t t_cap = (uint64_t)nb_max + len_max / MSM_SEG + 1;  // upper bound on the number of tasks
+    // serial run length per lane: ~4x the mean bucket population, within [32, 256] - short enough that the
+    // few over-full buckets of a degenerate top window do not set the kernel's critical path at small n
+    uint32_t seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n / half + 1)));
+    const uint64_t t_cap = (uint64_t)nb_max + len_max / seg + 1;  // upper bound on the number of tasks
     size_t total = 0;
     total += 4 * ws_pad(len_max * 4);                 // keys, vals, keys_sorted, vals_sorted
     total += 7 * ws_pad((size_t)nb_max * 4);          // start, count, count_sorted, iota, order, ntask, tbase
@@ -469,23 +497,28 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, count, count_s, iota, order, (size_t)nb, 0, bits_for(n), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
-        BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, count_s, nb, ntask);
+        BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, count_s, nb, seg, ntask);
         {
             ProfScope ps(ctx, "msm_scan_tasks");
             size_t t = tmp;
             hipError_t e = rocprim::exclusive_scan(tmp_buf, t, ntask, tbase, 0u, (size_t)nb, rocprim::plus<uint32_t>(), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
-        const uint32_t t_max = (uint32_t)((uint64_t)nb + len / MSM_SEG + 1);
+        const uint32_t t_max = (uint32_t)((uint64_t)nb + len / seg + 1);
         auto k_acc = msm_accumulate_kernel<C>;
         auto k_fold = msm_fold_kernel<C>;
+        auto k_fold_small = msm_fold_small_kernel<C>;
         auto k_red = msm_reduce_kernel<C>;
         BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, start, count_s, order, tbase, nb,
-                   t_max, buckets, partial);
+                   t_max, seg, buckets, partial);
         {
-            // only sorted positions < len / MSM_SEG can hold a multi-task bucket
-            const uint32_t n_fold = (uint32_t)std::min<uint64_t>(nb, len / MSM_SEG + 1);
-            BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_fold), dim3(64), 0, count_s, order, tbase, nb, partial, buckets);
+            // only sorted positions < len / seg can hold a multi-task bucket; of those only the first
+            // len / (seg * MSM_FOLD_SMALL) can need the workgroup-wide fold
+            const uint32_t n_pos = (uint32_t)std::min<uint64_t>(nb, len / seg + 1);
+            const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * MSM_FOLD_SMALL) + 1);
+            BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, count_s, order, tbase, nb, seg, partial, buckets);
+            BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, count_s, order, tbase, n_pos, seg,
+                       partial, buckets);
         }
         const uint32_t n_chunks = (uint32_t)wc * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);

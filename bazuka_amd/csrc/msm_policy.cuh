@@ -53,6 +53,52 @@ struct G1Fast {
 };
 static_assert(sizeof(G1A28) == 112 && sizeof(G1X28) == 224, "internal G1 layouts");
 
+// G2 over Fp2x28: generic XYZZ code on the reduced-radix field; bases converted per call (224 B each)
+struct G2Fast {
+    typedef Fp2Ops HostF;
+    typedef G2X28 Pt;
+    typedef G2A28 DevAff;
+    static constexpr int RAW = 192, PACKED = 193;
+    static constexpr bool CONVERT_BASES = true;
+    static constexpr int WSUM_THREADS = 128;  // 128 x 448 B = 56 KiB LDS
+    __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2x28Ops>(); }
+    __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p_in, bool neg) {
+        DevAff p = p_in;
+        if (neg) p.y = Fp2x28Ops::neg(p.y);
+        xyzz_add_mixed<Fp2x28Ops>(acc, p);
+    }
+    __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2x28Ops>(acc, q); }
+    __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return xyzz_mul_u32<Fp2x28Ops>(p, k); }
+    __device__ static __forceinline__ XyzzT<Fp2Ops> to_std(const Pt& p) { return g2x28::to_std(p); }
+    __device__ static __forceinline__ DevAff convert(const void* raw, uint64_t i) {
+        const U128* p = (const U128*)raw + i * 12;
+        G2Affine a;
+        Fp* f[4] = {&a.x.c0, &a.x.c1, &a.y.c0, &a.y.c1};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                U128 v = p[3 * e + k];
+                f[e]->l[4 * k] = v.x; f[e]->l[4 * k + 1] = v.y; f[e]->l[4 * k + 2] = v.z; f[e]->l[4 * k + 3] = v.w;
+            }
+        }
+        return g2x28::affine_to28(a);
+    }
+    // gather of one internal base: 224 B = 14 x 16 B
+    __device__ static __forceinline__ DevAff load(const void* internal, uint32_t idx) {
+        const U128* p = (const U128*)internal + (size_t)idx * 14;
+        DevAff a;
+        uint32_t* dst = a.x.c0.l;  // x.c0, x.c1, y.c0, y.c1: 4 x 56 B contiguous
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+            U128 v = p[k];
+            dst[4 * k] = v.x; dst[4 * k + 1] = v.y; dst[4 * k + 2] = v.z; dst[4 * k + 3] = v.w;
+        }
+        return a;
+    }
+};
+static_assert(sizeof(G2A28) == 224 && sizeof(G2X28) == 448, "internal G2 layouts");
+
 struct G2Plain {
     typedef Fp2Ops HostF;
     typedef XyzzT<Fp2Ops> Pt;

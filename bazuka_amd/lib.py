@@ -45,6 +45,8 @@ SIGNATURES = {
     "bzk_params_load": (_i32, [_vp, _vp, C.POINTER(_vp)]),
     "bzk_params_free": (None, [_vp, _vp]),
     "bzk_groth16_prove": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "bzk_params_read": (_i32, [_vp, _vp, _i32, _vp, _u64, C.POINTER(_u64)]),
+    "bzk_groth16_setup": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, C.POINTER(_vp), _vp, _u64]),
     "bzk_groth16_h_dev": (_i32, [_vp, _vp, _vp, _vp, _u32]),
     "bzk_mpn_create": (_i32, [_u32, _u32, C.POINTER(_vp)]),
     "bzk_mpn_destroy": (None, [_vp]),
@@ -71,6 +73,10 @@ SIGNATURES = {
 class ParamsDesc(C.Structure):
     _fields_ = [("n_in", _u32), ("n_aux", _u32), ("log_m", _u32), ("n_a", _u32), ("n_b", _u32), ("vk", _vp), ("h", _vp),
                 ("l", _vp), ("a", _vp), ("b_g1", _vp), ("b_g2", _vp), ("a_density", _vp), ("b_density", _vp)]
+
+
+class CsrDesc(C.Structure):
+    _fields_ = [("n_rows", _u64), ("row_ptr", _vp), ("col", _vp), ("val", _vp)]
 
 
 class Assignment(C.Structure):
@@ -256,6 +262,27 @@ class Bzk:
         out = C.create_string_buffer(387)
         self._ck(self.lib.bzk_groth16_prove(self.h, ph, C.byref(asg), _ptr(r), _ptr(s), out), "groth16_prove")
         return out.raw
+
+    def params_read(self, ph, which: int) -> bytes:
+        n = _u64()
+        self._ck(self.lib.bzk_params_read(self.h, ph, which, None, 0, C.byref(n)), "params_read")
+        buf = C.create_string_buffer(max(1, n.value))
+        self._ck(self.lib.bzk_params_read(self.h, ph, which, buf, n.value, None), "params_read")
+        return buf.raw[: n.value]
+
+    def groth16_setup(self, csr_abc, n_in: int, n_aux: int, toxic: bytes):
+        """csr_abc: three (n_rows, row_ptr_bytes(u32), col_bytes(u32), val_bytes) tuples.  Returns (params handle,
+        vk bincode bytes = Groth16VerifyingKey)."""
+        keep, descs = [], []
+        for n_rows, rp, col, val in csr_abc:
+            bufs = [C.create_string_buffer(bytes(x), max(1, len(x))) for x in (rp, col, val)]
+            keep.append(bufs)
+            descs.append(CsrDesc(n_rows, *[C.cast(b, C.c_void_p) for b in bufs]))
+        h = C.c_void_p()
+        vk = C.create_string_buffer(878 + 97 * n_in)
+        self._ck(self.lib.bzk_groth16_setup(self.h, C.byref(descs[0]), C.byref(descs[1]), C.byref(descs[2]), n_in, n_aux,
+                                            _ptr(toxic), C.byref(h), vk, len(vk)), "groth16_setup")
+        return h, vk.raw
 
     def groth16_h_dev(self, a, b, c, log_m: int):
         self._ck(self.lib.bzk_groth16_h_dev(self.h, _ptr(a), _ptr(b), _ptr(c), log_m), "groth16_h_dev")

@@ -151,6 +151,24 @@ void bzk_params_free(bzk_ctx* ctx, bzk_params* params);
 /* r, s: Montgomery scalars (the prover's blinding factors; bellman draws them from the rng) */
 int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* params, const bzk_assignment* asg, const uint8_t r[32],
                           const uint8_t s[32], uint8_t proof_out[387]);
+/* reads a CRS component back (tests): which = 0 vk (870 B), 1 h, 2 l, 3 a, 4 b_g1, 5 b_g2 */
+int32_t bzk_params_read(bzk_ctx* ctx, const bzk_params* params, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out);
+
+/* CRS generation on the GPU = bellman `generate_parameters(circuit, g1, g2, alpha, beta, gamma, delta, tau)` with
+ * g1, g2 the standard generators (the reference's dev-mode CRS: src/config/blockchain.rs:355-417).  The R1CS comes
+ * as CSR matrices over flat variable indices (inputs then aux), rows already including bellman's trailing
+ * `input_i * 0 = 0` constraints (bzk_r1cs_data views 6-14 of a circuit synthesized with record_matrices).
+ * toxic = tau | alpha | beta | gamma | delta (5 x 32 B Montgomery).  vk_out (optional) receives the bincode form of
+ * `Groth16VerifyingKey` (src/zk/groth16/mod.rs:22-31): 870 + 8 + 97 * n_in bytes. */
+typedef struct {
+    uint64_t n_rows;
+    const uint32_t* row_ptr; /* n_rows + 1 */
+    const uint32_t* col;     /* nnz */
+    const uint8_t* val;      /* nnz * 32, Montgomery */
+} bzk_csr;
+int32_t bzk_groth16_setup(bzk_ctx* ctx, const bzk_csr* A, const bzk_csr* B, const bzk_csr* C, uint32_t n_in, uint32_t n_aux,
+                          const uint8_t toxic[160], bzk_params** out_params, uint8_t* vk_out, uint64_t vk_cap);
+
 /* h-polynomial stage alone (7 NTTs + pointwise), device resident: a,b,c hold az,bz,cz zero-padded to
  * m scalars on entry; on return a[0 .. m-1) holds the h coefficients.  Exposed for parity tests. */
 int32_t bzk_groth16_h_dev(bzk_ctx* ctx, void* a_dev, void* b_dev, void* c_dev, uint32_t log_m);

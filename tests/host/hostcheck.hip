@@ -69,6 +69,41 @@ int hc_g1x28_sum_mixed(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* o
     st_g1(out97, g1x28::to_std(acc));
     return 0;
 }
+int hc_fp28_reduce_chain(const uint8_t* a, const uint8_t* b, int rounds, uint8_t* out) {
+    // exercises add / sub<K> / reduce on growing values: r = ((a + b) * 2 - b + ...) tracked against the oracle by the caller
+    Fp28 x = fp28::to28(ld<FpParams>(a)), y = fp28::to28(ld<FpParams>(b));
+    for (int i = 0; i < rounds; ++i) {
+        Fp28 t = fp28::add(fp28::add(x, y), fp28::add(x, x));   // 3x + y, unreduced
+        t = fp28::add(t, t);                                     // 6x + 2y
+        x = fp28::reduce(fp28::sub<6>(t, y));                    // 6x + y
+        if (x.l[13] >> 19) return -1;                           // < 3p  => top limb < 2^19
+    }
+    st<FpParams>(out, fp28::from28(x));
+    return 0;
+}
+int hc_g2x28_lincomb(const uint8_t* pts, const uint32_t* k, const uint8_t* neg, int n, uint8_t* out193) {
+    G2X28 acc = xyzz_identity<Fp2x28Ops>();
+    for (int i = 0; i < n; ++i) {
+        G2A28 a = g2x28::affine_to28(ld_g2(pts + 192 * i));
+        if (neg[i]) a.y = Fp2x28Ops::neg(a.y);
+        G2X28 t = xyzz_identity<Fp2x28Ops>();
+        xyzz_add_mixed<Fp2x28Ops>(t, a);
+        G2X28 m = xyzz_mul_u32<Fp2x28Ops>(t, k[i]);
+        xyzz_add<Fp2x28Ops>(acc, m);
+    }
+    st_g2(out193, g2x28::to_std(acc));
+    return 0;
+}
+int hc_g2x28_sum_mixed(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* out193) {
+    G2X28 acc = xyzz_identity<Fp2x28Ops>();
+    for (int i = 0; i < n; ++i) {
+        G2A28 a = g2x28::affine_to28(ld_g2(pts + 192 * i));
+        if (neg[i]) a.y = Fp2x28Ops::neg(a.y);
+        xyzz_add_mixed<Fp2x28Ops>(acc, a);
+    }
+    st_g2(out193, g2x28::to_std(acc));
+    return 0;
+}
 int hc_fr_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) { return field_op<FrParams>(op, a, b, out); }
 int hc_fp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) { return field_op<FpParams>(op, a, b, out); }
 

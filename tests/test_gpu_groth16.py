@@ -48,3 +48,41 @@ def test_groth16_h_stage_vs_oracle_2p16(bzk, co):
     bzk.groth16_h_dev(da, db, dc, log_m)
     torch.cuda.synchronize()
     assert dev_bytes(da)[: 32 * (m - 1)] == co.groth16_h(az, bz, cz, log_m, nthreads=co.ncpu())
+
+
+def _csr_bytes(co, r1):
+    import array
+    out = []
+    for which in range(3):
+        rp, col, val = array.array("I", [0]), array.array("I"), []
+        for row in r1["rows"]:
+            for v, c in row[which]:
+                col.append(v)
+                val.append(pr_mod.fr_to_mont_bytes(c))
+            rp.append(len(col))
+        out.append((len(r1["rows"]), rp.tobytes(), col.tobytes(), b"".join(val)))
+    return out
+
+
+from oracle import pyref as pr_mod  # noqa: E402
+
+
+@pytest.mark.parametrize("n_mul", [30, 1500])
+def test_gpu_setup_matches_oracle_crs(bzk, co, pr, n_mul):
+    """bzk_groth16_setup (device fixed-base multiplications) == oracle setup on the same toxic waste, byte for byte"""
+    r1 = synth_r1cs(n_mul, seed=4242 + n_mul)
+    A, B, Cm = r1cs_to_csr(co, r1)
+    log_m = log2_ceil(len(r1["rows"]))
+    tox = fr_bytes(fr_list(5, 99))
+    want = co.groth16_setup(A, B, Cm, r1["n_in"], r1["n_aux"], log_m, tox, nthreads=co.ncpu())
+    ph, vk = bzk.groth16_setup(_csr_bytes(co, r1), r1["n_in"], r1["n_aux"], tox)
+    assert vk[:870] == want["vk"]
+    assert vk[870:878] == r1["n_in"].to_bytes(8, "little") and vk[878:] == want["ic"]
+    for which, key in ((1, "h"), (2, "l"), (3, "a"), (4, "b_g1"), (5, "b_g2")):
+        assert bzk.params_read(ph, which) == want[key], key
+    # and the device-resident CRS proves: same bytes as the oracle prover
+    zb = fr_bytes(r1["z"])
+    az, bz, cz = co.r1cs_eval(A, B, Cm, zb, nthreads=co.ncpu())
+    r, s = fr_bytes(fr_list(2, 8))[:32], fr_bytes(fr_list(2, 8))[32:]
+    assert bzk.groth16_prove(ph, zb, az, bz, cz, r, s) == co.groth16_prove(want, zb, az, bz, cz, r, s, nthreads=co.ncpu())
+    bzk.params_free(ph)

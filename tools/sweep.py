@@ -1,0 +1,65 @@
+"""GPU measurement helper: MSM parameter sweep (window bits c, reduce chunk) and timings of the other
+kernels (Poseidon tree 2^24, NTT 2^20, G2 MSM).  Each configuration runs in a fresh ctx (env-driven knobs)."""
+import os, sys, time, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+def child(mode, log_n):
+    import torch
+    from bazuka_amd import Bzk
+    ctx = Bzk(0)
+    n = 1 << log_n
+    g = torch.Generator(device="cuda").manual_seed(7)
+    def rand_fr(cnt):
+        t = torch.randint(0, 256, (cnt, 32), dtype=torch.uint8, device="cuda", generator=g); t[:, 31] &= 0x3F
+        return t.contiguous()
+    def timeit(fn, reps=5):
+        fn(); ctx.sync(); best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize(); t = time.perf_counter(); fn(); ctx.sync(); best = min(best, time.perf_counter() - t)
+        return best * 1e3
+    if mode == "g1":
+        bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
+        ms = timeit(lambda: ctx.msm_g1_dev(bases, sc, n))
+        ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_g1_dev(bases, sc, n); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
+        print(json.dumps({"mode": mode, "log_n": log_n, "c": os.environ.get("BZK_MSM_C"), "chunk": os.environ.get("BZK_MSM_CHUNK"), "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 1), "prof": prof}))
+    elif mode == "g2":
+        bases = torch.empty(n * 192, dtype=torch.uint8, device="cuda"); ctx.g2_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
+        ms = timeit(lambda: ctx.msm_g2_dev(bases, sc, n), reps=2)
+        ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_g2_dev(bases, sc, n); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
+        print(json.dumps({"mode": mode, "log_n": log_n, "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 2), "prof": prof}))
+    elif mode == "tree":
+        leaves = rand_fr(n)
+        ms = timeit(lambda: ctx.merkle4_root_dev(leaves, log_n // 2), reps=3)
+        hashes = (n - 1) // 3
+        print(json.dumps({"mode": mode, "leaves": n, "ms": round(ms, 3), "Mhash/s": round(hashes / ms / 1e3, 2), "alg_GB/s": round((32 * n + 32 * hashes) / ms / 1e6, 2)}))
+    elif mode == "ntt":
+        d = rand_fr(n)
+        ms = timeit(lambda: ctx.ntt_dev(d, log_n, False, True))
+        print(json.dumps({"mode": mode, "log_n": log_n, "ms": round(ms, 4), "alg_GB/s": round(64 * n / ms / 1e6, 1)}))
+    elif mode == "h":
+        a, b, c = rand_fr(n), rand_fr(n), rand_fr(n)
+        ms = timeit(lambda: ctx.groth16_h_dev(a, b, c, log_n), reps=3)
+        print(json.dumps({"mode": mode, "log_m": log_n, "ms_7_ntts_plus_pointwise": round(ms, 3)}))
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        child(sys.argv[2], int(sys.argv[3])); sys.exit(0)
+    def run(mode, log_n, env=None):
+        e = dict(os.environ); e.update(env or {})
+        try:
+            out = subprocess.run([sys.executable, __file__, "child", mode, str(log_n)], env=e, capture_output=True, text=True, timeout=150)
+            lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            print(lines[-1] if lines else ("FAILED " + mode + " " + out.stderr[-300:]), flush=True)
+        except subprocess.TimeoutExpired:
+            print("TIMEOUT", mode, log_n, env, flush=True)
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "sweep"):
+        for c in (13, 14, 15, 16, 17):
+            run("g1", 20, {"BZK_MSM_C": str(c)})
+        for ch in (8, 32):
+            run("g1", 20, {"BZK_MSM_C": "16", "BZK_MSM_CHUNK": str(ch)})
+        for lg in (16, 18, 22, 24):
+            run("g1", lg)
+    if what in ("all", "others"):
+        run("tree", 24); run("tree", 20); run("ntt", 20); run("ntt", 24); run("h", 20); run("g2", 16); run("g2", 20)
