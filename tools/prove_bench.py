@@ -1,0 +1,47 @@
+"""Full Groth16 proofs/s for the 2^20-constraint class: UpdateCircuit(L=15, T=3, B=2) = 16 signed txs,
+903 037 constraints.  Everything is product code: host witness generator (C++), CRS on the GPU, prove on the GPU."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bazuka_amd import Bzk, lib as L
+
+def fr(x):  # Montgomery bytes of a small integer without the oracle: via the host hasher's field (x * R mod r)
+    R = (1 << 256) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    return (x * R % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001).to_bytes(32, "little")
+
+def main(n_proofs=5, lg=15, t=3, b=2):
+    ZIESHA = fr(1)
+    ctx = Bzk(0)
+    n_tx = 1 << (2 * b)
+    w = L.MpnWorld(lg, t)
+    for i in range(2 * n_tx):
+        w.add_account(i, b"acct%d" % i, ZIESHA, 10 ** 12)
+    def batch(k):
+        for i in range(n_tx):
+            w.push_tx(i, n_tx + i, ZIESHA, 100 + i + k, ZIESHA, i % 7)
+    out = {}
+    t0 = time.perf_counter(); batch(0); out["sign_16_tx_s"] = round(time.perf_counter() - t0, 3)
+    t0 = time.perf_counter(); r = w.update_synthesize(b, fr(99), ZIESHA, record_matrices=True); out["synthesize_with_matrices_s"] = round(time.perf_counter() - t0, 3)
+    assert r.satisfied and r.accepted == n_tx
+    out.update(n_constraints=r.n_constraints, n_aux=r.n_aux)
+    csr = [(r.n_constraints, r.view("rp" + x), r.view("col" + x), r.view("val" + x)) for x in "ABC"]
+    tox = b"".join(fr(x) for x in (1234567, 2345678, 3456789, 4567891, 5678912))
+    t0 = time.perf_counter(); ph, vk = ctx.groth16_setup(csr, r.n_in, r.n_aux, tox); out["gpu_setup_s"] = round(time.perf_counter() - t0, 3)
+    times_w, times_p = [], []
+    for k in range(n_proofs):
+        batch(k + 1)
+        t0 = time.perf_counter(); rk = w.update_synthesize(b, fr(99), ZIESHA); t1 = time.perf_counter()
+        assert rk.satisfied
+        z, az, bz, cz = rk.view("z"), rk.view("az"), rk.view("bz"), rk.view("cz")
+        t2 = time.perf_counter(); proof = ctx.groth16_prove(ph, z, az, bz, cz, fr(7 + k), fr(9 + k)); t3 = time.perf_counter()
+        times_w.append(t1 - t0); times_p.append(t3 - t2)
+    ctx.prof_enable(True); ctx.prof_reset()
+    ctx.groth16_prove(ph, z, az, bz, cz, fr(1), fr(2))
+    out["witness_s"] = round(min(times_w), 4); out["gpu_prove_s"] = round(min(times_p), 4)
+    out["proofs_per_s_gpu_only"] = round(1 / min(times_p), 2)
+    out["proofs_per_s_incl_witness_serial"] = round(1 / (min(times_p) + min(times_w)), 3)
+    out["prove_kernels_ms"] = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.2}
+    print(json.dumps(out))
+
+if __name__ == "__main__":
+    main(*(int(x) for x in sys.argv[1:]))
