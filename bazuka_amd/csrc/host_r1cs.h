@@ -26,10 +26,19 @@ typedef uint32_t Var;  // bit 31 set => aux variable, else input variable (0 = O
 static constexpr Var VAR_AUX = 0x80000000u;
 static constexpr Var VAR_ONE = 0;
 
+// Witness-only synthesis (the ProvingAssignment role with a loaded CRS) needs no linear combinations: the
+// gadgets hand every constraint's three VALUES to enforce().  `lc_tracking()` switches term bookkeeping off
+// for that mode (thread-local so that transactions can be synthesized on worker threads).
+inline bool& lc_tracking() {
+    static thread_local bool on = true;
+    return on;
+}
+
 struct LC {
     std::vector<std::pair<Var, Fr>> t;
     LC() {}
     LC& add(Var v, const Fr& c) {
+        if (!lc_tracking()) return *this;
         for (auto& e : t)
             if (e.first == v) {
                 e.second = fe_add<FrParams>(e.second, c);
@@ -41,6 +50,7 @@ struct LC {
     LC& add_var(Var v) { return add(v, Fr::one()); }
     LC& sub_var(Var v) { return add(v, fe_neg<FrParams>(Fr::one())); }
     LC& add_scaled(const LC& o, const Fr& k) {
+        if (!lc_tracking()) return *this;
         for (auto& e : o.t) add(e.first, fe_mul<FrParams>(e.second, k));
         return *this;
     }
@@ -88,24 +98,32 @@ class ConstraintSystem {
     }
     size_t num_constraints() const { return az.size(); }
 
-    void enforce(const LC& a, const LC& b, const LC& c) {
-        az.push_back(eval(a));
-        bz.push_back(eval(b));
-        cz.push_back(eval(c));
-        mark(a, a_in_d, a_aux_d);
-        mark(b, b_in_d, b_aux_d);
-        if (record_matrices) {
-            push_row(A, a);
-            push_row(B, b);
-            push_row(C, c);
+    // The caller supplies <A,z>, <B,z>, <C,z> (it computed them while building the witness).  In tracking mode
+    // the LCs are recorded (densities, matrices) and, when self_check is set, re-evaluated against the values.
+    bool self_check = false;
+    long check_failed_at = -1;
+    void enforce(const LC& a, const Fr& av, const LC& b, const Fr& bv, const LC& c, const Fr& cv) {
+        if (lc_tracking()) {
+            if (self_check && check_failed_at < 0 && (!eval(a).equals(av) || !eval(b).equals(bv) || !eval(c).equals(cv)))
+                check_failed_at = (long)az.size();
+            mark(a, a_in_d, a_aux_d);
+            mark(b, b_in_d, b_aux_d);
+            if (record_matrices) {
+                push_row(A, a);
+                push_row(B, b);
+                push_row(C, c);
+            }
         }
+        az.push_back(av);
+        bz.push_back(bv);
+        cz.push_back(cv);
     }
 
     // bellman appends `input_i * 0 = 0` for every input after synthesis (makes every input's A
     // polynomial non-zero); call exactly once.
     void finalize() {
         if (finalized) return;
-        for (size_t i = 0; i < inputs.size(); ++i) enforce(LC::of((Var)i), LC(), LC());
+        for (size_t i = 0; i < inputs.size(); ++i) enforce(LC::of((Var)i), inputs[i], LC(), Fr::zero(), LC(), Fr::zero());
         finalized = true;
     }
 
@@ -175,38 +193,41 @@ static inline Num num_alloc(ConstraintSystem& cs, const Fr& v) { return {cs.allo
 
 static inline void num_inputize(ConstraintSystem& cs, const Num& n) {
     Var in = cs.alloc_input(n.val);
-    cs.enforce(LC::of(in), LC::one(), LC::of(n.var));
+    cs.enforce(LC::of(in), n.val, LC::one(), Fr::one(), LC::of(n.var), n.val);
 }
 
 static inline Num num_mul(ConstraintSystem& cs, const Num& a, const Num& b) {  // AllocatedNum::mul
     Num r = num_alloc(cs, fe_mul<FrParams>(a.val, b.val));
-    cs.enforce(LC::of(a.var), LC::of(b.var), LC::of(r.var));
+    cs.enforce(LC::of(a.var), a.val, LC::of(b.var), b.val, LC::of(r.var), r.val);
     return r;
 }
 
 static inline Bit bit_alloc(ConstraintSystem& cs, bool v) {
     Bit b = {cs.alloc(fr_from_bool(v)), v};
-    cs.enforce(LC::one().sub_var(b.var), LC::of(b.var), LC());  // (1 - a) * a = 0
+    cs.enforce(LC::one().sub_var(b.var), fr_from_bool(!v), LC::of(b.var), fr_from_bool(v), LC(), Fr::zero());  // (1 - a) * a = 0
     return b;
 }
 static inline Bit bit_alloc_conditionally(ConstraintSystem& cs, bool v, const Bit& must_be_false) {
     Bit b = {cs.alloc(fr_from_bool(v)), v};
-    cs.enforce(LC::one().sub_var(must_be_false.var).sub_var(b.var), LC::of(b.var), LC());
+    cs.enforce(LC::one().sub_var(must_be_false.var).sub_var(b.var),
+               fe_sub<FrParams>(fe_sub<FrParams>(Fr::one(), fr_from_bool(must_be_false.val)), fr_from_bool(v)), LC::of(b.var),
+               fr_from_bool(v), LC(), Fr::zero());
     return b;
 }
 static inline Bit bit_and(ConstraintSystem& cs, const Bit& a, const Bit& b) {
     Bit r = {cs.alloc(fr_from_bool(a.val && b.val)), a.val && b.val};
-    cs.enforce(LC::of(a.var), LC::of(b.var), LC::of(r.var));
+    cs.enforce(LC::of(a.var), fr_from_bool(a.val), LC::of(b.var), fr_from_bool(b.val), LC::of(r.var), fr_from_bool(r.val));
     return r;
 }
 static inline Bit bit_and_not(ConstraintSystem& cs, const Bit& a, const Bit& b) {  // a AND (NOT b)
     Bit r = {cs.alloc(fr_from_bool(a.val && !b.val)), a.val && !b.val};
-    cs.enforce(LC::of(a.var), LC::one().sub_var(b.var), LC::of(r.var));
+    cs.enforce(LC::of(a.var), fr_from_bool(a.val), LC::one().sub_var(b.var), fr_from_bool(!b.val), LC::of(r.var), fr_from_bool(r.val));
     return r;
 }
 static inline Bit bit_nor(ConstraintSystem& cs, const Bit& a, const Bit& b) {  // (NOT a) AND (NOT b)
     Bit r = {cs.alloc(fr_from_bool(!a.val && !b.val)), !a.val && !b.val};
-    cs.enforce(LC::one().sub_var(a.var), LC::one().sub_var(b.var), LC::of(r.var));
+    cs.enforce(LC::one().sub_var(a.var), fr_from_bool(!a.val), LC::one().sub_var(b.var), fr_from_bool(!b.val), LC::of(r.var),
+               fr_from_bool(r.val));
     return r;
 }
 static inline Bool bool_and(ConstraintSystem& cs, const Bool& a, const Bool& b) {  // Boolean::and
@@ -263,7 +284,7 @@ static inline std::vector<Bit> num_to_bits_le_strict(ConstraintSystem& cs, const
         coeff = fe_dbl<FrParams>(coeff);
     }
     lc.sub_var(n.var);
-    cs.enforce(LC(), LC(), lc);  // unpacking constraint: 0 * 0 = sum(bits) - value
+    cs.enforce(LC(), Fr::zero(), LC(), Fr::zero(), lc, Fr::zero());  // unpacking constraint: 0 * 0 = sum(bits) - value
     std::vector<Bit> le(result.rbegin(), result.rend());
     return le;
 }
@@ -308,7 +329,7 @@ struct Number {
     }
     Num mul(ConstraintSystem& cs, const Number& o) const {  // number.rs:48-65
         Num r = num_alloc(cs, fe_mul<FrParams>(val, o.val));
-        cs.enforce(lc, o.lc, LC::of(r.var));
+        cs.enforce(lc, val, o.lc, o.val, LC::of(r.var), r.val);
         return r;
     }
     Num compress(ConstraintSystem& cs) const { return mul(cs, one()); }  // :66-72
@@ -316,17 +337,19 @@ struct Number {
         const bool z = val.is_zero();
         Bit isz = bit_alloc(cs, z);
         Num inv = num_alloc(cs, z ? Fr::zero() : fe_inv<FrParams>(val));
-        cs.enforce(LC().sub_lc(lc), LC::of(inv.var), LC::of(isz.var).sub_var(VAR_ONE));
-        cs.enforce(LC::of(isz.var), lc, LC());
+        cs.enforce(LC().sub_lc(lc), fe_neg<FrParams>(val), LC::of(inv.var), inv.val, LC::of(isz.var).sub_var(VAR_ONE),
+                   fe_sub<FrParams>(fr_from_bool(z), Fr::one()));
+        cs.enforce(LC::of(isz.var), fr_from_bool(z), lc, val, LC(), Fr::zero());
         return Bool::is(isz);
     }
     Bool is_equal(ConstraintSystem& cs, const Number& o) const { return minus(o).is_zero(cs); }  // :113-119
-    void assert_equal(ConstraintSystem& cs, const Number& o) const { cs.enforce(lc, LC::one(), o.lc); }  // :121-128
+    void assert_equal(ConstraintSystem& cs, const Number& o) const { cs.enforce(lc, val, LC::one(), Fr::one(), o.lc, o.val); }  // :121-128
     void assert_equal_if_enabled(ConstraintSystem& cs, const Bool& enabled, const Number& o) const {  // :130-177
         if (enabled.kind == Bool::IS) {
-            Var eis = cs.alloc(enabled.bit.val ? val : Fr::zero());
-            cs.enforce(LC::of(enabled.bit.var), lc, LC::of(eis));
-            cs.enforce(LC::of(enabled.bit.var), o.lc, LC::of(eis));
+            const Fr ev = enabled.bit.val ? val : Fr::zero(), en = fr_from_bool(enabled.bit.val);
+            Var eis = cs.alloc(ev);
+            cs.enforce(LC::of(enabled.bit.var), en, lc, val, LC::of(eis), ev);
+            cs.enforce(LC::of(enabled.bit.var), en, o.lc, o.val, LC::of(eis), ev);
         } else if (enabled.kind == Bool::CONST) {
             if (enabled.cval) assert_equal(cs, o);
         } else {
@@ -351,12 +374,14 @@ static inline Bool boolean_or(ConstraintSystem& cs, const Bool& a, const Bool& b
 static inline Num mux(ConstraintSystem& cs, const Bool& select, const Number& a, const Number& b) {
     if (select.kind == Bool::IS) {
         Num ret = num_alloc(cs, select.bit.val ? b.val : a.val);
-        cs.enforce(LC().add_lc(a.lc).sub_lc(b.lc), LC::of(select.bit.var), LC().add_lc(a.lc).sub_var(ret.var));
+        cs.enforce(LC().add_lc(a.lc).sub_lc(b.lc), fe_sub<FrParams>(a.val, b.val), LC::of(select.bit.var), fr_from_bool(select.bit.val),
+                   LC().add_lc(a.lc).sub_var(ret.var), fe_sub<FrParams>(a.val, ret.val));
         return ret;
     }
     if (select.kind == Bool::NOT) {
         Num ret = num_alloc(cs, select.bit.val ? a.val : b.val);
-        cs.enforce(LC().add_lc(b.lc).sub_lc(a.lc), LC::of(select.bit.var), LC().add_lc(b.lc).sub_var(ret.var));
+        cs.enforce(LC().add_lc(b.lc).sub_lc(a.lc), fe_sub<FrParams>(b.val, a.val), LC::of(select.bit.var), fr_from_bool(select.bit.val),
+                   LC().add_lc(b.lc).sub_var(ret.var), fe_sub<FrParams>(b.val, ret.val));
         return ret;
     }
     throw std::logic_error("mux(Boolean::Constant) is unimplemented in the reference");
@@ -380,7 +405,16 @@ struct UInt {
             u.bits.push_back(b);
             coeff = fe_dbl<FrParams>(coeff);
         }
-        cs.enforce(all, LC::one(), num.lc);
+        {
+            // sum(bit_i 2^i) recomputed from the allocated bits so that an out-of-range value is REPORTED as an
+            // unsatisfied constraint (as bellman's prover would produce an invalid proof), not silently accepted
+            Fr packed = Fr::zero(), cf = Fr::one();
+            for (int i = 0; i < num_bits; ++i) {
+                if (u.bits[i].val) packed = fe_add<FrParams>(packed, cf);
+                cf = fe_dbl<FrParams>(cf);
+            }
+            cs.enforce(all, packed, LC::one(), Fr::one(), num.lc, num.val);
+        }
         return u;
     }
     static UInt alloc(ConstraintSystem& cs, const Fr& val, int bits) {  // :34-41
@@ -496,9 +530,12 @@ struct APoint {
         Number rhs = Number::from_scaled(jubjub_d().v, x2y2).plus(Number::one());
         lhs.assert_equal_if_enabled(cs, enabled, rhs);
     }
-    APoint add_const(ConstraintSystem& cs, const PointAffine& b) const {  // :77-123
+    // `hint`: the sum, when the caller already knows it (ladder pre-pass); must equal what the formulas below give
+    APoint add_const(ConstraintSystem& cs, const PointAffine& b, const PointAffine* hint = nullptr) const {  // :77-123
         PointAffine a = value(), sumv;  // default (0,0) when either operand is off-curve
-        if (a.is_on_curve() && b.is_on_curve()) {
+        if (hint) {
+            sumv = *hint;
+        } else if (a.is_on_curve() && b.is_on_curve()) {
             sumv = a;
             sumv.add_assign(b);
         }
@@ -506,14 +543,19 @@ struct APoint {
         const Fr bx = b.x.v, by = b.y.v;
         const Fr dbb = fe_mul<FrParams>(fe_mul<FrParams>(jubjub_d().v, bx), by);
         Num common = num_mul(cs, x, y);
-        cs.enforce(LC::one().add(common.var, dbb), LC::of(sum.x.var), LC().add(x.var, by).add(y.var, bx));
+        const Fr kx = fe_mul<FrParams>(dbb, common.val);
+        cs.enforce(LC::one().add(common.var, dbb), fe_add<FrParams>(Fr::one(), kx), LC::of(sum.x.var), sum.x.val,
+                   LC().add(x.var, by).add(y.var, bx), fe_add<FrParams>(fe_mul<FrParams>(x.val, by), fe_mul<FrParams>(y.val, bx)));
         // y_1 - y_2: by*y - (A*bx)*x with A = -1
-        cs.enforce(LC::one().add(common.var, fe_neg<FrParams>(dbb)), LC::of(sum.y.var), LC().add(y.var, by).add(x.var, bx));
+        cs.enforce(LC::one().add(common.var, fe_neg<FrParams>(dbb)), fe_sub<FrParams>(Fr::one(), kx), LC::of(sum.y.var), sum.y.val,
+                   LC().add(y.var, by).add(x.var, bx), fe_add<FrParams>(fe_mul<FrParams>(y.val, by), fe_mul<FrParams>(x.val, bx)));
         return sum;
     }
-    APoint add(ConstraintSystem& cs, const APoint& o) const {  // :125-172
+    APoint add(ConstraintSystem& cs, const APoint& o, const PointAffine* hint = nullptr) const {  // :125-172
         PointAffine a = value(), b = o.value(), sumv;
-        if (a.is_on_curve() && b.is_on_curve()) {
+        if (hint) {
+            sumv = *hint;
+        } else if (a.is_on_curve() && b.is_on_curve()) {
             sumv = a;
             sumv.add_assign(b);
         }
@@ -521,10 +563,13 @@ struct APoint {
         const Fr d = jubjub_d().v;
         Num common = num_mul(cs, num_mul(cs, num_mul(cs, x, o.x), y), o.y);
         Num x1 = num_mul(cs, x, o.y), x2 = num_mul(cs, y, o.x);
-        cs.enforce(LC::one().add(common.var, d), LC::of(sum.x.var), LC::of(x1.var).add_var(x2.var));
+        const Fr kd = fe_mul<FrParams>(d, common.val);
+        cs.enforce(LC::one().add(common.var, d), fe_add<FrParams>(Fr::one(), kd), LC::of(sum.x.var), sum.x.val,
+                   LC::of(x1.var).add_var(x2.var), fe_add<FrParams>(x1.val, x2.val));
         Num y1 = num_mul(cs, y, o.y), y2 = num_mul(cs, x, o.x);
         // y_1 - A*y_2 with A = -1  =>  y_1 + y_2
-        cs.enforce(LC::one().add(common.var, fe_neg<FrParams>(d)), LC::of(sum.y.var), LC::of(y1.var).add_var(y2.var));
+        cs.enforce(LC::one().add(common.var, fe_neg<FrParams>(d)), fe_sub<FrParams>(Fr::one(), kd), LC::of(sum.y.var), sum.y.val,
+                   LC::of(y1.var).add_var(y2.var), fe_add<FrParams>(y1.val, y2.val));
         return sum;
     }
     APoint mul(ConstraintSystem& cs, const Num& b) const {  // :174-202
@@ -532,9 +577,18 @@ struct APoint {
         std::vector<Bit> bits(le.rbegin(), le.rend());  // MSB first
         APoint result = {mux(cs, Bool::is(bits[0]), Number::zero(), Number::from(x)),
                          mux(cs, Bool::is(bits[0]), Number::constant(Fr::one()), Number::from(y))};
+        // witness values of the whole ladder with one inversion (only when the base is a curve point; otherwise
+        // every sum is the off-curve default and the per-step path costs nothing)
+        std::vector<PointAffine> hd, ha;
+        const bool pre = value().is_on_curve();
+        if (pre) {
+            std::vector<bool> bv(bits.size());
+            for (size_t i = 0; i < bits.size(); ++i) bv[i] = bits[i].val;
+            jubjub_ladder(value(), bv, hd, ha);
+        }
         for (size_t i = 1; i < bits.size(); ++i) {
-            result = result.add(cs, result);
-            APoint rpb = result.add(cs, *this);
+            result = result.add(cs, result, pre ? &hd[i] : nullptr);
+            APoint rpb = result.add(cs, *this, pre ? &ha[i] : nullptr);
             Num rx = mux(cs, Bool::is(bits[i]), Number::from(result.x), Number::from(rpb.x));
             Num ry = mux(cs, Bool::is(bits[i]), Number::from(result.y), Number::from(rpb.y));
             result = {rx, ry};
@@ -548,9 +602,16 @@ static inline APoint g_base_mul(ConstraintSystem& cs, const PointAffine& base, c
     std::vector<Bit> bits(le.rbegin(), le.rend());
     APoint result = {mux(cs, Bool::is(bits[0]), Number::zero(), Number::constant(base.x.v)),
                      mux(cs, Bool::is(bits[0]), Number::constant(Fr::one()), Number::constant(base.y.v))};
+    std::vector<PointAffine> hd, ha;
+    const bool pre = base.is_on_curve();
+    if (pre) {
+        std::vector<bool> bv(bits.size());
+        for (size_t i = 0; i < bits.size(); ++i) bv[i] = bits[i].val;
+        jubjub_ladder(base, bv, hd, ha);
+    }
     for (size_t i = 1; i < bits.size(); ++i) {
-        result = result.add(cs, result);
-        APoint rpb = result.add_const(cs, base);
+        result = result.add(cs, result, pre ? &hd[i] : nullptr);
+        APoint rpb = result.add_const(cs, base, pre ? &ha[i] : nullptr);
         Num rx = mux(cs, Bool::is(bits[i]), Number::from(result.x), Number::from(rpb.x));
         Num ry = mux(cs, Bool::is(bits[i]), Number::from(result.y), Number::from(rpb.y));
         result = {rx, ry};

@@ -92,6 +92,8 @@ struct PointAffine {
     void add_assign(const PointAffine& o);
     PointAffine multiply(const ZkScalar& k) const;
 };
+void jubjub_ladder(const PointAffine& base, const std::vector<bool>& bits_msb_first, std::vector<PointAffine>& dbls,
+                   std::vector<PointAffine>& adds);  // dbls[i], adds[i] for i >= 1
 const ZkScalar& jubjub_d();
 const PointAffine& jubjub_base();
 const PointAffine& jubjub_base_cofactor();  // 8 * BASE

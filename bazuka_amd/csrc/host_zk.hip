@@ -184,8 +184,10 @@ bool PointAffine::is_on_curve() const {
 
 PointAffine PointAffine::dbl() const {  // curve.rs:48-57 (A = -1)
     ZkScalar xx = x.square(), yy = y.square();
-    ZkScalar dx = (yy - xx).invert();                                   // (A x^2 + y^2)^-1
-    ZkScalar dy = (ZkScalar::one() + ZkScalar::one() + xx - yy).invert();  // (2 - A x^2 - y^2)^-1
+    // (A x^2 + y^2)^-1 and (2 - A x^2 - y^2)^-1 from ONE inversion of their product
+    ZkScalar d1 = yy - xx, d2 = ZkScalar::one() + ZkScalar::one() + xx - yy;
+    ZkScalar pi = (d1 * d2).invert();
+    ZkScalar dx = pi * d2, dy = pi * d1;
     return {((x * y) * dx).dbl(), (yy + xx) * dy};
 }
 
@@ -195,7 +197,9 @@ void PointAffine::add_assign(const PointAffine& o) {  // curve.rs:19-36
         return;
     }
     ZkScalar dxy = jubjub_d() * x * o.x * y * o.y;
-    ZkScalar xi = (ZkScalar::one() + dxy).invert(), yi = (ZkScalar::one() - dxy).invert();
+    ZkScalar e1 = ZkScalar::one() + dxy, e2 = ZkScalar::one() - dxy;
+    ZkScalar pi = (e1 * e2).invert();  // one inversion for both denominators
+    ZkScalar xi = pi * e2, yi = pi * e1;
     ZkScalar nx = (x * o.y + y * o.x) * xi, ny = (y * o.y + x * o.x) * yi;
     x = nx;
     y = ny;
@@ -237,6 +241,43 @@ PointAffine PointAffine::multiply(const ZkScalar& k) const {  // curve.rs:58-68
         if ((c[i >> 5] >> (i & 31)) & 1) r.add_assign(self);
     }
     return r.to_affine();
+}
+
+// All intermediate points of the circuit's double-and-add ladder (eddsa/mod.rs:174-236), MSB first:
+//   R_0 = bit_0 ? base : (0, 1);   D_i = 2 R_{i-1};   A_i = D_i + base;   R_i = bit_i ? A_i : D_i
+// computed in projective coordinates with ONE field inversion for the whole ladder (Montgomery's trick) - the
+// per-step affine formulas of the reference cost two inversions each.
+void jubjub_ladder(const PointAffine& base, const std::vector<bool>& bits, std::vector<PointAffine>& dbls, std::vector<PointAffine>& adds) {
+    const size_t n = bits.size();
+    dbls.assign(n, PointAffine::zero());
+    adds.assign(n, PointAffine::zero());
+    if (n < 2) return;
+    const Proj pb = {base.x, base.y, ZkScalar::one()};
+    std::vector<Proj> pts(2 * (n - 1));
+    Proj r = bits[0] ? pb : Proj{ZkScalar::zero(), ZkScalar::one(), ZkScalar::one()};
+    for (size_t i = 1; i < n; ++i) {
+        Proj d = r.dbl();
+        Proj a = d;
+        a.add_assign(pb);
+        pts[2 * (i - 1)] = d;
+        pts[2 * (i - 1) + 1] = a;
+        r = bits[i] ? a : d;
+    }
+    // batch inversion of all Z
+    std::vector<ZkScalar> pref(pts.size());
+    ZkScalar acc = ZkScalar::one();
+    for (size_t k = 0; k < pts.size(); ++k) {
+        pref[k] = acc;
+        acc = acc * pts[k].Z;
+    }
+    ZkScalar inv = acc.invert();
+    for (size_t k = pts.size(); k-- > 0;) {
+        ZkScalar zi = inv * pref[k];
+        inv = inv * pts[k].Z;
+        PointAffine p = {pts[k].X * zi, pts[k].Y * zi};
+        if (k & 1) adds[k / 2 + 1] = p;
+        else dbls[k / 2 + 1] = p;
+    }
 }
 
 // ---- EdDSA (src/crypto/jubjub/mod.rs:112-167)

@@ -12,7 +12,10 @@
 // Output: the Groth16 assignment (z, A.z, B.z, C.z, densities) and, on request, the CSR matrices for
 // CRS generation.  The storage engine (KvStore / LevelDB keys) is out of scope: state lives in RAM.
 #include <array>
+#include <atomic>
+#include <chrono>
 #include <map>
+#include <thread>
 #include <memory>
 #include <unordered_map>
 
@@ -111,6 +114,7 @@ struct UpdateTransition {
     Money src_before_balance, src_before_fee_balance, dst_before_balance;
     Proof4 src_proof, src_balance_proof, src_fee_balance_proof, dst_proof, dst_balance_proof;
     uint64_t src_index = 0, src_token_index = 0, src_fee_token_index = 0, dst_index = 0, dst_token_index = 0;
+    ZkScalar state_after;  // account-tree root once this transition is applied (not a reference field: scheduling aid)
     static UpdateTransition null(int L, int T) {
         UpdateTransition t;
         std::array<ZkScalar, 3> z = {ZkScalar(), ZkScalar(), ZkScalar()};
@@ -133,23 +137,29 @@ using namespace bzk;
 struct bzk_mpn {
     int L, T;
     ZkScalar token_default, tokens_tree_default, account_default;
-    std::unique_ptr<SparseTree4> accounts;
+    std::unique_ptr<SparseTree4> accounts, empty_tokens;
     std::map<uint64_t, MpnAccount> acct;
     std::map<uint64_t, JubjubPrivateKey> keys;
     std::vector<MpnTx> mempool;
     uint64_t height = 0;
+    int threads = (int)std::max(1u, std::thread::hardware_concurrency());
 
     bzk_mpn(int l, int t) : L(l), T(t) {
         token_default = token_leaf(Money());
-        SparseTree4 tt(T, token_default);
-        tokens_tree_default = tt.root();
+        empty_tokens.reset(new SparseTree4(T, token_default));
+        tokens_tree_default = empty_tokens->root();
         account_default = account_hash(MpnAccount());
         accounts.reset(new SparseTree4(L, account_default));
     }
     SparseTree4 tokens_tree(const MpnAccount& a) const {
-        SparseTree4 t(T, token_default);
+        SparseTree4 t = *empty_tokens;  // copy of the empty tree (defaults computed once)
         for (auto& kv : a.tokens) t.set_leaf(kv.first, token_leaf(kv.second));
         return t;
+    }
+    void set_with_tokens_root(uint64_t i, const MpnAccount& a, const ZkScalar& tokens_root) {
+        acct[i] = a;
+        ZkScalar v[5] = {ZkScalar::from_u64(a.tx_nonce), ZkScalar::from_u64(a.withdraw_nonce), a.address.x, a.address.y, tokens_root};
+        accounts->set_leaf(i, poseidon_hash(v, 5));
     }
     ZkScalar tokens_hash(const MpnAccount& a) const { return a.tokens.empty() ? tokens_tree_default : tokens_tree(a).root(); }
     ZkScalar account_hash(const MpnAccount& a) const {
@@ -211,10 +221,15 @@ static void build_transitions(bzk_mpn& w, int log4_batch, const ZkScalar& fee_to
             ++rejected;
             continue;
         }
-        // work on a copy ("isolated" mirror); commit at the end
-        bzk_mpn iso_view = bzk_mpn(w.L, w.T);  // cheap shell; share state by copying the sparse tree
-        *iso_view.accounts = *w.accounts;
-        iso_view.acct = w.acct;
+        // All rejection tests of update.rs that depend only on account DATA are decided before the state is
+        // touched (the reference works on an isolated mirror and discards it on reject; the effect is the same).
+        MpnAccount src_after = src_before;
+        src_after.tx_nonce += 1;
+        src_after.tokens[sti].amount -= tx.amount.amount;
+        if (!src_after.tokens.count(sfi)) { ++rejected; continue; }
+        const Money src_fee_token = src_after.tokens[sfi];
+        if (src_fee_token.token_id != tx.fee.token_id || src_fee_token.amount < tx.fee.amount) { ++rejected; continue; }
+
         UpdateTransition t;
         t.enabled = true;
         t.tx = tx;
@@ -222,39 +237,42 @@ static void build_transitions(bzk_mpn& w, int log4_batch, const ZkScalar& fee_to
         t.src_token_index = sti; t.dst_token_index = dti; t.src_fee_token_index = sfi;
         t.src_before = src_before;
         t.src_before_balance = src_token;
-        t.src_before_balances_hash = w.tokens_hash(src_before);
-        t.src_proof = iso_view.accounts->prove(src_index);
-        MpnAccount src_after = src_before;
-        src_after.tx_nonce += 1;
-        t.src_balance_proof = w.tokens_tree(src_before).prove(sti);
-        src_after.tokens[sti].amount -= tx.amount.amount;
-        iso_view.set(src_index, src_after);
-        if (!src_after.tokens.count(sfi)) { ++rejected; continue; }
-        Money src_fee_token = src_after.tokens[sfi];
-        if (src_fee_token.token_id != tx.fee.token_id || src_fee_token.amount < tx.fee.amount) { ++rejected; continue; }
+        // token tree of the sender, updated in place step by step (one root path per update, as set_data does)
+        SparseTree4 stree = w.tokens_tree(src_before);
+        t.src_before_balances_hash = stree.root();
+        t.src_proof = w.accounts->prove(src_index);
+        t.src_balance_proof = stree.prove(sti);
+        stree.set_leaf(sti, token_leaf(src_after.tokens[sti]));
         t.src_before_fee_balance = src_fee_token;
-        t.src_fee_balance_proof = w.tokens_tree(src_after).prove(sfi);
+        t.src_fee_balance_proof = stree.prove(sfi);
         src_after.tokens[sfi].amount -= tx.fee.amount;
-        iso_view.set(src_index, src_after);
-        t.dst_proof = iso_view.accounts->prove(dst_index);
-        MpnAccount dst_before = iso_view.get(dst_index);
-        t.dst_balance_proof = w.tokens_tree(dst_before).prove(dti);
+        stree.set_leaf(sfi, token_leaf(src_after.tokens[sfi]));
+        w.set_with_tokens_root(src_index, src_after, stree.root());
+        t.dst_proof = w.accounts->prove(dst_index);
+        MpnAccount dst_before = w.get(dst_index);  // read AFTER the sender update (matters when src == dst)
+        SparseTree4 dtree = w.tokens_tree(dst_before);
+        t.dst_balance_proof = dtree.prove(dti);
         t.dst_before = dst_before;
-        t.dst_before_balances_hash = w.tokens_hash(dst_before);
+        t.dst_before_balances_hash = dtree.root();
         t.dst_before_balance = dst_before.tokens.count(dti) ? dst_before.tokens[dti] : Money();
         MpnAccount dst_after = dst_before;
         dst_after.address = tx.dst_pub;
         if (!dst_after.tokens.count(dti)) dst_after.tokens[dti] = Money{tx.amount.token_id, 0};
         dst_after.tokens[dti].amount += tx.amount.amount;
-        iso_view.set(dst_index, dst_after);
-        // commit
-        *w.accounts = *iso_view.accounts;
-        w.acct = iso_view.acct;
+        dtree.set_leaf(dti, token_leaf(dst_after.tokens[dti]));
+        w.set_with_tokens_root(dst_index, dst_after, dtree.root());
         fee_sum += tx.fee.amount;
+        t.state_after = w.accounts->root();
         out.push_back(std::move(t));
     }
     w.mempool.swap(rest);
 }
+
+struct LcModeGuard {
+    bool prev;
+    explicit LcModeGuard(bool on) : prev(lc_tracking()) { lc_tracking() = on; }
+    ~LcModeGuard() { lc_tracking() = prev; }
+};
 
 static MerkleProofWit alloc_proof(ConstraintSystem& cs, const Proof4& p) {
     MerkleProofWit w;
@@ -263,10 +281,100 @@ static MerkleProofWit alloc_proof(ConstraintSystem& cs, const Proof4& p) {
     return w;
 }
 
-// impl Circuit for UpdateCircuit (src/mpn/circuits/update_circuit.rs:49-494); steps = SURVEY App. F
+// One transition of `impl Circuit for UpdateCircuit` (src/mpn/circuits/update_circuit.rs:81-469); steps = SURVEY App. F.
+// Depends on the rest of the circuit only through `accepted_fee_token` and the running `state_wit`, and allocates
+// a fixed number of variables / constraints - which is what lets transitions be synthesized on worker threads.
+struct TxOut {
+    Num state_out, final_fee;
+};
+static TxOut synth_tx(ConstraintSystem& cs, int L, int T, const Num& accepted_fee_token, const Num& state_wit,
+                      const UpdateTransition& tr) {
+    Bool enabled = Bool::is(bit_alloc(cs, tr.enabled));                                                  // 1
+    UInt src_token_index = UInt::alloc(cs, fr_from_u64(tr.src_token_index), 2 * T);                      // 2
+    UInt src_fee_token_index = UInt::alloc(cs, fr_from_u64(tr.src_fee_token_index), 2 * T);
+    UInt dst_token_index = UInt::alloc(cs, fr_from_u64(tr.dst_token_index), 2 * T);
+    Num src_tx_nonce = num_alloc(cs, fr_from_u64(tr.src_before.tx_nonce));                               // 3
+    Num src_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.src_before.withdraw_nonce));
+    APoint src_addr = APoint::alloc(cs, tr.src_before.address);
+    src_addr.assert_on_curve(cs, enabled);
+    Num src_before_bh = num_alloc(cs, tr.src_before_balances_hash.v);                                    // 4
+    Num dst_before_bh = num_alloc(cs, tr.dst_before_balances_hash.v);
+    Num src_token_id = num_alloc(cs, tr.src_before_balance.token_id.v);                                  // 5
+    UInt src_balance = UInt::alloc_64(cs, tr.src_before_balance.amount);
+    Number src_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), src_balance.num});
+    Num src_fee_token_id = num_alloc(cs, tr.src_before_fee_balance.token_id.v);                          // 6
+    UInt src_fee_balance = UInt::alloc_64(cs, tr.src_before_fee_balance.amount);
+    Number src_fee_token_balance_hash = g_poseidon(cs, {Number::from(src_fee_token_id), src_fee_balance.num});
+    MerkleProofWit src_balance_proof = alloc_proof(cs, tr.src_balance_proof);                            // 7
+    g_check_proof4(cs, enabled, src_token_index, src_token_balance_hash, src_balance_proof, Number::from(src_before_bh));
+    UInt tx_amount = UInt::alloc_64(cs, tr.tx.amount.amount);                                            // 8
+    UInt tx_fee = UInt::alloc_64(cs, tr.tx.fee.amount);
+    Number new_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), src_balance.num.minus(tx_amount.num)});  // 9
+    Number balance_middle_root = g_calc_root4(cs, src_token_index, new_token_balance_hash, src_balance_proof);
+    MerkleProofWit src_fee_balance_proof = alloc_proof(cs, tr.src_fee_balance_proof);                    // 10
+    g_check_proof4(cs, enabled, src_fee_token_index, src_fee_token_balance_hash, src_fee_balance_proof, balance_middle_root);
+    Number new_fee_token_balance_hash =
+        g_poseidon(cs, {Number::from(src_fee_token_id), src_fee_balance.num.minus(tx_fee.num)});        // 11
+    Number src_balance_final_root = g_calc_root4(cs, src_fee_token_index, new_fee_token_balance_hash, src_fee_balance_proof);
+    Num tx_nonce = num_alloc(cs, fr_from_u64(tr.tx.nonce));                                              // 12
+    UInt tx_src_index = UInt::alloc(cs, fr_from_u64(tr.src_index), 2 * L);
+    Num tx_amount_token_id = num_alloc(cs, tr.tx.amount.token_id.v);
+    Num tx_fee_token_id = num_alloc(cs, tr.tx.fee.token_id.v);
+    Number::from(accepted_fee_token).assert_equal_if_enabled(cs, enabled, Number::from(tx_fee_token_id));  // 13
+    Number::from(src_token_id).assert_equal(cs, Number::from(tx_amount_token_id));
+    Number::from(src_fee_token_id).assert_equal(cs, Number::from(tx_fee_token_id));
+    Number src_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce), Number::from(src_addr.x),
+                                      Number::from(src_addr.y), Number::from(src_before_bh)});         // 14
+    Num dst_token_id = num_alloc(cs, tr.dst_before_balance.token_id.v);                                  // 15
+    Num dst_balance = num_alloc(cs, fr_from_u64(tr.dst_before_balance.amount));
+    Number dst_token_balance_hash = g_poseidon(cs, {Number::from(dst_token_id), Number::from(dst_balance)});
+    Number new_dst_token_balance_hash =
+        g_poseidon(cs, {Number::from(tx_amount_token_id), Number::from(dst_balance).plus(tx_amount.num)});
+    MerkleProofWit dst_balance_proof = alloc_proof(cs, tr.dst_balance_proof);                            // 16
+    g_check_proof4(cs, enabled, dst_token_index, dst_token_balance_hash, dst_balance_proof, Number::from(dst_before_bh));
+    Number dst_balance_final_root = g_calc_root4(cs, dst_token_index, new_dst_token_balance_hash, dst_balance_proof);
+    MerkleProofWit src_proof = alloc_proof(cs, tr.src_proof);                                            // 17
+    g_check_proof4(cs, enabled, tx_src_index, src_hash, src_proof, Number::from(state_wit));
+    Number new_src_tx_nonce = Number::from(src_tx_nonce).plus(Number::constant(Fr::one()));              // 18
+    Number new_src_hash = g_poseidon(cs, {new_src_tx_nonce, Number::from(src_withdraw_nonce), Number::from(src_addr.x),
+                                          Number::from(src_addr.y), src_balance_final_root});
+    Number middle_root = g_calc_root4(cs, tx_src_index, new_src_hash, src_proof);
+    APoint tx_dst_addr = APoint::alloc(cs, tr.tx.dst_pub);                                               // 19
+    tx_dst_addr.assert_on_curve(cs, enabled);
+    UInt tx_dst_index = UInt::alloc(cs, fr_from_u64(tr.dst_index), 2 * L);
+    Num dst_tx_nonce = num_alloc(cs, fr_from_u64(tr.dst_before.tx_nonce));
+    Num dst_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.dst_before.withdraw_nonce));
+    APoint dst_addr = APoint::alloc(cs, tr.dst_before.address);
+    Number dst_hash = g_poseidon(cs, {Number::from(dst_tx_nonce), Number::from(dst_withdraw_nonce), Number::from(dst_addr.x),
+                                      Number::from(dst_addr.y), Number::from(dst_before_bh)});         // 20
+    MerkleProofWit dst_proof = alloc_proof(cs, tr.dst_proof);
+    Bool is_dst_null = dst_addr.is_null(cs);
+    Bool is_dst_eq = dst_addr.is_equal(cs, tx_dst_addr);
+    Bool addr_valid = boolean_or(cs, is_dst_null, is_dst_eq);
+    assert_true(cs, addr_valid);
+    g_check_proof4(cs, enabled, tx_dst_index, dst_hash, dst_proof, middle_root);                         // 21
+    Number new_dst_hash = g_poseidon(cs, {Number::from(dst_tx_nonce), Number::from(dst_withdraw_nonce), Number::from(tx_dst_addr.x),
+                                          Number::from(tx_dst_addr.y), dst_balance_final_root});
+    Number next_state_wit = g_calc_root4(cs, tx_dst_index, new_dst_hash, dst_proof);
+    Num state_out = mux(cs, enabled, Number::from(state_wit), next_state_wit);                           // 22
+    UInt amount_plus_fee = UInt::constrain(cs, tx_amount.num.plus(tx_fee.num), 64);                      // 23
+    Bool is_lte = amount_plus_fee.lte(cs, src_balance);
+    assert_true(cs, is_lte);
+    Number::from(tx_nonce).assert_equal_if_enabled(cs, enabled, Number::from(src_tx_nonce).plus(Number::constant(Fr::one())));  // 24
+    Num final_fee = mux(cs, enabled, Number::zero(), tx_fee.num);
+    Number tx_hash = g_poseidon(cs, {Number::from(tx_nonce), Number::from(tx_dst_addr.x), Number::from(tx_dst_addr.y),
+                                     Number::from(tx_amount_token_id), tx_amount.num, Number::from(tx_fee_token_id), tx_fee.num});  // 25
+    APoint sig_r = APoint::alloc(cs, tr.tx.sig.r);
+    sig_r.assert_on_curve(cs, enabled);
+    Num sig_s = num_alloc(cs, tr.tx.sig.s.v);
+    g_verify_eddsa(cs, enabled, src_addr, tx_hash, sig_r, sig_s);
+        return {state_out, final_fee};
+}
+
+// impl Circuit for UpdateCircuit (src/mpn/circuits/update_circuit.rs:49-494)
 static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
                               const ZkScalar& aux_data, const ZkScalar& next_state, const ZkScalar& fee_token,
-                              const std::vector<UpdateTransition>& transitions) {
+                              const std::vector<UpdateTransition>& transitions, int nthreads) {
     Num commitment_wit = num_alloc(cs, commitment.v);
     num_inputize(cs, commitment_wit);
     Num height_wit = num_alloc(cs, fr_from_u64(height));
@@ -280,91 +388,91 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
     num_inputize(cs, claimed_next);
     Number fee_sum = Number::zero();
 
-    for (const UpdateTransition& tr : transitions) {
-        Bool enabled = Bool::is(bit_alloc(cs, tr.enabled));                                                  // 1
-        UInt src_token_index = UInt::alloc(cs, fr_from_u64(tr.src_token_index), 2 * T);                      // 2
-        UInt src_fee_token_index = UInt::alloc(cs, fr_from_u64(tr.src_fee_token_index), 2 * T);
-        UInt dst_token_index = UInt::alloc(cs, fr_from_u64(tr.dst_token_index), 2 * T);
-        Num src_tx_nonce = num_alloc(cs, fr_from_u64(tr.src_before.tx_nonce));                               // 3
-        Num src_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.src_before.withdraw_nonce));
-        APoint src_addr = APoint::alloc(cs, tr.src_before.address);
-        src_addr.assert_on_curve(cs, enabled);
-        Num src_before_bh = num_alloc(cs, tr.src_before_balances_hash.v);                                    // 4
-        Num dst_before_bh = num_alloc(cs, tr.dst_before_balances_hash.v);
-        Num src_token_id = num_alloc(cs, tr.src_before_balance.token_id.v);                                  // 5
-        UInt src_balance = UInt::alloc_64(cs, tr.src_before_balance.amount);
-        Number src_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), src_balance.num});
-        Num src_fee_token_id = num_alloc(cs, tr.src_before_fee_balance.token_id.v);                          // 6
-        UInt src_fee_balance = UInt::alloc_64(cs, tr.src_before_fee_balance.amount);
-        Number src_fee_token_balance_hash = g_poseidon(cs, {Number::from(src_fee_token_id), src_fee_balance.num});
-        MerkleProofWit src_balance_proof = alloc_proof(cs, tr.src_balance_proof);                            // 7
-        g_check_proof4(cs, enabled, src_token_index, src_token_balance_hash, src_balance_proof, Number::from(src_before_bh));
-        UInt tx_amount = UInt::alloc_64(cs, tr.tx.amount.amount);                                            // 8
-        UInt tx_fee = UInt::alloc_64(cs, tr.tx.fee.amount);
-        Number new_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), src_balance.num.minus(tx_amount.num)});  // 9
-        Number balance_middle_root = g_calc_root4(cs, src_token_index, new_token_balance_hash, src_balance_proof);
-        MerkleProofWit src_fee_balance_proof = alloc_proof(cs, tr.src_fee_balance_proof);                    // 10
-        g_check_proof4(cs, enabled, src_fee_token_index, src_fee_token_balance_hash, src_fee_balance_proof, balance_middle_root);
-        Number new_fee_token_balance_hash =
-            g_poseidon(cs, {Number::from(src_fee_token_id), src_fee_balance.num.minus(tx_fee.num)});        // 11
-        Number src_balance_final_root = g_calc_root4(cs, src_fee_token_index, new_fee_token_balance_hash, src_fee_balance_proof);
-        Num tx_nonce = num_alloc(cs, fr_from_u64(tr.tx.nonce));                                              // 12
-        UInt tx_src_index = UInt::alloc(cs, fr_from_u64(tr.src_index), 2 * L);
-        Num tx_amount_token_id = num_alloc(cs, tr.tx.amount.token_id.v);
-        Num tx_fee_token_id = num_alloc(cs, tr.tx.fee.token_id.v);
-        Number::from(accepted_fee_token).assert_equal_if_enabled(cs, enabled, Number::from(tx_fee_token_id));  // 13
-        Number::from(src_token_id).assert_equal(cs, Number::from(tx_amount_token_id));
-        Number::from(src_fee_token_id).assert_equal(cs, Number::from(tx_fee_token_id));
-        Number src_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce), Number::from(src_addr.x),
-                                          Number::from(src_addr.y), Number::from(src_before_bh)});         // 14
-        Num dst_token_id = num_alloc(cs, tr.dst_before_balance.token_id.v);                                  // 15
-        Num dst_balance = num_alloc(cs, fr_from_u64(tr.dst_before_balance.amount));
-        Number dst_token_balance_hash = g_poseidon(cs, {Number::from(dst_token_id), Number::from(dst_balance)});
-        Number new_dst_token_balance_hash =
-            g_poseidon(cs, {Number::from(tx_amount_token_id), Number::from(dst_balance).plus(tx_amount.num)});
-        MerkleProofWit dst_balance_proof = alloc_proof(cs, tr.dst_balance_proof);                            // 16
-        g_check_proof4(cs, enabled, dst_token_index, dst_token_balance_hash, dst_balance_proof, Number::from(dst_before_bh));
-        Number dst_balance_final_root = g_calc_root4(cs, dst_token_index, new_dst_token_balance_hash, dst_balance_proof);
-        MerkleProofWit src_proof = alloc_proof(cs, tr.src_proof);                                            // 17
-        g_check_proof4(cs, enabled, tx_src_index, src_hash, src_proof, Number::from(state_wit));
-        Number new_src_tx_nonce = Number::from(src_tx_nonce).plus(Number::constant(Fr::one()));              // 18
-        Number new_src_hash = g_poseidon(cs, {new_src_tx_nonce, Number::from(src_withdraw_nonce), Number::from(src_addr.x),
-                                              Number::from(src_addr.y), src_balance_final_root});
-        Number middle_root = g_calc_root4(cs, tx_src_index, new_src_hash, src_proof);
-        APoint tx_dst_addr = APoint::alloc(cs, tr.tx.dst_pub);                                               // 19
-        tx_dst_addr.assert_on_curve(cs, enabled);
-        UInt tx_dst_index = UInt::alloc(cs, fr_from_u64(tr.dst_index), 2 * L);
-        Num dst_tx_nonce = num_alloc(cs, fr_from_u64(tr.dst_before.tx_nonce));
-        Num dst_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.dst_before.withdraw_nonce));
-        APoint dst_addr = APoint::alloc(cs, tr.dst_before.address);
-        Number dst_hash = g_poseidon(cs, {Number::from(dst_tx_nonce), Number::from(dst_withdraw_nonce), Number::from(dst_addr.x),
-                                          Number::from(dst_addr.y), Number::from(dst_before_bh)});         // 20
-        MerkleProofWit dst_proof = alloc_proof(cs, tr.dst_proof);
-        Bool is_dst_null = dst_addr.is_null(cs);
-        Bool is_dst_eq = dst_addr.is_equal(cs, tx_dst_addr);
-        Bool addr_valid = boolean_or(cs, is_dst_null, is_dst_eq);
-        assert_true(cs, addr_valid);
-        g_check_proof4(cs, enabled, tx_dst_index, dst_hash, dst_proof, middle_root);                         // 21
-        Number new_dst_hash = g_poseidon(cs, {Number::from(dst_tx_nonce), Number::from(dst_withdraw_nonce), Number::from(tx_dst_addr.x),
-                                              Number::from(tx_dst_addr.y), dst_balance_final_root});
-        Number next_state_wit = g_calc_root4(cs, tx_dst_index, new_dst_hash, dst_proof);
-        state_wit = mux(cs, enabled, Number::from(state_wit), next_state_wit);                               // 22
-        UInt amount_plus_fee = UInt::constrain(cs, tx_amount.num.plus(tx_fee.num), 64);                      // 23
-        Bool is_lte = amount_plus_fee.lte(cs, src_balance);
-        assert_true(cs, is_lte);
-        Number::from(tx_nonce).assert_equal_if_enabled(cs, enabled, Number::from(src_tx_nonce).plus(Number::constant(Fr::one())));  // 24
-        Num final_fee = mux(cs, enabled, Number::zero(), tx_fee.num);
-        fee_sum.add_num(Fr::one(), final_fee);
-        Number tx_hash = g_poseidon(cs, {Number::from(tx_nonce), Number::from(tx_dst_addr.x), Number::from(tx_dst_addr.y),
-                                         Number::from(tx_amount_token_id), tx_amount.num, Number::from(tx_fee_token_id), tx_fee.num});  // 25
-        APoint sig_r = APoint::alloc(cs, tr.tx.sig.r);
-        sig_r.assert_on_curve(cs, enabled);
-        Num sig_s = num_alloc(cs, tr.tx.sig.s.v);
-        g_verify_eddsa(cs, enabled, src_addr, tx_hash, sig_r, sig_s);
+    bool done = false;
+    if (!lc_tracking() && nthreads > 1 && transitions.size() > 1) {
+        // Witness-only mode, parallel over transitions.  Variable identities do not matter here (no LCs), only the
+        // ORDER of the emitted values, so each worker fills a private system and the pieces are concatenated.
+        // The state entering transition t is predicted from the witness builder (`state_after` chain) and checked
+        // against what the circuit computes; on any disagreement (an invalid witness) fall back to the sequential
+        // walk so that the reported unsatisfied constraint is exactly the sequential one.
+        const size_t n = transitions.size();
+        size_t size_hint_aux = 0, size_hint_cons = 0;
+        {
+            ConstraintSystem probe(false);  // a disabled slot is cheap to synthesize and has the common shape
+            LcModeGuard g(false);
+            Num st0 = {VAR_ONE, state.v};
+            synth_tx(probe, L, T, accepted_fee_token, st0, UpdateTransition::null(L, T));
+            size_hint_aux = probe.aux.size();
+            size_hint_cons = probe.az.size();
+        }
+        cs.aux.reserve(cs.aux.size() + n * size_hint_aux + 4096);
+        cs.az.reserve(cs.az.size() + n * size_hint_cons + 4096);
+        cs.bz.reserve(cs.bz.size() + n * size_hint_cons + 4096);
+        cs.cz.reserve(cs.cz.size() + n * size_hint_cons + 4096);
+        std::vector<Fr> state_in(n + 1);
+        state_in[0] = state.v;
+        for (size_t t = 0; t < n; ++t) state_in[t + 1] = transitions[t].enabled ? transitions[t].state_after.v : state_in[t];
+        std::vector<std::unique_ptr<ConstraintSystem>> parts(n);
+        std::vector<TxOut> outs(n);
+        std::atomic<size_t> next(0);
+        auto worker = [&] {
+            LcModeGuard g(false);
+            for (;;) {
+                const size_t t = next.fetch_add(1);
+                if (t >= n) break;
+                parts[t].reset(new ConstraintSystem(false));
+                if (size_hint_aux) {  // every transition allocates the same number of variables / constraints
+                    parts[t]->aux.reserve(size_hint_aux);
+                    parts[t]->az.reserve(size_hint_cons);
+                    parts[t]->bz.reserve(size_hint_cons);
+                    parts[t]->cz.reserve(size_hint_cons);
+                }
+                Num st_in = {VAR_ONE, state_in[t]};
+                const auto q0 = std::chrono::steady_clock::now();
+                outs[t] = synth_tx(*parts[t], L, T, accepted_fee_token, st_in, transitions[t]);
+                if (getenv("BZK_DEBUG") && t < 3)
+                    fprintf(stderr, "[bzk]   tx %zu: %.3f s\n", t, std::chrono::duration<double>(std::chrono::steady_clock::now() - q0).count());
+            }
+        };
+        std::vector<std::thread> th;
+        const int nt = (int)std::min<size_t>((size_t)nthreads, n);
+        const auto tp0 = std::chrono::steady_clock::now();
+        for (int i = 1; i < nt; ++i) th.emplace_back(worker);
+        worker();
+        for (auto& x : th) x.join();
+        if (getenv("BZK_DEBUG"))
+            fprintf(stderr, "[bzk] %d workers: %.3f s\n", nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
+        bool chain_ok = true;
+        for (size_t t = 0; t < n; ++t) {
+            if (!outs[t].state_out.val.equals(state_in[t + 1])) {
+                if (getenv("BZK_DEBUG")) fprintf(stderr, "[bzk] state chain mismatch at transition %zu (enabled %d)\n", t, (int)transitions[t].enabled);
+                chain_ok = false;
+            }
+        }
+        if (chain_ok) {
+            for (size_t t = 0; t < n; ++t) {
+                ConstraintSystem& p = *parts[t];
+                cs.aux.insert(cs.aux.end(), p.aux.begin(), p.aux.end());
+                cs.az.insert(cs.az.end(), p.az.begin(), p.az.end());
+                cs.bz.insert(cs.bz.end(), p.bz.begin(), p.bz.end());
+                cs.cz.insert(cs.cz.end(), p.cz.begin(), p.cz.end());
+                fee_sum.add_num(Fr::one(), outs[t].final_fee);
+                parts[t].reset();
+            }
+            state_wit = {VAR_ONE, state_in[n]};
+            done = true;
+        }
+    }
+    if (!done) {
+        for (const UpdateTransition& tr : transitions) {
+            TxOut o = synth_tx(cs, L, T, accepted_fee_token, state_wit, tr);
+            state_wit = o.state_out;
+            fee_sum.add_num(Fr::one(), o.final_fee);
+        }
     }
     Number fee_hash = g_poseidon(cs, {Number::from(accepted_fee_token), fee_sum});
-    cs.enforce(LC::of(aux_wit.var), LC::one(), fee_hash.lc);
-    cs.enforce(LC::of(state_wit.var), LC::one(), LC::of(claimed_next.var));
+    cs.enforce(LC::of(aux_wit.var), aux_wit.val, LC::one(), Fr::one(), fee_hash.lc, fee_hash.val);
+    cs.enforce(LC::of(state_wit.var), state_wit.val, LC::one(), Fr::one(), LC::of(claimed_next.var), claimed_next.val);
     cs.finalize();
 }
 
@@ -407,6 +515,12 @@ void bzk_mpn_destroy(bzk_mpn* w) { delete w; }
 int32_t bzk_mpn_set_height(bzk_mpn* w, uint64_t height) {
     if (!w) return BZK_E_ARG;
     w->height = height;
+    return BZK_OK;
+}
+
+int32_t bzk_mpn_set_threads(bzk_mpn* w, int32_t n) {
+    if (!w || n < 1) return BZK_E_ARG;
+    w->threads = n;
     return BZK_OK;
 }
 
@@ -466,21 +580,32 @@ int32_t bzk_mpn_update_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t
     if (!w || !commitment || !fee_token || !out || log4_batch > 6) return BZK_E_ARG;
     *out = nullptr;
     try {
+        const bool dbg = getenv("BZK_DEBUG") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = now();
         const ZkScalar ft = ZkScalar::from_bytes(fee_token);
         const ZkScalar state = w->accounts->root();
         std::vector<UpdateTransition> trs;
         uint64_t fee_sum = 0, rejected = 0;
         build_transitions(*w, (int)log4_batch, ft, trs, fee_sum, rejected);
+        double t1 = now();
         const uint64_t accepted = trs.size();
         while (trs.size() < ((size_t)1 << (2 * log4_batch))) trs.push_back(UpdateTransition::null(w->L, w->T));
         ZkScalar auxin[2] = {ft, ZkScalar::from_u64(fee_sum)};
         const ZkScalar aux = poseidon_hash(auxin, 2);
         const ZkScalar next_state = w->accounts->root();
         std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
-        synthesize_update(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, next_state, ft, trs);
+        // KeypairAssembly role (matrices + densities, LCs re-evaluated against the supplied values as a self-check)
+        // or pure ProvingAssignment role (values only: no linear-combination bookkeeping at all)
+        LcModeGuard guard(record_matrices != 0);
+        r->cs.self_check = record_matrices != 0;
+        synthesize_update(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, next_state, ft, trs, w->threads);
+        if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;  // a gadget supplied a value that is not <LC, z>
+        double t2 = now();
         r->accepted = accepted;
         r->rejected = rejected;
         finish_r1cs(r.get());
+        if (dbg) fprintf(stderr, "[bzk] update_synthesize: transitions %.3f s, circuit %.3f s, finish %.3f s\n", t1 - t0, t2 - t1, now() - t2);
         *out = r.release();
         return BZK_OK;
     } catch (const std::bad_alloc&) {
@@ -503,9 +628,11 @@ int32_t bzk_mpn_update_empty(uint32_t log4_tree, uint32_t log4_token_tree, uint3
     try {
         std::vector<UpdateTransition> trs((size_t)1 << (2 * log4_batch), UpdateTransition::null((int)log4_tree, (int)log4_token_tree));
         std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
+        LcModeGuard guard(record_matrices != 0);
+        r->cs.self_check = record_matrices != 0;
         synthesize_update(r->cs, (int)log4_tree, (int)log4_token_tree, ZkScalar::from_bytes(commitment), height,
                           ZkScalar::from_bytes(state), ZkScalar::from_bytes(aux_data), ZkScalar::from_bytes(next_state),
-                          ZkScalar::from_bytes(fee_token), trs);
+                          ZkScalar::from_bytes(fee_token), trs, 1);
         finish_r1cs(r.get());
         *out = r.release();
         return BZK_OK;

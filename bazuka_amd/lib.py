@@ -51,6 +51,7 @@ SIGNATURES = {
     "bzk_mpn_create": (_i32, [_u32, _u32, C.POINTER(_vp)]),
     "bzk_mpn_destroy": (None, [_vp]),
     "bzk_mpn_set_height": (_i32, [_vp, _u64]),
+    "bzk_mpn_set_threads": (_i32, [_vp, _i32]),
     "bzk_mpn_add_account": (_i32, [_vp, _u64, _vp, _u32, _vp, _u64, _vp]),
     "bzk_mpn_add_key": (_i32, [_vp, _u64, _vp, _u32]),
     "bzk_mpn_root": (_i32, [_vp, _vp]),
@@ -354,6 +355,9 @@ class MpnWorld:
 
     def set_height(self, height: int):
         _st(self.lib.bzk_mpn_set_height(self.h, height), "set_height")
+
+    def set_threads(self, n: int):
+        _st(self.lib.bzk_mpn_set_threads(self.h, n), "set_threads")
 
     def add_account(self, index: int, seed: bytes, token_id: bytes, balance: int) -> bytes:
         out = C.create_string_buffer(64)

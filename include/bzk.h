@@ -185,6 +185,7 @@ typedef struct bzk_r1cs bzk_r1cs; /* a synthesized circuit instance: assignment 
 int32_t bzk_mpn_create(uint32_t log4_tree, uint32_t log4_token_tree, bzk_mpn** out);
 void bzk_mpn_destroy(bzk_mpn* w);
 int32_t bzk_mpn_set_height(bzk_mpn* w, uint64_t height);
+int32_t bzk_mpn_set_threads(bzk_mpn* w, int32_t n); /* worker threads of the witness generator (default: all cores) */
 /* account `index` := keys from `JubJub::generate_keys(seed)` (src/crypto/jubjub/mod.rs:112-124), token
  * slot 0 = (token_id, balance); pub_xy_out (optional) receives address x|y */
 int32_t bzk_mpn_add_account(bzk_mpn* w, uint64_t index, const uint8_t* seed, uint32_t seed_len, const uint8_t token_id[32],
