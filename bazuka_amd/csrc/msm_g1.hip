@@ -37,4 +37,23 @@ int32_t bzk_g1_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint
     return BZK_OK;
 }
 
+// static-base tables (see msm_impl.cuh 4c)
+int32_t bzk_msm_g1_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_table** out) {
+    MsmTable* t = nullptr;
+    int32_t st = msm_table_build<G1Fast>(ctx, bases_dev, n, &t);
+    if (out) *out = (bzk_msm_table*)t;
+    return st;
+}
+int32_t bzk_msm_g1_table_run_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                 uint8_t out[97]) {
+    return msm_table_entry<G1Fast>(ctx, (const MsmTable*)table, scalars_dev, n, flags, 0, -1, out);
+}
+int32_t bzk_msm_g1_table_windows_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                     uint32_t w_begin, uint32_t w_end, uint8_t out[97]) {
+    return msm_table_entry<G1Fast>(ctx, (const MsmTable*)table, scalars_dev, n, flags, (int)w_begin, (int)w_end, out);
+}
+
+void bzk_msm_table_free(bzk_ctx* ctx, bzk_msm_table* table) { msm_table_free(ctx, (MsmTable*)table); }
+uint32_t bzk_msm_table_window_count(const bzk_msm_table* table) { return table ? (uint32_t)((const MsmTable*)table)->w_total : 0; }
+
 }  // extern "C"

@@ -46,7 +46,7 @@ static int msm_windows_for(int c) { return (256 + c - 1) / c; }  // signed digit
 // 1. digits
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __restrict__ scalars, uint64_t n, int mont, int c,
-                                                         int w_total, int w_begin, int w_cnt,
+                                                         int w_total, int w_begin, int w_cnt, uint32_t table_stride,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -59,7 +59,9 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
     if (mont) s = fe_from_mont<FrParams>(s);
     const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
-    const uint32_t nb = (uint32_t)w_cnt * half;  // sentinel key (sorted behind every bucket)
+    // table mode (table_stride != 0): every window shares ONE bucket set (the table holds 2^(c w) P_i), the
+    // value indexes the table entry [w][i]; otherwise buckets are per window and the value is the base index
+    const uint32_t nb = table_stride ? half : (uint32_t)w_cnt * half;  // sentinel key (sorted behind every bucket)
     uint64_t buf = 0;
     int cnt = 0, w = 0;
     uint32_t carry = 0;
@@ -76,8 +78,13 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
         if (w >= w_begin && w < w_begin + w_cnt) {
             const uint32_t lw = (uint32_t)(w - w_begin);
             const uint64_t o = (uint64_t)lw * n + i;
-            keys[o] = d ? lw * half + (d - 1) : nb;
-            vals[o] = (uint32_t)i | (neg << 31);
+            if (table_stride) {
+                keys[o] = d ? (d - 1) : nb;
+                vals[o] = ((uint32_t)w * table_stride + (uint32_t)i) | (neg << 31);
+            } else {
+                keys[o] = d ? lw * half + (d - 1) : nb;
+                vals[o] = (uint32_t)i | (neg << 31);
+            }
         }
         ++w;
     };
@@ -130,6 +137,31 @@ __global__ void __launch_bounds__(128) msm_convert_bases_kernel(const void* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4c. static-base tables: tab[w][i] = 2^(c w) * P_i in the internal affine form.  Built once per base set (a
+// Groth16 CRS query is static); with them all windows feed ONE bucket set, so the bucket reduction shrinks
+// from W windows to one and the host-side Horner disappears.  Costs W x the base memory - what 288 GB is for.
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restrict__ raw, uint64_t n, int c, int w_total,
+                                                             typename C::DevAff* __restrict__ tab) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typename C::DevAff a = C::convert(raw, i);
+    tab[i] = a;
+    typename C::Pt p = C::identity();
+    C::add_mixed(p, a, false);
+#pragma unroll 1
+    for (int w = 1; w < w_total; ++w) {
+#pragma unroll 1
+        for (int d = 0; d < c; ++d) p = C::dbl(p);
+        a = C::to_dev_affine(p);
+        tab[(uint64_t)w * n + i] = a;
+        p = C::identity();  // restart from the affine form: keeps the coordinates small and exact
+        C::add_mixed(p, a, false);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 5. bucket accumulation (dominant kernel)
 //
 // Work unit = a TASK: a run of at most MSM_SEG consecutive entries of one bucket.  Buckets are taken in
@@ -148,8 +180,8 @@ static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* _
     ntask[i] = c <= seg ? 1u : (c + seg - 1) / seg;  // empty buckets keep one task (writes the identity)
 }
 
-template <class C>
-__global__ void __launch_bounds__(128) msm_accumulate_kernel(const void* __restrict__ bases, const uint32_t* __restrict__ vals,
+template <class C, int OCC>
+__global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                              const uint32_t* __restrict__ start,
                                                              const uint32_t* __restrict__ count_sorted,
                                                              const uint32_t* __restrict__ order,
@@ -266,20 +298,14 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// 7. per-window tree sum of the chunk results
+// 7. per-window sum of the chunk results: two shallow LDS trees (the reduction phase is latency-bound - every
+//    XYZZ add is ~14 dependent field products - so depth, not work, is what is minimised here)
+//    stage A: THREADS consecutive chunk results -> 1 partial        (grid = windows x groups)
+//    stage B: the <= THREADS partials of a window -> the window sum, converted to standard limbs
 // ------------------------------------------------------------------------------------------------
 template <class C, int THREADS>
-__global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const typename C::Pt* __restrict__ chunk_out, uint32_t per_win,
-                                                                 XyzzT<typename C::HostF>* __restrict__ win_out) {
+__device__ __forceinline__ typename C::Pt block_tree_sum(typename C::Pt acc, typename C::Pt* sh) {
     typedef typename C::Pt Pt;
-    __shared__ Pt sh[THREADS];
-    const uint32_t w = blockIdx.x;
-    const Pt* src = chunk_out + (size_t)w * per_win;
-    Pt acc = C::identity();
-    for (uint32_t i = threadIdx.x; i < per_win; i += THREADS) {
-        Pt p = src[i];
-        C::add(acc, p);
-    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = THREADS / 2; s > 0; s >>= 1) {
@@ -290,7 +316,35 @@ __global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const typename 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) win_out[w] = C::to_std(sh[0]);  // standard 12 x 32-bit XYZZ for the host-side Horner
+    return sh[0];
+}
+
+template <class C, int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_window_partial_kernel(const typename C::Pt* __restrict__ chunk_out, uint32_t per_win,
+                                                                     uint32_t groups, typename C::Pt* __restrict__ partial_out) {
+    typedef typename C::Pt Pt;
+    __shared__ Pt sh[THREADS];
+    const uint32_t w = blockIdx.x / groups, g = blockIdx.x % groups;
+    const uint32_t i = g * THREADS + threadIdx.x;
+    Pt acc = i < per_win ? chunk_out[(size_t)w * per_win + i] : C::identity();
+    Pt r = block_tree_sum<C, THREADS>(acc, sh);
+    if (threadIdx.x == 0) partial_out[(size_t)w * groups + g] = r;
+}
+
+template <class C, int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const typename C::Pt* __restrict__ partials, uint32_t groups,
+                                                                 XyzzT<typename C::HostF>* __restrict__ win_out) {
+    typedef typename C::Pt Pt;
+    __shared__ Pt sh[THREADS];
+    const uint32_t w = blockIdx.x;
+    const Pt* src = partials + (size_t)w * groups;
+    Pt acc = C::identity();
+    for (uint32_t i = threadIdx.x; i < groups; i += THREADS) {
+        Pt p = src[i];
+        C::add(acc, p);
+    }
+    Pt r = block_tree_sum<C, THREADS>(acc, sh);
+    if (threadIdx.x == 0) win_out[w] = C::to_std(r);  // standard 12 x 32-bit XYZZ for the host
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,28 +452,37 @@ static int bits_for(uint64_t v) {
 }
 
 // Computes sum over windows [w_begin, w_end) of 2^(c w) S_w into `result` (host XYZZ, standard limbs).
+struct MsmTable {
+    void* data = nullptr;  // DevAff[w_total][n]
+    uint64_t n = 0;
+    int c = 0, w_total = 0;
+};
+
 template <class C>
 static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
-                       int w_end, XyzzT<typename C::HostF>& result) {
+                       int w_end, XyzzT<typename C::HostF>& result, const MsmTable* table = nullptr) {
     typedef typename C::HostF F;
     typedef typename C::Pt Pt;
     typedef XyzzT<F> StdPt;
     result = xyzz_identity<F>();
     if (n == 0 || w_begin >= w_end) return BZK_OK;
     if (n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
-    const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n);
+    const int c = table ? table->c : (ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n));
     const int w_total = msm_windows_for(c);
     if (w_end > w_total) return BZK_E_ARG;
+    if (table && (n > table->n || (uint64_t)w_total * table->n >= ((uint64_t)1 << 31))) return BZK_E_ARG;
     const uint32_t half = 1u << (c - 1);
-    uint32_t ch = ctx->msm_chunk_override > 0 ? (uint32_t)ctx->msm_chunk_override : 16u;
+    uint32_t ch = ctx->msm_chunk_override > 0 ? (uint32_t)ctx->msm_chunk_override : 8u;
     if (ch > half) ch = half;
     while (half % ch) --ch;
     const uint32_t per_win = half / ch;
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
     int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w_end - w_begin), ((uint64_t)1 << 30) / n));
+    if (table) group = w_end - w_begin;  // one shared bucket set: all requested windows in one pass
     const uint64_t len_max = (uint64_t)group * n;
-    const uint32_t nb_max = (uint32_t)group * half;
+    if (len_max >= ((uint64_t)1 << 31)) return BZK_E_ARG;
+    const uint32_t nb_max = table ? half : (uint32_t)group * half;
 
     // rocPRIM temp sizes
     size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
@@ -427,7 +490,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         uint32_t* nul = nullptr;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp1, nul, nul, nul, nul, (size_t)len_max, 0, bits_for(nb_max), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
-        e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_max, 0, bits_for(n), ctx->stream);
+        e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_max, 0, bits_for(len_max), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)nb_max, rocprim::plus<uint32_t>(), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
@@ -436,6 +499,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     // serial run length per lane: ~4x the mean bucket population, within [32, 256] - short enough that the
     // few over-full buckets of a degenerate top window do not set the kernel's critical path at small n
     uint32_t seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n / half + 1)));
+    if (table) seg = 64;  // shared buckets are all heavily populated: short runs keep every SIMD busy
     const uint64_t t_cap = (uint64_t)nb_max + len_max / seg + 1;  // upper bound on the number of tasks
     size_t total = 0;
     total += 4 * ws_pad(len_max * 4);                 // keys, vals, keys_sorted, vals_sorted
@@ -443,8 +507,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     total += ws_pad((size_t)t_cap * sizeof(Pt));      // per-task partial sums (multi-task buckets only)
     total += ws_pad((size_t)nb_max * sizeof(Pt));     // buckets
     total += ws_pad((size_t)group * per_win * sizeof(Pt));
+    total += ws_pad(((size_t)group * (per_win / C::WSUM_THREADS + 1)) * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(StdPt));
-    if (C::CONVERT_BASES) total += ws_pad((size_t)n * sizeof(typename C::DevAff));
+    if (C::CONVERT_BASES && !table) total += ws_pad((size_t)n * sizeof(typename C::DevAff));
     total += ws_pad(tmp) + 4096;
     BZK_TRY(ws_reserve(ctx, total));
     BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(StdPt)));
@@ -463,9 +528,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     Pt* partial = cur.take<Pt>(t_cap);
     Pt* buckets = cur.take<Pt>(nb_max);
     Pt* chunk_out = cur.take<Pt>((size_t)group * per_win);
+    Pt* wpart = cur.take<Pt>((size_t)group * (per_win / C::WSUM_THREADS + 1));
     StdPt* win_out = cur.take<StdPt>(w_total);
-    const void* bases = bases_raw;
-    if (C::CONVERT_BASES) {
+    const void* bases = table ? table->data : bases_raw;
+    if (C::CONVERT_BASES && !table) {
         typename C::DevAff* conv = cur.take<typename C::DevAff>(n);
         auto k_conv = msm_convert_bases_kernel<C>;
         BZK_LAUNCH(ctx, "msm_convert_bases", k_conv, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, bases_raw, n, conv);
@@ -478,9 +544,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
         const uint64_t len = (uint64_t)wc * n;
-        const uint32_t nb = (uint32_t)wc * half;
+        const uint32_t nb = table ? half : (uint32_t)wc * half;
+        const int n_red_win = table ? 1 : wc;  // bucket sets to reduce
         BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                   (const U128*)scalars, n, mont, c, w_total, wb, wc, keys, vals);
+                   (const U128*)scalars, n, mont, c, w_total, wb, wc, (uint32_t)(table ? table->n : 0), keys, vals);
         {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
@@ -494,7 +561,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         {
             ProfScope ps(ctx, "msm_sort_buckets");
             size_t t = tmp;
-            hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, count, count_s, iota, order, (size_t)nb, 0, bits_for(n), ctx->stream);
+            hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, count, count_s, iota, order, (size_t)nb, 0, bits_for(len), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, count_s, nb, seg, ntask);
@@ -505,7 +572,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         const uint32_t t_max = (uint32_t)((uint64_t)nb + len / seg + 1);
-        auto k_acc = msm_accumulate_kernel<C>;
+        // 2 waves/SIMD: forcing 3 or 4 (__launch_bounds__) spills 68 / 223 VGPRs and measured 13 % / 80 % slower
+        auto k_acc = msm_accumulate_kernel<C, 2>;
         auto k_fold = msm_fold_kernel<C>;
         auto k_fold_small = msm_fold_small_kernel<C>;
         auto k_red = msm_reduce_kernel<C>;
@@ -520,13 +588,20 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, count_s, order, tbase, n_pos, seg,
                        partial, buckets);
         }
-        const uint32_t n_chunks = (uint32_t)wc * per_win;
+        const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);
         constexpr int WT = C::WSUM_THREADS;
+        const uint32_t groups = (per_win + WT - 1) / WT;
+        auto k_wp = msm_window_partial_kernel<C, WT>;
         auto k_ws = msm_window_sum_kernel<C, WT>;
-        BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)wc), dim3(WT), 0, chunk_out, per_win, win_out);
-        BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)wc * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
+        BZK_LAUNCH(ctx, "msm_window_partial", k_wp, dim3((unsigned)n_red_win * groups), dim3(WT), 0, chunk_out, per_win, groups, wpart);
+        BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_out);
+        BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)n_red_win * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (table) {  // the table already carries the 2^(c w) factors: the single bucket-set sum IS the result
+            memcpy(&result, ctx->pinned, sizeof(StdPt));
+            return BZK_OK;
+        }
         memcpy(&wsum[wb - w_begin], ctx->pinned, (size_t)wc * sizeof(StdPt));
     }
     // Horner over the window sums (host): result = 2^(c*w_begin) * sum_k 2^(c k) S_{w_begin+k}
@@ -573,6 +648,58 @@ static int32_t msm_entry_host(bzk_ctx* ctx, const uint8_t* bases, const uint8_t*
     if (db) (void)hipFree(db);
     if (ds) (void)hipFree(ds);
     return st;
+}
+
+template <class C>
+static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, MsmTable** out) {
+    if (!ctx || !out || !bases_raw || n == 0) return BZK_E_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    int c = msm_pick_c(n);
+    if (const char* e = getenv("BZK_MSM_TABLE_C")) {
+        int v = atoi(e);
+        if (v >= 4 && v <= 20) c = v;
+    }
+    const int w_total = msm_windows_for(c);
+    if ((uint64_t)w_total * n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
+    MsmTable* t = new (std::nothrow) MsmTable();
+    if (!t) return BZK_E_ALLOC;
+    t->n = n; t->c = c; t->w_total = w_total;
+    hipError_t e = hipMalloc(&t->data, (size_t)w_total * n * sizeof(typename C::DevAff));
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("table alloc: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        delete t;
+        return BZK_E_ALLOC;
+    }
+    auto k = msm_table_build_kernel<C>;
+    BZK_LAUNCH(ctx, "msm_table_build", k, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, bases_raw, n, c, w_total, (typename C::DevAff*)t->data);
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = t;
+    return BZK_OK;
+}
+
+static void msm_table_free(bzk_ctx* ctx, MsmTable* t) {
+    if (!t) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (t->data) (void)hipFree(t->data);
+    delete t;
+}
+
+template <class C>
+static int32_t msm_table_entry(bzk_ctx* ctx, const MsmTable* t, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
+                               int w_end, uint8_t* out) {
+    typedef typename C::HostF F;
+    if (!ctx || !t || !out || (n && !scalars)) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (w_end < 0) w_end = t->w_total;
+    XyzzT<F> r;
+    BZK_TRY(msm_run<C>(ctx, nullptr, scalars, n, flags, w_begin, w_end, r, t));
+    PointIO<F>::pack(r, out);
+    return BZK_OK;
 }
 
 template <class F>

@@ -23,6 +23,13 @@ struct G1Fast {
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p, bool neg) { g1x28::add_mixed(acc, p, neg); }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { g1x28::add_full(acc, q); }
     __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return g1x28::mul_u32(p, k); }
+    __device__ static __forceinline__ Pt dbl(const Pt& p) { return g1x28::dbl(p); }
+    __device__ static __forceinline__ DevAff to_dev_affine(const Pt& p) {  // p must not be the identity
+        using namespace fp28;
+        Fp28 i3 = fp28::inv(p.ZZZ);                       // 1/ZZZ
+        Fp28 i2 = fp28::mul(fp28::sqr(p.ZZ), fp28::sqr(i3));  // 1/ZZ = ZZ^2 / ZZZ^2
+        return {fp28::mul(p.X, i2), fp28::mul(p.Y, i3)};
+    }
     __device__ static __forceinline__ XyzzT<FpOps> to_std(const Pt& p) { return g1x28::to_std(p); }
     // raw 96-byte affine (12 x 32-bit Montgomery-384) -> internal
     __device__ static __forceinline__ DevAff convert(const void* raw, uint64_t i) {
@@ -69,6 +76,12 @@ struct G2Fast {
     }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2x28Ops>(acc, q); }
     __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return xyzz_mul_u32<Fp2x28Ops>(p, k); }
+    __device__ static __forceinline__ Pt dbl(const Pt& p) { return xyzz_dbl<Fp2x28Ops>(p); }
+    __device__ static __forceinline__ DevAff to_dev_affine(const Pt& p) {
+        DevAff a;
+        xyzz_to_affine<Fp2x28Ops>(p, a);
+        return a;
+    }
     __device__ static __forceinline__ XyzzT<Fp2Ops> to_std(const Pt& p) { return g2x28::to_std(p); }
     __device__ static __forceinline__ DevAff convert(const void* raw, uint64_t i) {
         const U128* p = (const U128*)raw + i * 12;
@@ -114,6 +127,12 @@ struct G2Plain {
     }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2Ops>(acc, q); }
     __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return xyzz_mul_u32<Fp2Ops>(p, k); }
+    __device__ static __forceinline__ Pt dbl(const Pt& p) { return xyzz_dbl<Fp2Ops>(p); }
+    __device__ static __forceinline__ DevAff to_dev_affine(const Pt& p) {
+        DevAff a;
+        xyzz_to_affine<Fp2Ops>(p, a);
+        return a;
+    }
     __device__ static __forceinline__ XyzzT<Fp2Ops> to_std(const Pt& p) { return p; }
     __device__ static __forceinline__ DevAff convert(const void*, uint64_t) { return DevAff(); }
     __device__ static __forceinline__ DevAff load(const void* bases, uint32_t idx) {

@@ -66,6 +66,14 @@ SIGNATURES = {
     "bzk_host_jubjub_keys": (_i32, [_vp, _u32, _vp]),
     "bzk_host_jubjub_sign": (_i32, [_vp, _vp, _vp]),
     "bzk_host_jubjub_verify": (_i32, [_vp, _vp, _vp]),
+    "bzk_msm_g1_table_build": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_msm_g2_table_build": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_msm_g1_table_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "bzk_msm_g2_table_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "bzk_msm_g1_table_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    "bzk_msm_g2_table_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    "bzk_msm_table_window_count": (_u32, [_vp]),
+    "bzk_msm_table_free": (None, [_vp, _vp]),
     "bzk_g1_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
     "bzk_g2_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
 }
@@ -231,6 +239,30 @@ class Bzk:
         out = C.create_string_buffer(193)
         self._ck(self.lib.bzk_msm_g2_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, w0, w1, out), "msm_g2_windows_dev")
         return out.raw
+
+    def msm_table_build(self, bases, n: int, g2=False):
+        h = C.c_void_p()
+        fn = self.lib.bzk_msm_g2_table_build if g2 else self.lib.bzk_msm_g1_table_build
+        self._ck(fn(self.h, _ptr(bases), n, C.byref(h)), "msm_table_build")
+        return h
+
+    def msm_table_run_dev(self, table, scalars, n: int, g2=False, canonical=False) -> bytes:
+        out = C.create_string_buffer(193 if g2 else 97)
+        fn = self.lib.bzk_msm_g2_table_run_dev if g2 else self.lib.bzk_msm_g1_table_run_dev
+        self._ck(fn(self.h, table, _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, out), "msm_table_run")
+        return out.raw
+
+    def msm_table_windows_dev(self, table, scalars, n: int, w0: int, w1: int, g2=False, canonical=False) -> bytes:
+        out = C.create_string_buffer(193 if g2 else 97)
+        fn = self.lib.bzk_msm_g2_table_windows_dev if g2 else self.lib.bzk_msm_g1_table_windows_dev
+        self._ck(fn(self.h, table, _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, w0, w1, out), "msm_table_windows")
+        return out.raw
+
+    def msm_table_window_count(self, table) -> int:
+        return self.lib.bzk_msm_table_window_count(table)
+
+    def msm_table_free(self, table):
+        self.lib.bzk_msm_table_free(self.h, table)
 
     def g1_sum(self, packed: bytes) -> bytes:
         out = C.create_string_buffer(97)

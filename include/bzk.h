@@ -217,6 +217,22 @@ int32_t bzk_host_jubjub_keys(const uint8_t* seed, uint32_t len, uint8_t out[128]
 int32_t bzk_host_jubjub_sign(const uint8_t key[128], const uint8_t msg[32], uint8_t sig_out[96]); /* r.x|r.y|s */
 int32_t bzk_host_jubjub_verify(const uint8_t pub_xy[64], const uint8_t msg[32], const uint8_t sig[96]); /* 1 / 0 */
 
+/* ---- static-base tables (the Groth16 CRS queries are fixed point sets) -------------------------------------------
+ * build: tab[w][i] = 2^(c w) * base_i for every window, kept in HBM (W x the base memory, internal limb form).  With a
+ * table every window feeds ONE bucket set: the bucket reduction shrinks from W windows to one and no host-side Horner
+ * remains.  Same result bytes as bzk_msm_*_dev on the same inputs.  n scalars (n <= table size) use bases [0, n). */
+typedef struct bzk_msm_table bzk_msm_table;
+int32_t bzk_msm_g1_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_table** out);
+int32_t bzk_msm_g2_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_table** out);
+int32_t bzk_msm_g1_table_run_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[97]);
+int32_t bzk_msm_g2_table_run_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[193]);
+int32_t bzk_msm_g1_table_windows_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                     uint32_t w_begin, uint32_t w_end, uint8_t out[97]);
+int32_t bzk_msm_g2_table_windows_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                     uint32_t w_begin, uint32_t w_end, uint8_t out[193]);
+uint32_t bzk_msm_table_window_count(const bzk_msm_table* table);
+void bzk_msm_table_free(bzk_ctx* ctx, bzk_msm_table* table);
+
 /* synthetic-input helpers (device side, for benches and tests): base_i = k_i * G with
  * k_i = SplitMix64(seed + 0x632BE59BD9B4E019 * (start+i)).next() | 1 ; raw affine out */
 int32_t bzk_g1_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev);

@@ -140,3 +140,53 @@ def test_msm_g2_2p16_vs_oracle(bzk, co):
     bzk.g2_synth_bases_dev(77, 0, n, bases)
     scb = rand_scalars_bytes(n, 16)
     assert bzk.msm_g2_dev(bases, to_dev(scb), n) == co.msm_g2(dev_bytes(bases), scb, nthreads=co.ncpu())
+
+
+def test_msm_g1_static_table_matches_plain_and_oracle(bzk, co):
+    """static-base tables (bzk_msm_g1_table_*): same bytes as the per-call pipeline and the oracle; prefix use
+    (fewer scalars than table entries) and window-range shards"""
+    n = 6000
+    hb = co.g1_bases(71, 0, n, nthreads=co.ncpu())
+    bases = to_dev(hb)
+    tab = bzk.msm_table_build(bases, n)
+    for m, seed in ((n, 1), (n - 1234, 2), (1, 3)):
+        scb = rand_scalars_bytes(m, seed)
+        sc = to_dev(scb)
+        got = bzk.msm_table_run_dev(tab, sc, m)
+        assert got == bzk.msm_g1_dev(bases, sc, m)
+        assert got == co.msm_g1(hb[: 96 * m], scb, nthreads=co.ncpu())
+    W = bzk.msm_table_window_count(tab)
+    sc = to_dev(rand_scalars_bytes(n, 9))
+    full = bzk.msm_table_run_dev(tab, sc, n)
+    cuts = [0, W // 3, W // 2, W]
+    shards = b"".join(bzk.msm_table_windows_dev(tab, sc, n, cuts[i], cuts[i + 1]) for i in range(3))
+    assert bzk.g1_sum(shards) == full
+    # skewed scalars (many ones / zeros) through the shared bucket set
+    import numpy as np
+    a = np.frombuffer(rand_scalars_bytes(n, 4), dtype=np.uint8).reshape(n, 32).copy()
+    a[: n // 3] = np.frombuffer(fr_bytes([1]), dtype=np.uint8)
+    a[n // 3: n // 2] = 0
+    wb = a.tobytes()
+    assert bzk.msm_table_run_dev(tab, to_dev(wb), n) == co.msm_g1(hb, wb, nthreads=co.ncpu())
+    bzk.msm_table_free(tab)
+
+
+def test_msm_g2_static_table_matches_oracle(bzk, co):
+    n = 1500
+    hb = co.g2_bases(73, 0, n, nthreads=co.ncpu())
+    bases = to_dev(hb)
+    tab = bzk.msm_table_build(bases, n, g2=True)
+    scb = rand_scalars_bytes(n, 5)
+    assert bzk.msm_table_run_dev(tab, to_dev(scb), n, g2=True) == co.msm_g2(hb, scb, nthreads=co.ncpu())
+    bzk.msm_table_free(tab)
+
+
+def test_msm_g1_static_table_2p20(bzk, co):
+    n = 1 << 20
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(0x42415A554B41, 0, n, bases)
+    tab = bzk.msm_table_build(bases, n)
+    scb = rand_scalars_bytes(n, 2020)
+    sc = to_dev(scb)
+    assert bzk.msm_table_run_dev(tab, sc, n) == bzk.msm_g1_dev(bases, sc, n)
+    bzk.msm_table_free(tab)

@@ -23,6 +23,13 @@ def child(mode, log_n):
         ms = timeit(lambda: ctx.msm_g1_dev(bases, sc, n))
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_g1_dev(bases, sc, n); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
         print(json.dumps({"mode": mode, "log_n": log_n, "c": os.environ.get("BZK_MSM_C"), "chunk": os.environ.get("BZK_MSM_CHUNK"), "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 1), "prof": prof}))
+    elif mode == "g1tab":
+        bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
+        t0 = time.perf_counter(); tab = ctx.msm_table_build(bases, n); tb = time.perf_counter() - t0
+        ms = timeit(lambda: ctx.msm_table_run_dev(tab, sc, n))
+        same = ctx.msm_table_run_dev(tab, sc, n) == ctx.msm_g1_dev(bases, sc, n)
+        ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_table_run_dev(tab, sc, n); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
+        print(json.dumps({"mode": mode, "log_n": log_n, "table_c": os.environ.get("BZK_MSM_TABLE_C"), "build_s": round(tb, 3), "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 1), "same_as_plain": same, "prof": prof}))
     elif mode == "g2":
         bases = torch.empty(n * 192, dtype=torch.uint8, device="cuda"); ctx.g2_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
         ms = timeit(lambda: ctx.msm_g2_dev(bases, sc, n), reps=2)
@@ -61,5 +68,17 @@ if __name__ == "__main__":
             run("g1", 20, {"BZK_MSM_C": "16", "BZK_MSM_CHUNK": str(ch)})
         for lg in (16, 18, 22, 24):
             run("g1", lg)
+    if what in ("occ",):
+        for occ in (2, 3, 4):
+            run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
+            run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("chunk",):
+        for ch in (2, 4, 8, 16):
+            run("g1", 20, {"BZK_MSM_CHUNK": str(ch)})
+        run("g1", 22, {"BZK_MSM_CHUNK": "4"}); run("g1", 16, {"BZK_MSM_CHUNK": "4"})
+        run("g2", 20, {"BZK_MSM_CHUNK": "4"}); run("g2", 20, {"BZK_MSM_CHUNK": "8"})
+    if what in ("all", "tab"):
+        for c in (15, 16, 17, 18, 19):
+            run("g1tab", 20, {"BZK_MSM_TABLE_C": str(c)})
     if what in ("all", "others"):
         run("tree", 24); run("tree", 20); run("ntt", 20); run("ntt", 24); run("h", 20); run("g2", 16); run("g2", 20)
