@@ -22,7 +22,7 @@
 #include <mutex>
 #include <vector>
 
-#include "bzk_field.cuh"
+#include "bzk_poseidon29.cuh"
 #include "bzk_internal.h"
 #include "host_zk.h"
 
@@ -251,16 +251,35 @@ __global__ void __launch_bounds__(128) poseidon_kernel(const Fr* __restrict__ in
     out[i] = st[1];
 }
 
+// ---- reduced-radix kernel (widths 2..8, i.e. every arity the MPN circuits and trees use)
+// State in 9 x 29-bit limbs (bzk_fr29.cuh).  Per round: add constant + carry-normalise; S-box through the
+// resident product function; each MDS row = up to 6 products accumulated UNREDUCED in 64-bit columns and ONE
+// Montgomery reduction (rows wider than 6 use two groups).  Bounds: see the header of bzk_fr29.cuh.
+template <int T>
+__global__ void __launch_bounds__(128) poseidon29_kernel(const Fr* __restrict__ in, uint64_t n, const Fr29* __restrict__ consts,
+                                                         int rf, int rp, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = poseidon29_hash<T>(in + i * (T - 1), consts, rf, rp);
+}
+
+typedef void (*poseidon29_fn)(const Fr*, uint64_t, const Fr29*, int, int, Fr*);
+static poseidon29_fn poseidon29_table(int t) {
+    switch (t) {
+        case 2: return poseidon29_kernel<2>;
+        case 3: return poseidon29_kernel<3>;
+        case 4: return poseidon29_kernel<4>;
+        case 5: return poseidon29_kernel<5>;
+        case 6: return poseidon29_kernel<6>;
+        case 7: return poseidon29_kernel<7>;
+        case 8: return poseidon29_kernel<8>;
+        default: return nullptr;
+    }
+}
+
 typedef void (*poseidon_fn)(const Fr*, uint64_t, const Fr*, int, int, Fr*);
 static poseidon_fn poseidon_table(int t) {
     switch (t) {
-        case 2: return poseidon_kernel<2>;
-        case 3: return poseidon_kernel<3>;
-        case 4: return poseidon_kernel<4>;
-        case 5: return poseidon_kernel<5>;
-        case 6: return poseidon_kernel<6>;
-        case 7: return poseidon_kernel<7>;
-        case 8: return poseidon_kernel<8>;
         case 9: return poseidon_kernel<9>;
         case 10: return poseidon_kernel<10>;
         case 11: return poseidon_kernel<11>;
@@ -274,7 +293,9 @@ static poseidon_fn poseidon_table(int t) {
     }
 }
 
-static int32_t poseidon_consts_dev(bzk_ctx* ctx, int t, const Fr** out, int* rf, int* rp) {
+// device copy of the constants: widths <= 8 in the 9 x 29-bit internal form (rc are plain addends: x * 2^261),
+// wider ones in the 8 x 32-bit form of the generic kernel
+static int32_t poseidon_consts_dev(bzk_ctx* ctx, int t, const void** out, int* rf, int* rp) {
     const HostParams& P = host_params(t);
     *rf = P.rf;
     *rp = P.rp;
@@ -282,12 +303,20 @@ static int32_t poseidon_consts_dev(bzk_ctx* ctx, int t, const Fr** out, int* rf,
         std::vector<Fr> flat(P.rc);
         flat.insert(flat.end(), P.mds.begin(), P.mds.end());
         void* d = nullptr;
-        BZK_HIP(ctx, hipMalloc(&d, flat.size() * sizeof(Fr)));
-        BZK_HIP(ctx, hipMemcpyAsync(d, flat.data(), flat.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (t <= 8) {
+            std::vector<Fr29> f29(flat.size());
+            for (size_t i = 0; i < flat.size(); ++i) f29[i] = fr29::norm(fr29::to29(flat[i]));
+            BZK_HIP(ctx, hipMalloc(&d, f29.size() * sizeof(Fr29)));
+            BZK_HIP(ctx, hipMemcpyAsync(d, f29.data(), f29.size() * sizeof(Fr29), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            BZK_HIP(ctx, hipMalloc(&d, flat.size() * sizeof(Fr)));
+            BZK_HIP(ctx, hipMemcpyAsync(d, flat.data(), flat.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
         ctx->poseidon_dev[t] = d;
     }
-    *out = (const Fr*)ctx->poseidon_dev[t];
+    *out = ctx->poseidon_dev[t];
     return BZK_OK;
 }
 
@@ -295,13 +324,18 @@ int32_t poseidon_launch(bzk_ctx* ctx, const void* in_dev, uint32_t arity, uint64
     if (arity < 1 || arity > 16) return BZK_E_ARG;
     if (n == 0) return BZK_OK;
     const int t = (int)arity + 1;
-    const Fr* consts;
+    const void* consts;
     int rf, rp;
     BZK_TRY(poseidon_consts_dev(ctx, t, &consts, &rf, &rp));
-    poseidon_fn k = poseidon_table(t);
     const uint64_t blocks = (n + 127) / 128;
     if (blocks > 0x7fffffffull) return BZK_E_ARG;
-    BZK_LAUNCH(ctx, "poseidon", k, dim3((unsigned)blocks), dim3(128), 0, (const Fr*)in_dev, n, consts, rf, rp, (Fr*)out_dev);
+    if (t <= 8) {
+        poseidon29_fn k = poseidon29_table(t);
+        BZK_LAUNCH(ctx, "poseidon", k, dim3((unsigned)blocks), dim3(128), 0, (const Fr*)in_dev, n, (const Fr29*)consts, rf, rp, (Fr*)out_dev);
+    } else {
+        poseidon_fn k = poseidon_table(t);
+        BZK_LAUNCH(ctx, "poseidon", k, dim3((unsigned)blocks), dim3(128), 0, (const Fr*)in_dev, n, (const Fr*)consts, rf, rp, (Fr*)out_dev);
+    }
     return BZK_OK;
 }
 

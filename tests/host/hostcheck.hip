@@ -2,6 +2,7 @@
 // so that limb-level logic is checked against the oracle in this GPU-less container.
 #define BZK_FP28_CHECK 1
 #include "../../bazuka_amd/csrc/bzk_fp28.cuh"
+#include "../../bazuka_amd/csrc/bzk_poseidon29.cuh"
 #include <string.h>
 using namespace bzk;
 
@@ -102,6 +103,32 @@ int hc_g2x28_sum_mixed(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* o
         xyzz_add_mixed<Fp2x28Ops>(acc, a);
     }
     st_g2(out193, g2x28::to_std(acc));
+    return 0;
+}
+// Fr in 9 x 29-bit limbs
+int hc_fr29_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    st<FrParams>(out, fr29::from29(fr29::mul(fr29::to29(ld<FrParams>(a)), fr29::to29(ld<FrParams>(b)))));
+    return 0;
+}
+// one Poseidon hash through the device function; consts = rc then mds, 8 x 32-bit Montgomery (n_consts entries)
+int hc_poseidon29(const uint8_t* in, int arity, const uint8_t* consts, int n_consts, int rf, int rp, uint8_t* out) {
+    Fr inp[8];
+    for (int k = 0; k < arity; ++k) inp[k] = ld<FrParams>(in + 32 * k);
+    Fr29* c = new Fr29[n_consts];
+    for (int i = 0; i < n_consts; ++i) c[i] = fr29::to29(ld<FrParams>(consts + 32 * i));
+    Fr r;
+    switch (arity + 1) {
+        case 2: r = poseidon29_hash<2>(inp, c, rf, rp); break;
+        case 3: r = poseidon29_hash<3>(inp, c, rf, rp); break;
+        case 4: r = poseidon29_hash<4>(inp, c, rf, rp); break;
+        case 5: r = poseidon29_hash<5>(inp, c, rf, rp); break;
+        case 6: r = poseidon29_hash<6>(inp, c, rf, rp); break;
+        case 7: r = poseidon29_hash<7>(inp, c, rf, rp); break;
+        case 8: r = poseidon29_hash<8>(inp, c, rf, rp); break;
+        default: delete[] c; return -1;
+    }
+    delete[] c;
+    st<FrParams>(out, r);
     return 0;
 }
 int hc_fr_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) { return field_op<FrParams>(op, a, b, out); }

@@ -120,3 +120,74 @@ def test_device_curve_code_on_host_matches_oracle(hc, co, pr):
     assert out.raw == co.g1_add(P + b"\0", Q + b"\0")
     hc.hc_g1_sum_mixed(P + negP, 2, out)
     assert out.raw[96] == 1
+
+
+def test_reduced_radix_fields_on_host_match_oracle(hc, co, pr):
+    """bzk_fp28.cuh / bzk_fr29.cuh (the device arithmetic) executed on the CPU with their bound assertions on"""
+    rnd = random.Random(5)
+    pv = [0, 1, pr.P_MOD - 1, pr.P_MOD - 2, 2 ** 380] + [rnd.randrange(pr.P_MOD) for _ in range(100)]
+    for a in pv:
+        A = pr.fp_to_mont_bytes(a)
+        out = C.create_string_buffer(48)
+        hc.hc_fp28_roundtrip(A, out)
+        assert out.raw == A
+    for _ in range(200):
+        a, b = rnd.choice(pv), rnd.choice(pv)
+        out = C.create_string_buffer(48)
+        hc.hc_fp28_mul(pr.fp_to_mont_bytes(a), pr.fp_to_mont_bytes(b), out)
+        assert out.raw == pr.fp_to_mont_bytes(a * b % pr.P_MOD)
+    rv = [0, 1, pr.R_MOD - 1, 2 ** 254] + [rnd.randrange(pr.R_MOD) for _ in range(100)]
+    for _ in range(200):
+        a, b = rnd.choice(rv), rnd.choice(rv)
+        out = C.create_string_buffer(32)
+        hc.hc_fr29_mul(pr.fr_to_mont_bytes(a), pr.fr_to_mont_bytes(b), out)
+        assert out.raw == pr.fr_to_mont_bytes(a * b % pr.R_MOD)
+    for _ in range(20):
+        a, b, rounds = rnd.randrange(pr.P_MOD), rnd.randrange(pr.P_MOD), rnd.randrange(1, 30)
+        out = C.create_string_buffer(48)
+        assert hc.hc_fp28_reduce_chain(pr.fp_to_mont_bytes(a), pr.fp_to_mont_bytes(b), rounds, out) == 0
+        x = a
+        for _i in range(rounds):
+            x = (6 * x + b) % pr.P_MOD
+        assert out.raw == pr.fp_to_mont_bytes(x)
+
+
+def test_reduced_radix_curves_on_host_match_oracle(hc, co, pr):
+    rnd = random.Random(6)
+    n = 10
+    bases = co.g1_bases(7, 0, n)
+    ks = [rnd.randrange(1, 2 ** 32) for _ in range(n)]
+    ks[0], ks[1], ks[2], ks[3] = 1, 0, 2, 0xFFFFFFFF
+    neg = bytes(rnd.randrange(2) for _ in range(n))
+    sc = b"".join(((pr.R_MOD - k) % pr.R_MOD if neg[i] else k).to_bytes(32, "little") for i, k in enumerate(ks))
+    out = C.create_string_buffer(97)
+    hc.hc_g1x28_lincomb(bases, (C.c_uint32 * n)(*ks), neg, n, out)
+    assert out.raw == co.msm_g1(bases, sc, mont=False, naive=True)
+    b2 = co.g2_bases(7, 0, n)
+    out2 = C.create_string_buffer(193)
+    hc.hc_g2x28_lincomb(b2, (C.c_uint32 * n)(*ks), neg, n, out2)
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    m = 150  # long chains of mixed adds: the weak-reduction bounds must hold indefinitely
+    b3 = co.g1_bases(9, 0, m)
+    negs = bytes(rnd.randrange(2) for _ in range(m))
+    hc.hc_g1x28_sum_mixed(b3, negs, m, out)
+    sc = b"".join(((pr.R_MOD - 1) if negs[i] else 1).to_bytes(32, "little") for i in range(m))
+    assert out.raw == co.msm_g1(b3, sc, mont=False, naive=True)
+    P = bases[:96]
+    hc.hc_g1x28_sum_mixed(P + P, bytes([0, 0]), 2, out)
+    assert out.raw == co.g1_add(P + b"\0", P + b"\0")  # doubling through the mixed add
+    hc.hc_g1x28_sum_mixed(P + P, bytes([0, 1]), 2, out)
+    assert out.raw[96] == 1  # cancellation
+
+
+def test_poseidon29_device_function_on_host_matches_oracle(hc, co, pr):
+    rnd = random.Random(7)
+    for arity in range(1, 8):
+        consts = co.poseidon_params(arity + 1)
+        rp = 56 if arity + 1 <= 5 else 57
+        cases = [list(range(arity)), [pr.R_MOD - 1] * arity] + [[rnd.randrange(pr.R_MOD) for _ in range(arity)] for _ in range(3)]
+        for inp in cases:
+            ib = b"".join(pr.fr_to_mont_bytes(x) for x in inp)
+            out = C.create_string_buffer(32)
+            assert hc.hc_poseidon29(ib, arity, consts, len(consts) // 32, 8, rp, out) == 0
+            assert out.raw == co.poseidon_batch(ib, arity), arity
