@@ -94,6 +94,8 @@ struct PointAffine {
 };
 void jubjub_ladder(const PointAffine& base, const std::vector<bool>& bits_msb_first, std::vector<PointAffine>& dbls,
                    std::vector<PointAffine>& adds);  // dbls[i], adds[i] for i >= 1
+PointAffine jubjub_decompress(const ZkScalar& x, bool y_is_odd);  // PointCompressed::decompress (curve.rs:78-88)
+const PointAffine& jubjub_default_pubkey();  // `PublicKey::default().decompress()` = (0, r - 1)
 const ZkScalar& jubjub_d();
 const PointAffine& jubjub_base();
 const PointAffine& jubjub_base_cofactor();  // 8 * BASE

@@ -177,6 +177,19 @@ const PointAffine& jubjub_base_cofactor() {
     return b;
 }
 
+PointAffine jubjub_decompress(const ZkScalar& x, bool y_is_odd) {
+    // y = sqrt((1 - A x^2) / (1 - D x^2)) with A = -1, sign chosen by parity
+    ZkScalar xx = x.square();
+    ZkScalar y;
+    ((ZkScalar::one() - jubjub_d() * xx).invert() * (ZkScalar::one() + xx)).sqrt(&y);
+    if (y.is_odd() != y_is_odd) y = -y;
+    return {x, y};
+}
+const PointAffine& jubjub_default_pubkey() {
+    static const PointAffine p = jubjub_decompress(ZkScalar::zero(), false);
+    return p;
+}
+
 bool PointAffine::is_on_curve() const {
     ZkScalar xx = x.square(), yy = y.square();
     return yy - xx == ZkScalar::one() + jubjub_d() * xx * yy;

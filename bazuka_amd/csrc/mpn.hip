@@ -123,6 +123,65 @@ struct UpdateTransition {
         t.src_balance_proof.assign(T, z);
         t.src_fee_balance_proof.assign(T, z);
         t.dst_balance_proof.assign(T, z);
+        // `tx: Default::default()`: the circuit allocates `tx.dst_pub_key.0.decompress()`, and the default
+        // compressed key (x = 0, even y) decompresses to (0, r - 1), not to (0, 0)
+        t.tx.dst_pub = jubjub_default_pubkey();
+        t.tx.src_pub = jubjub_default_pubkey();
+        return t;
+    }
+};
+
+// ---- deposits / withdrawals (src/mpn/mod.rs:426-489; MpnDeposit / MpnWithdraw src/core/transaction.rs:163-174)
+struct DepositTx {
+    PointAffine mpn_address = jubjub_default_pubkey();
+    Money amount;
+};
+struct DepositTransition {
+    bool enabled = false;
+    DepositTx tx;
+    MpnAccount before;
+    ZkScalar before_balances_hash;
+    Money before_balance;
+    Proof4 proof, balance_proof;
+    uint64_t account_index = 0, token_index = 0;
+    ZkScalar state_after;
+    static DepositTransition null(int L, int T) {
+        DepositTransition t;
+        std::array<ZkScalar, 3> z = {ZkScalar(), ZkScalar(), ZkScalar()};
+        t.proof.assign(L, z);
+        t.balance_proof.assign(T, z);
+        return t;
+    }
+};
+struct WithdrawTx {
+    PointAffine mpn_address = jubjub_default_pubkey();
+    uint32_t nonce = 0;
+    JubjubSignature sig;
+    Money amount, fee;
+    ZkScalar fingerprint;  // ContractWithdraw::fingerprint() - an opaque scalar here (L1 serialisation is out of scope)
+    ZkScalar sign_message() const {
+        ZkScalar v[2] = {fingerprint, ZkScalar::from_u64(nonce)};
+        return poseidon_hash(v, 2);
+    }
+    ZkScalar calldata() const {
+        ZkScalar v[6] = {mpn_address.x, mpn_address.y, ZkScalar::from_u64(nonce), sig.r.x, sig.r.y, sig.s};
+        return poseidon_hash(v, 6);
+    }
+};
+struct WithdrawTransition {
+    bool enabled = false;
+    WithdrawTx tx;
+    MpnAccount before;
+    Money before_token_balance, before_fee_balance;
+    Proof4 proof, token_balance_proof, fee_balance_proof;
+    uint64_t account_index = 0, token_index = 0, fee_token_index = 0;
+    ZkScalar before_token_hash, state_after;
+    static WithdrawTransition null(int L, int T) {
+        WithdrawTransition t;
+        std::array<ZkScalar, 3> z = {ZkScalar(), ZkScalar(), ZkScalar()};
+        t.proof.assign(L, z);
+        t.token_balance_proof.assign(T, z);
+        t.fee_balance_proof.assign(T, z);
         return t;
     }
 };
@@ -141,6 +200,8 @@ struct bzk_mpn {
     std::map<uint64_t, MpnAccount> acct;
     std::map<uint64_t, JubjubPrivateKey> keys;
     std::vector<MpnTx> mempool;
+    std::vector<DepositTx> deposit_queue;
+    std::vector<WithdrawTx> withdraw_queue;
     uint64_t height = 0;
     int threads = (int)std::max(1u, std::thread::hardware_concurrency());
 
@@ -476,6 +537,293 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
     cs.finalize();
 }
 
+// ------------------------------------------------------------------------------------------------
+// reveal gadget (src/zk/groth16/gadgets/reveal/mod.rs:13-61) for the one shape the MPN circuits use:
+// List{log4 = B, Struct[k scalars]}: a Poseidon of the k fields per item, then a 4-ary Poseidon tree
+// ------------------------------------------------------------------------------------------------
+static Number g_reveal_batch(ConstraintSystem& cs, const std::vector<std::vector<Number>>& items) {
+    std::vector<Number> leaves;
+    for (auto& fields : items) leaves.push_back(g_poseidon(cs, fields));
+    while (leaves.size() != 1) {
+        std::vector<Number> next;
+        for (size_t i = 0; i < leaves.size(); i += 4) next.push_back(g_poseidon(cs, {leaves[i], leaves[i + 1], leaves[i + 2], leaves[i + 3]}));
+        leaves.swap(next);
+    }
+    return leaves[0];
+}
+// native counterpart: ZkStateBuilder::compress of the same model with only the first `n_set` items present
+static ZkScalar native_batch_root(const std::vector<std::vector<ZkScalar>>& items, int log4_batch, int n_fields) {
+    std::vector<ZkScalar> zero_fields((size_t)n_fields);
+    const ZkScalar def = poseidon_hash(zero_fields);  // compress_default of the Struct
+    std::vector<ZkScalar> leaves((size_t)1 << (2 * log4_batch), def);
+    for (size_t i = 0; i < items.size(); ++i) leaves[i] = poseidon_hash(items[i]);
+    while (leaves.size() != 1) {
+        std::vector<ZkScalar> next;
+        for (size_t i = 0; i < leaves.size(); i += 4) next.push_back(poseidon_hash(&leaves[i], 4));
+        leaves.swap(next);
+    }
+    return leaves[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// deposit::deposit (src/mpn/deposit.rs:11-233) and DepositCircuit (src/mpn/circuits/deposit_circuit.rs:47-293)
+// ------------------------------------------------------------------------------------------------
+static void build_deposits(bzk_mpn& w, int log4_batch, std::vector<DepositTransition>& out, uint64_t& rejected) {
+    const size_t cap = (size_t)1 << (2 * log4_batch);
+    rejected = 0;
+    std::vector<DepositTx> rest;
+    for (const DepositTx& tx : w.deposit_queue) {
+        if (out.size() == cap) { rest.push_back(tx); continue; }
+        long index = -1;
+        for (auto& kv : w.acct)
+            if (kv.second.address == tx.mpn_address) { index = (long)kv.first; break; }
+        if (index < 0) index = w.acct.empty() ? 0 : (long)(w.acct.rbegin()->first + 1);
+        MpnAccount acc = w.get(index);
+        long ti = acc.find_token_index(w.L, tx.amount.token_id, true);
+        if (ti < 0) { ++rejected; continue; }
+        const bool has = acc.tokens.count(ti) != 0;
+        if ((!(acc.address == PointAffine()) && !(tx.mpn_address == acc.address)) || (has && acc.tokens[ti].token_id != tx.amount.token_id)) {
+            ++rejected;
+            continue;
+        }
+        DepositTransition t;
+        t.enabled = true;
+        t.tx = tx;
+        t.account_index = index;
+        t.token_index = ti;
+        t.before = acc;
+        SparseTree4 tree = w.tokens_tree(acc);
+        t.before_balances_hash = tree.root();
+        t.before_balance = has ? acc.tokens[ti] : Money();
+        t.balance_proof = tree.prove(ti);
+        t.proof = w.accounts->prove(index);
+        MpnAccount upd = acc;
+        upd.address = tx.mpn_address;
+        if (!has) upd.tokens[ti] = Money{tx.amount.token_id, 0};
+        upd.tokens[ti].amount += tx.amount.amount;
+        tree.set_leaf(ti, token_leaf(upd.tokens[ti]));
+        w.set_with_tokens_root(index, upd, tree.root());
+        t.state_after = w.accounts->root();
+        out.push_back(std::move(t));
+    }
+    w.deposit_queue.swap(rest);
+}
+
+static ZkScalar deposit_aux(const std::vector<DepositTransition>& trs, int log4_batch) {
+    std::vector<std::vector<ZkScalar>> items;
+    for (auto& t : trs) {
+        if (!t.enabled) break;
+        ZkScalar pk[2] = {t.tx.mpn_address.x, t.tx.mpn_address.y};
+        items.push_back({ZkScalar::from_u64(1), t.tx.amount.token_id, ZkScalar::from_u64(t.tx.amount.amount), poseidon_hash(pk, 2)});
+    }
+    return native_batch_root(items, log4_batch, 4);
+}
+
+static void synthesize_deposit(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
+                               const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<DepositTransition>& trs) {
+    Num commitment_wit = num_alloc(cs, commitment.v);
+    num_inputize(cs, commitment_wit);
+    Num height_wit = num_alloc(cs, fr_from_u64(height));
+    num_inputize(cs, height_wit);
+    Num state_wit = num_alloc(cs, state.v);
+    num_inputize(cs, state_wit);
+    Num aux_wit = num_alloc(cs, aux_data.v);
+    num_inputize(cs, aux_wit);
+    Num claimed_next = num_alloc(cs, next_state.v);
+    num_inputize(cs, claimed_next);
+    struct TxWit { Bool enabled; Num token_id; UInt amount; APoint pub_key; };
+    std::vector<TxWit> wits;
+    std::vector<std::vector<Number>> children;
+    for (const DepositTransition& tr : trs) {
+        Bit enabled = bit_alloc(cs, tr.enabled);
+        Num token_id = num_alloc(cs, tr.tx.amount.token_id.v);
+        UInt amount = UInt::alloc_64(cs, tr.tx.amount.amount);
+        APoint pub_key = APoint::alloc(cs, tr.tx.mpn_address);
+        wits.push_back({Bool::is(enabled), token_id, amount, pub_key});
+        Number pkh = g_poseidon(cs, {Number::from(pub_key.x), Number::from(pub_key.y)});
+        Num calldata = mux(cs, Bool::is(enabled), Number::zero(), pkh);
+        children.push_back({Number::from(enabled), Number::from(token_id), amount.num, Number::from(calldata)});
+    }
+    Number tx_root = g_reveal_batch(cs, children);
+    cs.enforce(LC::of(aux_wit.var), aux_wit.val, LC::one(), Fr::one(), tx_root.lc, tx_root.val);
+    for (size_t i = 0; i < trs.size(); ++i) {
+        const DepositTransition& tr = trs[i];
+        const TxWit& tw = wits[i];
+        UInt tx_index = UInt::alloc(cs, fr_from_u64(tr.account_index), 2 * L);
+        UInt tx_token_index = UInt::alloc(cs, fr_from_u64(tr.token_index), 2 * T);
+        tw.pub_key.assert_on_curve(cs, tw.enabled);
+        Num src_tx_nonce = num_alloc(cs, fr_from_u64(tr.before.tx_nonce));
+        Num src_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.before.withdraw_nonce));
+        APoint src_addr = APoint::alloc(cs, tr.before.address);
+        Num src_balances_hash = num_alloc(cs, tr.before_balances_hash.v);
+        Num src_token_id = num_alloc(cs, tr.before_balance.token_id.v);
+        Num src_balance = num_alloc(cs, fr_from_u64(tr.before_balance.amount));
+        Number src_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), Number::from(src_balance)});
+        MerkleProofWit balance_proof = alloc_proof(cs, tr.balance_proof);
+        g_check_proof4(cs, tw.enabled, tx_token_index, src_token_balance_hash, balance_proof, Number::from(src_balances_hash));
+        Number src_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce), Number::from(src_addr.x),
+                                          Number::from(src_addr.y), Number::from(src_balances_hash)});
+        MerkleProofWit proof = alloc_proof(cs, tr.proof);
+        Bool tok_null = Number::from(src_token_id).is_zero(cs);
+        Bool tok_eq = Number::from(src_token_id).is_equal(cs, Number::from(tw.token_id));
+        assert_true(cs, boolean_or(cs, tok_null, tok_eq));
+        Bool addr_null = src_addr.is_null(cs);
+        Bool addr_eq = src_addr.is_equal(cs, tw.pub_key);
+        assert_true(cs, boolean_or(cs, addr_null, addr_eq));
+        g_check_proof4(cs, tw.enabled, tx_index, src_hash, proof, Number::from(state_wit));
+        Number new_leaf = g_poseidon(cs, {Number::from(tw.token_id), Number::from(src_balance).plus(tw.amount.num)});
+        Number new_balances_hash = g_calc_root4(cs, tx_token_index, new_leaf, balance_proof);
+        Number new_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce), Number::from(tw.pub_key.x),
+                                          Number::from(tw.pub_key.y), new_balances_hash});
+        Number next_state_wit = g_calc_root4(cs, tx_index, new_hash, proof);
+        state_wit = mux(cs, tw.enabled, Number::from(state_wit), next_state_wit);
+    }
+    cs.enforce(LC::of(state_wit.var), state_wit.val, LC::one(), Fr::one(), LC::of(claimed_next.var), claimed_next.val);
+    cs.finalize();
+}
+
+// ------------------------------------------------------------------------------------------------
+// withdraw::withdraw (src/mpn/withdraw.rs:10-259) and WithdrawCircuit (src/mpn/circuits/withdraw_circuit.rs:50-413)
+// ------------------------------------------------------------------------------------------------
+static void build_withdraws(bzk_mpn& w, int log4_batch, std::vector<WithdrawTransition>& out, uint64_t& rejected) {
+    const size_t cap = (size_t)1 << (2 * log4_batch);
+    rejected = 0;
+    std::vector<WithdrawTx> rest;
+    for (const WithdrawTx& tx : w.withdraw_queue) {
+        if (out.size() == cap) { rest.push_back(tx); continue; }
+        long index = -1;
+        for (auto& kv : w.acct)
+            if (kv.second.address == tx.mpn_address) { index = (long)kv.first; break; }
+        if (index < 0) { ++rejected; continue; }
+        MpnAccount acc = w.get(index);
+        long ti = acc.find_token_index(w.L, tx.amount.token_id, false), fi = acc.find_token_index(w.L, tx.fee.token_id, false);
+        if (ti < 0 || fi < 0 || !acc.tokens.count(ti)) { ++rejected; continue; }
+        const Money acc_token = acc.tokens[ti];
+        if ((!(acc.address == PointAffine()) && !(tx.mpn_address == acc.address)) ||
+            !jubjub_verify(tx.mpn_address, tx.sign_message(), tx.sig) || tx.nonce != acc.withdraw_nonce + 1 ||
+            tx.amount.token_id != acc_token.token_id || tx.amount.amount > acc_token.amount) {
+            ++rejected;
+            continue;
+        }
+        MpnAccount upd = acc;
+        upd.address = tx.mpn_address;
+        upd.withdraw_nonce += 1;
+        upd.tokens[ti].amount -= tx.amount.amount;
+        if (!upd.tokens.count(fi)) { ++rejected; continue; }
+        const Money acc_fee = upd.tokens[fi];
+        if (tx.fee.token_id != acc_fee.token_id || tx.fee.amount > acc_fee.amount) { ++rejected; continue; }
+        WithdrawTransition t;
+        t.enabled = true;
+        t.tx = tx;
+        t.account_index = index; t.token_index = ti; t.fee_token_index = fi;
+        t.before = acc;
+        t.before_token_balance = acc_token;
+        t.before_fee_balance = acc_fee;
+        SparseTree4 tree = w.tokens_tree(acc);
+        t.before_token_hash = tree.root();
+        t.token_balance_proof = tree.prove(ti);
+        tree.set_leaf(ti, token_leaf(upd.tokens[ti]));
+        t.fee_balance_proof = tree.prove(fi);
+        upd.tokens[fi].amount -= tx.fee.amount;
+        tree.set_leaf(fi, token_leaf(upd.tokens[fi]));
+        t.proof = w.accounts->prove(index);  // siblings of the account leaf (independent of the leaf itself)
+        w.set_with_tokens_root(index, upd, tree.root());
+        t.state_after = w.accounts->root();
+        out.push_back(std::move(t));
+    }
+    w.withdraw_queue.swap(rest);
+}
+
+static ZkScalar withdraw_aux(const std::vector<WithdrawTransition>& trs, int log4_batch) {
+    std::vector<std::vector<ZkScalar>> items;
+    for (auto& t : trs) {
+        if (!t.enabled) break;
+        items.push_back({ZkScalar::from_u64(1), t.tx.amount.token_id, ZkScalar::from_u64(t.tx.amount.amount), t.tx.fee.token_id,
+                         ZkScalar::from_u64(t.tx.fee.amount), t.tx.fingerprint, t.tx.calldata()});
+    }
+    return native_batch_root(items, log4_batch, 7);
+}
+
+static void synthesize_withdraw(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
+                                const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<WithdrawTransition>& trs) {
+    Num commitment_wit = num_alloc(cs, commitment.v);
+    num_inputize(cs, commitment_wit);
+    Num height_wit = num_alloc(cs, fr_from_u64(height));
+    num_inputize(cs, height_wit);
+    Num state_wit = num_alloc(cs, state.v);
+    num_inputize(cs, state_wit);
+    Num aux_wit = num_alloc(cs, aux_data.v);
+    num_inputize(cs, aux_wit);
+    Num claimed_next = num_alloc(cs, next_state.v);
+    num_inputize(cs, claimed_next);
+    struct TxWit { Bool enabled; Num amount_token_id; UInt amount; Num fee_token_id; UInt fee; Num fingerprint; APoint pub_key; Num nonce; APoint sig_r; Num sig_s; };
+    std::vector<TxWit> wits;
+    std::vector<std::vector<Number>> children;
+    for (const WithdrawTransition& tr : trs) {
+        Bit enabled = bit_alloc(cs, tr.enabled);
+        Num amount_token_id = num_alloc(cs, tr.tx.amount.token_id.v);
+        UInt amount = UInt::alloc_64(cs, tr.tx.amount.amount);
+        Num fee_token_id = num_alloc(cs, tr.tx.fee.token_id.v);
+        UInt fee = UInt::alloc_64(cs, tr.tx.fee.amount);
+        Num fingerprint = num_alloc(cs, tr.enabled ? tr.tx.fingerprint.v : Fr::zero());
+        APoint pub_key = APoint::alloc(cs, tr.tx.mpn_address);
+        Num nonce = num_alloc(cs, fr_from_u64(tr.tx.nonce));
+        APoint sig_r = APoint::alloc(cs, tr.tx.sig.r);
+        Num sig_s = num_alloc(cs, tr.tx.sig.s.v);
+        wits.push_back({Bool::is(enabled), amount_token_id, amount, fee_token_id, fee, fingerprint, pub_key, nonce, sig_r, sig_s});
+        Number cdh = g_poseidon(cs, {Number::from(pub_key.x), Number::from(pub_key.y), Number::from(nonce), Number::from(sig_r.x),
+                                     Number::from(sig_r.y), Number::from(sig_s)});
+        Num calldata = mux(cs, Bool::is(enabled), Number::zero(), cdh);
+        children.push_back({Number::from(enabled), Number::from(amount_token_id), amount.num, Number::from(fee_token_id), fee.num,
+                            Number::from(fingerprint), Number::from(calldata)});
+    }
+    Number tx_root = g_reveal_batch(cs, children);
+    cs.enforce(LC::of(aux_wit.var), aux_wit.val, LC::one(), Fr::one(), tx_root.lc, tx_root.val);
+    for (size_t i = 0; i < trs.size(); ++i) {
+        const WithdrawTransition& tr = trs[i];
+        const TxWit& tw = wits[i];
+        UInt tx_index = UInt::alloc(cs, fr_from_u64(tr.account_index), 2 * L);
+        UInt tx_token_index = UInt::alloc(cs, fr_from_u64(tr.token_index), 2 * T);
+        UInt tx_fee_token_index = UInt::alloc(cs, fr_from_u64(tr.fee_token_index), 2 * T);
+        tw.pub_key.assert_on_curve(cs, tw.enabled);
+        Number tx_hash = g_poseidon(cs, {Number::from(tw.fingerprint), Number::from(tw.nonce)});
+        tw.sig_r.assert_on_curve(cs, tw.enabled);
+        g_verify_eddsa(cs, tw.enabled, tw.pub_key, tx_hash, tw.sig_r, tw.sig_s);
+        Num src_tx_nonce = num_alloc(cs, fr_from_u64(tr.before.tx_nonce));
+        Num src_withdraw_nonce = num_alloc(cs, fr_from_u64(tr.before.withdraw_nonce));
+        APoint src_addr = APoint::alloc(cs, tr.before.address);
+        src_addr.assert_on_curve(cs, tw.enabled);
+        Num before_token_hash = num_alloc(cs, tr.before_token_hash.v);
+        Num src_token_id = num_alloc(cs, tr.before_token_balance.token_id.v);
+        Number::from(src_token_id).assert_equal(cs, Number::from(tw.amount_token_id));
+        Num src_balance = num_alloc(cs, fr_from_u64(tr.before_token_balance.amount));
+        Number src_token_balance_hash = g_poseidon(cs, {Number::from(src_token_id), Number::from(src_balance)});
+        MerkleProofWit token_proof = alloc_proof(cs, tr.token_balance_proof);
+        g_check_proof4(cs, tw.enabled, tx_token_index, src_token_balance_hash, token_proof, Number::from(before_token_hash));
+        Number new_token_leaf = g_poseidon(cs, {Number::from(src_token_id), Number::from(src_balance).minus(tw.amount.num)});
+        Number balance_middle_root = g_calc_root4(cs, tx_token_index, new_token_leaf, token_proof);
+        Num src_fee_token_id = num_alloc(cs, tr.before_fee_balance.token_id.v);
+        Number::from(src_fee_token_id).assert_equal(cs, Number::from(tw.fee_token_id));
+        Num src_fee_balance = num_alloc(cs, fr_from_u64(tr.before_fee_balance.amount));
+        Number src_fee_leaf = g_poseidon(cs, {Number::from(src_fee_token_id), Number::from(src_fee_balance)});
+        MerkleProofWit fee_proof = alloc_proof(cs, tr.fee_balance_proof);
+        g_check_proof4(cs, tw.enabled, tx_fee_token_index, src_fee_leaf, fee_proof, balance_middle_root);
+        Number new_fee_leaf = g_poseidon(cs, {Number::from(src_fee_token_id), Number::from(src_fee_balance).minus(tw.fee.num)});
+        Number src_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce), Number::from(src_addr.x),
+                                          Number::from(src_addr.y), Number::from(before_token_hash)});
+        MerkleProofWit proof = alloc_proof(cs, tr.proof);
+        g_check_proof4(cs, tw.enabled, tx_index, src_hash, proof, Number::from(state_wit));
+        Number::from(tw.nonce).assert_equal_if_enabled(cs, tw.enabled, Number::from(src_withdraw_nonce).plus(Number::constant(Fr::one())));
+        Number balance_final_root = g_calc_root4(cs, tx_fee_token_index, new_fee_leaf, fee_proof);
+        Number new_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce).plus(Number::constant(Fr::one())),
+                                          Number::from(tw.pub_key.x), Number::from(tw.pub_key.y), balance_final_root});
+        Number next_state_wit = g_calc_root4(cs, tx_index, new_hash, proof);
+        state_wit = mux(cs, tw.enabled, Number::from(state_wit), next_state_wit);
+    }
+    cs.enforce(LC::of(state_wit.var), state_wit.val, LC::one(), Fr::one(), LC::of(claimed_next.var), claimed_next.val);
+    cs.finalize();
+}
+
 static void finish_r1cs(bzk_r1cs* r) {
     ConstraintSystem& cs = r->cs;
     const size_t n_in = cs.inputs.size(), n_aux = cs.aux.size();
@@ -633,6 +981,126 @@ int32_t bzk_mpn_update_empty(uint32_t log4_tree, uint32_t log4_token_tree, uint3
         synthesize_update(r->cs, (int)log4_tree, (int)log4_token_tree, ZkScalar::from_bytes(commitment), height,
                           ZkScalar::from_bytes(state), ZkScalar::from_bytes(aux_data), ZkScalar::from_bytes(next_state),
                           ZkScalar::from_bytes(fee_token), trs, 1);
+        finish_r1cs(r.get());
+        *out = r.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception&) {
+        return BZK_E_INTERNAL;
+    }
+}
+
+// ---- deposits and withdrawals: the other two MpnWorkData variants (src/mpn/mod.rs:243-248)
+int32_t bzk_mpn_push_deposit(bzk_mpn* w, uint64_t key_index, const uint8_t token_id[32], uint64_t amount) {
+    if (!w || !token_id || !w->keys.count(key_index)) return BZK_E_ARG;
+    DepositTx tx;
+    tx.mpn_address = w->keys[key_index].public_key;
+    tx.amount = Money{ZkScalar::from_bytes(token_id), amount};
+    w->deposit_queue.push_back(tx);
+    return BZK_OK;
+}
+
+// signed as the wallet does (src/wallet/tx_builder.rs:376-425): sig over H2(fingerprint, nonce), nonce = account's
+// withdraw nonce + 1 (+ already queued withdrawals of that account)
+int32_t bzk_mpn_push_withdraw(bzk_mpn* w, uint64_t account_index, const uint8_t token_id[32], uint64_t amount,
+                              const uint8_t fee_token[32], uint64_t fee, const uint8_t fingerprint[32]) {
+    if (!w || !token_id || !fee_token || !fingerprint || !w->keys.count(account_index)) return BZK_E_ARG;
+    WithdrawTx tx;
+    tx.mpn_address = w->keys[account_index].public_key;
+    uint32_t queued = 0;
+    for (auto& q : w->withdraw_queue)
+        if (q.mpn_address == tx.mpn_address) ++queued;
+    tx.nonce = w->get(account_index).withdraw_nonce + 1 + queued;
+    tx.amount = Money{ZkScalar::from_bytes(token_id), amount};
+    tx.fee = Money{ZkScalar::from_bytes(fee_token), fee};
+    tx.fingerprint = ZkScalar::from_bytes(fingerprint);
+    tx.sig = jubjub_sign(w->keys[account_index], tx.sign_message());
+    w->withdraw_queue.push_back(tx);
+    return BZK_OK;
+}
+
+int32_t bzk_mpn_deposit_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], int32_t record_matrices,
+                                   bzk_r1cs** out) {
+    if (!w || !commitment || !out || log4_batch > 6) return BZK_E_ARG;
+    *out = nullptr;
+    try {
+        const ZkScalar state = w->accounts->root();
+        std::vector<DepositTransition> trs;
+        uint64_t rejected = 0;
+        build_deposits(*w, (int)log4_batch, trs, rejected);
+        const uint64_t accepted = trs.size();
+        const ZkScalar aux = deposit_aux(trs, (int)log4_batch);
+        while (trs.size() < ((size_t)1 << (2 * log4_batch))) trs.push_back(DepositTransition::null(w->L, w->T));
+        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
+        LcModeGuard guard(record_matrices != 0);
+        r->cs.self_check = record_matrices != 0;
+        synthesize_deposit(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs);
+        if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
+        r->accepted = accepted;
+        r->rejected = rejected;
+        finish_r1cs(r.get());
+        *out = r.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception&) {
+        return BZK_E_INTERNAL;
+    }
+}
+
+int32_t bzk_mpn_withdraw_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], int32_t record_matrices,
+                                    bzk_r1cs** out) {
+    if (!w || !commitment || !out || log4_batch > 6) return BZK_E_ARG;
+    *out = nullptr;
+    try {
+        const ZkScalar state = w->accounts->root();
+        std::vector<WithdrawTransition> trs;
+        uint64_t rejected = 0;
+        build_withdraws(*w, (int)log4_batch, trs, rejected);
+        const uint64_t accepted = trs.size();
+        const ZkScalar aux = withdraw_aux(trs, (int)log4_batch);
+        while (trs.size() < ((size_t)1 << (2 * log4_batch))) trs.push_back(WithdrawTransition::null(w->L, w->T));
+        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
+        LcModeGuard guard(record_matrices != 0);
+        r->cs.self_check = record_matrices != 0;
+        synthesize_withdraw(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs);
+        if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
+        r->accepted = accepted;
+        r->rejected = rejected;
+        finish_r1cs(r.get());
+        *out = r.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception&) {
+        return BZK_E_INTERNAL;
+    }
+}
+
+// `MpnCircuit::empty` for the other two circuits (src/mpn/circuits/test.rs:151-229): kind 0 = deposit, 1 = withdraw
+int32_t bzk_mpn_circuit_empty(int32_t kind, uint32_t log4_tree, uint32_t log4_token_tree, uint32_t log4_batch,
+                              const uint8_t commitment[32], uint64_t height, const uint8_t state[32], const uint8_t aux_data[32],
+                              const uint8_t next_state[32], int32_t record_matrices, bzk_r1cs** out) {
+    if (!commitment || !state || !aux_data || !next_state || !out || log4_batch > 6 || log4_tree == 0 || log4_tree > 30 ||
+        log4_token_tree == 0 || log4_token_tree > 8 || kind < 0 || kind > 1)
+        return BZK_E_ARG;
+    *out = nullptr;
+    try {
+        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
+        LcModeGuard guard(record_matrices != 0);
+        r->cs.self_check = record_matrices != 0;
+        const size_t n = (size_t)1 << (2 * log4_batch);
+        if (kind == 0) {
+            std::vector<DepositTransition> trs(n, DepositTransition::null((int)log4_tree, (int)log4_token_tree));
+            synthesize_deposit(r->cs, (int)log4_tree, (int)log4_token_tree, ZkScalar::from_bytes(commitment), height,
+                               ZkScalar::from_bytes(state), ZkScalar::from_bytes(aux_data), ZkScalar::from_bytes(next_state), trs);
+        } else {
+            std::vector<WithdrawTransition> trs(n, WithdrawTransition::null((int)log4_tree, (int)log4_token_tree));
+            synthesize_withdraw(r->cs, (int)log4_tree, (int)log4_token_tree, ZkScalar::from_bytes(commitment), height,
+                                ZkScalar::from_bytes(state), ZkScalar::from_bytes(aux_data), ZkScalar::from_bytes(next_state), trs);
+        }
+        if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
         finish_r1cs(r.get());
         *out = r.release();
         return BZK_OK;

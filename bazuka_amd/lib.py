@@ -56,6 +56,11 @@ SIGNATURES = {
     "bzk_mpn_add_key": (_i32, [_vp, _u64, _vp, _u32]),
     "bzk_mpn_root": (_i32, [_vp, _vp]),
     "bzk_mpn_push_tx": (_i32, [_vp, _u64, _u64, _vp, _u64, _vp, _u64]),
+    "bzk_mpn_push_deposit": (_i32, [_vp, _u64, _vp, _u64]),
+    "bzk_mpn_push_withdraw": (_i32, [_vp, _u64, _vp, _u64, _vp, _u64, _vp]),
+    "bzk_mpn_deposit_synthesize": (_i32, [_vp, _u32, _vp, _i32, C.POINTER(_vp)]),
+    "bzk_mpn_withdraw_synthesize": (_i32, [_vp, _u32, _vp, _i32, C.POINTER(_vp)]),
+    "bzk_mpn_circuit_empty": (_i32, [_i32, _u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
     "bzk_mpn_update_synthesize": (_i32, [_vp, _u32, _vp, _vp, _i32, C.POINTER(_vp)]),
     "bzk_mpn_update_empty": (_i32, [_u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
     "bzk_r1cs_info": (_i32, [_vp, C.POINTER(_u64)]),
@@ -407,6 +412,22 @@ class MpnWorld:
     def push_tx(self, src: int, dst: int, token_id: bytes, amount: int, fee_token: bytes, fee: int):
         _st(self.lib.bzk_mpn_push_tx(self.h, src, dst, _ptr(token_id), amount, _ptr(fee_token), fee), "push_tx")
 
+    def push_deposit(self, key_index: int, token_id: bytes, amount: int):
+        _st(self.lib.bzk_mpn_push_deposit(self.h, key_index, _ptr(token_id), amount), "push_deposit")
+
+    def push_withdraw(self, account: int, token_id: bytes, amount: int, fee_token: bytes, fee: int, fingerprint: bytes):
+        _st(self.lib.bzk_mpn_push_withdraw(self.h, account, _ptr(token_id), amount, _ptr(fee_token), fee, _ptr(fingerprint)), "push_withdraw")
+
+    def deposit_synthesize(self, log4_batch: int, commitment: bytes, record_matrices=False) -> R1cs:
+        h = C.c_void_p()
+        _st(self.lib.bzk_mpn_deposit_synthesize(self.h, log4_batch, _ptr(commitment), int(record_matrices), C.byref(h)), "deposit_synthesize")
+        return R1cs(h)
+
+    def withdraw_synthesize(self, log4_batch: int, commitment: bytes, record_matrices=False) -> R1cs:
+        h = C.c_void_p()
+        _st(self.lib.bzk_mpn_withdraw_synthesize(self.h, log4_batch, _ptr(commitment), int(record_matrices), C.byref(h)), "withdraw_synthesize")
+        return R1cs(h)
+
     def update_synthesize(self, log4_batch: int, commitment: bytes, fee_token: bytes, record_matrices=False) -> R1cs:
         h = C.c_void_p()
         _st(self.lib.bzk_mpn_update_synthesize(self.h, log4_batch, _ptr(commitment), _ptr(fee_token), int(record_matrices),
@@ -418,6 +439,14 @@ def mpn_update_empty(L, T, B, commitment, height, state, aux, next_state, fee_to
     h = C.c_void_p()
     _st(load_library().bzk_mpn_update_empty(L, T, B, _ptr(commitment), height, _ptr(state), _ptr(aux), _ptr(next_state),
                                             _ptr(fee_token), int(record_matrices), C.byref(h)), "update_empty")
+    return R1cs(h)
+
+
+def mpn_circuit_empty(kind, L, T, B, commitment, height, state, aux, next_state, record_matrices=False) -> R1cs:
+    """kind: 0 deposit, 1 withdraw"""
+    h = C.c_void_p()
+    _st(load_library().bzk_mpn_circuit_empty(kind, L, T, B, _ptr(commitment), height, _ptr(state), _ptr(aux), _ptr(next_state),
+                                             int(record_matrices), C.byref(h)), "circuit_empty")
     return R1cs(h)
 
 

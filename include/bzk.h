@@ -199,6 +199,20 @@ int32_t bzk_mpn_push_tx(bzk_mpn* w, uint64_t src_index, uint64_t dst_index, cons
  * circuit.  Public inputs = [commitment, height, state, aux_data, next_state]. */
 int32_t bzk_mpn_update_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], const uint8_t fee_token[32],
                                   int32_t record_matrices, bzk_r1cs** out);
+/* Deposit / Withdraw (the other two `MpnWorkData` variants, src/mpn/mod.rs:243-248): DepositCircuit
+ * (src/mpn/circuits/deposit_circuit.rs:47-293) with witness builder src/mpn/deposit.rs:11-233, WithdrawCircuit
+ * (src/mpn/circuits/withdraw_circuit.rs:50-413) with src/mpn/withdraw.rs:10-259.  aux_data = root of the batch
+ * tree (`reveal`, src/zk/groth16/gadgets/reveal/mod.rs:13-61).  `fingerprint` = ContractWithdraw::fingerprint()
+ * (src/core/transaction.rs:204-211), taken as an opaque scalar: the L1 payment serialisation is out of scope. */
+int32_t bzk_mpn_push_deposit(bzk_mpn* w, uint64_t key_index, const uint8_t token_id[32], uint64_t amount);
+int32_t bzk_mpn_push_withdraw(bzk_mpn* w, uint64_t account_index, const uint8_t token_id[32], uint64_t amount,
+                              const uint8_t fee_token[32], uint64_t fee, const uint8_t fingerprint[32]);
+int32_t bzk_mpn_deposit_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], int32_t record_matrices, bzk_r1cs** out);
+int32_t bzk_mpn_withdraw_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], int32_t record_matrices, bzk_r1cs** out);
+/* all-disabled instances (kind 0 = deposit, 1 = withdraw), src/mpn/circuits/test.rs:151-229 */
+int32_t bzk_mpn_circuit_empty(int32_t kind, uint32_t log4_tree, uint32_t log4_token_tree, uint32_t log4_batch,
+                              const uint8_t commitment[32], uint64_t height, const uint8_t state[32], const uint8_t aux_data[32],
+                              const uint8_t next_state[32], int32_t record_matrices, bzk_r1cs** out);
 /* `MpnCircuit::empty(L, T, B)` with explicit public inputs (src/mpn/circuits/test.rs:117-132) */
 int32_t bzk_mpn_update_empty(uint32_t log4_tree, uint32_t log4_token_tree, uint32_t log4_batch, const uint8_t commitment[32],
                              uint64_t height, const uint8_t state[32], const uint8_t aux_data[32], const uint8_t next_state[32],

@@ -56,3 +56,30 @@ def test_update_batch_prove_on_gpu_verifies_and_matches_oracle(bzk, co):
     bad = bzk.groth16_prove(ph, bytes(zbad), r.view("az"), r.view("bz"), r.view("cz"), rs[:32], rs[32:])
     assert not pr.groth16_verify(vk, pub, pr.proof_from_bytes(bad))
     bzk.params_free(ph)
+
+
+def test_deposit_and_withdraw_batches_prove_on_gpu(bzk, co):
+    """The other two MpnWorkData variants (src/mpn/mod.rs:243-248): a deposit batch then a withdraw batch, each
+    set up + proved on the GPU, verified by the oracle's pairing check, proof bytes == the oracle prover's."""
+    w = L.MpnWorld(3, 3)
+    for i in range(2):
+        w.add_account(i, b"acct%d" % i, ZIESHA, 10 ** 9)
+    w.add_key(6, b"fresh")
+    w.push_deposit(0, ZIESHA, 1000)
+    w.push_deposit(6, ZIESHA, 5)
+    dep = w.deposit_synthesize(1, F(456), record_matrices=True)
+    w.push_withdraw(0, ZIESHA, 400, ZIESHA, 2, F(4242))
+    w.push_withdraw(1, ZIESHA, 9, ZIESHA, 0, F(7))
+    wd = w.withdraw_synthesize(1, F(457), record_matrices=True)
+    for r, log_m, seed in ((dep, 16, 5), (wd, 17, 6)):
+        assert r.satisfied and r.accepted == 2
+        ph, vkb = bzk.groth16_setup(_csr(r), r.n_in, r.n_aux, fr_bytes(fr_list(5, 1000 + seed)))
+        rs = fr_bytes(fr_list(2, seed))
+        z = r.view("z")
+        proof = bzk.groth16_prove(ph, z, r.view("az"), r.view("bz"), r.view("cz"), rs[:32], rs[32:])
+        pub = [U(z[32 * i:32 * i + 32]) for i in range(1, 6)]
+        assert pr.groth16_verify(pr.vk_from_bytes(vkb), pub, pr.proof_from_bytes(proof))
+        assert not pr.groth16_verify(pr.vk_from_bytes(vkb), [pub[0] + 1] + pub[1:], pr.proof_from_bytes(proof))
+        op = _oracle_params(bzk, ph, r, log_m)
+        assert proof == co.groth16_prove(op, z, r.view("az"), r.view("bz"), r.view("cz"), rs[:32], rs[32:], nthreads=co.ncpu())
+        bzk.params_free(ph)

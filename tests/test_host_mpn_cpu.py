@@ -134,3 +134,75 @@ def test_c1_empty_update_circuit_cpu_prove_verify(co):
           "ic": [pr.g1_from_bytes(params["ic"][97 * i:97 * i + 97]) for i in range(6)]}
     assert pr.groth16_verify(vk, [456, 0, 123, aux, 123], pr.proof_from_bytes(proof))
     assert not pr.groth16_verify(vk, [457, 0, 123, aux, 123], pr.proof_from_bytes(proof))
+
+
+# ---- Deposit / Withdraw: src/mpn/circuits/{deposit,withdraw}_circuit.rs, src/mpn/{deposit,withdraw}.rs
+
+def _batch_root(items, log4_batch, n_fields):
+    """ZkStateBuilder::compress of List{Struct[n_fields]} (the reference test helpers deposits_root / withdraws_root,
+    src/mpn/circuits/test.rs:10-96) in plain Python."""
+    leaves = [pr.poseidon(it) for it in items] + [pr.poseidon([0] * n_fields)] * (4 ** log4_batch - len(items))
+    while len(leaves) > 1:
+        leaves = [pr.poseidon(leaves[i:i + 4]) for i in range(0, len(leaves), 4)]
+    return leaves[0]
+
+
+def test_deposit_withdraw_empty_circuit_sizes_match_survey_model():
+    """All-disabled instances of the reference tests (src/mpn/circuits/test.rs:151-229): public inputs
+    [456, 0, 123, root of the empty batch, 123]; sizes == SURVEY App. B."""
+    d = L.mpn_circuit_empty(0, 3, 3, 1, F(456), 0, F(123), F(_batch_root([], 1, 4)), F(123))
+    assert (d.n_in, d.n_aux, d.n_constraints) == (6, 37077, 37017) and d.satisfied
+    w = L.mpn_circuit_empty(1, 3, 3, 1, F(456), 0, F(123), F(_batch_root([], 1, 7)), F(123))
+    assert (w.n_in, w.n_aux, w.n_constraints) == (6, 96641, 96521) and w.satisfied
+
+
+def test_deposit_batch_state_transition_and_aux():
+    w = _world(3, 3, 2)
+    w.add_key(5, b"fresh")                      # a key without an account: the deposit creates the account
+    r0 = w.root()
+    w.push_deposit(0, ZIESHA, 1000)             # existing account, existing token slot
+    w.push_deposit(5, ZIESHA, 77)               # new account
+    w.push_deposit(1, F(9), 5)                  # existing account, new token -> next free slot
+    r = w.deposit_synthesize(1, F(456))
+    assert r.accepted == 3 and r.rejected == 0 and r.satisfied
+    z = r.view("z")
+    pub = [U(z[32 * i:32 * i + 32]) for i in range(6)]
+    keys = [L.host_jubjub_keys(s)[:64] for s in (b"acct0", b"fresh", b"acct1")]
+    pkh = [pr.poseidon([U(k[:32]), U(k[32:])]) for k in keys]
+    items = [[1, 1, 1000, pkh[0]], [1, 1, 77, pkh[1]], [1, 9, 5, pkh[2]]]
+    assert pub == [1, 456, 0, U(r0), _batch_root(items, 1, 4), U(w.root())]
+    assert w.root() != r0
+
+
+def test_withdraw_batch_state_transition_and_rejects():
+    w = _world(3, 3, 3)
+    r0 = w.root()
+    w.push_withdraw(0, ZIESHA, 500, ZIESHA, 3, F(1234))
+    w.push_withdraw(1, ZIESHA, 1, ZIESHA, 0, F(99))
+    w.push_withdraw(0, ZIESHA, 7, ZIESHA, 1, F(55))      # second withdrawal of account 0: nonce 2
+    w.push_withdraw(2, ZIESHA, 10 ** 13, ZIESHA, 0, F(1))  # overdraw: rejected by the builder
+    r = w.withdraw_synthesize(1, F(8))
+    assert r.accepted == 3 and r.rejected == 1 and r.satisfied
+    z = r.view("z")
+    pub = [U(z[32 * i:32 * i + 32]) for i in range(6)]
+    assert pub[:4] == [1, 8, 0, U(r0)] and pub[5] == U(w.root()) and w.root() != r0
+    # calldata = H6(pk.x, pk.y, nonce, sig.r.x, sig.r.y, sig.s) with the wallet's signature over H2(fingerprint, nonce)
+    items = []
+    for seed, nonce, amt, fee, fp in ((b"acct0", 1, 500, 3, 1234), (b"acct1", 1, 1, 0, 99), (b"acct0", 2, 7, 1, 55)):
+        key = L.host_jubjub_keys(seed)
+        sig = L.host_jubjub_sign(key, F(pr.poseidon([fp, nonce])))
+        cd = pr.poseidon([U(key[:32]), U(key[32:64]), nonce, U(sig[:32]), U(sig[32:64]), U(sig[64:])])
+        items.append([1, 1, amt, 1, fee, fp, cd])
+    assert pub[4] == _batch_root(items, 1, 7)
+
+
+def test_deposit_then_withdraw_production_sizes():
+    """mirrors src/mpn/withdraw.rs:264-353: one deposit then one withdraw at (L=15, T=3), 1 transition each."""
+    w = L.MpnWorld(15, 3)
+    w.add_key(0, b"depositor")
+    w.push_deposit(0, ZIESHA, 10 ** 6)
+    d = w.deposit_synthesize(1, F(1))
+    assert d.accepted == 1 and d.satisfied
+    w.push_withdraw(0, ZIESHA, 10 ** 5, ZIESHA, 10, F(4242))
+    r = w.withdraw_synthesize(1, F(1))
+    assert r.accepted == 1 and r.satisfied
