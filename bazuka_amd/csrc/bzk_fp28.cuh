@@ -117,9 +117,28 @@ BZK_HD Fp28 mul_body(const Fp28& a, const Fp28& b) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // one resident copy of the product per kernel image: by-value arguments travel in VGPRs
-__device__ __noinline__ static Fp28 mul_call(Fp28 a, Fp28 b) { return mul_body(a, b); }
-BZK_HD Fp28 mul(const Fp28& a, const Fp28& b) { return mul_call(a, b); }
-BZK_HD Fp28 sqr(const Fp28& a) { return mul_call(a, a); }
+// The product is a real call (I-cache: see the header).  The operands travel as four-lane VECTOR arguments, not
+// as two structs: clang's AMDGPU ABI gives aggregate arguments 16 argument registers in total, so the second
+// 14-dword struct of mul_call(Fp28, Fp28) was passed through a scratch copy (56 B stored by the caller and
+// re-loaded by the callee on every product - measured as 1.2 GB of HBM writes per 2^20-point accumulate launch).
+// Vector arguments are not aggregates and go straight into v0..v27.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __noinline__ static Fp28 mul_call(u32x4 a0, u32x4 a1, u32x4 a2, u32x2 a3, u32x4 b0, u32x4 b1, u32x4 b2, u32x2 b3) {
+    Fp28 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a.l[i] = a0[i]; a.l[4 + i] = a1[i]; a.l[8 + i] = a2[i];
+        b.l[i] = b0[i]; b.l[4 + i] = b1[i]; b.l[8 + i] = b2[i];
+    }
+    a.l[12] = a3[0]; a.l[13] = a3[1];
+    b.l[12] = b3[0]; b.l[13] = b3[1];
+    return mul_body(a, b);
+}
+#define BZK_FP28_VEC(x) u32x4{x.l[0], x.l[1], x.l[2], x.l[3]}, u32x4{x.l[4], x.l[5], x.l[6], x.l[7]}, \
+                        u32x4{x.l[8], x.l[9], x.l[10], x.l[11]}, u32x2{x.l[12], x.l[13]}
+BZK_HD Fp28 mul(const Fp28& a, const Fp28& b) { return mul_call(BZK_FP28_VEC(a), BZK_FP28_VEC(b)); }
+BZK_HD Fp28 sqr(const Fp28& a) { return mul_call(BZK_FP28_VEC(a), BZK_FP28_VEC(a)); }
 #else
 BZK_HD Fp28 mul(const Fp28& a, const Fp28& b) { return mul_body(a, b); }
 BZK_HD Fp28 sqr(const Fp28& a) { return mul_body(a, a); }

@@ -101,8 +101,22 @@ BZK_HD Fr29 mul_body(const Fr29& a, const Fr29& b) {
     return wide_reduce(w);
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __noinline__ static Fr29 mul_call(Fr29 a, Fr29 b) { return mul_body(a, b); }
-BZK_HD Fr29 mul(const Fr29& a, const Fr29& b) { return mul_call(a, b); }
+// vector (non-aggregate) arguments: two 9-dword structs exceed the ABI's 16 aggregate argument registers and the
+// second one would travel through scratch memory (see bzk_fp28.cuh)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __noinline__ static Fr29 mul_call(u32x4 a0, u32x4 a1, uint32_t a2, u32x4 b0, u32x4 b1, uint32_t b2) {
+    Fr29 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a.l[i] = a0[i]; a.l[4 + i] = a1[i];
+        b.l[i] = b0[i]; b.l[4 + i] = b1[i];
+    }
+    a.l[8] = a2;
+    b.l[8] = b2;
+    return mul_body(a, b);
+}
+#define BZK_FR29_VEC(x) u32x4{x.l[0], x.l[1], x.l[2], x.l[3]}, u32x4{x.l[4], x.l[5], x.l[6], x.l[7]}, x.l[8]
+BZK_HD Fr29 mul(const Fr29& a, const Fr29& b) { return mul_call(BZK_FR29_VEC(a), BZK_FR29_VEC(b)); }
 #else
 BZK_HD Fr29 mul(const Fr29& a, const Fr29& b) { return mul_body(a, b); }
 #endif

@@ -35,6 +35,10 @@ struct bzk_ctx {
     bool debug = false;  // env BZK_DEBUG=1: synchronise + log after every launch (hang localisation)
     // NTT twiddle cache: per log_n, forward and inverse tables
     void* ntt_tw[33][2] = {};
+    // lanes: child contexts (own stream, workspace, pinned staging) for independent sub-jobs of one call that
+    // should overlap on the device - the five MSMs of a Groth16 proof.  Created on first use, owned by the parent.
+    std::vector<bzk_ctx*> lanes;
+    bool timing = false;  // env BZK_TIMING=1: host-side phase timings of bzk_groth16_prove on stderr
 };
 
 #define BZK_HIP(ctx, call)                                                                  \
@@ -60,6 +64,7 @@ void bzk_params_set_vk_internal(bzk_params* p, const uint8_t vk[870]);
 namespace bzk {
 
 int32_t ws_reserve(bzk_ctx* ctx, size_t bytes);           // ensures ctx->ws has >= bytes
+bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i);                // i-th child context (nullptr on failure)
 int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes);
 
 // bump allocator over ctx->ws

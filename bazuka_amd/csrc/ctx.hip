@@ -44,6 +44,20 @@ int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes) {
     return BZK_OK;
 }
 
+bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
+    while (ctx->lanes.size() <= i) {
+        bzk_ctx* c = nullptr;
+        if (bzk_ctx_create(ctx->device, nullptr, &c) != BZK_OK) return nullptr;
+        ctx->lanes.push_back(c);
+    }
+    bzk_ctx* c = ctx->lanes[i];
+    c->prof = ctx->prof;
+    c->debug = ctx->debug;
+    c->msm_c_override = ctx->msm_c_override;
+    c->msm_chunk_override = ctx->msm_chunk_override;
+    return c;
+}
+
 }  // namespace bzk
 
 extern "C" {
@@ -93,6 +107,7 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     if (const char* e = getenv("BZK_MSM_C")) ctx->msm_c_override = atoi(e);
     if (const char* e = getenv("BZK_MSM_CHUNK")) ctx->msm_chunk_override = atoi(e);
     if (const char* e = getenv("BZK_DEBUG")) ctx->debug = atoi(e) != 0;
+    if (const char* e = getenv("BZK_TIMING")) ctx->timing = atoi(e) != 0;
     *out = ctx;
     return BZK_OK;
 }
@@ -101,6 +116,7 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (bzk_ctx* c : ctx->lanes) bzk_ctx_destroy(c);
     for (auto& r : ctx->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -165,6 +181,7 @@ int32_t bzk_prof_enable(bzk_ctx* ctx, int32_t on) {
 int32_t bzk_prof_reset(bzk_ctx* ctx) {
     if (!ctx) return BZK_E_ARG;
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (bzk_ctx* c : ctx->lanes) BZK_TRY(bzk_prof_reset(c));
     for (auto& r : ctx->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -178,6 +195,13 @@ int32_t bzk_prof_query(bzk_ctx* ctx, const char* name, uint64_t* launches, doubl
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t n = 0;
     double tot = 0;
+    for (bzk_ctx* c : ctx->lanes) {  // kernels launched on the lanes count towards the parent's totals
+        uint64_t ln = 0;
+        double lt = 0;
+        BZK_TRY(bzk_prof_query(c, name, &ln, &lt));
+        n += ln;
+        tot += lt;
+    }
     for (auto& r : ctx->recs) {
         if (strcmp(r.name, name) != 0) continue;
         float ms = 0;
@@ -195,12 +219,17 @@ int32_t bzk_prof_dump(bzk_ctx* ctx, char* buf, uint64_t cap) {
     if (!ctx || !buf || !cap) return BZK_E_ARG;
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::map<std::string, std::pair<uint64_t, double>> agg;
-    for (auto& r : ctx->recs) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            auto& e = agg[r.name];
-            e.first++;
-            e.second += ms;
+    std::vector<bzk_ctx*> all(ctx->lanes);
+    all.push_back(ctx);
+    for (bzk_ctx* c : all) {
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& r : c->recs) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                auto& e = agg[r.name];
+                e.first++;
+                e.second += ms;
+            }
         }
     }
     std::string s;

@@ -12,6 +12,9 @@
 // (/root/reference/src/zk/groth16/mod.rs:33-38).
 #include <string.h>
 
+#include <chrono>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bzk_curve.cuh"
@@ -220,28 +223,68 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
     (void)hipSetDevice(ctx->device);
     const uint64_t m = (uint64_t)1 << p->log_m, nv = (uint64_t)p->n_in + p->n_aux;
     if (asg->n_rows > m) return BZK_E_ARG;
-    // stage the assignment
-    void* ev[3] = {p->d_a, p->d_b, p->d_c};
-    const uint8_t* hv[3] = {asg->az, asg->bz, asg->cz};
-    for (int k = 0; k < 3; ++k) {
-        BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
-        if (m > asg->n_rows)
-            BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
-    }
+    // Schedule: the five MSMs are independent, and each ends in a latency-bound tail (bucket reduction, window
+    // sums, 97-byte read-back) that leaves most CUs idle.  They run on separate lanes (stream + workspace each,
+    // one host thread per lane) so that one MSM's tail overlaps another's accumulation; l, a, b only need z, so
+    // they start while az/bz/cz are still being copied and the h polynomial is computed on the main stream.
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    bzk_ctx* lane[3];
+    for (int i = 0; i < 3; ++i)
+        if (!(lane[i] = bzk::ctx_lane(ctx, (size_t)i))) return BZK_E_DEVICE;
     BZK_HIP(ctx, hipMemcpyAsync(p->d_z, asg->z, nv * 32, hipMemcpyHostToDevice, ctx->stream));
-    // h polynomial
-    BZK_TRY(groth16_h(ctx, p->d_a, p->d_b, p->d_c, p->log_m));
     // density-filtered scalar vectors
     if (p->n_a)
         BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_a + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->a_idx, p->n_a, (Fr*)p->d_sa);
     if (p->n_b)
         BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_b + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->b_idx, p->n_b, (Fr*)p->d_sb);
+    hipEvent_t z_ready;
+    BZK_HIP(ctx, hipEventCreateWithFlags(&z_ready, hipEventDisableTiming));
+    BZK_HIP(ctx, hipEventRecord(z_ready, ctx->stream));
+    for (int i = 0; i < 3; ++i) BZK_HIP(ctx, hipStreamWaitEvent(lane[i]->stream, z_ready, 0));
+    const auto t1 = clk::now();
     uint8_t pH[97], pL[97], pA[97], pB1[97], pB2[193];
-    BZK_TRY(bzk_msm_g1_dev(ctx, p->h, p->d_a, m - 1, 0, pH));
-    BZK_TRY(bzk_msm_g1_dev(ctx, p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, 0, pL));
-    BZK_TRY(bzk_msm_g1_dev(ctx, p->a, p->d_sa, p->n_a, 0, pA));
-    BZK_TRY(bzk_msm_g1_dev(ctx, p->b_g1, p->d_sb, p->n_b, 0, pB1));
-    BZK_TRY(bzk_msm_g2_dev(ctx, p->b_g2, p->d_sb, p->n_b, 0, pB2));
+    int32_t st[3] = {BZK_OK, BZK_OK, BZK_OK};
+    const int dev = ctx->device;
+    std::thread th[3];
+    th[0] = std::thread([&] {
+        (void)hipSetDevice(dev);
+        st[0] = bzk_msm_g2_dev(lane[0], p->b_g2, p->d_sb, p->n_b, 0, pB2);
+    });
+    th[1] = std::thread([&] {
+        (void)hipSetDevice(dev);
+        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, 0, pL);
+        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, 0, pB1);
+    });
+    th[2] = std::thread([&] {
+        (void)hipSetDevice(dev);
+        st[2] = bzk_msm_g1_dev(lane[2], p->a, p->d_sa, p->n_a, 0, pA);
+    });
+    // main stream: stage the evaluations, h polynomial, h MSM
+    int32_t st_main = BZK_OK;
+    auto main_part = [&]() -> int32_t {
+        void* ev[3] = {p->d_a, p->d_b, p->d_c};
+        const uint8_t* hv[3] = {asg->az, asg->bz, asg->cz};
+        for (int k = 0; k < 3; ++k) {
+            BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+            if (m > asg->n_rows)
+                BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
+        }
+        BZK_TRY(groth16_h(ctx, p->d_a, p->d_b, p->d_c, p->log_m));
+        return bzk_msm_g1_dev(ctx, p->h, p->d_a, m - 1, 0, pH);
+    };
+    const auto t2 = clk::now();
+    st_main = main_part();
+    const auto t3 = clk::now();
+    for (auto& t : th) t.join();
+    (void)hipEventDestroy(z_ready);
+    const auto t4 = clk::now();
+    if (st_main != BZK_OK) return st_main;
+    for (int i = 0; i < 3; ++i)
+        if (st[i] != BZK_OK) {
+            ctx->last_error = "lane " + std::to_string(i) + ": " + lane[i]->last_error;
+            return st[i];
+        }
     // assembly (host)
     Fr r, s;
     memcpy(r.l, r32, 32);
@@ -269,6 +312,11 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
     pack_g1(ga, proof);
     pack_g2(gb, proof + 97);
     pack_g1(gc, proof + 290);
+    if (ctx->timing) {
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[bzk] groth16_prove: z staged %.2f ms, lanes started %.2f, h chain %.2f, lanes joined +%.2f, assembly %.2f\n",
+                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, clk::now()));
+    }
     return BZK_OK;
 }
 

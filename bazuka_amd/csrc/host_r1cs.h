@@ -66,6 +66,32 @@ struct LC {
     static LC one() { return LC().add_var(VAR_ONE); }
 };
 
+// Allocator for the arrays that are handed to the GPU (z, A.z, B.z, C.z: 116 MB per 2^20-class proof): large
+// blocks come from a process-wide pool of PINNED host memory, so that bzk_groth16_prove's hipMemcpyAsync is a
+// true asynchronous DMA at PCIe rate instead of a staged pageable copy.  Blocks return to the pool on free (the
+// next proof of the same shape reuses them; hipHostMalloc itself is slow).  No device / hipHostMalloc failure
+// => plain malloc: this is memory plumbing only, it computes nothing.
+void* pinned_pool_take(size_t bytes);   // host_pinned pool, mpn.hip
+void pinned_pool_give(void* p, size_t bytes);
+template <class T>
+struct PinnedPoolAlloc {
+    using value_type = T;
+    PinnedPoolAlloc() = default;
+    template <class U>
+    PinnedPoolAlloc(const PinnedPoolAlloc<U>&) {}
+    T* allocate(size_t n) {
+        void* p = pinned_pool_take(n * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return (T*)p;
+    }
+    void deallocate(T* p, size_t n) { pinned_pool_give(p, n * sizeof(T)); }
+    template <class U>
+    bool operator==(const PinnedPoolAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const PinnedPoolAlloc<U>&) const { return false; }
+};
+using FrVec = std::vector<Fr, PinnedPoolAlloc<Fr>>;
+
 struct CsrBuilder {
     std::vector<uint32_t> row_ptr{0}, col;
     std::vector<Fr> val;
@@ -74,8 +100,9 @@ struct CsrBuilder {
 class ConstraintSystem {
    public:
     bool record_matrices;
-    std::vector<Fr> inputs, aux;   // assignment; inputs[0] = 1
-    std::vector<Fr> az, bz, cz;    // per-constraint evaluations
+    std::vector<Fr> inputs;        // assignment, inputs[0] = 1
+    FrVec aux;                     // assignment, auxiliary variables
+    FrVec az, bz, cz;              // per-constraint evaluations
     CsrBuilder A, B, C;            // only when record_matrices (columns still Var-encoded until finalize)
     std::vector<uint8_t> a_in_d, a_aux_d, b_in_d, b_aux_d;  // densities by appearance
     bool finalized = false;

@@ -17,6 +17,7 @@
 #include <map>
 #include <thread>
 #include <memory>
+#include <mutex>
 #include <unordered_map>
 
 #include "bzk_internal.h"
@@ -239,13 +240,76 @@ struct bzk_mpn {
 
 struct bzk_r1cs {
     ConstraintSystem cs;
-    std::vector<uint8_t> z_bytes, a_density, b_density;
+    std::vector<uint8_t, bzk::PinnedPoolAlloc<uint8_t>> z_bytes;
+    std::vector<uint8_t> a_density, b_density;
     std::vector<uint32_t> colA, colB, colC;  // flat variable indices (after finalize)
     uint64_t accepted = 0, rejected = 0;
     explicit bzk_r1cs(bool rec) : cs(rec) {}
 };
 
 namespace bzk {
+
+// ---- pinned host pool behind PinnedPoolAlloc (host_r1cs.h)
+namespace {
+struct PinnedPool {
+    static constexpr size_t MIN_PINNED = (size_t)1 << 22;  // smaller blocks: malloc
+    static constexpr size_t MAX_POOLED = (size_t)16 << 30;
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;     // capacity -> block
+    std::map<void*, std::pair<size_t, bool>> live;  // block -> (capacity, pinned)
+    size_t pooled = 0;
+    int have_device = -1;
+    void* take(size_t bytes) {
+        if (bytes < MIN_PINNED) return malloc(bytes ? bytes : 1);
+        std::lock_guard<std::mutex> g(mu);
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + (bytes >> 1)) {
+            void* p = it->second;
+            pooled -= it->first;
+            live[p] = {it->first, true};
+            free_blocks.erase(it);
+            return p;
+        }
+        if (have_device < 0) {
+            int n = 0;
+            have_device = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0;
+            (void)hipGetLastError();
+        }
+        void* p = nullptr;
+        if (have_device && hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p) {
+            live[p] = {bytes, true};
+            return p;
+        }
+        (void)hipGetLastError();
+        p = malloc(bytes);
+        if (p) live[p] = {bytes, false};
+        return p;
+    }
+    void give(void* p, size_t bytes) {
+        if (!p) return;
+        if (bytes < MIN_PINNED) return free(p);
+        std::lock_guard<std::mutex> g(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return free(p);
+        const size_t cap = it->second.first;
+        const bool pinned = it->second.second;
+        live.erase(it);
+        if (!pinned) return free(p);
+        if (pooled + cap > MAX_POOLED) {
+            (void)hipHostFree(p);
+            return;
+        }
+        pooled += cap;
+        free_blocks.emplace(cap, p);
+    }
+};
+PinnedPool& pinned_pool() {
+    static PinnedPool* pool = new PinnedPool();  // never destroyed: blocks may be released during static teardown
+    return *pool;
+}
+}  // namespace
+void* pinned_pool_take(size_t bytes) { return pinned_pool().take(bytes); }
+void pinned_pool_give(void* p, size_t bytes) { pinned_pool().give(p, bytes); }
 
 // update::update for the queued transactions (src/mpn/update.rs:8-299); mutates the world.
 static void build_transitions(bzk_mpn& w, int log4_batch, const ZkScalar& fee_token, std::vector<UpdateTransition>& out,

@@ -572,8 +572,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         const uint32_t t_max = (uint32_t)((uint64_t)nb + len / seg + 1);
-        // 2 waves/SIMD: forcing 3 or 4 (__launch_bounds__) spills 68 / 223 VGPRs and measured 13 % / 80 % slower
-        auto k_acc = msm_accumulate_kernel<C, 2>;
+        // G1: 2 waves/SIMD: forcing 3 or 4 (__launch_bounds__) spills 68 / 223 VGPRs and measured 13 % / 80 % slower.
+        // G2: 1 wave/SIMD (512 registers: 35 spilled instead of 402 at 2 waves), see msm_policy.cuh
+        auto k_acc = msm_accumulate_kernel<C, C::ACC_OCC>;
         auto k_fold = msm_fold_kernel<C>;
         auto k_fold_small = msm_fold_small_kernel<C>;
         auto k_red = msm_reduce_kernel<C>;

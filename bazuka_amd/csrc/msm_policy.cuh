@@ -8,6 +8,9 @@
 
 namespace bzk {
 
+#ifndef BZK_G2_ACC_OCC
+#define BZK_G2_ACC_OCC 1
+#endif
 struct alignas(16) U128 {
     uint32_t x, y, z, w;
 };
@@ -19,6 +22,7 @@ struct G1Fast {
     static constexpr int RAW = 96, PACKED = 97;
     static constexpr bool CONVERT_BASES = true;
     static constexpr int WSUM_THREADS = 256;  // 256 x 224 B = 56 KiB LDS
+    static constexpr int ACC_OCC = 2;
     __device__ static __forceinline__ Pt identity() { return g1x28::identity(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p, bool neg) { g1x28::add_mixed(acc, p, neg); }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { g1x28::add_full(acc, q); }
@@ -68,6 +72,9 @@ struct G2Fast {
     static constexpr int RAW = 192, PACKED = 193;
     static constexpr bool CONVERT_BASES = true;
     static constexpr int WSUM_THREADS = 128;  // 128 x 448 B = 56 KiB LDS
+    // waves per SIMD the accumulate kernel is compiled for: 2 -> 256 VGPRs, 402 spilled to scratch; 1 -> 512 (VGPR + AGPR),
+    // 35 spilled (profiles/r01_run15: 12.7 ms vs 13.0 ms at 2^20)
+    static constexpr int ACC_OCC = BZK_G2_ACC_OCC;
     __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2x28Ops>(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p_in, bool neg) {
         DevAff p = p_in;
@@ -119,6 +126,7 @@ struct G2Plain {
     static constexpr int RAW = 192, PACKED = 193;
     static constexpr bool CONVERT_BASES = false;
     static constexpr int WSUM_THREADS = 128;  // 128 x 384 B = 48 KiB LDS
+    static constexpr int ACC_OCC = 2;
     __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2Ops>(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p_in, bool neg) {
         DevAff p = p_in;

@@ -36,6 +36,19 @@ def _fr(x: int) -> bytes:
     return (x * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little")
 
 
+def _pmc_traffic(log_n):
+    """HBM bytes per msm_accumulate launch from the committed PMC passes of this same command
+    (profiles/r01_pmc_traffic.json, written by tools/pmc_traffic.py from two rocprofv3 --pmc runs; counters cannot
+    be collected from inside the timed process).  None when no measurement of this configuration is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if log_n != LOG_N or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def full_prove_section(ctx, n_proofs: int = 4):
     """Second half of BASELINE.json's metric: Groth16 proofs/s for the 2^20-constraint MPN class =
     UpdateCircuit(L=15, T=3, B=2): 16 signed transactions, 903 037 constraints, 2^20 NTT domain.
@@ -85,22 +98,50 @@ def full_prove_section(ctx, n_proofs: int = 4):
     out["gpu_prove_s"] = round(min(tp), 4)
     out["proofs_per_s_gpu_only"] = round(1 / min(tp), 2)
     out["proofs_per_s_serial"] = round(1 / (min(tp) + min(tw)), 3)
-    # pipelined: the host synthesizes batch k+1 (GIL released inside libbzk) while the GPU proves batch k
-    n_pipe = 6
-    t0 = time.perf_counter()
-    for k in range(n_pipe):
-        nxt = {}
+    # pipelined: host producers synthesize the next batches (GIL released inside libbzk) while the GPU proves.
+    # Each producer owns an independent account tree - the shape of Bazuka's own work distribution, where a
+    # prover holds several independent MpnWork items at once (src/mpn/mod.rs:79-107).
+    import queue
+    n_prod, n_warm, n_pipe = 4, 8, 16
+    synth_s = []
+    q = queue.Queue(maxsize=4)
+    stop = threading.Event()
 
-        def make():
-            batch()
-            nxt["r"] = w.update_synthesize(b, _fr(99), ZIESHA)
+    def producer(seed):
+        pw = L.MpnWorld(lg, t)
+        for i in range(2 * n_tx):
+            pw.add_account(i, b"p%dacct%d" % (seed, i), ZIESHA, 10 ** 12)
+        k = 0
+        while not stop.is_set():
+            k += 1
+            for i in range(n_tx):
+                pw.push_tx(i, n_tx + i, ZIESHA, 100 + i + k, ZIESHA, i % 7)
+            ts = time.perf_counter()
+            rr = pw.update_synthesize(b, _fr(99), ZIESHA)
+            synth_s.append(time.perf_counter() - ts)
+            assert rr.satisfied and rr.n_constraints == r.n_constraints  # host-side self check of the witness
+            while not stop.is_set():
+                try:
+                    q.put(rr, timeout=0.05)
+                    break
+                except queue.Full:
+                    pass
 
-        th = threading.Thread(target=make)
+    threads = [threading.Thread(target=producer, args=(s,), daemon=True) for s in range(n_prod)]
+    for th in threads:
         th.start()
-        ctx.groth16_prove(ph, cur.view("z"), cur.view("az"), cur.view("bz"), cur.view("cz"), _fr(3 + k), _fr(5 + k))
-        th.join()
-        cur = nxt["r"]
+    t0 = None
+    for k in range(n_warm + n_pipe):
+        if k == n_warm:
+            t0 = time.perf_counter()
+        rr = q.get()
+        ctx.groth16_prove(ph, rr.view("z"), rr.view("az"), rr.view("bz"), rr.view("cz"), _fr(3 + k), _fr(5 + k))
     out["proofs_per_s_pipelined"] = round(n_pipe / (time.perf_counter() - t0), 3)
+    out["producer_synth_s_mean_under_load"] = round(sum(synth_s) / len(synth_s), 4)
+    out["pipeline"] = f"{n_prod} host producers (16 worker threads each) -> 1 GPU prover, {n_pipe} proofs timed"
+    stop.set()
+    for th in threads:
+        th.join()
     ctx.params_free(ph)
     return out
 
@@ -126,10 +167,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU: libbzk has no CPU path"
+    # BZK_BENCH_DRYRUN_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks
+    # share devices, the 97-byte exchange goes through gloo on the host).  Never set by the driver; the line
+    # printed in that mode is marked "dryrun" and is not a measurement.
+    dry = os.environ.get("BZK_BENCH_DRYRUN_BACKEND")
+    if dry:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group(dry)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     ctx = Bzk(local_rank, torch.cuda.current_stream().cuda_stream)
@@ -150,7 +200,7 @@ def main():
         if world == 1:
             return ctx.msm_g1_dev(bases, scalars, n)
         part = ctx.msm_g1_windows_dev(bases, scalars, n, w0, w1)
-        return allgather_fold(part, device=dev)  # RCCL all-gather of 97-byte partials + local fold
+        return allgather_fold(part, device=None if dry else dev)  # RCCL all-gather of 97-byte partials + local fold
 
     def fence():
         if world > 1:
@@ -178,6 +228,9 @@ def main():
         r0 = r.clone()
         dist.broadcast(r0, 0)
         assert bool((r == r0).all()), "ranks disagree on the MSM result"
+        # untimed: the window-sharded + folded result equals the unsharded MSM of the same points on one GPU
+        if rank == 0:
+            assert ctx.msm_g1_dev(bases, scalars, n) == result, "window-sharded MSM differs from the single-GPU MSM"
 
     prof = ctx.prof_dump()
     acc_n, acc_ms = prof.get("msm_accumulate", (0, 0.0))
@@ -202,6 +255,8 @@ def main():
                    "parallelism": "single-gpu" if world == 1 else f"window-sharded x{world} + RCCL all-gather of partial sums"},
         "proofs_per_sec": None,
     }
+    if dry:
+        out["dryrun"] = f"ranks share GPUs, exchange over {dry}: NOT a measurement"
     if rank == 0:
         if acc_n:
             per_launch_ms = acc_ms / acc_n
@@ -209,7 +264,7 @@ def main():
             achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                               "traffic": None, "avg_launch_ms": round(per_launch_ms, 4),
+                               "traffic": _pmc_traffic(args.log_n), "avg_launch_ms": round(per_launch_ms, 4),
                                "note": "integer-ALU bound (381-bit Montgomery carry chains); HBM fraction is "
                                        "structurally ~1e-3, see DESIGN.md"}
         out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}

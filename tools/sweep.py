@@ -34,7 +34,7 @@ def child(mode, log_n):
         bases = torch.empty(n * 192, dtype=torch.uint8, device="cuda"); ctx.g2_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
         ms = timeit(lambda: ctx.msm_g2_dev(bases, sc, n), reps=2)
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_g2_dev(bases, sc, n); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
-        print(json.dumps({"mode": mode, "log_n": log_n, "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 2), "prof": prof}))
+        print(json.dumps({"mode": mode, "log_n": log_n, "occ_alt": os.environ.get("BZK_MSM_OCC_ALT"), "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 2), "prof": prof}))
     elif mode == "tree":
         leaves = rand_fr(n)
         ms = timeit(lambda: ctx.merkle4_root_dev(leaves, log_n // 2), reps=3)
@@ -72,6 +72,12 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r16",):
+        run("g1", 20); run("g1", 22); run("g1", 24); run("g2", 20); run("g2", 18); run("tree", 24); run("h", 20)
+    if what in ("g2occ",):
+        for alt in ("0", "1"):
+            run("g2", 20, {"BZK_MSM_OCC_ALT": alt})
+            run("g2", 18, {"BZK_MSM_OCC_ALT": alt})
     if what in ("chunk",):
         for ch in (2, 4, 8, 16):
             run("g1", 20, {"BZK_MSM_CHUNK": str(ch)})
