@@ -24,6 +24,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_N = 20
+# micro-benchmarked peak of the library's own Fp product (chains of dependent calls, all CUs busy):
+# tools/ubench_int "Fp28 lib mul", profiles/r01_ubench_int.txt.  10 products per XYZZ mixed add.
+FP_MUL_PEAK_G = 76.2
+MULS_PER_MIXED_ADD = 10
 SEED = 0x42415A554B41
 HBM_PEAK_GBS = 8000.0
 
@@ -49,7 +53,7 @@ def _pmc_traffic(log_n):
         return None
 
 
-def full_prove_section(ctx, n_proofs: int = 4):
+def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
     """Second half of BASELINE.json's metric: Groth16 proofs/s for the 2^20-constraint MPN class =
     UpdateCircuit(L=15, T=3, B=2): 16 signed transactions, 903 037 constraints, 2^20 NTT domain.
     Product code only: host witness/R1CS generator (C++ worker threads), CRS generated on the GPU
@@ -102,7 +106,7 @@ def full_prove_section(ctx, n_proofs: int = 4):
     # Each producer owns an independent account tree - the shape of Bazuka's own work distribution, where a
     # prover holds several independent MpnWork items at once (src/mpn/mod.rs:79-107).
     import queue
-    n_prod, n_warm, n_pipe = 4, 8, 16
+    n_warm, n_pipe = 8, 16
     synth_s = []
     q = queue.Queue(maxsize=4)
     stop = threading.Event()
@@ -257,6 +261,19 @@ def main():
     }
     if dry:
         out["dryrun"] = f"ranks share GPUs, exchange over {dry}: NOT a measurement"
+    # Second half of the metric: full Groth16 proofs/s.  Every rank proves its own batches (replicas).
+    proofs, rates = None, []
+    if not args.no_proofs:
+        try:
+            proofs = full_prove_section(ctx, n_prod=4 if world == 1 else 2)
+        except Exception as e:  # the headline MSM line must still be printed
+            proofs = {"error": repr(e)}
+        if world > 1:
+            mine = torch.tensor([float(proofs.get("proofs_per_s_pipelined", float("nan")))], dtype=torch.float64,
+                                device="cpu" if dry else dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            rates = [float(x.item()) for x in allr]
     if rank == 0:
         if acc_n:
             per_launch_ms = acc_ms / acc_n
@@ -267,6 +284,11 @@ def main():
                                "traffic": _pmc_traffic(args.log_n), "avg_launch_ms": round(per_launch_ms, 4),
                                "note": "integer-ALU bound (381-bit Montgomery carry chains); HBM fraction is "
                                        "structurally ~1e-3, see DESIGN.md"}
+            pairs = n * (w1 - w0)  # one mixed add per (point, window) pair (zero digits skipped: ~2^-16 of them)
+            gmul = pairs * MULS_PER_MIXED_ADD / (per_launch_ms * 1e-3) / 1e9
+            out["roofline"]["alu"] = {"achieved": round(gmul, 2), "peak": FP_MUL_PEAK_G, "unit": "G Fp-mul/s",
+                                      "frac": round(gmul / FP_MUL_PEAK_G, 4),
+                                      "peak_source": "tools/ubench_int.hip, library product as dependent calls (profiles/)"}
         out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import coracle as co
@@ -281,12 +303,13 @@ def main():
                                    "sample": f"the full 2^{args.log_n}-point MSM of this run, 1 run, "
                                              f"window-per-thread Pippenger (bellman-equivalent), {dt:.2f} s",
                                    "parity": "bit-exact (97-byte affine result)"}
-        if world == 1 and not args.no_proofs:
-            try:
-                out["proofs"] = full_prove_section(ctx)
-                out["proofs_per_sec"] = out["proofs"]["proofs_per_s_pipelined"]
-            except Exception as e:  # the headline MSM line must still be printed
-                out["proofs"] = {"error": repr(e)}
+        if proofs is not None:
+            out["proofs"] = proofs
+            if world == 1:
+                out["proofs_per_sec"] = proofs.get("proofs_per_s_pipelined")
+            else:  # proofs do not shard: N GPUs = N independent replicas, rates add
+                out["proofs"]["per_rank_pipelined"] = [round(x, 3) for x in rates]
+                out["proofs_per_sec"] = None if any(x != x for x in rates) else round(sum(rates), 3)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdint.h>
 #include "../bazuka_amd/csrc/bzk_field.cuh"
+#include "../bazuka_amd/csrc/bzk_fp28.cuh"
+#include "../bazuka_amd/csrc/bzk_fr29.cuh"
 using namespace bzk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -149,11 +151,11 @@ __global__ void k_femul_call(uint32_t* out, int iters) {
 }
 
 // reduced-radix prototype: 14 x 28-bit limbs, column accumulators in 64 bits, no carry chains
-struct Fp28 { uint32_t l[14]; };
+struct UFp28 { uint32_t l[14]; };
 __device__ constexpr uint32_t P28[14] = {0xfffaaab, 0xffeffff, 0x53ffffb, 0x3fffeb1, 0xf6241ea, 0x0a0f6b0, 0x12bf673,
                                          0x084f385, 0x764774b, 0x034bacd, 0xba7b643, 0x069a4b1, 0xea397fe, 0x01a0111};
 template <bool CALL>
-__device__ __forceinline__ Fp28 mul28_body(const Fp28& a, const Fp28& b) {
+__device__ __forceinline__ UFp28 mul28_body(const UFp28& a, const UFp28& b) {
     constexpr int N = 14, W = 28;
     constexpr uint32_t MASK = (1u << W) - 1, PINV = 0xffcfffd;
     uint64_t c[2 * N];
@@ -170,7 +172,7 @@ __device__ __forceinline__ Fp28 mul28_body(const Fp28& a, const Fp28& b) {
         for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P28[j];
         c[i + 1] += c[i] >> W;
     }
-    Fp28 r;
+    UFp28 r;
 #pragma unroll
     for (int k = N; k < 2 * N - 1; ++k) {
         c[k + 1] += c[k] >> W;
@@ -179,10 +181,10 @@ __device__ __forceinline__ Fp28 mul28_body(const Fp28& a, const Fp28& b) {
     r.l[N - 1] = (uint32_t)c[2 * N - 1] & MASK;
     return r;
 }
-__device__ __noinline__ Fp28 mul28_call(Fp28 a, Fp28 b) { return mul28_body<true>(a, b); }
+__device__ __noinline__ UFp28 mul28_call(UFp28 a, UFp28 b) { return mul28_body<true>(a, b); }
 template <int ILP, bool CALL>
 __global__ void k_mul28(uint32_t* out, int iters) {
-    Fp28 x[ILP], y;
+    UFp28 x[ILP], y;
 #pragma unroll
     for (int i = 0; i < 14; ++i) y.l[i] = (P28[i] ^ threadIdx.x) & 0xfffffff;
 #pragma unroll
@@ -196,6 +198,44 @@ __global__ void k_mul28(uint32_t* out, int iters) {
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < ILP; ++k) s ^= x[k].l[0] ^ x[k].l[13];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// the library's own products (vector-argument calls): chains of dependent products, the shape of an XYZZ add
+template <int ILP>
+__global__ void k_mul28_lib(uint32_t* out, int iters) {
+    bzk::Fp28 x[ILP], y;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) y.l[i] = (P28[i] ^ threadIdx.x) & 0xfffffff;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k)
+#pragma unroll
+        for (int i = 0; i < 14; ++i) x[k].l[i] = (P28[13 - i] + k) & 0xfffffff;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) x[k] = bzk::fp28::mul(x[k], y);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) s ^= x[k].l[0] ^ x[k].l[13];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int ILP>
+__global__ void k_mul29_lib(uint32_t* out, int iters) {
+    bzk::Fr29 x[ILP], y;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) y.l[i] = (bzk::fr29::R.v[i] ^ threadIdx.x) & 0x1fffffff;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) x[k].l[i] = (bzk::fr29::R.v[8 - i] + k) & 0x1fffffff;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) x[k] = bzk::fr29::mul(x[k], y);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) s ^= x[k].l[0] ^ x[k].l[8];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -254,6 +294,9 @@ int main() {
             run("Fp mul 14x28 inline", [&](int b, int t) { hipLaunchKernelGGL((k_mul28<1, false>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
             run("Fp mul 14x28 inline", [&](int b, int t) { hipLaunchKernelGGL((k_mul28<2, false>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
             run("Fp mul 14x28 via CALL", [&](int b, int t) { hipLaunchKernelGGL((k_mul28<1, true>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
+            run("Fp28 lib mul (vector-arg CALL)", [&](int b, int t) { hipLaunchKernelGGL((k_mul28_lib<1>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 1, bl, 256);
+            run("Fp28 lib mul (vector-arg CALL)", [&](int b, int t) { hipLaunchKernelGGL((k_mul28_lib<2>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
+            run("Fr29 lib mul (vector-arg CALL)", [&](int b, int t) { hipLaunchKernelGGL((k_mul29_lib<2>), dim3(b), dim3(t), 0, 0, (uint32_t*)buf, it2); }, 2, bl, 256);
         }
     }
     CK(hipFree(buf));
