@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "bzk_poseidon29.cuh"
+#include "bzk_poseidon_opt.h"
 #include "bzk_internal.h"
 #include "host_zk.h"
 
@@ -293,23 +294,69 @@ static poseidon_fn poseidon_table(int t) {
     }
 }
 
-// device copy of the constants: widths <= 8 in the 9 x 29-bit internal form (rc are plain addends: x * 2^261),
-// wider ones in the 8 x 32-bit form of the generic kernel
+// host evaluation of the very function the kernel runs (it is __host__ __device__), for the start-up self check
+static Fr host_hash29(int t, const Fr* in, const Fr29* c, int rf, int rp) {
+    switch (t) {
+        case 2: return poseidon29_hash<2>(in, c, rf, rp);
+        case 3: return poseidon29_hash<3>(in, c, rf, rp);
+        case 4: return poseidon29_hash<4>(in, c, rf, rp);
+        case 5: return poseidon29_hash<5>(in, c, rf, rp);
+        case 6: return poseidon29_hash<6>(in, c, rf, rp);
+        case 7: return poseidon29_hash<7>(in, c, rf, rp);
+        default: return poseidon29_hash<8>(in, c, rf, rp);
+    }
+}
+// the reference's plain round function on the host (8 x 32-bit limbs), the yardstick of the self check
+static Fr host_hash_plain(const HostParams& P, const Fr* in) {
+    const int T = P.t, half = P.rf / 2;
+    std::vector<Fr> st((size_t)T, Fr::zero()), nw((size_t)T);
+    for (int k = 1; k < T; ++k) st[k] = in[k - 1];
+    for (int r = 0; r < P.rf + P.rp; ++r) {
+        for (int k = 0; k < T; ++k) st[k] = fe_add<FrParams>(st[k], P.rc[(size_t)r * T + k]);
+        const bool full = r < half || r >= half + P.rp;
+        for (int k = 0; k < (full ? T : 1); ++k) {
+            Fr x2 = fe_sqr<FrParams>(st[k]);
+            st[k] = fe_mul<FrParams>(fe_sqr<FrParams>(x2), st[k]);
+        }
+        for (int j = 0; j < T; ++j) {
+            Fr acc = Fr::zero();
+            for (int k = 0; k < T; ++k) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(P.mds[(size_t)j * T + k], st[k]));
+            nw[j] = acc;
+        }
+        st.swap(nw);
+    }
+    return st[1];
+}
+
+// device copy of the constants: widths <= 8 in the sparse-partial-round form (bzk_poseidon_opt.h), 9 x 29-bit
+// internal representation (rc are plain addends: x * 2^261); wider ones in the 8 x 32-bit form of the generic kernel
 static int32_t poseidon_consts_dev(bzk_ctx* ctx, int t, const void** out, int* rf, int* rp) {
     const HostParams& P = host_params(t);
     *rf = P.rf;
     *rp = P.rp;
     if (!ctx->poseidon_dev[t]) {
-        std::vector<Fr> flat(P.rc);
-        flat.insert(flat.end(), P.mds.begin(), P.mds.end());
         void* d = nullptr;
         if (t <= 8) {
+            std::vector<Fr> flat;
+            if (!poseidon_optimize(t, P.rf, P.rp, P.rc, P.mds, flat)) {
+                ctx->last_error = "poseidon: no sparse form for width " + std::to_string(t);
+                return BZK_E_INTERNAL;
+            }
             std::vector<Fr29> f29(flat.size());
             for (size_t i = 0; i < flat.size(); ++i) f29[i] = fr29::norm(fr29::to29(flat[i]));
+            // self check: the derived constants reproduce the plain round function (fails loudly, no fallback)
+            Fr probe[8];
+            for (int k = 0; k < 8; ++k) probe[k] = fe_mul<FrParams>(P.mds[(size_t)(k % (t * t))], P.rc[(size_t)k]);
+            if (!host_hash29(t, probe, f29.data(), P.rf, P.rp).equals(host_hash_plain(P, probe))) {
+                ctx->last_error = "poseidon: sparse-round constants failed the self check for width " + std::to_string(t);
+                return BZK_E_INTERNAL;
+            }
             BZK_HIP(ctx, hipMalloc(&d, f29.size() * sizeof(Fr29)));
             BZK_HIP(ctx, hipMemcpyAsync(d, f29.data(), f29.size() * sizeof(Fr29), hipMemcpyHostToDevice, ctx->stream));
             BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         } else {
+            std::vector<Fr> flat(P.rc);
+            flat.insert(flat.end(), P.mds.begin(), P.mds.end());
             BZK_HIP(ctx, hipMalloc(&d, flat.size() * sizeof(Fr)));
             BZK_HIP(ctx, hipMemcpyAsync(d, flat.data(), flat.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
             BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));

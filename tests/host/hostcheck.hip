@@ -3,6 +3,7 @@
 #define BZK_FP28_CHECK 1
 #include "../../bazuka_amd/csrc/bzk_fp28.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon29.cuh"
+#include "../../bazuka_amd/csrc/bzk_poseidon_opt.h"
 #include <string.h>
 using namespace bzk;
 
@@ -110,24 +111,30 @@ int hc_fr29_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     st<FrParams>(out, fr29::from29(fr29::mul(fr29::to29(ld<FrParams>(a)), fr29::to29(ld<FrParams>(b)))));
     return 0;
 }
-// one Poseidon hash through the device function; consts = rc then mds, 8 x 32-bit Montgomery (n_consts entries)
+// one Poseidon hash through the device function; consts = rc then mds in the reference's plain layout, 8 x 32-bit
+// Montgomery (n_consts entries): the sparse-partial-round constants are derived here exactly as the library does
 int hc_poseidon29(const uint8_t* in, int arity, const uint8_t* consts, int n_consts, int rf, int rp, uint8_t* out) {
+    const int T = arity + 1;
+    if (n_consts != (rf + rp) * T + T * T) return -2;
     Fr inp[8];
     for (int k = 0; k < arity; ++k) inp[k] = ld<FrParams>(in + 32 * k);
-    Fr29* c = new Fr29[n_consts];
-    for (int i = 0; i < n_consts; ++i) c[i] = fr29::to29(ld<FrParams>(consts + 32 * i));
+    std::vector<Fr> rc((size_t)(rf + rp) * T), mds((size_t)T * T), flat;
+    for (size_t i = 0; i < rc.size(); ++i) rc[i] = ld<FrParams>(consts + 32 * i);
+    for (size_t i = 0; i < mds.size(); ++i) mds[i] = ld<FrParams>(consts + 32 * (rc.size() + i));
+    if (!poseidon_optimize(T, rf, rp, rc, mds, flat)) return -3;
+    std::vector<Fr29> c(flat.size());
+    for (size_t i = 0; i < flat.size(); ++i) c[i] = fr29::norm(fr29::to29(flat[i]));
     Fr r;
-    switch (arity + 1) {
-        case 2: r = poseidon29_hash<2>(inp, c, rf, rp); break;
-        case 3: r = poseidon29_hash<3>(inp, c, rf, rp); break;
-        case 4: r = poseidon29_hash<4>(inp, c, rf, rp); break;
-        case 5: r = poseidon29_hash<5>(inp, c, rf, rp); break;
-        case 6: r = poseidon29_hash<6>(inp, c, rf, rp); break;
-        case 7: r = poseidon29_hash<7>(inp, c, rf, rp); break;
-        case 8: r = poseidon29_hash<8>(inp, c, rf, rp); break;
-        default: delete[] c; return -1;
+    switch (T) {
+        case 2: r = poseidon29_hash<2>(inp, c.data(), rf, rp); break;
+        case 3: r = poseidon29_hash<3>(inp, c.data(), rf, rp); break;
+        case 4: r = poseidon29_hash<4>(inp, c.data(), rf, rp); break;
+        case 5: r = poseidon29_hash<5>(inp, c.data(), rf, rp); break;
+        case 6: r = poseidon29_hash<6>(inp, c.data(), rf, rp); break;
+        case 7: r = poseidon29_hash<7>(inp, c.data(), rf, rp); break;
+        case 8: r = poseidon29_hash<8>(inp, c.data(), rf, rp); break;
+        default: return -1;
     }
-    delete[] c;
     st<FrParams>(out, r);
     return 0;
 }

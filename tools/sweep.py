@@ -40,6 +40,10 @@ def child(mode, log_n):
         ms = timeit(lambda: ctx.merkle4_root_dev(leaves, log_n // 2), reps=3)
         hashes = (n - 1) // 3
         print(json.dumps({"mode": mode, "leaves": n, "ms": round(ms, 3), "Mhash/s": round(hashes / ms / 1e3, 2), "alg_GB/s": round((32 * n + 32 * hashes) / ms / 1e6, 2)}))
+    elif mode == "hash":
+        ar = int(os.environ.get("ARITY", "4")); inp = rand_fr(n * ar); out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+        ms = timeit(lambda: ctx.poseidon_batch_dev(inp, ar, n, out), reps=3)
+        print(json.dumps({"mode": mode, "arity": ar, "n": n, "ms": round(ms, 3), "Mhash/s": round(n / ms / 1e3, 2)}))
     elif mode == "ntt":
         d = rand_fr(n)
         ms = timeit(lambda: ctx.ntt_dev(d, log_n, False, True))
@@ -72,6 +76,8 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r18",):
+        run("tree", 24); run("tree", 20); run("hash", 22, {"ARITY": "2"}); run("hash", 22, {"ARITY": "4"}); run("hash", 22, {"ARITY": "7"})
     if what in ("r16",):
         run("g1", 20); run("g1", 22); run("g1", 24); run("g2", 20); run("g2", 18); run("tree", 24); run("h", 20)
     if what in ("g2occ",):
