@@ -10,6 +10,7 @@
 // The NTTs and MSMs are the HIP kernels of ntt.hip / msm_g1.hip / msm_g2.hip; the last three lines
 // are ~10 point operations done on the host.  Proof bytes = Groth16Proof layout
 // (/root/reference/src/zk/groth16/mod.rs:33-38).
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -246,20 +247,46 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
     uint8_t pH[97], pL[97], pA[97], pB1[97], pB2[193];
     int32_t st[3] = {BZK_OK, BZK_OK, BZK_OK};
     const int dev = ctx->device;
+    // env BZK_PROVE_SERIAL=1: the same five MSMs one after the other on the lanes' streams (clean per-kernel event
+    // timings for profiling; the lanes otherwise overlap and stretch each other's intervals)
+    static const bool serial = getenv("BZK_PROVE_SERIAL") && atoi(getenv("BZK_PROVE_SERIAL")) != 0;
     std::thread th[3];
-    th[0] = std::thread([&] {
+    auto job0 = [&] {
         (void)hipSetDevice(dev);
         st[0] = bzk_msm_g2_dev(lane[0], p->b_g2, p->d_sb, p->n_b, 0, pB2);
-    });
-    th[1] = std::thread([&] {
+    };
+    auto job1 = [&] {
         (void)hipSetDevice(dev);
         st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, 0, pL);
         if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, 0, pB1);
-    });
-    th[2] = std::thread([&] {
+    };
+    auto job2 = [&] {
         (void)hipSetDevice(dev);
         st[2] = bzk_msm_g1_dev(lane[2], p->a, p->d_sa, p->n_a, 0, pA);
-    });
+    };
+    if (serial) {
+        auto dump = [&](int i, const char* what) {
+            if (!ctx->timing || !ctx->prof) return;
+            char buf[2048];
+            if (bzk_prof_dump(lane[i], buf, sizeof buf) == BZK_OK) {
+                for (char* c = buf; *c; ++c)
+                    if (*c == '\n') *c = ';';
+                fprintf(stderr, "[bzk] serial %s: %s\n", what, buf);
+            }
+            (void)bzk_prof_reset(lane[i]);
+        };
+        job0(); dump(0, "b_g2");
+        (void)hipSetDevice(dev);
+        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, 0, pL);
+        dump(1, "l");
+        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, 0, pB1);
+        dump(1, "b_g1");
+        job2(); dump(2, "a");
+    } else {
+        th[0] = std::thread(job0);
+        th[1] = std::thread(job1);
+        th[2] = std::thread(job2);
+    }
     // main stream: stage the evaluations, h polynomial, h MSM
     int32_t st_main = BZK_OK;
     auto main_part = [&]() -> int32_t {
@@ -276,7 +303,8 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
     const auto t2 = clk::now();
     st_main = main_part();
     const auto t3 = clk::now();
-    for (auto& t : th) t.join();
+    if (!serial)
+        for (auto& t : th) t.join();
     (void)hipEventDestroy(z_ready);
     const auto t4 = clk::now();
     if (st_main != BZK_OK) return st_main;

@@ -122,8 +122,12 @@ def _ptr(x):
         return None
     if isinstance(x, int):
         return C.c_void_p(x)
-    if isinstance(x, (bytes, bytearray)):
-        return C.cast(C.c_char_p(bytes(x)), C.c_void_p)
+    if isinstance(x, bytes):
+        return C.cast(C.c_char_p(x), C.c_void_p)  # the object's own buffer (caller keeps x alive across the call)
+    if isinstance(x, bytearray):
+        return C.cast((C.c_char * len(x)).from_buffer(x), C.c_void_p)
+    if isinstance(x, C.Array):
+        return C.cast(C.addressof(x), C.c_void_p)
     if hasattr(x, "data_ptr"):
         return C.c_void_p(x.data_ptr())
     return C.cast(x, C.c_void_p)
@@ -294,9 +298,10 @@ class Bzk:
     def params_free(self, ph):
         self.lib.bzk_params_free(self.h, ph)
 
-    def groth16_prove(self, ph, z: bytes, az: bytes, bz: bytes, cz: bytes, r: bytes, s: bytes) -> bytes:
-        bufs = [C.create_string_buffer(bytes(x), max(1, len(x))) for x in (z, az, bz, cz)]
-        asg = Assignment(*[C.cast(b, C.c_void_p) for b in bufs], len(az) // 32)
+    def groth16_prove(self, ph, z, az, bz, cz, r: bytes, s: bytes) -> bytes:
+        """z / az / bz / cz: bytes or zero-copy ctypes views (R1cs.raw) - passed by address, never copied here."""
+        keep = [x if not isinstance(x, bytearray) else bytes(x) for x in (z, az, bz, cz)]
+        asg = Assignment(*[_ptr(x) for x in keep], len(az) // 32)
         out = C.create_string_buffer(387)
         self._ck(self.lib.bzk_groth16_prove(self.h, ph, C.byref(asg), _ptr(r), _ptr(s), out), "groth16_prove")
         return out.raw
@@ -356,9 +361,18 @@ class R1cs:
         self.satisfied = first_bad == 0
 
     def view(self, name: str) -> bytes:
+        """a COPY of the array as bytes (tests); the prover path uses raw()"""
         n = _u64()
         p = self.lib.bzk_r1cs_data(self.h, self.VIEWS[name], C.byref(n))
         return C.string_at(p, n.value) if n.value else b""
+
+    def raw(self, name: str):
+        """zero-copy ctypes view of the array inside the generator's (pinned) buffer; valid while this object lives"""
+        n = _u64()
+        p = self.lib.bzk_r1cs_data(self.h, self.VIEWS[name], C.byref(n))
+        arr = (C.c_char * max(1, n.value)).from_address(p) if n.value else (C.c_char * 1)()
+        arr._owner = self
+        return arr
 
     def free(self):
         if self.h:

@@ -92,7 +92,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
         cur = w.update_synthesize(b, _fr(99), ZIESHA)
         t1 = time.perf_counter()
         assert cur.satisfied
-        views = [cur.view(x) for x in ("z", "az", "bz", "cz")]
+        views = [cur.raw(x) for x in ("z", "az", "bz", "cz")]
         t2 = time.perf_counter()
         ctx.groth16_prove(ph, *views, _fr(7 + k), _fr(9 + k))
         t3 = time.perf_counter()
@@ -139,7 +139,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
         if k == n_warm:
             t0 = time.perf_counter()
         rr = q.get()
-        ctx.groth16_prove(ph, rr.view("z"), rr.view("az"), rr.view("bz"), rr.view("cz"), _fr(3 + k), _fr(5 + k))
+        ctx.groth16_prove(ph, rr.raw("z"), rr.raw("az"), rr.raw("bz"), rr.raw("cz"), _fr(3 + k), _fr(5 + k))
     out["proofs_per_s_pipelined"] = round(n_pipe / (time.perf_counter() - t0), 3)
     out["producer_synth_s_mean_under_load"] = round(sum(synth_s) / len(synth_s), 4)
     out["pipeline"] = f"{n_prod} host producers (16 worker threads each) -> 1 GPU prover, {n_pipe} proofs timed"

@@ -90,6 +90,7 @@ def test_update_batch_new_destination_partial_batch_and_rejects():
     w.push_tx(3, 9, ZIESHA, 5, ZIESHA, 1)          # destination slot is empty: allowed (null address)
     r = w.update_synthesize(1, F(1), ZIESHA)
     assert r.accepted == 1 and r.satisfied          # 3 padded null transitions
+    assert bytes(r.raw("z")) == r.view("z") and len(r.raw("az")) == 32 * r.n_constraints  # zero-copy view == copy
     before = w.root()
     w.push_tx(0, 1, ZIESHA, 10 ** 13, ZIESHA, 0)   # overspend: rejected by the witness builder
     w.push_tx(0, 1, F(7), 1, ZIESHA, 0)            # unknown token: rejected

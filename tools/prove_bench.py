@@ -23,7 +23,7 @@ def main(n_proofs=5, lg=15, t=3, b=2):
     t0 = time.perf_counter(); batch(0); out["sign_16_tx_s"] = round(time.perf_counter() - t0, 3)
     t0 = time.perf_counter(); r = w.update_synthesize(b, fr(99), ZIESHA, record_matrices=True); out["synthesize_with_matrices_s"] = round(time.perf_counter() - t0, 3)
     assert r.satisfied and r.accepted == n_tx
-    out.update(n_constraints=r.n_constraints, n_aux=r.n_aux)
+    out.update(n_constraints=r.n_constraints, n_aux=r.n_aux, n_a=sum(r.view("a_density")), n_b=sum(r.view("b_density")))
     csr = [(r.n_constraints, r.view("rp" + x), r.view("col" + x), r.view("val" + x)) for x in "ABC"]
     tox = b"".join(fr(x) for x in (1234567, 2345678, 3456789, 4567891, 5678912))
     t0 = time.perf_counter(); ph, vk = ctx.groth16_setup(csr, r.n_in, r.n_aux, tox); out["gpu_setup_s"] = round(time.perf_counter() - t0, 3)
@@ -32,7 +32,7 @@ def main(n_proofs=5, lg=15, t=3, b=2):
         batch(k + 1)
         t0 = time.perf_counter(); rk = w.update_synthesize(b, fr(99), ZIESHA); t1 = time.perf_counter()
         assert rk.satisfied
-        z, az, bz, cz = rk.view("z"), rk.view("az"), rk.view("bz"), rk.view("cz")
+        z, az, bz, cz = rk.raw("z"), rk.raw("az"), rk.raw("bz"), rk.raw("cz")
         t2 = time.perf_counter(); proof = ctx.groth16_prove(ph, z, az, bz, cz, fr(7 + k), fr(9 + k)); t3 = time.perf_counter()
         times_w.append(t1 - t0); times_p.append(t3 - t2)
     # pipelined: the host synthesizes batch k+1 (C++ worker threads, GIL released) while the GPU proves batch k
@@ -45,7 +45,7 @@ def main(n_proofs=5, lg=15, t=3, b=2):
         def make(k=k):
             batch(2000 + k); nxt["r"] = w.update_synthesize(b, fr(99), ZIESHA)
         th = threading.Thread(target=make); th.start()
-        ctx.groth16_prove(ph, cur.view("z"), cur.view("az"), cur.view("bz"), cur.view("cz"), fr(3 + k), fr(5 + k))
+        ctx.groth16_prove(ph, cur.raw("z"), cur.raw("az"), cur.raw("bz"), cur.raw("cz"), fr(3 + k), fr(5 + k))
         th.join(); cur = nxt["r"]
     out["proofs_per_s_pipelined"] = round(n_pipe / (time.perf_counter() - t0), 3)
     ctx.prof_enable(True); ctx.prof_reset()

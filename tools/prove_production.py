@@ -47,7 +47,7 @@ def main(b=4, n_proofs=2, compare=0):
             batch(k)
             t0 = time.perf_counter(); cur = w.update_synthesize(b, fr(99), ZIESHA); tw.append(time.perf_counter() - t0)
             assert cur.accepted == n_tx
-        z, az, bz, cz = cur.view("z"), cur.view("az"), cur.view("bz"), cur.view("cz")
+        z, az, bz, cz = cur.raw("z"), cur.raw("az"), cur.raw("bz"), cur.raw("cz")
         t0 = time.perf_counter(); proof = ctx.groth16_prove(ph, z, az, bz, cz, fr(7 + k), fr(9 + k)); tp.append(time.perf_counter() - t0)
     out["witness_s"] = round(min(tw), 3) if tw else None
     out["gpu_prove_s"] = [round(x, 4) for x in tp]
@@ -71,7 +71,7 @@ def main(b=4, n_proofs=2, compare=0):
             d[key] = ctx.params_read(ph, which)
         d["n_a"], d["n_b"] = sum(d["a_density"]), sum(d["b_density"])
         t0 = time.perf_counter()
-        want = co.groth16_prove(d, z, az, bz, cz, fr(7 + n_proofs - 1), fr(9 + n_proofs - 1), nthreads=co.ncpu())
+        want = co.groth16_prove(d, bytes(z), bytes(az), bytes(bz), bytes(cz), fr(7 + n_proofs - 1), fr(9 + n_proofs - 1), nthreads=co.ncpu())
         out["oracle_prove"] = {"s": round(time.perf_counter() - t0, 1), "cores": co.ncpu(), "bytes_equal": want == proof}
     print(json.dumps(out), flush=True)
     assert ok and not bad
