@@ -53,6 +53,7 @@ bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
     bzk_ctx* c = ctx->lanes[i];
     c->prof = ctx->prof;
     c->debug = ctx->debug;
+    c->timing = ctx->timing;
     c->msm_c_override = ctx->msm_c_override;
     c->msm_chunk_override = ctx->msm_chunk_override;
     return c;

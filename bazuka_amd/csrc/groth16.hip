@@ -249,20 +249,23 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
     const int dev = ctx->device;
     // env BZK_PROVE_SERIAL=1: the same five MSMs one after the other on the lanes' streams (clean per-kernel event
     // timings for profiling; the lanes otherwise overlap and stretch each other's intervals)
+    // the witness MSMs (l, a, b_g1, b_g2) run on de-duplicated scalars: half of a Groth16 assignment is repeats
+    // (msm_impl.cuh section 8); env BZK_PROVE_NODEDUP=1 switches that off for A/B measurements
+    static const uint32_t wflags = (getenv("BZK_PROVE_NODEDUP") && atoi(getenv("BZK_PROVE_NODEDUP")) != 0) ? 0u : BZK_F_DEDUP;
     static const bool serial = getenv("BZK_PROVE_SERIAL") && atoi(getenv("BZK_PROVE_SERIAL")) != 0;
     std::thread th[3];
     auto job0 = [&] {
         (void)hipSetDevice(dev);
-        st[0] = bzk_msm_g2_dev(lane[0], p->b_g2, p->d_sb, p->n_b, 0, pB2);
+        st[0] = bzk_msm_g2_dev(lane[0], p->b_g2, p->d_sb, p->n_b, wflags, pB2);
     };
     auto job1 = [&] {
         (void)hipSetDevice(dev);
-        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, 0, pL);
-        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, 0, pB1);
+        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, wflags, pL);
+        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, wflags, pB1);
     };
     auto job2 = [&] {
         (void)hipSetDevice(dev);
-        st[2] = bzk_msm_g1_dev(lane[2], p->a, p->d_sa, p->n_a, 0, pA);
+        st[2] = bzk_msm_g1_dev(lane[2], p->a, p->d_sa, p->n_a, wflags, pA);
     };
     if (serial) {
         auto dump = [&](int i, const char* what) {
@@ -277,9 +280,9 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
         };
         job0(); dump(0, "b_g2");
         (void)hipSetDevice(dev);
-        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, 0, pL);
+        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, wflags, pL);
         dump(1, "l");
-        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, 0, pB1);
+        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, wflags, pB1);
         dump(1, "b_g1");
         job2(); dump(2, "a");
     } else {

@@ -47,7 +47,8 @@ static int msm_windows_for(int c) { return (256 + c - 1) / c; }  // signed digit
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __restrict__ scalars, uint64_t n, int mont, int c,
                                                          int w_total, int w_begin, int w_cnt, uint32_t table_stride,
-                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                         const uint32_t* __restrict__ rep, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s;
@@ -83,7 +84,7 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
                 vals[o] = ((uint32_t)w * table_stride + (uint32_t)i) | (neg << 31);
             } else {
                 keys[o] = d ? lw * half + (d - 1) : nb;
-                vals[o] = (uint32_t)i | (neg << 31);
+                vals[o] = (rep ? rep[i] : (uint32_t)i) | (neg << 31);
             }
         }
         ++w;
@@ -451,6 +452,167 @@ static int bits_for(uint64_t v) {
     return b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 8. scalar de-duplication (flag BZK_F_DEDUP).  A Groth16 witness repeats itself: of the 904 876 assignment values
+// of the 16-tx Update circuit only 486 398 are distinct (277 k values occur exactly twice, the bits 0/1 thousands of
+// times).  Equal scalars s contribute s * (P_i + P_j + ...), so the bases of each group are summed ONCE (one mixed
+// add per duplicate, through the same task-based accumulation as the buckets), the sums are brought to affine form
+// with a batched inversion and the bucket phase then runs over the distinct scalars only - instead of repeating
+// every duplicate's addition in each of the W windows.  Zero scalars are dropped.  The result is the same group
+// element; grouping is by a 64-bit hash sort with a full 256-bit comparison of sorted neighbours (a hash collision
+// can only split a group, never merge two).
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) dedup_hash_kernel(const U128* __restrict__ scalars, uint64_t n, uint64_t* __restrict__ hkey,
+                                                                uint32_t* __restrict__ idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const U128 a = scalars[2 * i], b = scalars[2 * i + 1];
+    const uint32_t l[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        any |= l[k];
+        h = (h ^ l[k]) * 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    if (h == ~0ull) h = ~0ull - 1;
+    hkey[i] = any ? h : ~0ull;  // zero scalars sort to the end and are dropped
+    idx[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ bool dedup_same(const U128* __restrict__ scalars, uint32_t i, uint32_t j) {
+    const U128 a0 = scalars[2 * (uint64_t)i], a1 = scalars[2 * (uint64_t)i + 1], b0 = scalars[2 * (uint64_t)j], b1 = scalars[2 * (uint64_t)j + 1];
+    return a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+}
+
+// head[i]: sorted position i starts a group of equal non-zero scalars; mhead[i]: ... of at least two members
+static __global__ void __launch_bounds__(256) dedup_heads_kernel(const U128* __restrict__ scalars, const uint64_t* __restrict__ hkey_s,
+                                                                 const uint32_t* __restrict__ idx_s, uint64_t n, uint32_t* __restrict__ head,
+                                                                 uint32_t* __restrict__ mhead) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool alive = hkey_s[i] != ~0ull;
+    bool h = false, m = false;
+    if (alive) {
+        h = i == 0 || hkey_s[i - 1] != hkey_s[i] || !dedup_same(scalars, idx_s[i - 1], idx_s[i]);
+        if (h) m = i + 1 < n && hkey_s[i + 1] == hkey_s[i] && dedup_same(scalars, idx_s[i + 1], idx_s[i]);
+    }
+    head[i] = h ? 1u : 0u;
+    mhead[i] = m ? 1u : 0u;
+}
+
+// per sorted position: the bucket key of the group-sum accumulation (multi-member groups only) and, at group heads,
+// the compacted scalar, its base index (`rep`: the original base, or n + m for the m-th group sum) and gof[m] = g
+static __global__ void __launch_bounds__(256) dedup_assign_kernel(const U128* __restrict__ scalars, const uint64_t* __restrict__ hkey_s,
+                                                                  const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ head,
+                                                                  const uint32_t* __restrict__ mhead, const uint32_t* __restrict__ gid_ex,
+                                                                  const uint32_t* __restrict__ mid_ex, uint64_t n, uint32_t sentinel,
+                                                                  uint32_t* __restrict__ key2, U128* __restrict__ scal2,
+                                                                  uint32_t* __restrict__ rep, uint32_t* __restrict__ gof) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool alive = hkey_s[i] != ~0ull;
+    const bool h = head[i] != 0, m = mhead[i] != 0;
+    const bool member = alive && (m || !h);  // belongs to a group of >= 2
+    key2[i] = member ? mid_ex[i] + mhead[i] - 1 : sentinel;
+    if (h) {
+        const uint32_t g = gid_ex[i], src = idx_s[i];
+        scal2[2 * (uint64_t)g] = scalars[2 * (uint64_t)src];
+        scal2[2 * (uint64_t)g + 1] = scalars[2 * (uint64_t)src + 1];
+        if (m) {
+            rep[g] = (uint32_t)n + mid_ex[i];
+            gof[mid_ex[i]] = g;
+        } else {
+            rep[g] = src;
+        }
+    }
+}
+
+// group sums (XYZZ) -> internal affine form, batched inversion: one lane per K consecutive sums (Montgomery's trick,
+// prefix products parked in `pref`).  A sum that is the identity (P + (-P)) cannot be a base: its scalar is zeroed.
+template <class C>
+__global__ void __launch_bounds__(64) dedup_affine_kernel(const typename C::Pt* __restrict__ sums, uint32_t m_total, uint32_t K,
+                                                          typename C::Fld* __restrict__ pref, typename C::DevAff* __restrict__ out,
+                                                          const uint32_t* __restrict__ gof, U128* __restrict__ scal2) {
+    typedef typename C::Fld Fld;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = (uint64_t)t * K;
+    if (lo >= m_total) return;
+    const uint32_t hi = (uint32_t)(lo + K < m_total ? lo + K : m_total);
+    Fld acc = C::f_one();
+    for (uint32_t i = (uint32_t)lo; i < hi; ++i) {
+        pref[i] = acc;
+        const typename C::Pt p = sums[i];
+        if (!C::is_identity(p)) acc = C::f_mul(acc, p.ZZZ);
+    }
+    Fld inv = C::f_inv(acc);
+    for (uint32_t i = hi; i-- > (uint32_t)lo;) {
+        const typename C::Pt p = sums[i];
+        if (C::is_identity(p)) {
+            const uint32_t g = gof[i];
+            scal2[2 * (uint64_t)g] = U128{0, 0, 0, 0};
+            scal2[2 * (uint64_t)g + 1] = U128{0, 0, 0, 0};
+            continue;
+        }
+        const Fld i3 = C::f_mul(inv, pref[i]);  // 1 / ZZZ_i
+        inv = C::f_mul(inv, p.ZZZ);
+        out[i] = C::affine_with_inv(p, i3);
+    }
+}
+
+// bucket phase shared by the windows and by the group sums: boundaries of each key's run in the sorted pair list,
+// buckets in population order, task table, task-based accumulation, folds.  Result: buckets[key] for key < nb.
+template <class Pt>
+struct BucketArrays {
+    uint32_t *start, *count, *count_s, *iota, *order, *ntask, *tbase;
+    Pt* partial;
+};
+template <class C>
+static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
+                                 uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
+                                 bool group_sums = false) {
+    BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
+    BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
+    BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
+    BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, nb);
+    {
+        ProfScope ps(ctx, "msm_sort_buckets");
+        size_t t = tmp;
+        hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, A.count, A.count_s, A.iota, A.order, (size_t)nb, 0, bits_for(len), ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+    }
+    BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count_s, nb, seg, A.ntask);
+    {
+        ProfScope ps(ctx, "msm_scan_tasks");
+        size_t t = tmp;
+        hipError_t e = rocprim::exclusive_scan(tmp_buf, t, A.ntask, A.tbase, 0u, (size_t)nb, rocprim::plus<uint32_t>(), ctx->stream);
+        if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+    }
+    const uint32_t t_max = (uint32_t)((uint64_t)nb + len / seg + 1);
+    // G1: 2 waves/SIMD: forcing 3 or 4 (__launch_bounds__) spills 68 / 223 VGPRs and measured 13 % / 80 % slower.
+    // G2: 1 wave/SIMD (512 registers: 8 spilled instead of 402 at 2 waves), see msm_policy.cuh
+    auto k_acc = msm_accumulate_kernel<C, C::ACC_OCC>;
+    auto k_fold = msm_fold_kernel<C>;
+    auto k_fold_small = msm_fold_small_kernel<C>;
+    if (group_sums) {
+        BZK_LAUNCH(ctx, "dedup_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
+                   nb, t_max, seg, buckets, A.partial);
+    } else {
+        BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
+                   nb, t_max, seg, buckets, A.partial);
+    }
+    // only sorted positions < len / seg can hold a multi-task bucket; of those only the first
+    // len / (seg * MSM_FOLD_SMALL) can need the workgroup-wide fold
+    const uint32_t n_pos = (uint32_t)std::min<uint64_t>(nb, len / seg + 1);
+    const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * MSM_FOLD_SMALL) + 1);
+    BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, A.count_s, A.order, A.tbase, nb, seg, A.partial, buckets);
+    BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, A.count_s, A.order, A.tbase, n_pos, seg, A.partial,
+               buckets);
+    return BZK_OK;
+}
+
+
 // Computes sum over windows [w_begin, w_end) of 2^(c w) S_w into `result` (host XYZZ, standard limbs).
 struct MsmTable {
     void* data = nullptr;  // DevAff[w_total][n]
@@ -476,6 +638,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (ch > half) ch = half;
     while (half % ch) --ch;
     const uint32_t per_win = half / ch;
+    const bool dedup = (flags & BZK_F_DEDUP) && C::CONVERT_BASES && !table && n >= 4096 && n < ((uint64_t)1 << 30);
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
     int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w_end - w_begin), ((uint64_t)1 << 30) / n));
@@ -483,112 +646,163 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const uint64_t len_max = (uint64_t)group * n;
     if (len_max >= ((uint64_t)1 << 31)) return BZK_E_ARG;
     const uint32_t nb_max = table ? half : (uint32_t)group * half;
+    const uint32_t m_max = dedup ? (uint32_t)(n / 2 + 1) : 0;  // group sums: at most n / 2 groups of >= 2 members
+    const uint32_t nb_alloc = std::max(nb_max, m_max);
 
     // rocPRIM temp sizes
-    size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
+    size_t tmp1 = 0, tmp2 = 0, tmp3 = 0, tmp4 = 0;
     {
         uint32_t* nul = nullptr;
+        uint64_t* nul64 = nullptr;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp1, nul, nul, nul, nul, (size_t)len_max, 0, bits_for(nb_max), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
-        e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_max, 0, bits_for(len_max), ctx->stream);
+        e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_alloc, 0, bits_for(len_max), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
-        e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)nb_max, rocprim::plus<uint32_t>(), ctx->stream);
+        e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)std::max<uint64_t>(nb_alloc, dedup ? n : 0), rocprim::plus<uint32_t>(),
+                                    ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
+        if (dedup) {
+            e = rocprim::radix_sort_pairs(nullptr, tmp4, nul64, nul64, nul, nul, (size_t)n, 0, 64, ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
+        }
     }
-    const size_t tmp = std::max(std::max(tmp1, tmp2), tmp3);
+    const size_t tmp = std::max(std::max(tmp1, tmp2), std::max(tmp3, tmp4));
     // serial run length per lane: ~4x the mean bucket population, within [32, 256] - short enough that the
     // few over-full buckets of a degenerate top window do not set the kernel's critical path at small n
     uint32_t seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n / half + 1)));
     if (table) seg = 64;  // shared buckets are all heavily populated: short runs keep every SIMD busy
-    const uint64_t t_cap = (uint64_t)nb_max + len_max / seg + 1;  // upper bound on the number of tasks
+    const uint32_t seg_dd = 8;  // group sums are latency-bound (a 7 k-member group of bits is one bucket): short serial runs
+    const uint64_t t_cap = std::max<uint64_t>((uint64_t)nb_max + len_max / seg + 1, dedup ? (uint64_t)m_max + n / seg_dd + 1 : 0);
     size_t total = 0;
     total += 4 * ws_pad(len_max * 4);                 // keys, vals, keys_sorted, vals_sorted
-    total += 7 * ws_pad((size_t)nb_max * 4);          // start, count, count_sorted, iota, order, ntask, tbase
+    total += 7 * ws_pad((size_t)nb_alloc * 4);        // start, count, count_sorted, iota, order, ntask, tbase
     total += ws_pad((size_t)t_cap * sizeof(Pt));      // per-task partial sums (multi-task buckets only)
-    total += ws_pad((size_t)nb_max * sizeof(Pt));     // buckets
+    total += ws_pad((size_t)nb_alloc * sizeof(Pt));   // buckets
     total += ws_pad((size_t)group * per_win * sizeof(Pt));
     total += ws_pad(((size_t)group * (per_win / C::WSUM_THREADS + 1)) * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(StdPt));
-    if (C::CONVERT_BASES && !table) total += ws_pad((size_t)n * sizeof(typename C::DevAff));
-    total += ws_pad(tmp) + 4096;
+    if (C::CONVERT_BASES && !table) total += ws_pad((size_t)(n + m_max) * sizeof(typename C::DevAff));
+    if (dedup) {
+        total += 2 * ws_pad(n * 8) + 9 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
+    }
+    total += ws_pad(tmp) + 8192;
     BZK_TRY(ws_reserve(ctx, total));
-    BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(StdPt)));
+    BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(StdPt) + 64));
     WsCursor cur(ctx->ws);
     uint32_t* keys = cur.take<uint32_t>(len_max);
     uint32_t* vals = cur.take<uint32_t>(len_max);
     uint32_t* keys_s = cur.take<uint32_t>(len_max);
     uint32_t* vals_s = cur.take<uint32_t>(len_max);
-    uint32_t* start = cur.take<uint32_t>(nb_max);
-    uint32_t* count = cur.take<uint32_t>(nb_max);
-    uint32_t* count_s = cur.take<uint32_t>(nb_max);
-    uint32_t* iota = cur.take<uint32_t>(nb_max);
-    uint32_t* order = cur.take<uint32_t>(nb_max);
-    uint32_t* ntask = cur.take<uint32_t>(nb_max);
-    uint32_t* tbase = cur.take<uint32_t>(nb_max);
-    Pt* partial = cur.take<Pt>(t_cap);
-    Pt* buckets = cur.take<Pt>(nb_max);
+    BucketArrays<Pt> BA;
+    BA.start = cur.take<uint32_t>(nb_alloc);
+    BA.count = cur.take<uint32_t>(nb_alloc);
+    BA.count_s = cur.take<uint32_t>(nb_alloc);
+    BA.iota = cur.take<uint32_t>(nb_alloc);
+    BA.order = cur.take<uint32_t>(nb_alloc);
+    BA.ntask = cur.take<uint32_t>(nb_alloc);
+    BA.tbase = cur.take<uint32_t>(nb_alloc);
+    BA.partial = cur.take<Pt>(t_cap);
+    Pt* buckets = cur.take<Pt>(nb_alloc);
     Pt* chunk_out = cur.take<Pt>((size_t)group * per_win);
     Pt* wpart = cur.take<Pt>((size_t)group * (per_win / C::WSUM_THREADS + 1));
     StdPt* win_out = cur.take<StdPt>(w_total);
     const void* bases = table ? table->data : bases_raw;
+    typename C::DevAff* conv = nullptr;
     if (C::CONVERT_BASES && !table) {
-        typename C::DevAff* conv = cur.take<typename C::DevAff>(n);
+        conv = cur.take<typename C::DevAff>(n + m_max);
         auto k_conv = msm_convert_bases_kernel<C>;
         BZK_LAUNCH(ctx, "msm_convert_bases", k_conv, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, bases_raw, n, conv);
         bases = conv;
     }
+    uint64_t* hkey = nullptr;
+    uint64_t* hkey_s = nullptr;
+    uint32_t *didx = nullptr, *didx_s = nullptr, *head = nullptr, *mhead = nullptr, *gid_ex = nullptr, *mid_ex = nullptr, *key2 = nullptr,
+             *rep = nullptr, *gof = nullptr;
+    U128* scal2 = nullptr;
+    typename C::Fld* pref = nullptr;
+    if (dedup) {
+        hkey = cur.take<uint64_t>(n);
+        hkey_s = cur.take<uint64_t>(n);
+        didx = cur.take<uint32_t>(n);
+        didx_s = cur.take<uint32_t>(n);
+        head = cur.take<uint32_t>(n);
+        mhead = cur.take<uint32_t>(n);
+        gid_ex = cur.take<uint32_t>(n);
+        mid_ex = cur.take<uint32_t>(n);
+        key2 = cur.take<uint32_t>(n);
+        rep = cur.take<uint32_t>(n);
+        gof = cur.take<uint32_t>(n);
+        scal2 = cur.take<U128>(2 * n);
+        pref = cur.take<typename C::Fld>(m_max);
+    }
     void* tmp_buf = cur.take<char>(tmp);
+
+    uint64_t n_eff = n;
+    const void* scal_eff = scalars;
+    if (dedup) {
+        const unsigned gb = (unsigned)((n + 255) / 256);
+        BZK_LAUNCH(ctx, "dedup_hash", dedup_hash_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, n, hkey, didx);
+        {
+            ProfScope ps(ctx, "dedup_sort");
+            size_t t = tmp;
+            hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, hkey, hkey_s, didx, didx_s, (size_t)n, 0, 64, ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("dedup sort: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+        }
+        BZK_LAUNCH(ctx, "dedup_heads", dedup_heads_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, (const uint64_t*)hkey_s,
+                   (const uint32_t*)didx_s, n, head, mhead);
+        {
+            ProfScope ps(ctx, "dedup_scan");
+            size_t t = tmp;
+            hipError_t e = rocprim::exclusive_scan(tmp_buf, t, head, gid_ex, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream);
+            if (e == hipSuccess) {
+                t = tmp;
+                e = rocprim::exclusive_scan(tmp_buf, t, mhead, mid_ex, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream);
+            }
+            if (e != hipSuccess) { ctx->last_error = std::string("dedup scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+        }
+        // group counts to the host (launch sizes of what follows)
+        uint32_t* hp = (uint32_t*)ctx->pinned;
+        BZK_HIP(ctx, hipMemcpyAsync(hp + 0, gid_ex + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(hp + 1, head + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(hp + 2, mid_ex + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(hp + 3, mhead + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t G = hp[0] + hp[1], M = hp[2] + hp[3];
+        if (ctx->timing) fprintf(stderr, "[bzk] dedup: n %llu -> %u distinct non-zero scalars, %u groups of >= 2\n", (unsigned long long)n, G, M);
+        if (G == 0) return BZK_OK;  // every scalar is zero
+        if (M > m_max) { ctx->last_error = "dedup: group count out of range"; return BZK_E_INTERNAL; }
+        BZK_LAUNCH(ctx, "dedup_assign", dedup_assign_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, (const uint64_t*)hkey_s,
+                   (const uint32_t*)didx_s, (const uint32_t*)head, (const uint32_t*)mhead, (const uint32_t*)gid_ex, (const uint32_t*)mid_ex,
+                   n, 0xffffffffu, key2, scal2, rep, gof);
+        if (M) {
+            BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true));
+            const uint32_t K = 16;
+            auto k_aff = dedup_affine_kernel<C>;
+            BZK_LAUNCH(ctx, "dedup_affine", k_aff, dim3((unsigned)(((M + K - 1) / K + 63) / 64)), dim3(64), 0, (const Pt*)buckets, M, K, pref,
+                       conv + n, (const uint32_t*)gof, scal2);
+        }
+        n_eff = G;
+        scal_eff = scal2;
+        seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n_eff / half + 1)));
+    }
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;
     std::vector<StdPt> wsum((size_t)(w_end - w_begin));
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
-        const uint64_t len = (uint64_t)wc * n;
+        const uint64_t len = (uint64_t)wc * n_eff;
         const uint32_t nb = table ? half : (uint32_t)wc * half;
         const int n_red_win = table ? 1 : wc;  // bucket sets to reduce
-        BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                   (const U128*)scalars, n, mont, c, w_total, wb, wc, (uint32_t)(table ? table->n : 0), keys, vals);
+        BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
+                   mont, c, w_total, wb, wc, (uint32_t)(table ? table->n : 0), (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
         {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
             hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, keys, keys_s, vals, vals_s, (size_t)len, 0, bits_for(nb), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
-        BZK_HIP(ctx, hipMemsetAsync(start, 0, (size_t)nb * 4, ctx->stream));
-        BZK_HIP(ctx, hipMemsetAsync(count, 0, (size_t)nb * 4, ctx->stream));
-        BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, start, count);
-        BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, start, count, iota, nb);
-        {
-            ProfScope ps(ctx, "msm_sort_buckets");
-            size_t t = tmp;
-            hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, count, count_s, iota, order, (size_t)nb, 0, bits_for(len), ctx->stream);
-            if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
-        }
-        BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, count_s, nb, seg, ntask);
-        {
-            ProfScope ps(ctx, "msm_scan_tasks");
-            size_t t = tmp;
-            hipError_t e = rocprim::exclusive_scan(tmp_buf, t, ntask, tbase, 0u, (size_t)nb, rocprim::plus<uint32_t>(), ctx->stream);
-            if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
-        }
-        const uint32_t t_max = (uint32_t)((uint64_t)nb + len / seg + 1);
-        // G1: 2 waves/SIMD: forcing 3 or 4 (__launch_bounds__) spills 68 / 223 VGPRs and measured 13 % / 80 % slower.
-        // G2: 1 wave/SIMD (512 registers: 35 spilled instead of 402 at 2 waves), see msm_policy.cuh
-        auto k_acc = msm_accumulate_kernel<C, C::ACC_OCC>;
-        auto k_fold = msm_fold_kernel<C>;
-        auto k_fold_small = msm_fold_small_kernel<C>;
+        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp));
         auto k_red = msm_reduce_kernel<C>;
-        BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, start, count_s, order, tbase, nb,
-                   t_max, seg, buckets, partial);
-        {
-            // only sorted positions < len / seg can hold a multi-task bucket; of those only the first
-            // len / (seg * MSM_FOLD_SMALL) can need the workgroup-wide fold
-            const uint32_t n_pos = (uint32_t)std::min<uint64_t>(nb, len / seg + 1);
-            const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * MSM_FOLD_SMALL) + 1);
-            BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, count_s, order, tbase, nb, seg, partial, buckets);
-            BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, count_s, order, tbase, n_pos, seg,
-                       partial, buckets);
-        }
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);
         constexpr int WT = C::WSUM_THREADS;

@@ -34,6 +34,16 @@ struct G1Fast {
         Fp28 i2 = fp28::mul(fp28::sqr(p.ZZ), fp28::sqr(i3));  // 1/ZZ = ZZ^2 / ZZZ^2
         return {fp28::mul(p.X, i2), fp28::mul(p.Y, i3)};
     }
+    // batched to-affine of the de-duplication stage (msm_impl.cuh section 8)
+    typedef Fp28 Fld;
+    __device__ static __forceinline__ bool is_identity(const Pt& p) { return g1x28::is_identity(p); }
+    __device__ static __forceinline__ Fld f_one() { return fp28::one(); }
+    __device__ static __forceinline__ Fld f_mul(const Fld& a, const Fld& b) { return fp28::mul(a, b); }
+    __device__ static __forceinline__ Fld f_inv(const Fld& a) { return fp28::inv(a); }
+    __device__ static __forceinline__ DevAff affine_with_inv(const Pt& p, const Fld& i3) {  // i3 = 1/ZZZ
+        Fp28 t = fp28::mul(p.ZZ, i3);  // ZZ/ZZZ ; its square is 1/ZZ (ZZ^3 = ZZZ^2)
+        return {fp28::mul(p.X, fp28::sqr(t)), fp28::mul(p.Y, i3)};
+    }
     __device__ static __forceinline__ XyzzT<FpOps> to_std(const Pt& p) { return g1x28::to_std(p); }
     // raw 96-byte affine (12 x 32-bit Montgomery-384) -> internal
     __device__ static __forceinline__ DevAff convert(const void* raw, uint64_t i) {
@@ -87,6 +97,18 @@ struct G2Fast {
     __device__ static __forceinline__ DevAff to_dev_affine(const Pt& p) {
         DevAff a;
         xyzz_to_affine<Fp2x28Ops>(p, a);
+        return a;
+    }
+    typedef Fp2x28 Fld;
+    __device__ static __forceinline__ bool is_identity(const Pt& p) { return xyzz_is_identity<Fp2x28Ops>(p); }
+    __device__ static __forceinline__ Fld f_one() { return Fp2x28Ops::one(); }
+    __device__ static __forceinline__ Fld f_mul(const Fld& a, const Fld& b) { return Fp2x28Ops::mul(a, b); }
+    __device__ static __forceinline__ Fld f_inv(const Fld& a) { return Fp2x28Ops::inv(a); }
+    __device__ static __forceinline__ DevAff affine_with_inv(const Pt& p, const Fld& i3) {
+        Fld t = Fp2x28Ops::mul(p.ZZ, i3);
+        DevAff a;
+        a.x = Fp2x28Ops::mul(p.X, Fp2x28Ops::sqr(t));
+        a.y = Fp2x28Ops::mul(p.Y, i3);
         return a;
     }
     __device__ static __forceinline__ XyzzT<Fp2Ops> to_std(const Pt& p) { return g2x28::to_std(p); }

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbzk.so")
 
 BZK_F_CANONICAL = 1
+BZK_F_DEDUP = 2
 _lib = None
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/bzk.h
@@ -143,6 +144,7 @@ class Bzk:
         if st != 0:
             raise BzkError(f"bzk_ctx_create failed: {self.lib.bzk_strerror(st).decode()} (no CPU fallback exists)")
         self.h = h
+        self.device = device
 
     def close(self):
         if getattr(self, "h", None):
@@ -202,16 +204,16 @@ class Bzk:
         self._ck(self.lib.bzk_ntt(self.h, buf, log_n, int(inverse), int(coset)), "ntt")
         return buf.raw
 
-    def msm_g1(self, bases: bytes, scalars: bytes, canonical=False) -> bytes:
+    def msm_g1(self, bases: bytes, scalars: bytes, canonical=False, dedup=False) -> bytes:
         n = len(scalars) // 32
         out = C.create_string_buffer(97)
-        self._ck(self.lib.bzk_msm_g1(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, out), "msm_g1")
+        self._ck(self.lib.bzk_msm_g1(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g1")
         return out.raw
 
-    def msm_g2(self, bases: bytes, scalars: bytes, canonical=False) -> bytes:
+    def msm_g2(self, bases: bytes, scalars: bytes, canonical=False, dedup=False) -> bytes:
         n = len(scalars) // 32
         out = C.create_string_buffer(193)
-        self._ck(self.lib.bzk_msm_g2(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, out), "msm_g2")
+        self._ck(self.lib.bzk_msm_g2(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g2")
         return out.raw
 
     # ---- device-pointer forms (x = torch tensor / int device address)
@@ -226,14 +228,14 @@ class Bzk:
     def ntt_dev(self, data, log_n: int, inverse=False, coset=False):
         self._ck(self.lib.bzk_ntt_dev(self.h, _ptr(data), log_n, int(inverse), int(coset)), "ntt_dev")
 
-    def msm_g1_dev(self, bases, scalars, n: int, canonical=False) -> bytes:
+    def msm_g1_dev(self, bases, scalars, n: int, canonical=False, dedup=False) -> bytes:
         out = C.create_string_buffer(97)
-        self._ck(self.lib.bzk_msm_g1_dev(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, out), "msm_g1_dev")
+        self._ck(self.lib.bzk_msm_g1_dev(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g1_dev")
         return out.raw
 
-    def msm_g2_dev(self, bases, scalars, n: int, canonical=False) -> bytes:
+    def msm_g2_dev(self, bases, scalars, n: int, canonical=False, dedup=False) -> bytes:
         out = C.create_string_buffer(193)
-        self._ck(self.lib.bzk_msm_g2_dev(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, out), "msm_g2_dev")
+        self._ck(self.lib.bzk_msm_g2_dev(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g2_dev")
         return out.raw
 
     def msm_window_count(self, n: int) -> int:

@@ -106,7 +106,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
     # Each producer owns an independent account tree - the shape of Bazuka's own work distribution, where a
     # prover holds several independent MpnWork items at once (src/mpn/mod.rs:79-107).
     import queue
-    n_warm, n_pipe = 8, 16
+    n_warm, n_pipe = 8, 24
     synth_s = []
     q = queue.Queue(maxsize=4)
     stop = threading.Event()
@@ -134,18 +134,49 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
     threads = [threading.Thread(target=producer, args=(s,), daemon=True) for s in range(n_prod)]
     for th in threads:
         th.start()
-    t0 = None
-    for k in range(n_warm + n_pipe):
-        if k == n_warm:
-            t0 = time.perf_counter()
-        rr = q.get()
-        ctx.groth16_prove(ph, rr.raw("z"), rr.raw("az"), rr.raw("bz"), rr.raw("cz"), _fr(3 + k), _fr(5 + k))
-    out["proofs_per_s_pipelined"] = round(n_pipe / (time.perf_counter() - t0), 3)
+    # Two prover slots on the same GPU (each its own context, streams and CRS copy - 288 GB is there to be used):
+    # the latency-bound tails of one proof (bucket reduction, window sums, batched inversions) overlap the
+    # throughput-bound bucket accumulation of the other.
+    from bazuka_amd import Bzk
+    n_slots = max(1, int(os.environ.get("BZK_BENCH_SLOTS", "3")))
+    slots = [(ctx, ph)]
+    for _ in range(n_slots - 1):
+        cx = Bzk(ctx.device)
+        slots.append((cx, cx.groth16_setup(csr, r.n_in, r.n_aux, tox)[0]))
+    done = {"n": 0}
+    finished = []
+    lock = threading.Lock()
+
+    def consumer(slot):
+        c, p = slots[slot]
+        k = 0
+        while True:
+            with lock:
+                if done["n"] >= n_warm + n_pipe:
+                    return
+                done["n"] += 1
+            rr = q.get()
+            c.groth16_prove(p, rr.raw("z"), rr.raw("az"), rr.raw("bz"), rr.raw("cz"), _fr(3 + k), _fr(5 + k))
+            k += 1
+            with lock:
+                finished.append(time.perf_counter())
+
+    cons = [threading.Thread(target=consumer, args=(i,)) for i in range(len(slots))]
+    for th in cons:
+        th.start()
+    for th in cons:
+        th.join()
+    finished.sort()  # completion times: rate over the last n_pipe completions
+    out["proofs_per_s_pipelined"] = round(n_pipe / (finished[n_warm + n_pipe - 1] - finished[n_warm - 1]), 3)
     out["producer_synth_s_mean_under_load"] = round(sum(synth_s) / len(synth_s), 4)
-    out["pipeline"] = f"{n_prod} host producers (16 worker threads each) -> 1 GPU prover, {n_pipe} proofs timed"
+    out["pipeline"] = (f"{n_prod} host producers (16 worker threads each) -> {len(slots)} prover slots on 1 GPU, "
+                       f"{n_pipe} proofs timed")
     stop.set()
     for th in threads:
         th.join()
+    for cx, px in slots[1:]:
+        cx.params_free(px)
+        cx.close()
     ctx.params_free(ph)
     return out
 
@@ -265,7 +296,7 @@ def main():
     proofs, rates = None, []
     if not args.no_proofs:
         try:
-            proofs = full_prove_section(ctx, n_prod=4 if world == 1 else 2)
+            proofs = full_prove_section(ctx, n_prod=6 if world == 1 else 3)
         except Exception as e:  # the headline MSM line must still be printed
             proofs = {"error": repr(e)}
         if world > 1:

@@ -38,6 +38,8 @@ extern "C" {
 #define BZK_E_INTERNAL (-5) /* invariant violated (bug) */
 
 #define BZK_F_CANONICAL 1u  /* scalars are canonical integers instead of Montgomery limbs */
+#define BZK_F_DEDUP 2u      /* MSM entries: the scalar vector repeats itself (a Groth16 witness): bases of equal scalars
+                             * are summed once before the bucket phase, zero scalars dropped.  Same result. */
 
 typedef struct bzk_ctx bzk_ctx;
 

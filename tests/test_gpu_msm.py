@@ -190,3 +190,67 @@ def test_msm_g1_static_table_2p20(bzk, co):
     sc = to_dev(scb)
     assert bzk.msm_table_run_dev(tab, sc, n) == bzk.msm_g1_dev(bases, sc, n)
     bzk.msm_table_free(tab)
+
+
+# ---- scalar de-duplication (BZK_F_DEDUP): what bzk_groth16_prove uses for the witness MSMs
+
+def _witness_like_scalars(n, seed):
+    """the shape of a Groth16 assignment: most values occur twice, bits by the thousands, zeros, a few heavy values"""
+    import random
+    rnd = random.Random(seed)
+    distinct = fr_list(n // 2, seed)
+    sc = [distinct[rnd.randrange(len(distinct))] for _ in range(n)]
+    for i in range(0, n, 9):
+        sc[i] = 1
+    for i in range(4, n, 11):
+        sc[i] = 0
+    heavy = distinct[0]
+    for i in range(2, n, 5):
+        sc[i] = heavy
+    return sc
+
+
+@pytest.mark.parametrize("n", [4096, 5000, 70000])
+def test_msm_g1_dedup_equals_plain_and_oracle(bzk, co, pr, n):
+    bases = bytearray(co.g1_bases(77, 0, n, nthreads=co.ncpu()))
+    sc = _witness_like_scalars(n, n)
+    # equal scalars on equal points (doubling inside a group sum) and on P, -P (a group sum that is the identity)
+    bases[96:192] = bases[0:96]
+    bases[3 * 96:4 * 96] = _neg_y(pr, bytes(bases[2 * 96:3 * 96]))
+    sc[0] = sc[1] = 0x1234567
+    sc[2] = sc[3] = 0x7654321
+    for mont in (True, False):
+        scb = fr_bytes(sc, mont=mont)
+        want = co.msm_g1(bytes(bases), scb, mont=mont, nthreads=co.ncpu())
+        assert bzk.msm_g1(bytes(bases), scb, canonical=not mont, dedup=True) == want
+        assert bzk.msm_g1(bytes(bases), scb, canonical=not mont) == want
+
+
+def test_msm_g1_dedup_degenerate_inputs(bzk, co, pr):
+    n = 6000
+    bases = co.g1_bases(78, 0, n, nthreads=co.ncpu())
+    assert bzk.msm_g1(bases, fr_bytes([0] * n), dedup=True) == pr.g1_to_bytes(None)          # nothing left
+    one = fr_bytes([5] * n)
+    assert bzk.msm_g1(bases, one, dedup=True) == co.msm_g1(bases, one, nthreads=co.ncpu())    # one group of n members
+    uniq = rand_scalars_bytes(n, 99)
+    assert bzk.msm_g1(bases, uniq, dedup=True) == co.msm_g1(bases, uniq, nthreads=co.ncpu())  # no duplicates at all
+
+
+def test_msm_g2_dedup_equals_oracle(bzk, co):
+    n = 9000
+    bases = co.g2_bases(79, 0, n, nthreads=co.ncpu())
+    scb = fr_bytes(_witness_like_scalars(n, 3))
+    want = co.msm_g2(bases, scb, nthreads=co.ncpu())
+    assert bzk.msm_g2(bases, scb, dedup=True) == want
+    assert bzk.msm_g2(bases, scb) == want
+
+
+def test_msm_g1_dedup_2p20_witness_like_property(bzk, co):
+    """BASELINE size: de-duplicated == plain on 2^20 witness-like scalars (both bit-exact vs the oracle elsewhere)"""
+    n = 1 << 20
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(5, 0, n, bases)
+    sc = to_dev(fr_bytes(_witness_like_scalars(n, 20)))
+    a = bzk.msm_g1_dev(bases, sc, n, dedup=True)
+    assert a == bzk.msm_g1_dev(bases, sc, n)
+    assert a == co.msm_g1(dev_bytes(bases), dev_bytes(sc), nthreads=co.ncpu())
