@@ -140,6 +140,15 @@ BZK_HD Fr29 norm(const Fr29& a) {
     return r;
 }
 
+// a - b + 3r for a normalised b with k <= 2 (a product output); limbs below the top are raised so that none can
+// underflow (same construction as fp28::sub<K>); result k = ka + 3, normalised
+static constexpr Consts D3 = {{0x20000003u, 0x3fffffe7u, 0x3ec4ff3eu, 0x31d811feu, 0x3880ffb2u, 0x240c0e71u, 0x3f6266b5u, 0x3f2f9b0du, 0x015bc8f4u}};
+BZK_HD Fr29 sub3(const Fr29& a, const Fr29& b) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = a.l[i] + D3.v[i] - b.l[i];
+    return norm(r);
+}
 // x^5 for a normalised x with k <= 7  (49, 4, 14 <= 70)
 BZK_HD Fr29 sbox5(const Fr29& x) {
     Fr29 x2 = mul(x, x);
@@ -174,6 +183,22 @@ BZK_HD Fr repack_to32(const Fr29& a) {  // normalised, value < 2^256
 BZK_HD Fr29 to29(const Fr& a) { return mul(repack_from32(a), from_consts(C_IN)); }  // k 2
 BZK_HD Fr from29(const Fr29& a) {  // any k <= 35 -> canonical 8 x 32-bit Montgomery-256 limbs
     Fr29 t = mul(a, from_consts(C_OUT));  // [0, 2r)
+    Fr29 s;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t d = t.l[i] - R.v[i] - borrow;
+        borrow = d >> 31;
+        s.l[i] = d & MASK;
+    }
+    if (!borrow) t = s;
+    return repack_to32(t);
+}
+
+// out = canonical 8 x 32-bit limbs of (a * s * 2^-261 mod r): with s = x * 2^256 this is Montgomery-256(a' * x) for
+// a = a' * 2^261; from29() is the case s = C_OUT.  Any ka <= 35, s < r.
+BZK_HD Fr from29_scaled(const Fr29& a, const Fr29& s_) {
+    Fr29 t = mul(a, s_);  // [0, 2r)
     Fr29 s;
     uint32_t borrow = 0;
 #pragma unroll

@@ -47,7 +47,21 @@ int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes) {
 bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
     while (ctx->lanes.size() <= i) {
         bzk_ctx* c = nullptr;
-        if (bzk_ctx_create(ctx->device, nullptr, &c) != BZK_OK) return nullptr;
+        // lane 0 carries the job with the longest latency-bound tail (the G2 MSM of a proof): its stream gets the
+        // highest priority so that this tail is reached early and hides under the other lanes' accumulation
+        hipStream_t s = nullptr;
+        if (ctx->lanes.empty()) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                s = nullptr;
+            }
+        }
+        if (bzk_ctx_create(ctx->device, s, &c) != BZK_OK) {
+            if (s) (void)hipStreamDestroy(s);
+            return nullptr;
+        }
+        if (s) c->own_stream = true;  // created here, destroyed with the lane
         ctx->lanes.push_back(c);
     }
     bzk_ctx* c = ctx->lanes[i];

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "bzk_field.cuh"
+#include "bzk_fr29.cuh"
 #include "bzk_internal.h"
 
 namespace bzk {
@@ -109,36 +110,61 @@ __global__ void __launch_bounds__(256) ntt_scale_kernel(Fr* __restrict__ data, u
 
 // ------------------------------------------------------------------------------------------------
 // One pass = an R-point DFT (R = 2^b <= 1024) along one digit of the index, for a tile of CC adjacent
-// "columns", entirely in LDS: decimation-in-frequency butterflies (output rows bit-reversed inside the tile,
-// undone by the store), compact twiddle table w_R^j.
+// "columns", entirely in LDS, on the 9 x 29-bit reduced-radix field (bzk_fr29.cuh; 163 G products/s against 88 for
+// the 8 x 32-bit CIOS).  Decimation in time: rows enter the tile bit-reversed and leave it in natural order; a
+// butterfly is  t = v * w ; (u, v) <- (u + t, u - t + 3r)  - the subtrahend is always a fresh product (k 2), so no
+// conditional subtraction is needed: values grow by at most 3r per stage (k <= 32 after 10 stages, the product
+// accepts k <= 35) and only carries are propagated.  Elements are padded to 48 B (three 16-B accesses) in LDS and in
+// the inter-pass buffer.
 //   COL   pass: element (a, c) of the tile lives at src[base + a*S + c]; the result row ka is multiplied by the
 //               inter-pass twiddle w_N'^(inner * ka) (N' = R*S, two-level table: lo[e & 1023] * hi[e >> 10]) and
 //               written to the same position of dst.
 //   FINAL pass: rows are contiguous (S = 1); the tile takes CC rows whose OUTPUT indices are adjacent and writes
 //               X[(k1 + c) + R1 * (k2 + R2 * ka)]: the digit reversal of the whole transform, in CC-wide chunks.
-// The coset pre-scale (g^i, first pass) and the 1/n (and g^-k) post-scale (final pass) are fused into load / store.
+// Conversions ride on products that are needed anyway: the first load multiplies the raw 8 x 32-bit Montgomery-256
+// limbs by 2^266 (or by g^i * 2^266 for a coset transform), the last store by 2^256 (or by 1/n, g^-k / n times it)
+// and reduces to canonical limbs.
 // ------------------------------------------------------------------------------------------------
+struct alignas(16) Fr29P {
+    uint32_t l[12];  // 9 used
+};
+__device__ __forceinline__ Fr29 ld29(const Fr29P& p) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p.l[i];
+    return r;
+}
+__device__ __forceinline__ Fr29P st29(const Fr29& a) {
+    Fr29P p;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p.l[i] = a.l[i];
+    p.l[9] = p.l[10] = p.l[11] = 0;
+    return p;
+}
+
 struct NttPass {
-    const Fr* src;
-    Fr* dst;
-    int b, log_cc, final_pass;
-    uint64_t S;        // COL: column stride = size of the inner dimension
-    uint32_t R1, R2;   // FINAL: sizes of the digits already transformed
-    const Fr* tw_r;    // w_R^j, j < R/2
-    const Fr* tlo;     // COL: w_N'^j, j < 1024
-    const Fr* thi;     // COL: w_N'^(1024 j)
-    const Fr* pre;     // g^i by input index (first pass of a forward coset transform) or null
-    const Fr* post;    // g^-k / n by output index (inverse coset transform) or null
-    const Fr* post_c;  // 1/n (plain inverse transform) or null
+    const void* src;   // first pass: Fr (8 x 32-bit Montgomery-256); later passes: Fr29P
+    void* dst;         // final pass: Fr; earlier passes: Fr29P
+    int b, log_cc, final_pass, first_pass;
+    uint64_t S;           // COL: column stride = size of the inner dimension
+    uint32_t R1, R2;      // FINAL: sizes of the digits already transformed
+    const Fr29P* tw_r;    // w_R^j * 2^261, j < R/2
+    const Fr29P* tlo;     // COL: w_N'^j * 2^261, j < 1024
+    const Fr29P* thi;     // COL: w_N'^(1024 j) * 2^261
+    const Fr29P* pre;     // first pass: g^i * 2^266 by input index (forward coset transform) or null (constant 2^266)
+    const Fr29P* post;    // final pass: (g^-k / n) * 2^256 by output index (inverse coset transform) or null
+    const Fr29P* post_c;  // final pass: one element: 2^256 (forward) or 2^256 / n (inverse)
 };
 
 __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Fr* tile = (Fr*)smem;
+    Fr29P* tile = (Fr29P*)smem;
     const int b = a.b, lc = a.log_cc;
     const uint32_t R = 1u << b, CC = 1u << lc, tile_n = R << lc;
     uint64_t base = 0, inner0 = 0;
     uint32_t k1 = 0, k2 = 0;
+    const Fr29 c_in = fr29::from_consts(fr29::C_IN);
+    // load: global row r goes to LDS row bitrev(r) (decimation in time)
     if (!a.final_pass) {
         const uint64_t gpo = a.S >> lc;  // column groups per outer block
         const uint64_t o = blockIdx.x / gpo, cg = blockIdx.x % gpo;
@@ -147,9 +173,10 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
         for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
             const uint32_t c = t & (CC - 1), r = t >> lc;
             const uint64_t addr = base + (uint64_t)r * a.S + c;
-            Fr v = a.src[addr];
-            if (a.pre) v = fr_mul(v, a.pre[addr]);
-            tile[t] = v;
+            Fr29 v;
+            if (a.first_pass) v = fr29::mul(fr29::repack_from32(((const Fr*)a.src)[addr]), a.pre ? ld29(a.pre[addr]) : c_in);
+            else v = ld29(((const Fr29P*)a.src)[addr]);
+            tile[(bitrev(r, b) << lc) + c] = st29(v);
         }
     } else {
         const uint32_t groups = a.R1 >> lc;
@@ -158,57 +185,61 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
         for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
             const uint32_t r = t & (R - 1), c = t >> b;
             const uint64_t addr = ((uint64_t)(k1 + c) * a.R2 + k2) * R + r;
-            Fr v = a.src[addr];
-            if (a.pre) v = fr_mul(v, a.pre[addr]);
-            tile[(r << lc) + c] = v;
+            Fr29 v;
+            if (a.first_pass) v = fr29::mul(fr29::repack_from32(((const Fr*)a.src)[addr]), a.pre ? ld29(a.pre[addr]) : c_in);
+            else v = ld29(((const Fr29P*)a.src)[addr]);
+            tile[(bitrev(r, b) << lc) + c] = st29(v);
         }
     }
     __syncthreads();
-    for (int s = b - 1; s >= 0; --s) {
+    for (int s = 0; s < b; ++s) {
         const uint32_t m = 1u << s;
         for (uint32_t q = threadIdx.x; q < tile_n / 2; q += blockDim.x) {
             const uint32_t c = q & (CC - 1), bq = q >> lc;
             const uint32_t j = bq & (m - 1);
             const uint32_t k = ((bq >> s) << (s + 1)) + j;
             const uint32_t i0 = (k << lc) + c, i1 = ((k + m) << lc) + c;
-            const Fr u = tile[i0], v = tile[i1];
-            tile[i0] = fe_add<FrParams>(u, v);
-            Fr d = fe_sub<FrParams>(u, v);
-            if (j) d = fr_mul(d, a.tw_r[j << (b - 1 - s)]);
-            tile[i1] = d;
+            const Fr29 u = ld29(tile[i0]);
+            Fr29 t = ld29(tile[i1]);
+            t = fr29::mul(t, ld29(a.tw_r[j << (b - 1 - s)]));  // k 2 (j = 0: the table holds 2^261 = one)
+            tile[i0] = st29(fr29::norm(fr29::add(u, t)));
+            tile[i1] = st29(fr29::sub3(u, t));
         }
         __syncthreads();
     }
     for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
-        const uint32_t c = t & (CC - 1), p = t >> lc;
-        const uint32_t ka = bitrev(p, b);
-        Fr v = tile[t];
+        const uint32_t c = t & (CC - 1), ka = t >> lc;  // natural order after the DIT stages
+        Fr29 v = ld29(tile[t]);
         if (!a.final_pass) {
             const uint64_t e = (inner0 + c) * ka;
-            if (e) {
-                Fr w = a.tlo[e & 1023];
-                if (e >> 10) w = fr_mul(w, a.thi[e >> 10]);
-                v = fr_mul(v, w);
-            }
-            a.dst[base + (uint64_t)ka * a.S + c] = v;
+            Fr29 w = ld29(a.tlo[e & 1023]);
+            if (e >> 10) w = fr29::mul(w, ld29(a.thi[e >> 10]));
+            ((Fr29P*)a.dst)[base + (uint64_t)ka * a.S + c] = st29(fr29::mul(v, w));
         } else {
             const uint64_t k = (uint64_t)(k1 + c) + (uint64_t)a.R1 * (k2 + (uint64_t)a.R2 * ka);
-            if (a.post) v = fr_mul(v, a.post[k]);
-            else if (a.post_c) v = fr_mul(v, *a.post_c);
-            a.dst[k] = v;
+            ((Fr*)a.dst)[k] = fr29::from29_scaled(v, ld29(a.post ? a.post[k] : *a.post_c));
         }
     }
 }
 
-// per-size plan: digit split, twiddle tables for both directions, coset tables
+// out[i] = 9 x 29-bit limbs of the raw value of (tab[i] * c) in Montgomery-256 form, i.e. (x_i * c') * 2^256 mod r:
+// c = Montgomery(2^5) turns Montgomery-256 twiddles into Montgomery-261 ones, c = Montgomery(2^10) gives the x * 2^266
+// multipliers of the first load, c = one keeps x * 2^256 (multipliers of the final store)
+__global__ void __launch_bounds__(256) ntt_table29_kernel(const Fr* __restrict__ tab, uint64_t count, Fr c, Fr29P* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    out[i] = st29(fr29::repack_from32(fr_mul(tab[i], c)));
+}
+
+// per-size plan: digit split, twiddle tables for both directions, coset tables (all in the 48-byte 9 x 29-bit form)
 struct NttTables {
     int nb = 0, b[3] = {0, 0, 0};
-    Fr* tw_r[2][3] = {};   // [inverse][pass]: w_R^j
-    Fr* tlo[2][2] = {};    // [inverse][col pass]
-    Fr* thi[2][2] = {};
-    Fr* g_pow = nullptr;        // g^j, j < n
-    Fr* ginv_scaled = nullptr;  // g^-j / n
-    Fr* n_inv = nullptr;        // single element 1/n
+    Fr29P* tw_r[2][3] = {};   // [inverse][pass]: w_R^j
+    Fr29P* tlo[2][2] = {};    // [inverse][col pass]
+    Fr29P* thi[2][2] = {};
+    Fr29P* pre_g = nullptr;        // g^j * 2^266, j < n
+    Fr29P* post_ginv = nullptr;    // (g^-j / n) * 2^256
+    Fr29P* post_one = nullptr;     // [0] = 2^256, [1] = 2^256 / n
 };
 
 static int ntt_bmax() {
@@ -219,16 +250,29 @@ static int ntt_bmax() {
     }();
     return v;
 }
-static uint32_t ntt_tile_elems() {  // LDS tile in field elements (32 B each); default 1024 = 32 KiB -> 5 workgroups per CU (measured best, run 19)
+static uint32_t ntt_tile_elems() {  // LDS tile in field elements (48 B each); default 1024 = 48 KiB -> 3 workgroups per CU
     static uint32_t v = [] {
         const char* e = getenv("BZK_NTT_TILE");
         uint32_t x = e ? (uint32_t)atoi(e) : 1024u;
-        return x < 1024u ? 1024u : (x > 4096u ? 4096u : x);
+        return x < 1024u ? 1024u : (x > 2048u ? 2048u : x);
     }();
     return v;
 }
 
 static Fr host_pow_u64(const Fr& base, uint64_t e) { return host_pow(base, e); }
+
+// device table of `count` powers of `base`, converted to the 29-bit form with the extra factor `c`
+static int32_t build_table29(bzk_ctx* ctx, const Fr& base, uint64_t count, const Fr& c, Fr29P** out) {
+    void* raw = nullptr;
+    BZK_TRY(build_pow_table(ctx, base, count, &raw));
+    void* p = nullptr;
+    BZK_HIP(ctx, hipMalloc(&p, (count ? count : 1) * sizeof(Fr29P)));
+    BZK_LAUNCH(ctx, "ntt_table29", ntt_table29_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (const Fr*)raw, count, c, (Fr29P*)p);
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BZK_HIP(ctx, hipFree(raw));
+    *out = (Fr29P*)p;
+    return BZK_OK;
+}
 
 static int32_t ntt_tables(bzk_ctx* ctx, int log_n, NttTables** out) {
     if (ctx->ntt_tw[log_n][1]) {
@@ -250,36 +294,35 @@ static int32_t ntt_tables(bzk_ctx* ctx, int log_n, NttTables** out) {
     }
     const Fr w = host_omega(log_n), g = host_from_u64(7);
     const Fr dirs[2] = {w, fe_inv<FrParams>(w)};
-    void* p;
+    const Fr c5 = host_from_u64(32), c10 = host_from_u64(1024), c0 = Fr::one();
     for (int d = 0; d < 2; ++d) {
         for (int k = 0; k < T->nb; ++k) {
             const uint64_t R = (uint64_t)1 << T->b[k];
-            BZK_TRY(build_pow_table(ctx, host_pow_u64(dirs[d], n / R), R / 2 ? R / 2 : 1, &p));
-            T->tw_r[d][k] = (Fr*)p;
+            BZK_TRY(build_table29(ctx, host_pow_u64(dirs[d], n / R), R / 2 ? R / 2 : 1, c5, &T->tw_r[d][k]));
         }
         // inter-pass twiddles: pass 0 over the whole transform (N' = n), pass 1 (three-digit plans) over N' = n / R1
         for (int k = 0; k + 1 < T->nb; ++k) {
             const uint64_t np = k == 0 ? n : n >> T->b[0];
             const Fr base = k == 0 ? dirs[d] : host_pow_u64(dirs[d], (uint64_t)1 << T->b[0]);
-            BZK_TRY(build_pow_table(ctx, base, 1024, &p));
-            T->tlo[d][k] = (Fr*)p;
-            BZK_TRY(build_pow_table(ctx, host_pow_u64(base, 1024), (np + 1023) / 1024, &p));
-            T->thi[d][k] = (Fr*)p;
+            BZK_TRY(build_table29(ctx, base, 1024, c5, &T->tlo[d][k]));
+            BZK_TRY(build_table29(ctx, host_pow_u64(base, 1024), (np + 1023) / 1024, c5, &T->thi[d][k]));
         }
     }
-    BZK_TRY(build_pow_table(ctx, g, n, &p));
-    T->g_pow = (Fr*)p;
-    // g^-j / n: scale the table's first-level factors instead of a pass over the table
+    BZK_TRY(build_table29(ctx, g, n, c10, &T->pre_g));
     {
+        // (g^-j / n) * 2^256: the powers table scaled by 1/n, kept as raw Montgomery-256 values
         const Fr gi = fe_inv<FrParams>(g), ninv = fe_inv<FrParams>(host_from_u64(n));
-        BZK_TRY(build_pow_table(ctx, gi, n, &p));
-        T->ginv_scaled = (Fr*)p;
-        BZK_HIP(ctx, hipMalloc(&p, sizeof(Fr)));
-        BZK_HIP(ctx, hipMemcpyAsync(p, &ninv, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-        T->n_inv = (Fr*)p;
-        BZK_LAUNCH(ctx, "ntt_scale", ntt_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, T->ginv_scaled, n,
-                   (const Fr*)T->n_inv, (const Fr*)nullptr);
+        BZK_TRY(build_table29(ctx, gi, n, ninv, &T->post_ginv));
+        Fr two[2] = {Fr::one(), ninv};
+        void* raw = nullptr;
+        void* p = nullptr;
+        BZK_HIP(ctx, hipMalloc(&raw, sizeof two));
+        BZK_HIP(ctx, hipMalloc(&p, 2 * sizeof(Fr29P)));
+        BZK_HIP(ctx, hipMemcpyAsync(raw, two, sizeof two, hipMemcpyHostToDevice, ctx->stream));
+        BZK_LAUNCH(ctx, "ntt_table29", ntt_table29_kernel, dim3(1), dim3(256), 0, (const Fr*)raw, (uint64_t)2, c0, (Fr29P*)p);
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BZK_HIP(ctx, hipFree(raw));
+        T->post_one = (Fr29P*)p;
     }
     ctx->ntt_tw[log_n][1] = T;
     *out = T;
@@ -292,11 +335,10 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
     if (log_n == 0) return BZK_OK;
     NttTables* T;
     BZK_TRY(ntt_tables(ctx, (int)log_n, &T));
-    Fr* data = (Fr*)data_dev;
-    Fr* tmp = data;
+    Fr29P* tmp = nullptr;
     if (T->nb > 1) {
-        BZK_TRY(ws_reserve(ctx, ws_pad(n * sizeof(Fr)) + 512));
-        tmp = (Fr*)ctx->ws;
+        BZK_TRY(ws_reserve(ctx, ws_pad(n * sizeof(Fr29P)) + 512));
+        tmp = (Fr29P*)ctx->ws;
     }
     const int d = inverse ? 1 : 0;
     const uint32_t tile_max = ntt_tile_elems();
@@ -314,11 +356,12 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
         NttPass a;
         memset(&a, 0, sizeof a);
         a.b = b;
+        a.first_pass = k == 0;
         a.final_pass = k == T->nb - 1;
-        a.src = k == 0 ? data : tmp;
-        a.dst = a.final_pass ? data : tmp;
+        a.src = k == 0 ? data_dev : (const void*)tmp;
+        a.dst = a.final_pass ? data_dev : (void*)tmp;
         a.tw_r = T->tw_r[d][k];
-        a.pre = (k == 0 && coset && !inverse) ? T->g_pow : nullptr;
+        a.pre = (k == 0 && coset && !inverse) ? T->pre_g : nullptr;
         uint64_t lanes;  // how many adjacent columns exist
         if (!a.final_pass) {
             a.S = S;
@@ -328,8 +371,8 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
         } else {
             a.R1 = T->nb >= 2 ? 1u << T->b[0] : 1u;
             a.R2 = T->nb == 3 ? 1u << T->b[1] : 1u;
-            a.post = (inverse && coset) ? T->ginv_scaled : nullptr;
-            a.post_c = (inverse && !coset) ? T->n_inv : nullptr;
+            a.post = (inverse && coset) ? T->post_ginv : nullptr;
+            a.post_c = T->post_one + (inverse ? 1 : 0);
             lanes = a.R1;
         }
         int lc = 0;
@@ -338,9 +381,9 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
         const uint64_t tiles = n >> (b + lc);
         if (tiles > 0x7fffffffull) return BZK_E_ARG;
         if (a.final_pass) {
-            BZK_LAUNCH(ctx, "ntt_final", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr) << (b + lc), a);
+            BZK_LAUNCH(ctx, "ntt_final", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr29P) << (b + lc), a);
         } else {
-            BZK_LAUNCH(ctx, "ntt_col", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr) << (b + lc), a);
+            BZK_LAUNCH(ctx, "ntt_col", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr29P) << (b + lc), a);
         }
     }
     return BZK_OK;
@@ -358,9 +401,9 @@ void ntt_free_tables(bzk_ctx* ctx) {
                 if (T->thi[d][k]) (void)hipFree(T->thi[d][k]);
             }
         }
-        (void)hipFree(T->g_pow);
-        (void)hipFree(T->ginv_scaled);
-        (void)hipFree(T->n_inv);
+        (void)hipFree(T->pre_g);
+        (void)hipFree(T->post_ginv);
+        (void)hipFree(T->post_one);
         delete T;
         ctx->ntt_tw[i][1] = nullptr;
     }

@@ -76,6 +76,11 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r26",):
+        for lg in (16, 18, 20, 22, 24):
+            run("ntt", lg)
+        run("ntt", 20, {"BZK_NTT_TILE": "2048"}); run("ntt", 24, {"BZK_NTT_TILE": "2048"})
+        run("h", 20); run("h", 24)
     if what in ("r19",):
         for lg in (16, 18, 20, 22, 24):
             run("ntt", lg)
