@@ -2,7 +2,7 @@
 // loaded, added and handed back to the host.
 //   G1Fast  - Fp in reduced radix (bzk_fp28.cuh): buckets are G1X28 (224 B), bases are converted once per
 //             call to the internal 112-byte form (x, y in 14 x 28-bit limbs, Montgomery 2^392)
-//   G2Plain - Fp2 over the 12 x 32-bit field code (generic XYZZ), bases used in their raw 192-byte form
+//   G2Fast  - the same over Fp2 = Fp28[u]/(u^2+1) with the generic XYZZ formulas (buckets 448 B, bases 224 B)
 #pragma once
 #include "bzk_fp28.cuh"
 
@@ -140,45 +140,5 @@ struct G2Fast {
     }
 };
 static_assert(sizeof(G2A28) == 224 && sizeof(G2X28) == 448, "internal G2 layouts");
-
-struct G2Plain {
-    typedef Fp2Ops HostF;
-    typedef XyzzT<Fp2Ops> Pt;
-    typedef AffineT<Fp2Ops> DevAff;
-    static constexpr int RAW = 192, PACKED = 193;
-    static constexpr bool CONVERT_BASES = false;
-    static constexpr int WSUM_THREADS = 128;  // 128 x 384 B = 48 KiB LDS
-    static constexpr int ACC_OCC = 2;
-    __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2Ops>(); }
-    __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p_in, bool neg) {
-        DevAff p = p_in;
-        if (neg) p.y = Fp2Ops::neg(p.y);
-        xyzz_add_mixed<Fp2Ops>(acc, p);
-    }
-    __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2Ops>(acc, q); }
-    __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return xyzz_mul_u32<Fp2Ops>(p, k); }
-    __device__ static __forceinline__ Pt dbl(const Pt& p) { return xyzz_dbl<Fp2Ops>(p); }
-    __device__ static __forceinline__ DevAff to_dev_affine(const Pt& p) {
-        DevAff a;
-        xyzz_to_affine<Fp2Ops>(p, a);
-        return a;
-    }
-    __device__ static __forceinline__ XyzzT<Fp2Ops> to_std(const Pt& p) { return p; }
-    __device__ static __forceinline__ DevAff convert(const void*, uint64_t) { return DevAff(); }
-    __device__ static __forceinline__ DevAff load(const void* bases, uint32_t idx) {
-        const U128* p = (const U128*)bases + (size_t)idx * 12;
-        DevAff a;
-        Fp* f[4] = {&a.x.c0, &a.x.c1, &a.y.c0, &a.y.c1};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                U128 v = p[3 * e + k];
-                f[e]->l[4 * k] = v.x; f[e]->l[4 * k + 1] = v.y; f[e]->l[4 * k + 2] = v.z; f[e]->l[4 * k + 3] = v.w;
-            }
-        }
-        return a;
-    }
-};
 
 }  // namespace bzk

@@ -53,7 +53,7 @@ def _pmc_traffic(log_n):
         return None
 
 
-def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
+def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: int = 16):
     """Second half of BASELINE.json's metric: Groth16 proofs/s for the 2^20-constraint MPN class =
     UpdateCircuit(L=15, T=3, B=2): 16 signed transactions, 903 037 constraints, 2^20 NTT domain.
     Product code only: host witness/R1CS generator (C++ worker threads), CRS generated on the GPU
@@ -113,6 +113,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
 
     def producer(seed):
         pw = L.MpnWorld(lg, t)
+        pw.set_threads(prod_threads)
         for i in range(2 * n_tx):
             pw.add_account(i, b"p%dacct%d" % (seed, i), ZIESHA, 10 ** 12)
         k = 0
@@ -169,7 +170,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4):
     finished.sort()  # completion times: rate over the last n_pipe completions
     out["proofs_per_s_pipelined"] = round(n_pipe / (finished[n_warm + n_pipe - 1] - finished[n_warm - 1]), 3)
     out["producer_synth_s_mean_under_load"] = round(sum(synth_s) / len(synth_s), 4)
-    out["pipeline"] = (f"{n_prod} host producers (16 worker threads each) -> {len(slots)} prover slots on 1 GPU, "
+    out["pipeline"] = (f"{n_prod} host producers ({prod_threads} worker threads each) -> {len(slots)} prover slots on 1 GPU, "
                        f"{n_pipe} proofs timed")
     stop.set()
     for th in threads:
@@ -296,7 +297,9 @@ def main():
     proofs, rates = None, []
     if not args.no_proofs:
         try:
-            proofs = full_prove_section(ctx, n_prod=6 if world == 1 else 3)
+            # N ranks share the host: split its cores between the ranks' witness producers
+            pt = 16 if world == 1 else max(2, min(16, (os.cpu_count() or 64) // world // 6))
+            proofs = full_prove_section(ctx, n_prod=6, prod_threads=pt)
         except Exception as e:  # the headline MSM line must still be printed
             proofs = {"error": repr(e)}
         if world > 1:
