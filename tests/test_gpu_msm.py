@@ -254,3 +254,30 @@ def test_msm_g1_dedup_2p20_witness_like_property(bzk, co):
     a = bzk.msm_g1_dev(bases, sc, n, dedup=True)
     assert a == bzk.msm_g1_dev(bases, sc, n)
     assert a == co.msm_g1(dev_bytes(bases), dev_bytes(sc), nthreads=co.ncpu())
+
+
+def test_msm_g1_2p22_vs_oracle(bzk, co):
+    """four times the BASELINE size, bit-exact against the oracle (and de-duplicated == plain)"""
+    n = 1 << 22
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(9, 0, n, bases)
+    sc = to_dev(rand_scalars_bytes(n, 22))
+    got = bzk.msm_g1_dev(bases, sc, n)
+    assert got == co.msm_g1(dev_bytes(bases), dev_bytes(sc), nthreads=co.ncpu())
+    assert bzk.msm_g1_dev(bases, sc, n, dedup=True) == got
+
+
+def test_msm_g1_2p24_partition_property(bzk):
+    """the production circuit's size: MSM over 2^24 points == fold of the MSMs over its two halves"""
+    n = 1 << 24
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(10, 0, n, bases)
+    g = torch.Generator(device="cuda").manual_seed(24)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    sc[:, 31] &= 0x3F
+    sc = sc.contiguous().view(-1)
+    whole = bzk.msm_g1_dev(bases, sc, n)
+    h = n // 2
+    lo = bzk.msm_g1_dev(bases[:h * 96], sc[:h * 32], h)
+    hi = bzk.msm_g1_dev(bases[h * 96:], sc[h * 32:], h)
+    assert bzk.g1_sum(lo + hi) == whole
