@@ -207,3 +207,19 @@ def test_deposit_then_withdraw_production_sizes():
     w.push_withdraw(0, ZIESHA, 10 ** 5, ZIESHA, 10, F(4242))
     r = w.withdraw_synthesize(1, F(1))
     assert r.accepted == 1 and r.satisfied
+
+
+def test_deposit_withdraw_production_batches_match_survey_sizes():
+    """(L=15, T=3, B=3): 64 deposits / 64 withdrawals, the production batch shape (src/config/blockchain.rs:22-26);
+    sizes == SURVEY App. B (1 398 277 / 1 394 893 and 2 351 301 / 2 346 957), every constraint satisfied."""
+    w = _world(15, 3, 64)
+    for i in range(64):
+        w.push_deposit(i, ZIESHA, 1000 + i)
+    d = w.deposit_synthesize(3, F(11))
+    assert (d.accepted, d.rejected, d.satisfied) == (64, 0, True)
+    assert (d.n_in, d.n_aux, d.n_constraints) == (6, 1398277, 1394893)
+    for i in range(64):
+        w.push_withdraw(i, ZIESHA, 10 + i, ZIESHA, 1, F(777 + i))
+    r = w.withdraw_synthesize(3, F(12))
+    assert (r.accepted, r.rejected, r.satisfied) == (64, 0, True)
+    assert (r.n_in, r.n_aux, r.n_constraints) == (6, 2351301, 2346957)
