@@ -53,12 +53,13 @@ def _pmc_traffic(log_n):
         return None
 
 
-def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: int = 16):
+def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: int = 16, cpu_baseline: bool = False):
     """Second half of BASELINE.json's metric: Groth16 proofs/s for the 2^20-constraint MPN class =
     UpdateCircuit(L=15, T=3, B=2): 16 signed transactions, 903 037 constraints, 2^20 NTT domain.
     Product code only: host witness/R1CS generator (C++ worker threads), CRS generated on the GPU
     (bzk_groth16_setup), proof on the GPU.  Parity of this path (387 proof bytes == oracle, pairing check)
-    is the job of tests/test_gpu_mpn_prove.py; nothing here touches the oracle."""
+    is the job of tests/test_gpu_mpn_prove.py; the optional cpu_baseline leg below (N = 1, rank 0) times the CPU
+    oracle on one proof and compares its bytes with the GPU's - the oracle is never on the measured path."""
     import threading
     from bazuka_amd import lib as L
     ZIESHA = _fr(1)
@@ -100,6 +101,26 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
         tp.append(t3 - t2)
     out["witness_s"] = round(min(tw), 4)
     out["gpu_prove_s"] = round(min(tp), 4)
+    if cpu_baseline:
+        # The same proof on the host cores with the CPU oracle (kind "port": bellman's algorithms restated; the Rust
+        # prover cannot be built here), ONE proof of the same circuit from the same CRS, witness and (r, s) - which makes
+        # it the bit-exactness check of the timed GPU path as well.  This is the only place bench.py touches oracle/.
+        from oracle import coracle as co
+        d = {"n_in": r.n_in, "n_aux": r.n_aux, "log_m": (r.n_constraints - 1).bit_length(),
+             "a_density": r.view("a_density"), "b_density": r.view("b_density")}
+        for which, key in ((0, "vk"), (1, "h"), (2, "l"), (3, "a"), (4, "b_g1"), (5, "b_g2")):
+            d[key] = ctx.params_read(ph, which)
+        d["n_a"], d["n_b"] = sum(d["a_density"]), sum(d["b_density"])
+        rk, sk = _fr(7 + n_proofs - 1), _fr(9 + n_proofs - 1)
+        gpu_proof = ctx.groth16_prove(ph, *views, rk, sk)
+        t0 = time.perf_counter()
+        want = co.groth16_prove(d, cur.view("z"), cur.view("az"), cur.view("bz"), cur.view("cz"), rk, sk, nthreads=co.ncpu())
+        dt = time.perf_counter() - t0
+        assert want == gpu_proof, "GPU proof bytes differ from the CPU oracle's"
+        out["cpu_baseline"] = {"value": round(1 / dt, 4), "unit": "proofs/s", "cores": co.ncpu(), "kind": "port",
+                               "sample": f"1 proof of the same 16-tx circuit (same CRS, witness, r, s), {dt:.2f} s",
+                               "parity": "bit-exact (387 proof bytes)"}
+        del d
     out["proofs_per_s_gpu_only"] = round(1 / min(tp), 2)
     out["proofs_per_s_serial"] = round(1 / (min(tp) + min(tw)), 3)
     # pipelined: host producers synthesize the next batches (GIL released inside libbzk) while the GPU proves.
@@ -299,7 +320,7 @@ def main():
         try:
             # N ranks share the host: split its cores between the ranks' witness producers
             pt = 16 if world == 1 else max(2, min(16, (os.cpu_count() or 64) // world // 6))
-            proofs = full_prove_section(ctx, n_prod=6, prod_threads=pt)
+            proofs = full_prove_section(ctx, n_prod=6, prod_threads=pt, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # the headline MSM line must still be printed
             proofs = {"error": repr(e)}
         if world > 1:
