@@ -71,7 +71,8 @@ struct PoseidonHostParams {
     const Fr* mds;  // t * t row-major
 };
 PoseidonHostParams poseidon_host_params(int t);              // poseidon.hip
-ZkScalar poseidon_hash(const ZkScalar* vals, int arity);      // `ZkHasher::hash`
+ZkScalar poseidon_hash(const ZkScalar* vals, int arity);      // `ZkHasher::hash` (sparse-partial-round evaluation)
+ZkScalar poseidon_hash_plain(const ZkScalar* vals, int arity);  // the reference's round function, literally
 inline ZkScalar poseidon_hash(const std::vector<ZkScalar>& v) { return poseidon_hash(v.data(), (int)v.size()); }
 
 // ---- SHA3-256 (`hash_to_scalar`, src/zk/mod.rs:218-220)

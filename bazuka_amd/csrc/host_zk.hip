@@ -3,6 +3,11 @@
 #include "host_zk.h"
 
 #include <mutex>
+#include <vector>
+
+#include "bzk_poseidon_opt.h"
+
+#include <mutex>
 
 namespace bzk {
 
@@ -83,7 +88,11 @@ bool ZkScalar::sqrt(ZkScalar* out) const {
 // ------------------------------------------------------------------------------------------------
 // Poseidon (host)
 // ------------------------------------------------------------------------------------------------
-ZkScalar poseidon_hash(const ZkScalar* vals, int arity) {
+// Evaluated in the sparse-partial-round form (bzk_poseidon_opt.h: same function, 2T-1 instead of T^2 products in each
+// of the 56/57 partial rounds); the constants are derived once per width and checked against the plain round function
+// below on a probe vector.  `poseidon_hash_plain` stays: it IS the reference's algorithm (src/zk/poseidon/mod.rs:24-84)
+// and what the circuit gadget's witness follows round by round.
+ZkScalar poseidon_hash_plain(const ZkScalar* vals, int arity) {
     const int t = arity + 1;
     PoseidonHostParams P = poseidon_host_params(t);
     Fr st[17], nw[17];
@@ -107,6 +116,88 @@ ZkScalar poseidon_hash(const ZkScalar* vals, int arity) {
         for (int i = 0; i < t; ++i) st[i] = nw[i];
     }
     return ZkScalar(st[1]);
+}
+
+namespace {
+struct SparseConsts {
+    bool ready = false, usable = false;
+    int rf = 0, rp = 0;
+    std::vector<Fr> flat;  // layout of poseidon_optimize()
+};
+std::mutex g_sparse_mu;
+SparseConsts g_sparse[18];
+
+inline Fr sbox5(const Fr& x) {
+    Fr x2 = fe_sqr<FrParams>(x);
+    return fe_mul<FrParams>(fe_sqr<FrParams>(x2), x);
+}
+Fr hash_sparse(const SparseConsts& S, int t, const Fr* in) {
+    const int half = S.rf / 2;
+    const Fr* rc1 = S.flat.data();
+    const Fr* pre = rc1 + (size_t)half * t;
+    const Fr* part = pre + t;
+    const Fr* dmat = part + (size_t)S.rp * 2 * t;
+    const Fr* rc2 = dmat + (size_t)(t - 1) * (t - 1);
+    const Fr* mds = rc2 + (size_t)half * t;
+    Fr st[17], nw[17];
+    st[0] = Fr::zero();
+    for (int i = 1; i < t; ++i) st[i] = in[i - 1];
+    auto full_round = [&](const Fr* rc) {
+        for (int i = 0; i < t; ++i) st[i] = sbox5(fe_add<FrParams>(st[i], rc[i]));
+        for (int j = 0; j < t; ++j) {
+            Fr acc = Fr::zero();
+            for (int k = 0; k < t; ++k) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(mds[j * t + k], st[k]));
+            nw[j] = acc;
+        }
+        for (int i = 0; i < t; ++i) st[i] = nw[i];
+    };
+    for (int r = 0; r < half; ++r) full_round(rc1 + (size_t)r * t);
+    for (int i = 0; i < t; ++i) st[i] = fe_add<FrParams>(st[i], pre[i]);
+    for (int i = 0; i < S.rp; ++i) {
+        const Fr* c = part + (size_t)i * 2 * t;  // s_i, row0[t], what[t-1]
+        st[0] = fe_add<FrParams>(sbox5(st[0]), c[0]);
+        Fr n0 = Fr::zero();
+        for (int k = 0; k < t; ++k) n0 = fe_add<FrParams>(n0, fe_mul<FrParams>(c[1 + k], st[k]));
+        for (int j = 1; j < t; ++j) st[j] = fe_add<FrParams>(st[j], fe_mul<FrParams>(c[t + j], st[0]));
+        st[0] = n0;
+    }
+    for (int j = 0; j < t - 1; ++j) {
+        Fr acc = Fr::zero();
+        for (int k = 0; k < t - 1; ++k) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(dmat[j * (t - 1) + k], st[k + 1]));
+        nw[j] = acc;
+    }
+    for (int j = 1; j < t; ++j) st[j] = nw[j - 1];
+    for (int r = 0; r < half; ++r) full_round(rc2 + (size_t)r * t);
+    return st[1];
+}
+const SparseConsts& sparse_consts(int t) {
+    std::lock_guard<std::mutex> lk(g_sparse_mu);
+    SparseConsts& S = g_sparse[t];
+    if (S.ready) return S;
+    PoseidonHostParams P = poseidon_host_params(t);
+    S.rf = P.rf;
+    S.rp = P.rp;
+    std::vector<Fr> rc(P.rc, P.rc + (size_t)t * (P.rf + P.rp)), mds(P.mds, P.mds + (size_t)t * t);
+    S.usable = poseidon_optimize(t, P.rf, P.rp, rc, mds, S.flat);
+    if (S.usable) {  // probe: the derived constants must reproduce the plain function
+        ZkScalar probe[16];
+        for (int k = 0; k < t - 1; ++k) probe[k] = ZkScalar(fe_mul<FrParams>(P.mds[k % (t * t)], P.rc[k]));
+        Fr in[16];
+        for (int k = 0; k < t - 1; ++k) in[k] = probe[k].v;
+        S.usable = hash_sparse(S, t, in).equals(poseidon_hash_plain(probe, t - 1).v);
+    }
+    S.ready = true;
+    return S;
+}
+}  // namespace
+
+ZkScalar poseidon_hash(const ZkScalar* vals, int arity) {
+    const int t = arity + 1;
+    const SparseConsts& S = sparse_consts(t);
+    if (!S.usable) return poseidon_hash_plain(vals, arity);  // the plain form is the definition; never hit for the reference's parameters
+    Fr in[16];
+    for (int i = 0; i < arity; ++i) in[i] = vals[i].v;
+    return ZkScalar(hash_sparse(S, t, in));
 }
 
 // ------------------------------------------------------------------------------------------------

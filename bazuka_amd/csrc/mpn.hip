@@ -1186,7 +1186,23 @@ int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]) {
     info[3] = cs.A.col.size();
     info[4] = cs.B.col.size();
     info[5] = cs.C.col.size();
-    info[6] = (uint64_t)(cs.first_unsatisfied() + 1);
+    {   // a_k * b_k == c_k for every row: independent rows, checked by a few threads (0.9 M products for a 16-tx batch)
+        const size_t nrows = cs.num_constraints();
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(8, nrows / 65536));
+        std::vector<long> first((size_t)nt, -1);
+        auto scan = [&](unsigned t) {
+            const size_t lo = nrows * t / nt, hi = nrows * (t + 1) / nt;
+            for (size_t k = lo; k < hi; ++k)
+                if (!fe_mul<FrParams>(cs.az[k], cs.bz[k]).equals(cs.cz[k])) { first[t] = (long)k; return; }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto& x : th) x.join();
+        long bad = -1;
+        for (unsigned t = 0; t < nt && bad < 0; ++t) bad = first[t];
+        info[6] = (uint64_t)(bad + 1);
+    }
     info[7] = r->accepted;
     info[8] = r->rejected;
     return BZK_OK;
