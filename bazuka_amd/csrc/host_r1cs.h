@@ -109,7 +109,23 @@ class ConstraintSystem {
 
     explicit ConstraintSystem(bool record) : record_matrices(record) { inputs.push_back(Fr::one()); }
 
+    // Window mode (witness-only synthesis of one transition by a worker thread): values go straight into a slice of
+    // the parent system's arrays, whose size is known in advance (every transition of a circuit allocates the same
+    // number of variables and constraints).  Writing past the slice is refused and reported through `win_overflow`.
+    Fr *win_aux = nullptr, *win_az = nullptr, *win_bz = nullptr, *win_cz = nullptr;
+    size_t win_n_aux = 0, win_n_con = 0, win_cap_aux = 0, win_cap_con = 0;
+    bool win_overflow = false;
+    void set_window(Fr* a, size_t cap_a, Fr* x, Fr* y, Fr* z, size_t cap_c) {
+        win_aux = a; win_az = x; win_bz = y; win_cz = z;
+        win_cap_aux = cap_a; win_cap_con = cap_c;
+    }
+
     Var alloc(const Fr& v) {
+        if (win_aux) {
+            if (win_n_aux < win_cap_aux) win_aux[win_n_aux] = v;
+            else win_overflow = true;
+            return VAR_AUX | (Var)(win_n_aux++);
+        }
         aux.push_back(v);
         return VAR_AUX | (Var)(aux.size() - 1);
     }
@@ -123,13 +139,24 @@ class ConstraintSystem {
         for (auto& e : lc.t) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(e.second, value(e.first)));
         return acc;
     }
-    size_t num_constraints() const { return az.size(); }
+    size_t num_constraints() const { return win_aux ? win_n_con : az.size(); }
 
     // The caller supplies <A,z>, <B,z>, <C,z> (it computed them while building the witness).  In tracking mode
     // the LCs are recorded (densities, matrices) and, when self_check is set, re-evaluated against the values.
     bool self_check = false;
     long check_failed_at = -1;
     void enforce(const LC& a, const Fr& av, const LC& b, const Fr& bv, const LC& c, const Fr& cv) {
+        if (win_aux) {
+            if (win_n_con < win_cap_con) {
+                win_az[win_n_con] = av;
+                win_bz[win_n_con] = bv;
+                win_cz[win_n_con] = cv;
+            } else {
+                win_overflow = true;
+            }
+            ++win_n_con;
+            return;
+        }
         if (lc_tracking()) {
             if (self_check && check_failed_at < 0 && (!eval(a).equals(av) || !eval(b).equals(bv) || !eval(c).equals(cv)))
                 check_failed_at = (long)az.size();

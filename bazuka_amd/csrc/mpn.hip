@@ -523,38 +523,50 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
         const size_t n = transitions.size();
         size_t size_hint_aux = 0, size_hint_cons = 0;
         {
-            ConstraintSystem probe(false);  // a disabled slot is cheap to synthesize and has the common shape
-            LcModeGuard g(false);
-            Num st0 = {VAR_ONE, state.v};
-            synth_tx(probe, L, T, accepted_fee_token, st0, UpdateTransition::null(L, T));
-            size_hint_aux = probe.aux.size();
-            size_hint_cons = probe.az.size();
+            // every transition of a circuit allocates the same number of variables and constraints: measured once per
+            // (L, T) on a disabled slot
+            static std::mutex mu;
+            static std::map<std::pair<int, int>, std::pair<size_t, size_t>> shape;
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = shape.find({L, T});
+            if (it == shape.end()) {
+                ConstraintSystem probe(false);
+                LcModeGuard g(false);
+                Num st0 = {VAR_ONE, state.v};
+                synth_tx(probe, L, T, accepted_fee_token, st0, UpdateTransition::null(L, T));
+                it = shape.emplace(std::make_pair(L, T), std::make_pair(probe.aux.size(), probe.az.size())).first;
+            }
+            size_hint_aux = it->second.first;
+            size_hint_cons = it->second.second;
         }
-        cs.aux.reserve(cs.aux.size() + n * size_hint_aux + 4096);
-        cs.az.reserve(cs.az.size() + n * size_hint_cons + 4096);
-        cs.bz.reserve(cs.bz.size() + n * size_hint_cons + 4096);
-        cs.cz.reserve(cs.cz.size() + n * size_hint_cons + 4096);
+        // workers write straight into their slice of the final (pinned) arrays: no per-transition buffers, no merge copy
+        const size_t base_aux = cs.aux.size(), base_con = cs.az.size();
+        cs.aux.reserve(base_aux + n * size_hint_aux + 4096);
+        cs.az.reserve(base_con + n * size_hint_cons + 4096);
+        cs.bz.reserve(base_con + n * size_hint_cons + 4096);
+        cs.cz.reserve(base_con + n * size_hint_cons + 4096);
+        cs.aux.resize(base_aux + n * size_hint_aux);
+        cs.az.resize(base_con + n * size_hint_cons);
+        cs.bz.resize(base_con + n * size_hint_cons);
+        cs.cz.resize(base_con + n * size_hint_cons);
         std::vector<Fr> state_in(n + 1);
         state_in[0] = state.v;
         for (size_t t = 0; t < n; ++t) state_in[t + 1] = transitions[t].enabled ? transitions[t].state_after.v : state_in[t];
-        std::vector<std::unique_ptr<ConstraintSystem>> parts(n);
         std::vector<TxOut> outs(n);
+        std::vector<uint8_t> shape_ok(n, 0);
         std::atomic<size_t> next(0);
         auto worker = [&] {
             LcModeGuard g(false);
             for (;;) {
                 const size_t t = next.fetch_add(1);
                 if (t >= n) break;
-                parts[t].reset(new ConstraintSystem(false));
-                if (size_hint_aux) {  // every transition allocates the same number of variables / constraints
-                    parts[t]->aux.reserve(size_hint_aux);
-                    parts[t]->az.reserve(size_hint_cons);
-                    parts[t]->bz.reserve(size_hint_cons);
-                    parts[t]->cz.reserve(size_hint_cons);
-                }
+                ConstraintSystem part(false);
+                part.set_window(cs.aux.data() + base_aux + t * size_hint_aux, size_hint_aux, cs.az.data() + base_con + t * size_hint_cons,
+                                cs.bz.data() + base_con + t * size_hint_cons, cs.cz.data() + base_con + t * size_hint_cons, size_hint_cons);
                 Num st_in = {VAR_ONE, state_in[t]};
                 const auto q0 = std::chrono::steady_clock::now();
-                outs[t] = synth_tx(*parts[t], L, T, accepted_fee_token, st_in, transitions[t]);
+                outs[t] = synth_tx(part, L, T, accepted_fee_token, st_in, transitions[t]);
+                shape_ok[t] = !part.win_overflow && part.win_n_aux == size_hint_aux && part.win_n_con == size_hint_cons;
                 if (getenv("BZK_DEBUG") && t < 3)
                     fprintf(stderr, "[bzk]   tx %zu: %.3f s\n", t, std::chrono::duration<double>(std::chrono::steady_clock::now() - q0).count());
             }
@@ -569,23 +581,20 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
             fprintf(stderr, "[bzk] %d workers: %.3f s\n", nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
         bool chain_ok = true;
         for (size_t t = 0; t < n; ++t) {
-            if (!outs[t].state_out.val.equals(state_in[t + 1])) {
-                if (getenv("BZK_DEBUG")) fprintf(stderr, "[bzk] state chain mismatch at transition %zu (enabled %d)\n", t, (int)transitions[t].enabled);
+            if (!shape_ok[t] || !outs[t].state_out.val.equals(state_in[t + 1])) {
+                if (getenv("BZK_DEBUG")) fprintf(stderr, "[bzk] state chain / shape mismatch at transition %zu (enabled %d)\n", t, (int)transitions[t].enabled);
                 chain_ok = false;
             }
         }
         if (chain_ok) {
-            for (size_t t = 0; t < n; ++t) {
-                ConstraintSystem& p = *parts[t];
-                cs.aux.insert(cs.aux.end(), p.aux.begin(), p.aux.end());
-                cs.az.insert(cs.az.end(), p.az.begin(), p.az.end());
-                cs.bz.insert(cs.bz.end(), p.bz.begin(), p.bz.end());
-                cs.cz.insert(cs.cz.end(), p.cz.begin(), p.cz.end());
-                fee_sum.add_num(Fr::one(), outs[t].final_fee);
-                parts[t].reset();
-            }
+            for (size_t t = 0; t < n; ++t) fee_sum.add_num(Fr::one(), outs[t].final_fee);
             state_wit = {VAR_ONE, state_in[n]};
             done = true;
+        } else {  // back to the state before the workers ran; the sequential walk below redoes everything
+            cs.aux.resize(base_aux);
+            cs.az.resize(base_con);
+            cs.bz.resize(base_con);
+            cs.cz.resize(base_con);
         }
     }
     if (!done) {
