@@ -314,12 +314,20 @@ struct Fp2x28 {
 struct Fp2x28Ops {
     typedef Fp2x28 T;
     static constexpr int LIMBS = 28;
+    // Discipline (k: component < k*p): sums and differences are strongly reduced (< 3p); PRODUCTS are only
+    // carry-normalised (mul: c0 < 5p, c1 < 8p; sqr: c0 < 2p, c1 < 4p) - every consumer tolerates k <= 8 operands:
+    //   mul / sqr  operate on sums of two components: (8+8) * (8+8) = 256 <= 2048, limbs 29 + 29.6 bits <= 59.2
+    //   sub        uses the 12p offset table (subtrahend k < 12)
+    //   is_zero    reduces first
+    // which saves the ~100-instruction quotient-estimate reduction twice per product.
     BZK_HD static T zero() { return {fp28::zero(), fp28::zero()}; }
     BZK_HD static T one() { return {fp28::one(), fp28::zero()}; }
-    BZK_HD static bool is_zero(const T& a) { return fp28::reduced_is_zero(a.c0) && fp28::reduced_is_zero(a.c1); }
+    BZK_HD static bool is_zero(const T& a) {
+        return fp28::reduced_is_zero(fp28::reduce(a.c0)) && fp28::reduced_is_zero(fp28::reduce(a.c1));
+    }
     BZK_HD static T add(const T& a, const T& b) { return {fp28::reduce(fp28::add(a.c0, b.c0)), fp28::reduce(fp28::add(a.c1, b.c1))}; }
     BZK_HD static T sub(const T& a, const T& b) {
-        return {fp28::reduce(fp28::sub<6>(a.c0, b.c0)), fp28::reduce(fp28::sub<6>(a.c1, b.c1))};
+        return {fp28::reduce(fp28::sub<12>(a.c0, b.c0)), fp28::reduce(fp28::sub<12>(a.c1, b.c1))};
     }
     BZK_HD static T neg(const T& a) { return sub(zero(), a); }
     BZK_HD static T dbl(const T& a) { return add(a, a); }
@@ -327,17 +335,17 @@ struct Fp2x28Ops {
         using namespace fp28;
         Fp28 aa = fp28::mul(a.c0, b.c0), bb = fp28::mul(a.c1, b.c1);
         Fp28 s = fp28::mul(fp28::add(a.c0, a.c1), fp28::add(b.c0, b.c1));
-        return {reduce(fp28::sub<3>(aa, bb)), reduce(fp28::sub<3>(fp28::sub<3>(s, aa), bb))};
+        return {norm(fp28::sub<3>(aa, bb)), norm(fp28::sub<3>(fp28::sub<3>(s, aa), bb))};  // k 5, k 8
     }
     BZK_HD static T sqr(const T& a) {  // (c0 + c1)(c0 - c1), 2 c0 c1 : 2 base-field products
         using namespace fp28;
         Fp28 m = fp28::mul(a.c0, a.c1);
-        return {fp28::mul(fp28::add(a.c0, a.c1), fp28::sub<6>(a.c0, a.c1)), reduce(fp28::add(m, m))};
+        return {fp28::mul(fp28::add(a.c0, a.c1), fp28::sub<12>(a.c0, a.c1)), norm(fp28::add(m, m))};  // k 2, k 4
     }
     BZK_HD static T inv(const T& a) {
         using namespace fp28;
         Fp28 d = fp28::inv(reduce(fp28::add(fp28::sqr(a.c0), fp28::sqr(a.c1))));
-        return {fp28::mul(a.c0, d), fp28::mul(reduce(fp28::sub<6>(fp28::zero(), a.c1)), d)};
+        return {fp28::mul(a.c0, d), fp28::mul(reduce(fp28::sub<12>(fp28::zero(), a.c1)), d)};
     }
     BZK_HD static bool eq(const T& a, const T& b) { return is_zero(sub(a, b)); }
 };

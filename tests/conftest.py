@@ -29,7 +29,9 @@ def pr():
 
 @pytest.fixture(scope="session")
 def bzk():
-    """libbzk context on cuda:0 sharing torch's current stream.  GPU tests only - no fallback."""
+    """libbzk context on cuda:0.  torch's default stream has the null handle, for which bzk_ctx_create makes its own
+    non-blocking stream: tests that build inputs with torch kernels synchronise before handing them over.  GPU tests
+    only - no fallback."""
     import torch
     from bazuka_amd import Bzk
     assert torch.cuda.is_available(), "GPU test selected but no GPU visible"

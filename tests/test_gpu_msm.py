@@ -276,6 +276,7 @@ def test_msm_g1_2p24_partition_property(bzk):
     sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
     sc[:, 31] &= 0x3F
     sc = sc.contiguous().view(-1)
+    torch.cuda.synchronize()  # the scalars were produced on torch's stream; libbzk works on its own
     whole = bzk.msm_g1_dev(bases, sc, n)
     h = n // 2
     lo = bzk.msm_g1_dev(bases[:h * 96], sc[:h * 32], h)

@@ -63,6 +63,7 @@ def test_merkle4_full_size_2p24_composition(bzk):
     leaves = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
     leaves[:, 31] &= 0x3F
     leaves = leaves.contiguous()
+    torch.cuda.synchronize()  # the leaves were produced on torch's stream; libbzk works on its own
     root = bzk.merkle4_root_dev(leaves, 12)
     sub = n // 16
     subs = b"".join(bzk.merkle4_root_dev(leaves[i * sub:(i + 1) * sub], 10) for i in range(16))

@@ -76,6 +76,8 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r31",):
+        run("g2", 20); run("g2", 18); run("g1", 20)
     if what in ("r28",):
         for lg in (18, 20, 22, 24):
             run("g1", lg)
