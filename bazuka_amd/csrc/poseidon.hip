@@ -20,6 +20,8 @@
 #include <string.h>
 
 #include <mutex>
+#include <algorithm>
+#include <map>
 #include <vector>
 
 #include "bzk_poseidon29.cuh"
@@ -386,6 +388,46 @@ int32_t poseidon_launch(bzk_ctx* ctx, const void* in_dev, uint32_t arity, uint64
     return BZK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// device-resident dense 4-ary tree with batched updates and proofs (bzk_tree4_*): all levels in ONE heap-order
+// array, node i of depth k at (4^k - 1)/3 + i, leaves at depth log4 - the reference's aux numbering
+// (src/zk/state/mod.rs:355, 382-383) extended by the leaf level.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tree4_fill_kernel(Fr* __restrict__ dst, uint64_t count, Fr v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = v;
+}
+__global__ void __launch_bounds__(256) tree4_scatter_kernel(Fr* __restrict__ level, const uint64_t* __restrict__ idx,
+                                                            const Fr* __restrict__ vals, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) level[idx[i]] = vals[i];
+}
+// parents[j] of the level at `parent`: re-hash from its four children (contiguous in `child`)
+__global__ void __launch_bounds__(128) tree4_rehash_kernel(const Fr* __restrict__ child, Fr* __restrict__ parent,
+                                                           const uint64_t* __restrict__ parents, uint64_t n,
+                                                           const Fr29* __restrict__ consts, int rf, int rp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t p = parents[i];
+    parent[p] = poseidon29_hash<5>(child + 4 * p, consts, rf, rp);
+}
+// out[(q * log4 + layer) * 3 + s] = s-th sibling (index order, self skipped) of query q at depth log4 - layer
+__global__ void __launch_bounds__(256) tree4_prove_kernel(const Fr* __restrict__ nodes, uint32_t log4, const uint64_t* __restrict__ idx,
+                                                          uint64_t n, Fr* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * log4) return;
+    const uint64_t q = t / log4;
+    const uint32_t layer = (uint32_t)(t % log4);  // 0 = leaf level
+    const uint32_t depth = log4 - layer;
+    const uint64_t off = ((((uint64_t)1) << (2 * depth)) - 1) / 3;
+    const uint64_t cur = idx[q] >> (2 * layer);
+    const uint64_t base = cur & ~(uint64_t)3;
+    int s = 0;
+    for (uint64_t j = base; j < base + 4; ++j)
+        if (j != cur) out[t * 3 + s++] = nodes[off + j];
+}
+
 }  // namespace bzk
 
 using namespace bzk;
@@ -462,6 +504,154 @@ int32_t bzk_merkle4_root(bzk_ctx* ctx, const uint8_t* leaves, uint32_t log4, uin
     (void)hipFree(dl);
     (void)hipFree(dn);
     return st;
+}
+
+// ---- device-resident tree (see the kernels above)
+struct bzk_tree4 {
+    uint32_t log4 = 0;
+    Fr* nodes = nullptr;
+    uint64_t n_nodes = 0;
+};
+static inline uint64_t tree4_off(uint32_t depth) { return ((((uint64_t)1) << (2 * depth)) - 1) / 3; }
+
+int32_t bzk_tree4_create(bzk_ctx* ctx, uint32_t log4, const void* leaves_dev, const uint8_t default_leaf[32], bzk_tree4** out) {
+    if (!ctx || !out || log4 == 0 || log4 > 15 || (!leaves_dev && !default_leaf)) return BZK_E_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    bzk_tree4* t = new (std::nothrow) bzk_tree4();
+    if (!t) return BZK_E_ALLOC;
+    t->log4 = log4;
+    t->n_nodes = tree4_off(log4 + 1);
+    if (hipMalloc((void**)&t->nodes, t->n_nodes * sizeof(Fr)) != hipSuccess) {
+        (void)hipGetLastError();
+        delete t;
+        return BZK_E_ALLOC;
+    }
+    auto fail = [&](int32_t st) {
+        (void)hipFree(t->nodes);
+        delete t;
+        return st;
+    };
+    if (leaves_dev) {
+        const uint64_t n_leaves = (uint64_t)1 << (2 * log4);
+        if (hipMemcpyAsync(t->nodes + tree4_off(log4), leaves_dev, n_leaves * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            return fail(BZK_E_DEVICE);
+        for (int k = (int)log4 - 1; k >= 0; --k) {
+            const int32_t st = poseidon_launch(ctx, t->nodes + tree4_off(k + 1), 4, (uint64_t)1 << (2 * k), t->nodes + tree4_off(k));
+            if (st != BZK_OK) return fail(st);
+        }
+    } else {
+        // empty tree: every node of a level equals that level's default (src/zk/state/mod.rs:240-257: the default chain)
+        ZkScalar d;
+        memcpy(d.v.l, default_leaf, 32);
+        for (int k = (int)log4; k >= 0; --k) {
+            const uint64_t cnt = (uint64_t)1 << (2 * k);
+            hipLaunchKernelGGL(tree4_fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, t->nodes + tree4_off(k), cnt, d.v);
+            if (hipGetLastError() != hipSuccess) return fail(BZK_E_DEVICE);
+            ZkScalar c[4] = {d, d, d, d};
+            d = poseidon_hash(c, 4);
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(BZK_E_DEVICE);
+    *out = t;
+    return BZK_OK;
+}
+
+void bzk_tree4_free(bzk_ctx* ctx, bzk_tree4* t) {
+    if (!t) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(t->nodes);
+    delete t;
+}
+
+int32_t bzk_tree4_root(bzk_ctx* ctx, const bzk_tree4* t, uint8_t root[32]) {
+    if (!ctx || !t || !root) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    BZK_HIP(ctx, hipMemcpyAsync(root, t->nodes, 32, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+// Batched `set_data` on leaves (src/zk/state/mod.rs:310-420): write the n leaves, then re-hash, level by level, exactly
+// the parents that have a changed child (each once).  A later entry for the same index wins.
+int32_t bzk_tree4_update(bzk_ctx* ctx, bzk_tree4* t, const uint64_t* idx, const uint8_t* leaves, uint64_t n) {
+    if (!ctx || !t || (n && (!idx || !leaves))) return BZK_E_ARG;
+    if (n == 0) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n_leaves = (uint64_t)1 << (2 * t->log4);
+    std::map<uint64_t, uint64_t> last;  // index -> position of its last occurrence
+    for (uint64_t i = 0; i < n; ++i) {
+        if (idx[i] >= n_leaves) return BZK_E_ARG;
+        last[idx[i]] = i;
+    }
+    std::vector<uint64_t> uidx;
+    std::vector<Fr> uval;
+    uidx.reserve(last.size());
+    uval.reserve(last.size());
+    for (auto& kv : last) {
+        uidx.push_back(kv.first);
+        Fr v;
+        memcpy(v.l, leaves + 32 * kv.second, 32);
+        uval.push_back(v);
+    }
+    const uint64_t m = uidx.size();
+    const void* consts;
+    int rf, rp;
+    BZK_TRY(poseidon_consts_dev(ctx, 5, &consts, &rf, &rp));
+    BZK_TRY(ws_reserve(ctx, ws_pad(m * 8) + ws_pad(m * 32) + 512));
+    WsCursor cur(ctx->ws);
+    uint64_t* d_idx = cur.take<uint64_t>(m);
+    Fr* d_val = cur.take<Fr>(m);
+    BZK_HIP(ctx, hipMemcpyAsync(d_idx, uidx.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(d_val, uval.data(), m * 32, hipMemcpyHostToDevice, ctx->stream));
+    BZK_LAUNCH(ctx, "tree4_scatter", tree4_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, t->nodes + tree4_off(t->log4),
+               (const uint64_t*)d_idx, (const Fr*)d_val, m);
+    std::vector<uint64_t> parents(uidx);  // sorted (map order)
+    for (int k = (int)t->log4 - 1; k >= 0; --k) {
+        for (auto& p : parents) p >>= 2;
+        parents.erase(std::unique(parents.begin(), parents.end()), parents.end());
+        const uint64_t np = parents.size();
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_idx is reused level after level
+        BZK_HIP(ctx, hipMemcpyAsync(d_idx, parents.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
+        BZK_LAUNCH(ctx, "tree4_rehash", tree4_rehash_kernel, dim3((unsigned)((np + 127) / 128)), dim3(128), 0,
+                   (const Fr*)(t->nodes + tree4_off(k + 1)), t->nodes + tree4_off(k), (const uint64_t*)d_idx, np, (const Fr29*)consts, rf, rp);
+    }
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+// Batched `prove` (src/zk/state/mod.rs:218-264): for every index the log4 sibling triples, leaf level first, siblings
+// in index order with the node itself left out.  out: n * log4 * 3 scalars.
+int32_t bzk_tree4_prove(bzk_ctx* ctx, const bzk_tree4* t, const uint64_t* idx, uint64_t n, uint8_t* out) {
+    if (!ctx || !t || (n && (!idx || !out))) return BZK_E_ARG;
+    if (n == 0) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n_leaves = (uint64_t)1 << (2 * t->log4);
+    for (uint64_t i = 0; i < n; ++i)
+        if (idx[i] >= n_leaves) return BZK_E_ARG;
+    const uint64_t cells = n * t->log4;
+    BZK_TRY(ws_reserve(ctx, ws_pad(n * 8) + ws_pad(cells * 96) + 512));
+    WsCursor cur(ctx->ws);
+    uint64_t* d_idx = cur.take<uint64_t>(n);
+    Fr* d_out = cur.take<Fr>(cells * 3);
+    BZK_HIP(ctx, hipMemcpyAsync(d_idx, idx, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    BZK_LAUNCH(ctx, "tree4_prove", tree4_prove_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, (const Fr*)t->nodes, t->log4,
+               (const uint64_t*)d_idx, n, d_out);
+    BZK_HIP(ctx, hipMemcpyAsync(out, d_out, cells * 96, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+// node i of depth k (0 = root, log4 = leaves)
+int32_t bzk_tree4_node(bzk_ctx* ctx, const bzk_tree4* t, uint32_t depth, uint64_t index, uint8_t out[32]) {
+    if (!ctx || !t || !out || depth > t->log4 || index >= ((uint64_t)1 << (2 * depth))) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    BZK_HIP(ctx, hipMemcpyAsync(out, t->nodes + tree4_off(depth) + index, 32, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
 }
 
 }  // extern "C"

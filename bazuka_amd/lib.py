@@ -57,6 +57,12 @@ SIGNATURES = {
     "bzk_mpn_add_key": (_i32, [_vp, _u64, _vp, _u32]),
     "bzk_mpn_root": (_i32, [_vp, _vp]),
     "bzk_mpn_push_tx": (_i32, [_vp, _u64, _u64, _vp, _u64, _vp, _u64]),
+    "bzk_tree4_create": (_i32, [_vp, _u32, _vp, _vp, C.POINTER(_vp)]),
+    "bzk_tree4_free": (None, [_vp, _vp]),
+    "bzk_tree4_root": (_i32, [_vp, _vp, _vp]),
+    "bzk_tree4_update": (_i32, [_vp, _vp, _vp, _vp, _u64]),
+    "bzk_tree4_prove": (_i32, [_vp, _vp, _vp, _u64, _vp]),
+    "bzk_tree4_node": (_i32, [_vp, _vp, _u32, _u64, _vp]),
     "bzk_mpn_push_deposit": (_i32, [_vp, _u64, _vp, _u64]),
     "bzk_mpn_push_withdraw": (_i32, [_vp, _u64, _vp, _u64, _vp, _u64, _vp]),
     "bzk_mpn_deposit_synthesize": (_i32, [_vp, _u32, _vp, _i32, C.POINTER(_vp)]),
@@ -236,6 +242,35 @@ class Bzk:
     def msm_g2_dev(self, bases, scalars, n: int, canonical=False, dedup=False) -> bytes:
         out = C.create_string_buffer(193)
         self._ck(self.lib.bzk_msm_g2_dev(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g2_dev")
+        return out.raw
+
+    # ---- device-resident 4-ary tree
+    def tree4_create(self, log4: int, leaves_dev=None, default_leaf: bytes = bytes(32)):
+        h = C.c_void_p()
+        self._ck(self.lib.bzk_tree4_create(self.h, log4, _ptr(leaves_dev), _ptr(default_leaf), C.byref(h)), "tree4_create")
+        return h
+
+    def tree4_free(self, tree):
+        self.lib.bzk_tree4_free(self.h, tree)
+
+    def tree4_root(self, tree) -> bytes:
+        out = C.create_string_buffer(32)
+        self._ck(self.lib.bzk_tree4_root(self.h, tree, out), "tree4_root")
+        return out.raw
+
+    def tree4_update(self, tree, indices, leaves: bytes):
+        arr = (C.c_uint64 * len(indices))(*indices)
+        self._ck(self.lib.bzk_tree4_update(self.h, tree, arr, _ptr(leaves), len(indices)), "tree4_update")
+
+    def tree4_prove(self, tree, indices, log4: int) -> bytes:
+        arr = (C.c_uint64 * len(indices))(*indices)
+        out = C.create_string_buffer(max(1, len(indices) * log4 * 96))
+        self._ck(self.lib.bzk_tree4_prove(self.h, tree, arr, len(indices), out), "tree4_prove")
+        return out.raw[: len(indices) * log4 * 96]
+
+    def tree4_node(self, tree, depth: int, index: int) -> bytes:
+        out = C.create_string_buffer(32)
+        self._ck(self.lib.bzk_tree4_node(self.h, tree, depth, index, out), "tree4_node")
         return out.raw
 
     def msm_window_count(self, n: int) -> int:

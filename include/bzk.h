@@ -85,6 +85,23 @@ int32_t bzk_poseidon_batch_dev(bzk_ctx* ctx, const void* in_dev, uint32_t arity,
 int32_t bzk_merkle4_root(bzk_ctx* ctx, const uint8_t* leaves, uint32_t log4_size, uint8_t root[32], uint8_t* nodes_opt);
 int32_t bzk_merkle4_root_dev(bzk_ctx* ctx, const void* leaves_dev, uint32_t log4_size, uint8_t root[32], void* nodes_opt_dev);
 
+/* Device-resident tree with batched updates and proofs: the level loop of
+ * `KvStoreStateManager::set_data` (src/zk/state/mod.rs:310-420) and `prove` (218-264) for a dense
+ * `List{log4_size, Scalar}` kept in HBM: (4^(log4+1)-1)/3 scalars, all levels in heap order (node i of depth k at
+ * (4^k-1)/3 + i, leaves at depth log4).  log4 <= 15 (4^15 leaves = 46 GB: an account tree of the production size fits).
+ *   create : from 4^log4 leaves in device memory, or (leaves_dev NULL) the empty tree of `default_leaf`
+ *   update : n (index, leaf) pairs from host memory; re-hashes each affected parent once per level; a later entry
+ *            for the same index wins
+ *   prove  : for each of n indices log4 sibling triples, leaf level first, index order, self left out
+ *            (= the `Vec<[ZkScalar; 3]>` the circuits take); out = n * log4 * 96 bytes */
+typedef struct bzk_tree4 bzk_tree4;
+int32_t bzk_tree4_create(bzk_ctx* ctx, uint32_t log4_size, const void* leaves_dev, const uint8_t default_leaf[32], bzk_tree4** out);
+void    bzk_tree4_free(bzk_ctx* ctx, bzk_tree4* tree);
+int32_t bzk_tree4_root(bzk_ctx* ctx, const bzk_tree4* tree, uint8_t root[32]);
+int32_t bzk_tree4_update(bzk_ctx* ctx, bzk_tree4* tree, const uint64_t* indices, const uint8_t* leaves, uint64_t n);
+int32_t bzk_tree4_prove(bzk_ctx* ctx, const bzk_tree4* tree, const uint64_t* indices, uint64_t n, uint8_t* out);
+int32_t bzk_tree4_node(bzk_ctx* ctx, const bzk_tree4* tree, uint32_t depth, uint64_t index, uint8_t out[32]);
+
 /* ---- K3: radix-2 NTT over Fr -----------------------------------------------------------------
  * bellman 0.14 `EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}` (third-party crate; reached
  * from `create_random_proof`, src/mpn/circuits/test.rs:135,175,215).  In place, natural order in and
