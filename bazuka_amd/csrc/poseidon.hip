@@ -601,25 +601,34 @@ int32_t bzk_tree4_update(bzk_ctx* ctx, bzk_tree4* t, const uint64_t* idx, const 
     const void* consts;
     int rf, rp;
     BZK_TRY(poseidon_consts_dev(ctx, 5, &consts, &rf, &rp));
-    BZK_TRY(ws_reserve(ctx, ws_pad(m * 8) + ws_pad(m * 32) + 512));
+    // parent lists of every level, computed on the host (sorted unique), uploaded in one piece
+    std::vector<uint64_t> all(uidx);  // level log4 (the leaves) first
+    std::vector<uint64_t> level_off{0}, level_cnt{m};
+    {
+        std::vector<uint64_t> parents(uidx);  // sorted (map order)
+        for (int k = (int)t->log4 - 1; k >= 0; --k) {
+            for (auto& p : parents) p >>= 2;
+            parents.erase(std::unique(parents.begin(), parents.end()), parents.end());
+            level_off.push_back(all.size());
+            level_cnt.push_back(parents.size());
+            all.insert(all.end(), parents.begin(), parents.end());
+        }
+    }
+    BZK_TRY(ws_reserve(ctx, ws_pad(all.size() * 8) + ws_pad(m * 32) + 512));
     WsCursor cur(ctx->ws);
-    uint64_t* d_idx = cur.take<uint64_t>(m);
+    uint64_t* d_idx = cur.take<uint64_t>(all.size());
     Fr* d_val = cur.take<Fr>(m);
-    BZK_HIP(ctx, hipMemcpyAsync(d_idx, uidx.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(d_idx, all.data(), all.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     BZK_HIP(ctx, hipMemcpyAsync(d_val, uval.data(), m * 32, hipMemcpyHostToDevice, ctx->stream));
     BZK_LAUNCH(ctx, "tree4_scatter", tree4_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, t->nodes + tree4_off(t->log4),
                (const uint64_t*)d_idx, (const Fr*)d_val, m);
-    std::vector<uint64_t> parents(uidx);  // sorted (map order)
-    for (int k = (int)t->log4 - 1; k >= 0; --k) {
-        for (auto& p : parents) p >>= 2;
-        parents.erase(std::unique(parents.begin(), parents.end()), parents.end());
-        const uint64_t np = parents.size();
-        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_idx is reused level after level
-        BZK_HIP(ctx, hipMemcpyAsync(d_idx, parents.data(), np * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int k = (int)t->log4 - 1, lv = 1; k >= 0; --k, ++lv) {
+        const uint64_t np = level_cnt[lv];
         BZK_LAUNCH(ctx, "tree4_rehash", tree4_rehash_kernel, dim3((unsigned)((np + 127) / 128)), dim3(128), 0,
-                   (const Fr*)(t->nodes + tree4_off(k + 1)), t->nodes + tree4_off(k), (const uint64_t*)d_idx, np, (const Fr29*)consts, rf, rp);
+                   (const Fr*)(t->nodes + tree4_off(k + 1)), t->nodes + tree4_off(k), (const uint64_t*)(d_idx + level_off[lv]), np,
+                   (const Fr29*)consts, rf, rp);
     }
-    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `all` / `uval` are pageable host memory: keep them alive until here
     return BZK_OK;
 }
 
