@@ -201,10 +201,14 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
     const uint32_t i = lo;
     const uint32_t cnt = count_sorted[i];
     const uint32_t k = t - tbase[i];
-    if (k * seg >= cnt && !(cnt == 0 && k == 0)) return;  // beyond the last task
+    // a bucket of more than `seg` entries is cut into nt = ceil(cnt / seg) runs of EQUAL length q = ceil(cnt / nt)
+    // (not seg, seg, ..., remainder): neighbouring lanes - the tasks of one bucket - finish together
+    const uint32_t nt = cnt <= seg ? 1u : (cnt + seg - 1) / seg;
+    const uint32_t q = (cnt + nt - 1) / nt;
+    if (k >= nt) return;  // beyond the last task
     const uint32_t g = order[i];
-    const uint32_t s = start[g] + k * seg;
-    const uint32_t len = cnt - k * seg < seg ? cnt - k * seg : seg;
+    const uint32_t s = start[g] + k * q;
+    const uint32_t len = k * q >= cnt ? 0u : (cnt - k * q < q ? cnt - k * q : q);  // empty bucket: writes the identity
     typename C::Pt acc = C::identity();
     for (uint32_t j = 0; j < len; ++j) {
         const uint32_t v = vals[s + j];
@@ -671,8 +675,19 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     // few over-full buckets of a degenerate top window do not set the kernel's critical path at small n
     uint32_t seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n / half + 1)));
     if (table) seg = 64;  // shared buckets are all heavily populated: short runs keep every SIMD busy
+    // few, heavily populated buckets (a rank of a window-sharded MSM owns 2 windows of 2^23 points: 65 536 buckets of
+    // 256 entries): one task per bucket would leave the machine under-filled and the kernel as long as its longest
+    // run.  Cut the runs so that there are at least ~4 tasks per resident lane (131 072 lanes at 2 waves/SIMD).
+    auto enough_tasks = [&](uint32_t sg, uint64_t len_, uint32_t nb_) {
+        const uint64_t target = 4ull * 131072;
+        if (nb_ >= target || len_ / sg + nb_ >= target) return sg;
+        return (uint32_t)std::max<uint64_t>(32, len_ / (target - nb_));
+    };
+    if (!table) seg = std::min(seg, enough_tasks(seg, len_max, nb_max));
     const uint32_t seg_dd = 8;  // group sums are latency-bound (a 7 k-member group of bits is one bucket): short serial runs
-    const uint64_t t_cap = std::max<uint64_t>((uint64_t)nb_max + len_max / seg + 1, dedup ? (uint64_t)m_max + n / seg_dd + 1 : 0);
+    // capacity of the per-task partial sums: sized for the shortest run length any later adjustment can pick (32; 64 for tables)
+    const uint64_t t_cap = std::max<uint64_t>((uint64_t)nb_max + len_max / std::min<uint32_t>(seg, 32u) + 1,
+                                              dedup ? (uint64_t)m_max + n / seg_dd + 1 : 0);
     size_t total = 0;
     total += 4 * ws_pad(len_max * 4);                 // keys, vals, keys_sorted, vals_sorted
     total += 7 * ws_pad((size_t)nb_alloc * 4);        // start, count, count_sorted, iota, order, ntask, tbase
@@ -784,6 +799,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         n_eff = G;
         scal_eff = scal2;
         seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n_eff / half + 1)));
+        seg = std::min(seg, enough_tasks(seg, (uint64_t)group * n_eff, nb_max));
     }
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;

@@ -23,6 +23,12 @@ def child(mode, log_n):
         ms = timeit(lambda: ctx.msm_g1_dev(bases, sc, n))
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_g1_dev(bases, sc, n); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
         print(json.dumps({"mode": mode, "log_n": log_n, "c": os.environ.get("BZK_MSM_C"), "chunk": os.environ.get("BZK_MSM_CHUNK"), "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 1), "prof": prof}))
+    elif mode == "g1win":  # what one rank of an 8-GPU window-sharded MSM does: 2 windows over 2^log_n points
+        bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
+        W = ctx.msm_window_count(n); w1 = max(1, W // int(os.environ.get("SHARDS", "8")))
+        ms = timeit(lambda: ctx.msm_g1_windows_dev(bases, sc, n, 0, w1))
+        ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_g1_windows_dev(bases, sc, n, 0, w1); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
+        print(json.dumps({"mode": mode, "log_n": log_n, "windows": [0, w1], "of": W, "ms": round(ms, 3), "prof": prof}))
     elif mode == "g1tab":
         bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
         t0 = time.perf_counter(); tab = ctx.msm_table_build(bases, n); tb = time.perf_counter() - t0
@@ -76,6 +82,8 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r35",):
+        run("g1", 20); run("g1", 22); run("g1", 24); run("g1win", 23); run("g1win", 22, {"SHARDS": "4"}); run("g1win", 21, {"SHARDS": "2"})
     if what in ("r31",):
         run("g2", 20); run("g2", 18); run("g1", 20)
     if what in ("r28",):
