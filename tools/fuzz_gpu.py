@@ -1,0 +1,96 @@
+"""Differential fuzzing of the C ABI against the CPU oracle on random shapes (run on a GPU box):
+MSM G1/G2 (plain, de-duplicated, window partitions, witness-like / degenerate scalar mixes, repeated and negated bases),
+NTT (all four modes, every log size up to 14), Poseidon batches (every arity), 4-ary trees, tree updates.
+usage: python tools/fuzz_gpu.py [seconds=60] [seed=1]"""
+import json, os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bazuka_amd import Bzk
+from oracle import coracle as co, pyref as pr
+from util import fr_bytes, fr_list, rand_scalars_bytes
+
+
+def scalars(rnd, n):
+    mode = rnd.randrange(5)
+    if mode == 0:
+        return rand_scalars_bytes(n, rnd.randrange(1 << 30))
+    base = fr_list(max(1, n // rnd.choice((1, 2, 3, 50))), rnd.randrange(1 << 30))
+    sc = [base[rnd.randrange(len(base))] for _ in range(n)]
+    if mode >= 2:
+        for i in range(0, n, rnd.choice((2, 5, 9))):
+            sc[i] = rnd.choice((0, 1, 2, pr.R_MOD - 1, 1 << 15, (1 << 16) - 1, 1 << 254))
+    if mode == 4:
+        sc = [sc[0]] * n
+    return fr_bytes(sc)
+
+
+def neg_y(raw, size):
+    half = size // 2
+    if size == 96:
+        return raw[:48] + pr.fp_to_mont_bytes(-pr.fp_from_mont_bytes(raw[48:96]))
+    y0, y1 = pr.fp_from_mont_bytes(raw[96:144]), pr.fp_from_mont_bytes(raw[144:192])
+    return raw[:96] + pr.fp_to_mont_bytes(-y0) + pr.fp_to_mont_bytes(-y1)
+
+
+def main(seconds=60, seed=1):
+    import torch
+    torch.cuda.init()  # torch bundles its own HIP runtime: let it initialise before libbzk's (system ROCm) does
+    rnd = random.Random(seed)
+    ctx = Bzk(0)
+    nt = co.ncpu()
+    counts = {}
+    t_end = time.time() + seconds
+    while time.time() < t_end:
+        kind = rnd.choice(("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows"))
+        counts[kind] = counts.get(kind, 0) + 1
+        if kind in ("msm_g1", "msm_g2", "windows"):
+            g2 = kind == "msm_g2"
+            size = 192 if g2 else 96
+            n = rnd.choice((1, 2, 3, 7, 64, 300, 1000, 4096, 5000, 20000)) if not g2 else rnd.choice((1, 5, 300, 4096, 6000))
+            bases = bytearray((co.g2_bases if g2 else co.g1_bases)(rnd.randrange(1 << 30), 0, n, nthreads=nt))
+            if n >= 4 and rnd.random() < 0.5:  # repeated point, point and its negative
+                bases[size:2 * size] = bases[0:size]
+                bases[3 * size:4 * size] = neg_y(bytes(bases[2 * size:3 * size]), size)
+            bases = bytes(bases)
+            sc = scalars(rnd, n)
+            want = (co.msm_g2 if g2 else co.msm_g1)(bases, sc, nthreads=nt)
+            f = ctx.msm_g2 if g2 else ctx.msm_g1
+            assert f(bases, sc) == want, (kind, n, "plain")
+            assert f(bases, sc, dedup=True) == want, (kind, n, "dedup")
+            if kind == "windows" and n >= 2:
+                import torch
+                db = torch.frombuffer(bytearray(bases), dtype=torch.uint8).cuda(); ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+                W = ctx.msm_window_count(n)
+                cut = sorted({0, W, *[rnd.randrange(W + 1) for _ in range(rnd.randrange(1, 4))]})
+                parts = b"".join(ctx.msm_g1_windows_dev(db, ds, n, a, b) for a, b in zip(cut, cut[1:]))
+                assert ctx.g1_sum(parts) == want, (kind, n, cut)
+        elif kind == "ntt":
+            lg = rnd.randrange(0, 15)
+            data = rand_scalars_bytes(1 << lg, rnd.randrange(1 << 30))
+            inv, cs = rnd.random() < 0.5, rnd.random() < 0.5
+            assert ctx.ntt(data, lg, inv, cs) == co.ntt(data, lg, inv, cs, nthreads=nt), (lg, inv, cs)
+        elif kind == "poseidon":
+            ar = rnd.randrange(1, 17)
+            n = rnd.choice((1, 2, 63, 64, 65, 1000))
+            inp = rand_scalars_bytes(n * ar, rnd.randrange(1 << 30))
+            assert ctx.poseidon_batch(inp, ar) == co.poseidon_batch(inp, ar, nthreads=nt), (ar, n)
+        else:
+            log4 = rnd.randrange(1, 6)
+            leaves = rand_scalars_bytes(4 ** log4, rnd.randrange(1 << 30))
+            root = co.merkle4_root(leaves, log4, nthreads=nt)
+            assert ctx.merkle4_root(leaves, log4) == root
+            import torch
+            tree = ctx.tree4_create(log4, torch.frombuffer(bytearray(leaves), dtype=torch.uint8).cuda())
+            idx = [rnd.randrange(4 ** log4) for _ in range(rnd.randrange(1, 40))]
+            vals = rand_scalars_bytes(len(idx), rnd.randrange(1 << 30))
+            ctx.tree4_update(tree, idx, vals)
+            host = bytearray(leaves)
+            for k, i in enumerate(idx):
+                host[32 * i:32 * i + 32] = vals[32 * k:32 * k + 32]
+            assert ctx.tree4_root(tree) == co.merkle4_root(bytes(host), log4, nthreads=nt)
+            ctx.tree4_free(tree)
+    print(json.dumps({"seconds": seconds, "seed": seed, "cases": counts, "total": sum(counts.values()), "mismatches": 0}))
+
+
+if __name__ == "__main__":
+    main(*(int(x) for x in sys.argv[1:]))
