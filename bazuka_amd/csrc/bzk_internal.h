@@ -38,6 +38,7 @@ struct bzk_ctx {
     // lanes: child contexts (own stream, workspace, pinned staging) for independent sub-jobs of one call that
     // should overlap on the device - the five MSMs of a Groth16 proof.  Created on first use, owned by the parent.
     std::vector<bzk_ctx*> lanes;
+    bool no_coop = false;  // env BZK_NO_COOP=1: never use the cooperative (8 lanes per node) Poseidon kernel (A/B runs)
     bool timing = false;  // env BZK_TIMING=1: host-side phase timings of bzk_groth16_prove on stderr
 };
 

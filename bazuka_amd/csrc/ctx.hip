@@ -123,6 +123,7 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     if (const char* e = getenv("BZK_MSM_CHUNK")) ctx->msm_chunk_override = atoi(e);
     if (const char* e = getenv("BZK_DEBUG")) ctx->debug = atoi(e) != 0;
     if (const char* e = getenv("BZK_TIMING")) ctx->timing = atoi(e) != 0;
+    if (const char* e = getenv("BZK_NO_COOP")) ctx->no_coop = atoi(e) != 0;
     *out = ctx;
     return BZK_OK;
 }

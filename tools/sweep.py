@@ -82,6 +82,8 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r39",):
+        run("tree", 24); run("tree", 20); run("tree", 16); run("tree", 12)
     if what in ("r36",):
         run("g1", 20); run("g1", 22); run("g2", 20); run("g1win", 23)
     if what in ("r35",):
