@@ -33,8 +33,11 @@ namespace bzk {
 // parameters
 // ------------------------------------------------------------------------------------------------
 static int msm_pick_c(uint64_t n) {
+    // c = floor(log2(1.6 n)) - 4: the step to the next window size is taken at ~0.62 * 2^k rather than at 2^k - a proof's
+    // witness queries (0.7 - 0.9 M points) run 7 % faster with c = 16 than with 15 (profiles/r01_run40...)
+    const uint64_t n16 = n + n / 2 + n / 10;
     int lg = 0;
-    while (((uint64_t)1 << (lg + 1)) <= n) ++lg;
+    while (((uint64_t)1 << (lg + 1)) <= n16) ++lg;
     int c = lg - 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
