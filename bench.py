@@ -127,7 +127,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     # Each producer owns an independent account tree - the shape of Bazuka's own work distribution, where a
     # prover holds several independent MpnWork items at once (src/mpn/mod.rs:79-107).
     import queue
-    n_warm, n_pipe = 8, 24
+    n_warm, n_pipe = 12, 48
     synth_s = []
     q = queue.Queue(maxsize=4)
     stop = threading.Event()
