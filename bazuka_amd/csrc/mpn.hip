@@ -16,6 +16,7 @@
 #include <chrono>
 #include <map>
 #include <thread>
+#include <tuple>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -611,6 +612,84 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
 }
 
 // ------------------------------------------------------------------------------------------------
+// Per-transaction bodies of a circuit's main loop, run either sequentially on `cs` (matrix-recording mode, one thread,
+// or a witness that does not follow the predicted state chain) or - witness-only mode - by worker threads that write
+// straight into their slice of the final arrays (ConstraintSystem::set_window).  Every body allocates the same number
+// of variables and constraints (`shape`, measured once per circuit shape by the caller); the state entering
+// transaction i is predicted from the witness builder's `state_after` chain and checked against what the body
+// computes, so a bad witness falls back to the sequential walk and fails at exactly the sequential constraint.
+//   body(cs, i, state_in) -> state_out
+// ------------------------------------------------------------------------------------------------
+// shape (variables, constraints) of one per-transaction body, measured once per (circuit kind, L, T) on a scratch system
+template <class Probe>
+static std::pair<size_t, size_t> body_shape(int kind, int L, int T, Probe probe) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, std::pair<size_t, size_t>> cache;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(std::make_tuple(kind, L, T));
+        if (it != cache.end()) return it->second;
+    }
+    ConstraintSystem scratch(false);
+    const std::pair<size_t, size_t> sh = probe(scratch);
+    std::lock_guard<std::mutex> lk(mu);
+    cache[std::make_tuple(kind, L, T)] = sh;
+    return sh;
+}
+// predicted state entering each transaction (and leaving the last): the witness builder's `state_after` chain
+template <class Tr>
+static std::vector<Fr> chain_states(const ZkScalar& state, const std::vector<Tr>& trs) {
+    std::vector<Fr> st(trs.size() + 1);
+    st[0] = state.v;
+    for (size_t t = 0; t < trs.size(); ++t) st[t + 1] = trs[t].enabled ? trs[t].state_after.v : st[t];
+    return st;
+}
+
+template <class Body>
+static Num run_tx_bodies(ConstraintSystem& cs, int nthreads, size_t n, std::pair<size_t, size_t> shape, const Num& state0,
+                         const std::vector<Fr>& state_in, Body body) {
+    if (!lc_tracking() && nthreads > 1 && n > 1 && shape.first && shape.second) {
+        const size_t base_aux = cs.aux.size(), base_con = cs.az.size();
+        cs.aux.resize(base_aux + n * shape.first);
+        cs.az.resize(base_con + n * shape.second);
+        cs.bz.resize(base_con + n * shape.second);
+        cs.cz.resize(base_con + n * shape.second);
+        std::vector<uint8_t> ok(n, 0);
+        std::atomic<size_t> next(0);
+        auto worker = [&] {
+            LcModeGuard g(false);
+            for (;;) {
+                const size_t t = next.fetch_add(1);
+                if (t >= n) break;
+                ConstraintSystem part(false);
+                part.set_window(cs.aux.data() + base_aux + t * shape.first, shape.first, cs.az.data() + base_con + t * shape.second,
+                                cs.bz.data() + base_con + t * shape.second, cs.cz.data() + base_con + t * shape.second, shape.second);
+                const Num st_in = {VAR_ONE, state_in[t]};
+                const Num st_out = body(part, t, st_in);
+                ok[t] = !part.win_overflow && part.win_n_aux == shape.first && part.win_n_con == shape.second &&
+                        st_out.val.equals(state_in[t + 1]);
+            }
+        };
+        std::vector<std::thread> th;
+        const int nt = (int)std::min<size_t>((size_t)nthreads, n);
+        for (int i = 1; i < nt; ++i) th.emplace_back(worker);
+        worker();
+        for (auto& x : th) x.join();
+        bool all_ok = true;
+        for (size_t t = 0; t < n; ++t) all_ok = all_ok && ok[t];
+        if (getenv("BZK_DEBUG")) fprintf(stderr, "[bzk] run_tx_bodies: %zu bodies on %d threads, shape (%zu, %zu): %s\n", n, nt, shape.first, shape.second, all_ok ? "ok" : "MISMATCH -> sequential");
+        if (all_ok) return {VAR_ONE, state_in[n]};
+        cs.aux.resize(base_aux);
+        cs.az.resize(base_con);
+        cs.bz.resize(base_con);
+        cs.cz.resize(base_con);
+    }
+    Num st = state0;
+    for (size_t i = 0; i < n; ++i) st = body(cs, i, st);
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------
 // reveal gadget (src/zk/groth16/gadgets/reveal/mod.rs:13-61) for the one shape the MPN circuits use:
 // List{log4 = B, Struct[k scalars]}: a Poseidon of the k fields per item, then a 4-ary Poseidon tree
 // ------------------------------------------------------------------------------------------------
@@ -693,7 +772,8 @@ static ZkScalar deposit_aux(const std::vector<DepositTransition>& trs, int log4_
 }
 
 static void synthesize_deposit(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
-                               const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<DepositTransition>& trs) {
+                               const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<DepositTransition>& trs,
+                               int nthreads = 1) {
     Num commitment_wit = num_alloc(cs, commitment.v);
     num_inputize(cs, commitment_wit);
     Num height_wit = num_alloc(cs, fr_from_u64(height));
@@ -719,7 +799,7 @@ static void synthesize_deposit(ConstraintSystem& cs, int L, int T, const ZkScala
     }
     Number tx_root = g_reveal_batch(cs, children);
     cs.enforce(LC::of(aux_wit.var), aux_wit.val, LC::one(), Fr::one(), tx_root.lc, tx_root.val);
-    for (size_t i = 0; i < trs.size(); ++i) {
+    auto body = [&](ConstraintSystem& cs, size_t i, const Num& state_wit) -> Num {
         const DepositTransition& tr = trs[i];
         const TxWit& tw = wits[i];
         UInt tx_index = UInt::alloc(cs, fr_from_u64(tr.account_index), 2 * L);
@@ -749,8 +829,16 @@ static void synthesize_deposit(ConstraintSystem& cs, int L, int T, const ZkScala
         Number new_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce), Number::from(tw.pub_key.x),
                                           Number::from(tw.pub_key.y), new_balances_hash});
         Number next_state_wit = g_calc_root4(cs, tx_index, new_hash, proof);
-        state_wit = mux(cs, tw.enabled, Number::from(state_wit), next_state_wit);
-    }
+        return mux(cs, tw.enabled, Number::from(state_wit), next_state_wit);
+    };
+    state_wit = run_tx_bodies(cs, nthreads, trs.size(), body_shape(0, L, T, [&](ConstraintSystem& pcs) {
+                                  LcModeGuard g(false);
+                                  const Num st0 = {VAR_ONE, state.v};
+                                  const size_t a0 = pcs.aux.size(), c0 = pcs.az.size();
+                                  body(pcs, 0, st0);
+                                  return std::make_pair(pcs.aux.size() - a0, pcs.az.size() - c0);
+                              }),
+                              state_wit, chain_states(state, trs), body);
     cs.enforce(LC::of(state_wit.var), state_wit.val, LC::one(), Fr::one(), LC::of(claimed_next.var), claimed_next.val);
     cs.finalize();
 }
@@ -818,7 +906,8 @@ static ZkScalar withdraw_aux(const std::vector<WithdrawTransition>& trs, int log
 }
 
 static void synthesize_withdraw(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
-                                const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<WithdrawTransition>& trs) {
+                                const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<WithdrawTransition>& trs,
+                                int nthreads = 1) {
     Num commitment_wit = num_alloc(cs, commitment.v);
     num_inputize(cs, commitment_wit);
     Num height_wit = num_alloc(cs, fr_from_u64(height));
@@ -852,7 +941,7 @@ static void synthesize_withdraw(ConstraintSystem& cs, int L, int T, const ZkScal
     }
     Number tx_root = g_reveal_batch(cs, children);
     cs.enforce(LC::of(aux_wit.var), aux_wit.val, LC::one(), Fr::one(), tx_root.lc, tx_root.val);
-    for (size_t i = 0; i < trs.size(); ++i) {
+    auto body = [&](ConstraintSystem& cs, size_t i, const Num& state_wit) -> Num {
         const WithdrawTransition& tr = trs[i];
         const TxWit& tw = wits[i];
         UInt tx_index = UInt::alloc(cs, fr_from_u64(tr.account_index), 2 * L);
@@ -891,8 +980,16 @@ static void synthesize_withdraw(ConstraintSystem& cs, int L, int T, const ZkScal
         Number new_hash = g_poseidon(cs, {Number::from(src_tx_nonce), Number::from(src_withdraw_nonce).plus(Number::constant(Fr::one())),
                                           Number::from(tw.pub_key.x), Number::from(tw.pub_key.y), balance_final_root});
         Number next_state_wit = g_calc_root4(cs, tx_index, new_hash, proof);
-        state_wit = mux(cs, tw.enabled, Number::from(state_wit), next_state_wit);
-    }
+        return mux(cs, tw.enabled, Number::from(state_wit), next_state_wit);
+    };
+    state_wit = run_tx_bodies(cs, nthreads, trs.size(), body_shape(1, L, T, [&](ConstraintSystem& pcs) {
+                                  LcModeGuard g(false);
+                                  const Num st0 = {VAR_ONE, state.v};
+                                  const size_t a0 = pcs.aux.size(), c0 = pcs.az.size();
+                                  body(pcs, 0, st0);
+                                  return std::make_pair(pcs.aux.size() - a0, pcs.az.size() - c0);
+                              }),
+                              state_wit, chain_states(state, trs), body);
     cs.enforce(LC::of(state_wit.var), state_wit.val, LC::one(), Fr::one(), LC::of(claimed_next.var), claimed_next.val);
     cs.finalize();
 }
@@ -1108,7 +1205,7 @@ int32_t bzk_mpn_deposit_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_
         std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
         LcModeGuard guard(record_matrices != 0);
         r->cs.self_check = record_matrices != 0;
-        synthesize_deposit(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs);
+        synthesize_deposit(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs, w->threads);
         if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
         r->accepted = accepted;
         r->rejected = rejected;
@@ -1137,7 +1234,7 @@ int32_t bzk_mpn_withdraw_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8
         std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
         LcModeGuard guard(record_matrices != 0);
         r->cs.self_check = record_matrices != 0;
-        synthesize_withdraw(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs);
+        synthesize_withdraw(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs, w->threads);
         if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
         r->accepted = accepted;
         r->rejected = rejected;

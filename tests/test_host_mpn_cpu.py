@@ -223,3 +223,27 @@ def test_deposit_withdraw_production_batches_match_survey_sizes():
     r = w.withdraw_synthesize(3, F(12))
     assert (r.accepted, r.rejected, r.satisfied) == (64, 0, True)
     assert (r.n_in, r.n_aux, r.n_constraints) == (6, 2351301, 2346957)
+
+
+def test_witness_mode_equals_tracking_mode_for_all_three_circuits():
+    """The fast witness-only synthesis (worker threads writing slices of the final arrays) and the sequential
+    matrix-recording synthesis of the SAME batches emit identical z, A.z, B.z, C.z."""
+    def run(record):
+        w = _world(6, 2, 8)
+        w.add_key(20, b"fresh")
+        out = []
+        for i in range(4):
+            w.push_tx(i, 4 + i, ZIESHA, 10 + i, ZIESHA, i)
+        out.append(w.update_synthesize(1, F(1), ZIESHA, record_matrices=record))
+        w.push_deposit(0, ZIESHA, 1000)
+        w.push_deposit(20, ZIESHA, 5)
+        w.push_deposit(1, F(9), 5)
+        out.append(w.deposit_synthesize(1, F(2), record_matrices=record))
+        w.push_withdraw(0, ZIESHA, 400, ZIESHA, 2, F(4242))
+        w.push_withdraw(1, ZIESHA, 9, ZIESHA, 0, F(7))
+        out.append(w.withdraw_synthesize(1, F(3), record_matrices=record))
+        return out
+    for a, b in zip(run(True), run(False)):
+        assert a.satisfied and b.satisfied and (a.n_aux, a.n_constraints) == (b.n_aux, b.n_constraints)
+        for name in ("z", "az", "bz", "cz"):
+            assert a.view(name) == b.view(name), name
