@@ -1,6 +1,6 @@
 """GPU debug helper: runs one G1 MSM case in-process and prints per-kernel event times."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from bazuka_amd import Bzk

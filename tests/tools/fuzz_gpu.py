@@ -1,9 +1,9 @@
 """Differential fuzzing of the C ABI against the CPU oracle on random shapes (run on a GPU box):
 MSM G1/G2 (plain, de-duplicated, window partitions, witness-like / degenerate scalar mixes, repeated and negated bases),
 NTT (all four modes, every log size up to 14), Poseidon batches (every arity), 4-ary trees, tree updates.
-usage: python tools/fuzz_gpu.py [seconds=60] [seed=1]"""
+usage: python tests/tools/fuzz_gpu.py [seconds=60] [seed=1]"""
 import json, os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from bazuka_amd import Bzk
 from oracle import coracle as co, pyref as pr

@@ -2,9 +2,9 @@
 326-328): a deposit batch (L=15, T=3, B=3: 64 tx, 2^21 domain), a withdraw batch (64 tx, 2^22 domain) and - unless
 `small` is given - an update batch (B=4: 256 tx, 2^24 domain).  Product code end to end; every proof is checked with the
 oracle's pairing verifier against its batch's public inputs.
-usage: python tools/prove_block.py [small]"""
+usage: python tests/tools/prove_block.py [small]"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bazuka_amd import Bzk, lib as L
 

@@ -2,9 +2,9 @@
 14 443 117 constraints, NTT domain 2^24 (src/config/blockchain.rs:22-26) - or any other B given on the command line.
 Product code end to end (host generator, CRS on the GPU, proof on the GPU); the proof is then checked with the
 oracle's pairing verifier against the batch's public inputs, and (optionally) byte-compared with the oracle prover.
-usage: python tools/prove_production.py [log4_batch=4] [n_proofs=2] [compare_oracle=0]"""
+usage: python tests/tools/prove_production.py [log4_batch=4] [n_proofs=2] [compare_oracle=0]"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bazuka_amd import Bzk, lib as L
 

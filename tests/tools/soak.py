@@ -1,8 +1,8 @@
 """Soak test of the proof path: N proofs back to back through one prover slot fed by witness producers; reports proofs/s,
 host RSS and free device memory at the start, the middle and the end (leaks show up as drift), and checks the last proof
-with the oracle's pairing verifier.  usage: python tools/soak.py [n_proofs=600]"""
+with the oracle's pairing verifier.  usage: python tests/tools/soak.py [n_proofs=600]"""
 import json, os, queue, resource, sys, threading, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
