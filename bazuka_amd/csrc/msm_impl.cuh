@@ -794,7 +794,11 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                    n, 0xffffffffu, key2, scal2, rep, gof);
         if (M) {
             BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true));
-            const uint32_t K = 16;
+            static const uint32_t K = [] {  // sums per lane of the batched inversion (env BZK_DEDUP_K for A/B runs)
+                const char* e = getenv("BZK_DEDUP_K");
+                const int v = e ? atoi(e) : 16;
+                return (uint32_t)(v < 4 ? 4 : (v > 256 ? 256 : v));
+            }();
             auto k_aff = dedup_affine_kernel<C>;
             BZK_LAUNCH(ctx, "dedup_affine", k_aff, dim3((unsigned)(((M + K - 1) / K + 63) / 64)), dim3(64), 0, (const Pt*)buckets, M, K, pref,
                        conv + n, (const uint32_t*)gof, scal2);
