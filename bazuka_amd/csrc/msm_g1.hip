@@ -44,6 +44,12 @@ int32_t bzk_msm_g1_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, 
     if (out) *out = (bzk_msm_table*)t;
     return st;
 }
+int32_t bzk_msm_g1_table_build_levels(bzk_ctx* ctx, const void* bases_dev, uint64_t n, uint32_t levels, bzk_msm_table** out) {
+    MsmTable* t = nullptr;
+    int32_t st = msm_table_build<G1Fast>(ctx, bases_dev, n, &t, (int)levels);
+    if (out) *out = (bzk_msm_table*)t;
+    return st;
+}
 int32_t bzk_msm_g1_table_run_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags,
                                  uint8_t out[97]) {
     return msm_table_entry<G1Fast>(ctx, (const MsmTable*)table, scalars_dev, n, flags, 0, -1, out);
@@ -54,6 +60,10 @@ int32_t bzk_msm_g1_table_windows_dev(bzk_ctx* ctx, const bzk_msm_table* table, c
 }
 
 void bzk_msm_table_free(bzk_ctx* ctx, bzk_msm_table* table) { msm_table_free(ctx, (MsmTable*)table); }
-uint32_t bzk_msm_table_window_count(const bzk_msm_table* table) { return table ? (uint32_t)((const MsmTable*)table)->w_total : 0; }
+uint32_t bzk_msm_table_window_count(const bzk_msm_table* table) {
+    const MsmTable* t = (const MsmTable*)table;
+    return !t ? 0 : (uint32_t)(t->wpl > 1 ? t->wpl : t->w_total);
+}
+uint32_t bzk_msm_table_levels(const bzk_msm_table* table) { return table ? (uint32_t)((const MsmTable*)table)->levels : 0; }
 
 }  // extern "C"

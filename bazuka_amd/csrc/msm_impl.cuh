@@ -49,7 +49,7 @@ static int msm_windows_for(int c) { return (256 + c - 1) / c; }  // signed digit
 // 1. digits
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __restrict__ scalars, uint64_t n, int mont, int c,
-                                                         int w_total, int w_begin, int w_cnt, uint32_t table_stride,
+                                                         int w_total, int w_begin, int w_cnt, uint32_t table_stride, int table_wpl,
                                                          const uint32_t* __restrict__ rep, uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ vals) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,9 +63,12 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
     if (mont) s = fe_from_mont<FrParams>(s);
     const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
-    // table mode (table_stride != 0): every window shares ONE bucket set (the table holds 2^(c w) P_i), the
-    // value indexes the table entry [w][i]; otherwise buckets are per window and the value is the base index
-    const uint32_t nb = table_stride ? half : (uint32_t)w_cnt * half;  // sentinel key (sorted behind every bucket)
+    // table mode (table_stride != 0): the table holds level j = 2^(c wpl j) P_i, window w = j * wpl + w' feeds bucket set
+    // w' with table entry [j][i].  wpl = 1 (full table): every window shares ONE bucket set and [w_begin, w_begin + w_cnt)
+    // selects levels; wpl > 1 (folded table): the range selects bucket sets and `w_total` is levels * wpl (windows past
+    // the real top digit are zero).  Without a table buckets are per window and the value is the base index
+    const bool folded = table_stride && table_wpl > 1;
+    const uint32_t nb = (table_stride && !folded) ? half : (uint32_t)w_cnt * half;  // sentinel key (sorted behind every bucket)
     uint64_t buf = 0;
     int cnt = 0, w = 0;
     uint32_t carry = 0;
@@ -79,7 +82,15 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
         } else {
             carry = 0;
         }
-        if (w >= w_begin && w < w_begin + w_cnt) {
+        if (folded) {
+            const int lvl = w / table_wpl, ws = w % table_wpl;
+            if (ws >= w_begin && ws < w_begin + w_cnt) {
+                const uint32_t lw = (uint32_t)(ws - w_begin);
+                const uint64_t o = ((uint64_t)lvl * w_cnt + lw) * n + i;
+                keys[o] = d ? lw * half + (d - 1) : nb;
+                vals[o] = ((uint32_t)lvl * table_stride + (uint32_t)i) | (neg << 31);
+            }
+        } else if (w >= w_begin && w < w_begin + w_cnt) {
             const uint32_t lw = (uint32_t)(w - w_begin);
             const uint64_t o = (uint64_t)lw * n + i;
             if (table_stride) {
@@ -141,12 +152,14 @@ __global__ void __launch_bounds__(128) msm_convert_bases_kernel(const void* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// 4c. static-base tables: tab[w][i] = 2^(c w) * P_i in the internal affine form.  Built once per base set (a
-// Groth16 CRS query is static); with them all windows feed ONE bucket set, so the bucket reduction shrinks
-// from W windows to one and the host-side Horner disappears.  Costs W x the base memory - what 288 GB is for.
+// 4c. static-base tables: tab[j][i] = 2^(c wpl j) * P_i in the internal affine form, `levels` of them.  Built once per
+// base set (a Groth16 CRS query is static).  Full table (levels = W, wpl = 1): all windows feed ONE bucket set, so the
+// bucket reduction shrinks from W windows to one and the host-side Horner disappears; costs W x the base memory.
+// Folded table (levels = L < W, wpl = ceil(W / L)): windows j * wpl + w' share bucket set w' - the same number of
+// mixed adds, 1 / L of the buckets to reduce, for L x the base memory (L = 2: 234 MB at 2^20 points).
 // ------------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restrict__ raw, uint64_t n, int c, int w_total,
+__global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restrict__ raw, uint64_t n, int dbl_per_level, int levels,
                                                              typename C::DevAff* __restrict__ tab) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -155,9 +168,9 @@ __global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restr
     typename C::Pt p = C::identity();
     C::add_mixed(p, a, false);
 #pragma unroll 1
-    for (int w = 1; w < w_total; ++w) {
+    for (int w = 1; w < levels; ++w) {
 #pragma unroll 1
-        for (int d = 0; d < c; ++d) p = C::dbl(p);
+        for (int d = 0; d < dbl_per_level; ++d) p = C::dbl(p);
         a = C::to_dev_affine(p);
         tab[(uint64_t)w * n + i] = a;
         p = C::identity();  // restart from the affine form: keeps the coordinates small and exact
@@ -624,7 +637,8 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
 struct MsmTable {
     void* data = nullptr;  // DevAff[w_total][n]
     uint64_t n = 0;
-    int c = 0, w_total = 0;
+    int c = 0, w_total = 0;  // w_total: windows of the signed c-bit recoding
+    int levels = 0, wpl = 1; // table levels; windows per level (1 = full table)
 };
 
 template <class C>
@@ -638,8 +652,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
     const int c = table ? table->c : (ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n));
     const int w_total = msm_windows_for(c);
-    if (w_end > w_total) return BZK_E_ARG;
-    if (table && (n > table->n || (uint64_t)w_total * table->n >= ((uint64_t)1 << 31))) return BZK_E_ARG;
+    const bool folded = table && table->wpl > 1;  // bucket sets [w_begin, w_end) of a folded table, fed by every level
+    const int levels = table ? table->levels : 1;
+    if (w_end > (folded ? table->wpl : w_total)) return BZK_E_ARG;
+    if (table && (n > table->n || (uint64_t)levels * table->n >= ((uint64_t)1 << 31))) return BZK_E_ARG;
     const uint32_t half = 1u << (c - 1);
     uint32_t ch = ctx->msm_chunk_override > 0 ? (uint32_t)ctx->msm_chunk_override : 8u;
     if (ch > half) ch = half;
@@ -649,10 +665,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
     int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w_end - w_begin), ((uint64_t)1 << 30) / n));
-    if (table) group = w_end - w_begin;  // one shared bucket set: all requested windows in one pass
-    const uint64_t len_max = (uint64_t)group * n;
+    if (table) group = w_end - w_begin;  // shared bucket sets: all requested windows in one pass
+    const uint64_t len_max = (uint64_t)group * n * (folded ? (uint64_t)levels : 1);
     if (len_max >= ((uint64_t)1 << 31)) return BZK_E_ARG;
-    const uint32_t nb_max = table ? half : (uint32_t)group * half;
+    const uint32_t nb_max = (table && !folded) ? half : (uint32_t)group * half;
     const uint32_t m_max = dedup ? (uint32_t)(n / 2 + 1) : 0;  // group sums: at most n / 2 groups of >= 2 members
     const uint32_t nb_alloc = std::max(nb_max, m_max);
 
@@ -678,6 +694,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     // few over-full buckets of a degenerate top window do not set the kernel's critical path at small n
     uint32_t seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n / half + 1)));
     if (table) seg = 64;  // shared buckets are all heavily populated: short runs keep every SIMD busy
+    if (folded) seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (len_max / nb_max + 1)));
     // few, heavily populated buckets (a rank of a window-sharded MSM owns 2 windows of 2^23 points: 65 536 buckets of
     // 256 entries): one task per bucket would leave the machine under-filled and the kernel as long as its longest
     // run.  Cut the runs so that there are at least ~4 tasks per resident lane (131 072 lanes at 2 waves/SIMD).
@@ -686,7 +703,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         if (nb_ >= target || len_ / sg + nb_ >= target) return sg;
         return (uint32_t)std::max<uint64_t>(32, len_ / (target - nb_));
     };
-    if (!table) seg = std::min(seg, enough_tasks(seg, len_max, nb_max));
+    if (!table || folded) seg = std::min(seg, enough_tasks(seg, len_max, nb_max));
     const uint32_t seg_dd = 8;  // group sums are latency-bound (a 7 k-member group of bits is one bucket): short serial runs
     // capacity of the per-task partial sums: sized for the shortest run length any later adjustment can pick (32; 64 for tables)
     const uint64_t t_cap = std::max<uint64_t>((uint64_t)nb_max + len_max / std::min<uint32_t>(seg, 32u) + 1,
@@ -813,11 +830,12 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     std::vector<StdPt> wsum((size_t)(w_end - w_begin));
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
-        const uint64_t len = (uint64_t)wc * n_eff;
-        const uint32_t nb = table ? half : (uint32_t)wc * half;
-        const int n_red_win = table ? 1 : wc;  // bucket sets to reduce
+        const uint64_t len = (uint64_t)wc * n_eff * (folded ? (uint64_t)levels : 1);
+        const uint32_t nb = (table && !folded) ? half : (uint32_t)wc * half;
+        const int n_red_win = (table && !folded) ? 1 : wc;  // bucket sets to reduce
         BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
-                   mont, c, w_total, wb, wc, (uint32_t)(table ? table->n : 0), (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
+                   mont, c, folded ? levels * table->wpl : w_total, wb, wc, (uint32_t)(table ? table->n : 0), table ? table->wpl : 1,
+                   (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
         {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
@@ -836,7 +854,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_out);
         BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)n_red_win * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (table) {  // the table already carries the 2^(c w) factors: the single bucket-set sum IS the result
+        if (table && !folded) {  // the table already carries the 2^(c w) factors: the single bucket-set sum IS the result
             memcpy(&result, ctx->pinned, sizeof(StdPt));
             return BZK_OK;
         }
@@ -889,8 +907,8 @@ static int32_t msm_entry_host(bzk_ctx* ctx, const uint8_t* bases, const uint8_t*
 }
 
 template <class C>
-static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, MsmTable** out) {
-    if (!ctx || !out || !bases_raw || n == 0) return BZK_E_ARG;
+static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, MsmTable** out, int levels_req = 0) {
+    if (!ctx || !out || !bases_raw || n == 0 || levels_req < 0) return BZK_E_ARG;
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
     int c = msm_pick_c(n);
@@ -899,11 +917,15 @@ static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, 
         if (v >= 4 && v <= 20) c = v;
     }
     const int w_total = msm_windows_for(c);
-    if ((uint64_t)w_total * n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
+    // levels_req = 0 (or >= W): full table, one level per window; otherwise windows per level = ceil(W / levels_req)
+    // and only as many levels as that leaves non-empty
+    const int wpl = (levels_req == 0 || levels_req >= w_total) ? 1 : (w_total + levels_req - 1) / levels_req;
+    const int levels = (w_total + wpl - 1) / wpl;
+    if ((uint64_t)levels * n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
     MsmTable* t = new (std::nothrow) MsmTable();
     if (!t) return BZK_E_ALLOC;
-    t->n = n; t->c = c; t->w_total = w_total;
-    hipError_t e = hipMalloc(&t->data, (size_t)w_total * n * sizeof(typename C::DevAff));
+    t->n = n; t->c = c; t->w_total = w_total; t->levels = levels; t->wpl = wpl;
+    hipError_t e = hipMalloc(&t->data, (size_t)levels * n * sizeof(typename C::DevAff));
     if (e != hipSuccess) {
         ctx->last_error = std::string("table alloc: ") + hipGetErrorString(e);
         (void)hipGetLastError();
@@ -911,7 +933,7 @@ static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, 
         return BZK_E_ALLOC;
     }
     auto k = msm_table_build_kernel<C>;
-    BZK_LAUNCH(ctx, "msm_table_build", k, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, bases_raw, n, c, w_total, (typename C::DevAff*)t->data);
+    BZK_LAUNCH(ctx, "msm_table_build", k, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, bases_raw, n, c * wpl, levels, (typename C::DevAff*)t->data);
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = t;
     return BZK_OK;
@@ -933,7 +955,7 @@ static int32_t msm_table_entry(bzk_ctx* ctx, const MsmTable* t, const void* scal
     typedef typename C::HostF F;
     if (!ctx || !t || !out || (n && !scalars)) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
-    if (w_end < 0) w_end = t->w_total;
+    if (w_end < 0) w_end = t->wpl > 1 ? t->wpl : t->w_total;
     XyzzT<F> r;
     BZK_TRY(msm_run<C>(ctx, nullptr, scalars, n, flags, w_begin, w_end, r, t));
     PointIO<F>::pack(r, out);

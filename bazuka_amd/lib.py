@@ -80,6 +80,9 @@ SIGNATURES = {
     "bzk_host_jubjub_verify": (_i32, [_vp, _vp, _vp]),
     "bzk_msm_g1_table_build": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
     "bzk_msm_g2_table_build": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_msm_g1_table_build_levels": (_i32, [_vp, _vp, _u64, _u32, C.POINTER(_vp)]),
+    "bzk_msm_g2_table_build_levels": (_i32, [_vp, _vp, _u64, _u32, C.POINTER(_vp)]),
+    "bzk_msm_table_levels": (_u32, [_vp]),
     "bzk_msm_g1_table_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "bzk_msm_g2_table_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "bzk_msm_g1_table_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
@@ -286,11 +289,19 @@ class Bzk:
         self._ck(self.lib.bzk_msm_g2_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, w0, w1, out), "msm_g2_windows_dev")
         return out.raw
 
-    def msm_table_build(self, bases, n: int, g2=False):
+    def msm_table_build(self, bases, n: int, g2=False, levels: int = 0):
+        """levels = 0: full table (one level per window); levels = L: folded table (see include/bzk.h)"""
         h = C.c_void_p()
-        fn = self.lib.bzk_msm_g2_table_build if g2 else self.lib.bzk_msm_g1_table_build
-        self._ck(fn(self.h, _ptr(bases), n, C.byref(h)), "msm_table_build")
+        if levels:
+            fn = self.lib.bzk_msm_g2_table_build_levels if g2 else self.lib.bzk_msm_g1_table_build_levels
+            self._ck(fn(self.h, _ptr(bases), n, levels, C.byref(h)), "msm_table_build_levels")
+        else:
+            fn = self.lib.bzk_msm_g2_table_build if g2 else self.lib.bzk_msm_g1_table_build
+            self._ck(fn(self.h, _ptr(bases), n, C.byref(h)), "msm_table_build")
         return h
+
+    def msm_table_levels(self, table) -> int:
+        return self.lib.bzk_msm_table_levels(table)
 
     def msm_table_run_dev(self, table, scalars, n: int, g2=False, canonical=False) -> bytes:
         out = C.create_string_buffer(193 if g2 else 97)

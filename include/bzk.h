@@ -257,6 +257,13 @@ int32_t bzk_host_jubjub_verify(const uint8_t pub_xy[64], const uint8_t msg[32], 
 typedef struct bzk_msm_table bzk_msm_table;
 int32_t bzk_msm_g1_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_table** out);
 int32_t bzk_msm_g2_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_table** out);
+/* folded table: `levels` L < W levels tab[j][i] = 2^(c wpl j) * base_i, wpl = ceil(W / L): windows j * wpl + w' share bucket
+ * set w' - the same number of point additions, 1 / L of the buckets to reduce, L x the base memory (levels = 0 or >= W: the
+ * full table).  For a folded table the `windows` range of *_table_windows_dev selects bucket sets [w_begin, w_end) of the
+ * bzk_msm_table_window_count() = wpl sets; the partial results still add up to the full MSM (bzk_g1_sum / bzk_g2_sum). */
+int32_t bzk_msm_g1_table_build_levels(bzk_ctx* ctx, const void* bases_dev, uint64_t n, uint32_t levels, bzk_msm_table** out);
+int32_t bzk_msm_g2_table_build_levels(bzk_ctx* ctx, const void* bases_dev, uint64_t n, uint32_t levels, bzk_msm_table** out);
+uint32_t bzk_msm_table_levels(const bzk_msm_table* table);
 int32_t bzk_msm_g1_table_run_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[97]);
 int32_t bzk_msm_g2_table_run_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[193]);
 int32_t bzk_msm_g1_table_windows_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags,

@@ -192,6 +192,64 @@ def test_msm_g1_static_table_2p20(bzk, co):
     bzk.msm_table_free(tab)
 
 
+@pytest.mark.parametrize("levels", [2, 3, 4, 5])
+def test_msm_g1_folded_table_matches_plain_and_oracle(bzk, co, pr, levels):
+    """folded tables (bzk_msm_g1_table_build_levels): L levels 2^(c wpl j) P_i, windows j * wpl + w' share bucket set w';
+    same bytes as the per-call pipeline and the oracle for level counts that do and do not divide the window count,
+    prefix use, skewed scalars, bucket-set shards"""
+    n = 6000
+    hb = co.g1_bases(71, 0, n, nthreads=co.ncpu())
+    bases = to_dev(hb)
+    tab = bzk.msm_table_build(bases, n, levels=levels)
+    assert 1 < bzk.msm_table_levels(tab) <= levels
+    for m, seed in ((n, 1), (n - 1234, 2), (1, 3)):
+        scb = rand_scalars_bytes(m, seed)
+        sc = to_dev(scb)
+        got = bzk.msm_table_run_dev(tab, sc, m)
+        assert got == bzk.msm_g1_dev(bases, sc, m)
+        assert got == co.msm_g1(hb[: 96 * m], scb, nthreads=co.ncpu())
+    # extreme scalars: 0, 1, r - 1 (top window + carries), 2^254
+    ext = [0, 1, pr.R_MOD - 1, 1 << 254, (1 << 255) % pr.R_MOD] + fr_list(59, 7)
+    eb = fr_bytes(ext)
+    assert bzk.msm_table_run_dev(tab, to_dev(eb), len(ext)) == co.msm_g1(hb[: 96 * len(ext)], eb, nthreads=co.ncpu())
+    S = bzk.msm_table_window_count(tab)  # bucket sets of the folded table
+    sc = to_dev(rand_scalars_bytes(n, 9))
+    full = bzk.msm_table_run_dev(tab, sc, n)
+    assert full == bzk.msm_g1_dev(bases, sc, n)
+    cuts = [0, S // 3, S // 2, S]
+    shards = b"".join(bzk.msm_table_windows_dev(tab, sc, n, cuts[i], cuts[i + 1]) for i in range(3))
+    assert bzk.g1_sum(shards) == full
+    import numpy as np
+    a = np.frombuffer(rand_scalars_bytes(n, 4), dtype=np.uint8).reshape(n, 32).copy()
+    a[: n // 3] = np.frombuffer(fr_bytes([1]), dtype=np.uint8)
+    a[n // 3: n // 2] = 0
+    wb = a.tobytes()
+    assert bzk.msm_table_run_dev(tab, to_dev(wb), n) == co.msm_g1(hb, wb, nthreads=co.ncpu())
+    bzk.msm_table_free(tab)
+
+
+def test_msm_g2_folded_table_matches_oracle(bzk, co):
+    n = 1500
+    hb = co.g2_bases(73, 0, n, nthreads=co.ncpu())
+    bases = to_dev(hb)
+    tab = bzk.msm_table_build(bases, n, g2=True, levels=2)
+    scb = rand_scalars_bytes(n, 5)
+    assert bzk.msm_table_run_dev(tab, to_dev(scb), n, g2=True) == co.msm_g2(hb, scb, nthreads=co.ncpu())
+    bzk.msm_table_free(tab)
+
+
+def test_msm_g1_folded_table_2p20(bzk, co):
+    n = 1 << 20
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(0x42415A554B41, 0, n, bases)
+    sc = to_dev(rand_scalars_bytes(n, 2020))
+    want = bzk.msm_g1_dev(bases, sc, n)
+    for levels in (2, 4):
+        tab = bzk.msm_table_build(bases, n, levels=levels)
+        assert bzk.msm_table_run_dev(tab, sc, n) == want
+        bzk.msm_table_free(tab)
+
+
 # ---- scalar de-duplication (BZK_F_DEDUP): what bzk_groth16_prove uses for the witness MSMs
 
 def _witness_like_scalars(n, seed):

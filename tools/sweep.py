@@ -31,11 +31,12 @@ def child(mode, log_n):
         print(json.dumps({"mode": mode, "log_n": log_n, "windows": [0, w1], "of": W, "ms": round(ms, 3), "prof": prof}))
     elif mode == "g1tab":
         bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
-        t0 = time.perf_counter(); tab = ctx.msm_table_build(bases, n); tb = time.perf_counter() - t0
+        lv = int(os.environ.get("TAB_LEVELS", "0"))
+        t0 = time.perf_counter(); tab = ctx.msm_table_build(bases, n, levels=lv); tb = time.perf_counter() - t0
         ms = timeit(lambda: ctx.msm_table_run_dev(tab, sc, n))
         same = ctx.msm_table_run_dev(tab, sc, n) == ctx.msm_g1_dev(bases, sc, n)
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_table_run_dev(tab, sc, n); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
-        print(json.dumps({"mode": mode, "log_n": log_n, "table_c": os.environ.get("BZK_MSM_TABLE_C"), "build_s": round(tb, 3), "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 1), "same_as_plain": same, "prof": prof}))
+        print(json.dumps({"mode": mode, "log_n": log_n, "table_c": os.environ.get("BZK_MSM_TABLE_C"), "levels": ctx.msm_table_levels(tab), "build_s": round(tb, 3), "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 1), "same_as_plain": same, "prof": prof}))
     elif mode == "g2":
         bases = torch.empty(n * 192, dtype=torch.uint8, device="cuda"); ctx.g2_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
         ms = timeit(lambda: ctx.msm_g2_dev(bases, sc, n), reps=2)
@@ -120,6 +121,13 @@ if __name__ == "__main__":
             run("g1", 20, {"BZK_MSM_CHUNK": str(ch)})
         run("g1", 22, {"BZK_MSM_CHUNK": "4"}); run("g1", 16, {"BZK_MSM_CHUNK": "4"})
         run("g2", 20, {"BZK_MSM_CHUNK": "4"}); run("g2", 20, {"BZK_MSM_CHUNK": "8"})
+    if what in ("fold",):  # folded tables: 1 / L of the buckets for L x the base memory
+        run("g1", 20)
+        for lv in (2, 4, 8):
+            run("g1tab", 20, {"TAB_LEVELS": str(lv)})
+        run("g1tab", 20, {"TAB_LEVELS": "2", "BZK_MSM_TABLE_C": "17"})
+        run("g1tab", 20, {"TAB_LEVELS": "4", "BZK_MSM_TABLE_C": "17"})
+        run("g1", 22); run("g1tab", 22, {"TAB_LEVELS": "2"}); run("g1tab", 22, {"TAB_LEVELS": "4"})
     if what in ("all", "tab"):
         for c in (15, 16, 17, 18, 19):
             run("g1tab", 20, {"BZK_MSM_TABLE_C": str(c)})
