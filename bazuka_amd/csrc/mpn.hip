@@ -70,125 +70,10 @@ struct SparseTree4 {
     }
 };
 
-struct Money {
-    ZkScalar token_id;  // ContractId as scalar: Null -> 0, Ziesha -> 1, Custom(x) -> x (src/zk/mod.rs:280-288)
-    uint64_t amount = 0;
-};
-
-struct MpnAccount {
-    uint32_t tx_nonce = 0, withdraw_nonce = 0;
-    PointAffine address;  // default (0, 0) = empty slot
-    std::map<uint64_t, Money> tokens;
-    long find_token_index(int log4_cap, const ZkScalar& token, bool empty_allowed) const {
-        for (auto& kv : tokens)
-            if (kv.second.token_id == token) return (long)kv.first;
-        if (empty_allowed)
-            for (uint64_t i = 0; i < ((uint64_t)1 << (2 * log4_cap)); ++i)
-                if (!tokens.count(i)) return (long)i;
-        return -1;
-    }
-};
-
-static ZkScalar token_leaf(const Money& m) {
-    ZkScalar v[2] = {m.token_id, ZkScalar::from_u64(m.amount)};
-    return poseidon_hash(v, 2);
-}
-
-struct MpnTx {  // MpnTransaction with decompressed keys
-    uint32_t nonce = 0;
-    PointAffine src_pub, dst_pub;
-    Money amount, fee;
-    JubjubSignature sig;
-    ZkScalar hash() const {
-        ZkScalar v[7] = {ZkScalar::from_u64(nonce), dst_pub.x, dst_pub.y, amount.token_id, ZkScalar::from_u64(amount.amount),
-                         fee.token_id, ZkScalar::from_u64(fee.amount)};
-        return poseidon_hash(v, 7);
-    }
-};
-
-typedef std::vector<std::array<ZkScalar, 3>> Proof4;
-
-struct UpdateTransition {
-    bool enabled = false;
-    MpnTx tx;
-    MpnAccount src_before, dst_before;
-    ZkScalar src_before_balances_hash, dst_before_balances_hash;
-    Money src_before_balance, src_before_fee_balance, dst_before_balance;
-    Proof4 src_proof, src_balance_proof, src_fee_balance_proof, dst_proof, dst_balance_proof;
-    uint64_t src_index = 0, src_token_index = 0, src_fee_token_index = 0, dst_index = 0, dst_token_index = 0;
-    ZkScalar state_after;  // account-tree root once this transition is applied (not a reference field: scheduling aid)
-    static UpdateTransition null(int L, int T) {
-        UpdateTransition t;
-        std::array<ZkScalar, 3> z = {ZkScalar(), ZkScalar(), ZkScalar()};
-        t.src_proof.assign(L, z);
-        t.dst_proof.assign(L, z);
-        t.src_balance_proof.assign(T, z);
-        t.src_fee_balance_proof.assign(T, z);
-        t.dst_balance_proof.assign(T, z);
-        // `tx: Default::default()`: the circuit allocates `tx.dst_pub_key.0.decompress()`, and the default
-        // compressed key (x = 0, even y) decompresses to (0, r - 1), not to (0, 0)
-        t.tx.dst_pub = jubjub_default_pubkey();
-        t.tx.src_pub = jubjub_default_pubkey();
-        return t;
-    }
-};
-
-// ---- deposits / withdrawals (src/mpn/mod.rs:426-489; MpnDeposit / MpnWithdraw src/core/transaction.rs:163-174)
-struct DepositTx {
-    PointAffine mpn_address = jubjub_default_pubkey();
-    Money amount;
-};
-struct DepositTransition {
-    bool enabled = false;
-    DepositTx tx;
-    MpnAccount before;
-    ZkScalar before_balances_hash;
-    Money before_balance;
-    Proof4 proof, balance_proof;
-    uint64_t account_index = 0, token_index = 0;
-    ZkScalar state_after;
-    static DepositTransition null(int L, int T) {
-        DepositTransition t;
-        std::array<ZkScalar, 3> z = {ZkScalar(), ZkScalar(), ZkScalar()};
-        t.proof.assign(L, z);
-        t.balance_proof.assign(T, z);
-        return t;
-    }
-};
-struct WithdrawTx {
-    PointAffine mpn_address = jubjub_default_pubkey();
-    uint32_t nonce = 0;
-    JubjubSignature sig;
-    Money amount, fee;
-    ZkScalar fingerprint;  // ContractWithdraw::fingerprint() - an opaque scalar here (L1 serialisation is out of scope)
-    ZkScalar sign_message() const {
-        ZkScalar v[2] = {fingerprint, ZkScalar::from_u64(nonce)};
-        return poseidon_hash(v, 2);
-    }
-    ZkScalar calldata() const {
-        ZkScalar v[6] = {mpn_address.x, mpn_address.y, ZkScalar::from_u64(nonce), sig.r.x, sig.r.y, sig.s};
-        return poseidon_hash(v, 6);
-    }
-};
-struct WithdrawTransition {
-    bool enabled = false;
-    WithdrawTx tx;
-    MpnAccount before;
-    Money before_token_balance, before_fee_balance;
-    Proof4 proof, token_balance_proof, fee_balance_proof;
-    uint64_t account_index = 0, token_index = 0, fee_token_index = 0;
-    ZkScalar before_token_hash, state_after;
-    static WithdrawTransition null(int L, int T) {
-        WithdrawTransition t;
-        std::array<ZkScalar, 3> z = {ZkScalar(), ZkScalar(), ZkScalar()};
-        t.proof.assign(L, z);
-        t.token_balance_proof.assign(T, z);
-        t.fee_balance_proof.assign(T, z);
-        return t;
-    }
-};
-
 }  // namespace bzk
+
+#include "host_mpn_types.h"  // Money, MpnAccount, MpnTx, {Update,Deposit,Withdraw}Transition
+#include "host_bincode.h"    // MpnWork <-> bincode bytes (f-2: the prover's wire format)
 
 using namespace bzk;
 
@@ -205,6 +90,7 @@ struct bzk_mpn {
     std::vector<DepositTx> deposit_queue;
     std::vector<WithdrawTx> withdraw_queue;
     uint64_t height = 0;
+    ZkScalar contract_id = ZkScalar::from_u64(0x4D504E);  // ContractId::Custom of the MPN contract (payments of synthetic txs)
     int threads = (int)std::max(1u, std::thread::hardware_concurrency());
 
     bzk_mpn(int l, int t) : L(l), T(t) {
@@ -1175,7 +1061,7 @@ int32_t bzk_mpn_push_deposit(bzk_mpn* w, uint64_t key_index, const uint8_t token
 // withdraw nonce + 1 (+ already queued withdrawals of that account)
 int32_t bzk_mpn_push_withdraw(bzk_mpn* w, uint64_t account_index, const uint8_t token_id[32], uint64_t amount,
                               const uint8_t fee_token[32], uint64_t fee, const uint8_t fingerprint[32]) {
-    if (!w || !token_id || !fee_token || !fingerprint || !w->keys.count(account_index)) return BZK_E_ARG;
+    if (!w || !token_id || !fee_token || !w->keys.count(account_index)) return BZK_E_ARG;
     WithdrawTx tx;
     tx.mpn_address = w->keys[account_index].public_key;
     uint32_t queued = 0;
@@ -1184,8 +1070,17 @@ int32_t bzk_mpn_push_withdraw(bzk_mpn* w, uint64_t account_index, const uint8_t 
     tx.nonce = w->get(account_index).withdraw_nonce + 1 + queued;
     tx.amount = Money{ZkScalar::from_bytes(token_id), amount};
     tx.fee = Money{ZkScalar::from_bytes(fee_token), fee};
-    tx.fingerprint = ZkScalar::from_bytes(fingerprint);
-    tx.sig = jubjub_sign(w->keys[account_index], tx.sign_message());
+    if (fingerprint) {
+        tx.fingerprint = ZkScalar::from_bytes(fingerprint);  // opaque: such a withdrawal cannot be put on the wire
+        tx.sig = jubjub_sign(w->keys[account_index], tx.sign_message());
+    } else {
+        // as the wallet does (src/wallet/tx_builder.rs:376-425): fingerprint of the payment with zero calldata, signature
+        // over H2(fingerprint, nonce), then calldata = H6(address, nonce, signature) written into the payment
+        tx.payment = default_contract_withdraw(w->contract_id, tx.amount, tx.fee, ZkScalar());
+        tx.fingerprint = contract_withdraw_fingerprint(tx.payment);
+        tx.sig = jubjub_sign(w->keys[account_index], tx.sign_message());
+        tx.payment = default_contract_withdraw(w->contract_id, tx.amount, tx.fee, tx.calldata());
+    }
     w->withdraw_queue.push_back(tx);
     return BZK_OK;
 }
@@ -1341,11 +1236,319 @@ const void* bzk_r1cs_data(const bzk_r1cs* r, int32_t which, uint64_t* bytes) {
 }
 
 // host-side mirrors of the reference's ZkHasher / jubjub entry points (CPU; for wallets and tests)
+// ------------------------------------------------------------------------------------------------
+// f-2: MpnWork on the wire (host_bincode.h).  Worker side: decode -> synthesize (-> bzk_groth16_prove) -> ZkProof bytes;
+// validator side (`prepare_works`, src/mpn/mod.rs:298-424): the queued transactions of a world -> MpnWork bytes.
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct bzk_mpn_work {
+    MpnWork w;
+};
+
+namespace {
+thread_local std::string g_work_error;
+
+// root of the 4-ary tree after the leaf at `index` is replaced (calc_root of the merkle gadget, natively)
+ZkScalar root_from_path(const Proof4& proof, uint64_t index, ZkScalar node) {
+    for (const auto& sib : proof) {
+        ZkScalar c[4];
+        const int pos = (int)(index & 3);
+        for (int j = 0, k = 0; j < 4; ++j) c[j] = j == pos ? node : sib[k++];
+        node = poseidon_hash(c, 4);
+        index >>= 2;
+    }
+    return node;
+}
+ZkScalar h2(const ZkScalar& a, const ZkScalar& b) {
+    ZkScalar v[2] = {a, b};
+    return poseidon_hash(v, 2);
+}
+ZkScalar h5(const ZkScalar& a, const ZkScalar& b, const ZkScalar& c, const ZkScalar& d, const ZkScalar& e) {
+    ZkScalar v[5] = {a, b, c, d, e};
+    return poseidon_hash(v, 5);
+}
+// The account-tree root each enabled transition leaves behind, computed as the circuits compute `next_state_wit`
+// (update_circuit.rs:420-436, deposit_circuit.rs:262-283, withdraw_circuit.rs:380-401): what the witness builder's
+// worker threads use as the state entering the next transition.  A transition whose witness is inconsistent merely
+// mispredicts; the generator then falls back to the sequential walk (run_tx_bodies).
+void fill_state_after(MpnWork& w) {
+    for (UpdateTransition& t : w.updates) {
+        const ZkScalar leaf = h2(t.tx.amount.token_id, ZkScalar::from_u64(t.dst_before_balance.amount) + ZkScalar::from_u64(t.tx.amount.amount));
+        const ZkScalar bal = root_from_path(t.dst_balance_proof, t.dst_token_index, leaf);
+        const ZkScalar acc = h5(ZkScalar::from_u64(t.dst_before.tx_nonce), ZkScalar::from_u64(t.dst_before.withdraw_nonce), t.tx.dst_pub.x,
+                                t.tx.dst_pub.y, bal);
+        t.state_after = root_from_path(t.dst_proof, t.dst_index, acc);
+    }
+    for (DepositTransition& t : w.deposits) {
+        const ZkScalar leaf = h2(t.tx.amount.token_id, ZkScalar::from_u64(t.before_balance.amount) + ZkScalar::from_u64(t.tx.amount.amount));
+        const ZkScalar bal = root_from_path(t.balance_proof, t.token_index, leaf);
+        const ZkScalar acc = h5(ZkScalar::from_u64(t.before.tx_nonce), ZkScalar::from_u64(t.before.withdraw_nonce), t.tx.mpn_address.x,
+                                t.tx.mpn_address.y, bal);
+        t.state_after = root_from_path(t.proof, t.account_index, acc);
+    }
+    for (WithdrawTransition& t : w.withdraws) {
+        const ZkScalar leaf = h2(t.before_fee_balance.token_id, ZkScalar::from_u64(t.before_fee_balance.amount) - ZkScalar::from_u64(t.tx.fee.amount));
+        const ZkScalar bal = root_from_path(t.fee_balance_proof, t.fee_token_index, leaf);
+        const ZkScalar acc = h5(ZkScalar::from_u64(t.before.tx_nonce), ZkScalar::from_u64(t.before.withdraw_nonce) + ZkScalar::one(),
+                                t.tx.mpn_address.x, t.tx.mpn_address.y, bal);
+        t.state_after = root_from_path(t.proof, t.account_index, acc);
+    }
+}
+// a work whose shape the circuits cannot take is refused at decode time (the reference would panic or build a
+// circuit of a different size than its parameters)
+bool work_shape_ok(const MpnWork& w, std::string& why) {
+    const MpnWorkConfig& c = w.config;
+    if (c.log4_tree == 0 || c.log4_tree > 30 || c.log4_token_tree == 0 || c.log4_token_tree > 8) { why = "tree sizes out of range"; return false; }
+    if (w.log4_batch() > 6) { why = "batch size out of range"; return false; }
+    if (w.n_transitions() > ((size_t)1 << (2 * w.log4_batch()))) { why = "more transitions than the batch holds"; return false; }
+    const size_t L = c.log4_tree, T = c.log4_token_tree;
+    for (auto& t : w.updates)
+        if (t.src_proof.size() != L || t.dst_proof.size() != L || t.src_balance_proof.size() != T || t.src_fee_balance_proof.size() != T ||
+            t.dst_balance_proof.size() != T) { why = "update transition: proof depth"; return false; }
+    for (auto& t : w.deposits)
+        if (t.proof.size() != L || t.balance_proof.size() != T) { why = "deposit transition: proof depth"; return false; }
+    for (auto& t : w.withdraws)
+        if (t.proof.size() != L || t.token_balance_proof.size() != T || t.fee_balance_proof.size() != T) { why = "withdraw transition: proof depth"; return false; }
+    if (!verifier_key_well_formed(c.deposit_vk) || !verifier_key_well_formed(c.withdraw_vk) || !verifier_key_well_formed(c.update_vk)) {
+        why = "verifying key";
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+const char* bzk_mpn_work_last_error(void) { return g_work_error.c_str(); }
+
+int32_t bzk_mpn_work_decode(const uint8_t* bytes, uint64_t len, uint32_t flags, bzk_mpn_work** out, uint64_t* consumed) {
+    if (!bytes || !out) return BZK_E_ARG;
+    *out = nullptr;
+    try {
+        std::unique_ptr<bzk_mpn_work> h(new bzk_mpn_work());
+        BinReader r(bytes, (size_t)len);
+        if (!mpn_work_decode(r, flags, h->w)) {
+            g_work_error = r.err;
+            return BZK_E_ARG;
+        }
+        std::string why;
+        if (!work_shape_ok(h->w, why)) {
+            g_work_error = why;
+            return BZK_E_ARG;
+        }
+        fill_state_after(h->w);
+        if (consumed) *consumed = r.pos;
+        *out = h.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception& e) {
+        g_work_error = e.what();
+        return BZK_E_INTERNAL;
+    }
+}
+
+void bzk_mpn_work_free(bzk_mpn_work* h) { delete h; }
+
+// info[0..12) = kind (0 deposit, 1 withdraw, 2 update), log4_tree, log4_token_tree, log4 batch size of this kind, transitions
+//               on the wire (<= 4^batch; the rest is padded with null transitions), height, reward, new_root.state_size,
+//               mpn_num_update_batches, mpn_num_deposit_batches, mpn_num_withdraw_batches, byte length of this work's verifying key
+int32_t bzk_mpn_work_info(const bzk_mpn_work* h, uint64_t info[12]) {
+    if (!h || !info) return BZK_E_ARG;
+    const MpnWork& w = h->w;
+    info[0] = (uint64_t)w.kind;
+    info[1] = w.config.log4_tree;
+    info[2] = w.config.log4_token_tree;
+    info[3] = (uint64_t)w.log4_batch();
+    info[4] = w.n_transitions();
+    info[5] = w.height;
+    info[6] = w.reward;
+    info[7] = w.new_root_size;
+    info[8] = w.config.num_update_batches;
+    info[9] = w.config.num_deposit_batches;
+    info[10] = w.config.num_withdraw_batches;
+    info[11] = w.vk().size();
+    return BZK_OK;
+}
+
+// out = state | aux_data | next_state | new_root.state_hash | mpn_contract_id (as the circuits' scalar), 32 B each
+int32_t bzk_mpn_work_scalars(const bzk_mpn_work* h, uint8_t out[160]) {
+    if (!h || !out) return BZK_E_ARG;
+    h->w.state.to_bytes(out);
+    h->w.aux_data.to_bytes(out + 32);
+    h->w.next_state.to_bytes(out + 64);
+    h->w.new_root_hash.to_bytes(out + 96);
+    h->w.config.mpn_contract_id.to_bytes(out + 128);
+    return BZK_OK;
+}
+
+// which: -1 = the key this work is verified with (MpnWork::vk), 0 / 1 / 2 = deposit / withdraw / update key
+int32_t bzk_mpn_work_vk(const bzk_mpn_work* h, int32_t which, uint8_t* out, uint64_t cap, uint64_t* len) {
+    if (!h || which < -1 || which > 2) return BZK_E_ARG;
+    const MpnWorkConfig& c = h->w.config;
+    const std::vector<uint8_t>& vk = which < 0 ? h->w.vk() : which == 0 ? c.deposit_vk : which == 1 ? c.withdraw_vk : c.update_vk;
+    if (len) *len = vk.size();
+    if (out) {
+        if (cap < vk.size()) return BZK_E_ARG;
+        memcpy(out, vk.data(), vk.size());
+    }
+    return BZK_OK;
+}
+
+int32_t bzk_mpn_work_commitment(const bzk_mpn_work* h, const uint8_t prover_pub[32], uint8_t out[32]) {
+    if (!h || !prover_pub || !out) return BZK_E_ARG;
+    mpn_work_commitment(prover_pub, h->w.reward).to_bytes(out);
+    return BZK_OK;
+}
+
+int32_t bzk_mpn_work_encode(const bzk_mpn_work* h, uint8_t* out, uint64_t cap, uint64_t* len) {
+    if (!h) return BZK_E_ARG;
+    try {
+        for (auto& t : h->w.withdraws)
+            if (t.tx.payment.empty()) return BZK_E_ARG;  // opaque-fingerprint withdrawals have no wire form
+        BinWriter o;
+        mpn_work_encode(o, h->w);
+        if (len) *len = o.b.size();
+        if (out) {
+            if (cap < o.b.size()) return BZK_E_ARG;
+            memcpy(out, o.b.data(), o.b.size());
+        }
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    }
+}
+
+// The circuit instance a worker proves for this work: commitment = H(prover, reward), public inputs from the work,
+// transitions padded with `::null` to 4^batch (what the reference's provers do before `create_random_proof`).
+// fee_token: the update circuit's private `fee_token` (NULL = Ziesha, what prepare_works uses - src/mpn/mod.rs:400).
+int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* h, const uint8_t prover_pub[32], const uint8_t fee_token[32], int32_t threads,
+                                int32_t record_matrices, bzk_r1cs** out) {
+    if (!h || !prover_pub || !out) return BZK_E_ARG;
+    *out = nullptr;
+    try {
+        const MpnWork& w = h->w;
+        const int L = w.config.log4_tree, T = w.config.log4_token_tree, B = w.log4_batch();
+        const size_t cap = (size_t)1 << (2 * B);
+        const int nt = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+        const ZkScalar commitment = mpn_work_commitment(prover_pub, w.reward);
+        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
+        LcModeGuard guard(record_matrices != 0);
+        r->cs.self_check = record_matrices != 0;
+        if (w.kind == 2) {
+            std::vector<UpdateTransition> trs = w.updates;
+            while (trs.size() < cap) trs.push_back(UpdateTransition::null(L, T));
+            const ZkScalar ft = fee_token ? ZkScalar::from_bytes(fee_token) : ZkScalar::one();
+            synthesize_update(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, ft, trs, nt);
+        } else if (w.kind == 0) {
+            std::vector<DepositTransition> trs = w.deposits;
+            while (trs.size() < cap) trs.push_back(DepositTransition::null(L, T));
+            synthesize_deposit(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, trs, nt);
+        } else {
+            std::vector<WithdrawTransition> trs = w.withdraws;
+            while (trs.size() < cap) trs.push_back(WithdrawTransition::null(L, T));
+            synthesize_withdraw(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, trs, nt);
+        }
+        if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
+        r->accepted = w.n_transitions();
+        finish_r1cs(r.get());
+        *out = r.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception& e) {
+        g_work_error = e.what();
+        return BZK_E_INTERNAL;
+    }
+}
+
+// Validator side: one work of `prepare_works` (src/mpn/mod.rs:352-414) from the transactions queued in the world: runs the
+// witness builder of that kind (the world moves to the next state, as the reference's mirror does), fills the public
+// inputs [height, state, aux_data, next_state] and new_root.  kind: 0 deposit, 1 withdraw, 2 update.
+int32_t bzk_mpn_make_work(bzk_mpn* w, int32_t kind, const bzk_mpn_work_config* cfg, uint64_t reward, bzk_mpn_work** out) {
+    if (!w || !cfg || !out || kind < 0 || kind > 2) return BZK_E_ARG;
+    *out = nullptr;
+    if (cfg->log4_deposit_batch > 6 || cfg->log4_withdraw_batch > 6 || cfg->log4_update_batch > 6) return BZK_E_ARG;
+    if (!cfg->deposit_vk || !cfg->withdraw_vk || !cfg->update_vk) return BZK_E_ARG;
+    try {
+        std::unique_ptr<bzk_mpn_work> h(new bzk_mpn_work());
+        MpnWork& o = h->w;
+        MpnWorkConfig& c = o.config;
+        c.log4_tree = (uint8_t)w->L;
+        c.log4_token_tree = (uint8_t)w->T;
+        c.log4_deposit_batch = cfg->log4_deposit_batch;
+        c.log4_withdraw_batch = cfg->log4_withdraw_batch;
+        c.log4_update_batch = cfg->log4_update_batch;
+        c.mpn_contract_id = w->contract_id;
+        c.num_update_batches = cfg->num_update_batches;
+        c.num_deposit_batches = cfg->num_deposit_batches;
+        c.num_withdraw_batches = cfg->num_withdraw_batches;
+        c.deposit_vk.assign(cfg->deposit_vk, cfg->deposit_vk + cfg->deposit_vk_len);
+        c.withdraw_vk.assign(cfg->withdraw_vk, cfg->withdraw_vk + cfg->withdraw_vk_len);
+        c.update_vk.assign(cfg->update_vk, cfg->update_vk + cfg->update_vk_len);
+        if (!verifier_key_well_formed(c.deposit_vk) || !verifier_key_well_formed(c.withdraw_vk) || !verifier_key_well_formed(c.update_vk))
+            return BZK_E_ARG;
+        o.kind = kind;
+        o.height = w->height;
+        o.state = w->accounts->root();
+        o.reward = reward;
+        uint64_t rejected = 0;
+        if (kind == 2) {
+            uint64_t fee_sum = 0;
+            build_transitions(*w, c.log4_update_batch, ZkScalar::one(), o.updates, fee_sum, rejected);
+            o.aux_data = h2(ZkScalar::one(), ZkScalar::from_u64(fee_sum));
+        } else if (kind == 0) {
+            build_deposits(*w, c.log4_deposit_batch, o.deposits, rejected);
+            o.aux_data = deposit_aux(o.deposits, c.log4_deposit_batch);
+        } else {
+            for (auto& tx : w->withdraw_queue)
+                if (tx.payment.empty()) return BZK_E_ARG;  // queued with an opaque fingerprint: no wire form
+            build_withdraws(*w, c.log4_withdraw_batch, o.withdraws, rejected);
+            o.aux_data = withdraw_aux(o.withdraws, c.log4_withdraw_batch);
+        }
+        o.next_state = w->accounts->root();
+        o.new_root_hash = o.next_state;
+        o.new_root_size = cfg->new_root_state_size;
+        *out = h.release();
+        return BZK_OK;
+    } catch (const std::bad_alloc&) {
+        return BZK_E_ALLOC;
+    } catch (const std::exception&) {
+        return BZK_E_INTERNAL;
+    }
+}
+
+// ZkProof::Groth16(Box<Groth16Proof>) (src/zk/mod.rs:646-651): u32 variant 0 + the 387 proof bytes bzk_groth16_prove writes
+int32_t bzk_zkproof_encode(const uint8_t proof[387], uint8_t out[391]) {
+    if (!proof || !out) return BZK_E_ARG;
+    const uint32_t tag = 0;
+    memcpy(out, &tag, 4);
+    memcpy(out + 4, proof, 387);
+    return BZK_OK;
+}
+int32_t bzk_zkproof_decode(const uint8_t* in, uint64_t len, uint8_t proof[387]) {
+    if (!in || !proof || len < 391) return BZK_E_ARG;
+    uint32_t tag;
+    memcpy(&tag, in, 4);
+    if (tag != 0) return BZK_E_ARG;
+    for (int off : {4 + 96, 4 + 97 + 192, 4 + 97 + 193 + 96})
+        if (in[off] > 1) return BZK_E_ARG;  // the three `bool` infinity flags
+    memcpy(proof, in + 4, 387);
+    return BZK_OK;
+}
+
 int32_t bzk_host_poseidon(const uint8_t* in, uint32_t arity, uint8_t out[32]) {
     if (!in || !out || arity < 1 || arity > 16) return BZK_E_ARG;
     ZkScalar v[16];
     for (uint32_t i = 0; i < arity; ++i) v[i] = ZkScalar::from_bytes(in + 32 * i);
     poseidon_hash(v, (int)arity).to_bytes(out);
+    return BZK_OK;
+}
+// `ZkScalar::new(bytes)` (src/zk/mod.rs:262-271): the little-endian integer mod r, as Montgomery limbs; len <= 64
+int32_t bzk_host_scalar_new(const uint8_t* in, uint32_t len, uint8_t out[32]) {
+    if ((!in && len) || !out || len > 64) return BZK_E_ARG;
+    ZkScalar::from_le_bytes_mod(in, len).to_bytes(out);
     return BZK_OK;
 }
 int32_t bzk_host_sha3_256(const uint8_t* in, uint64_t len, uint8_t out[32]) {

@@ -89,6 +89,19 @@ SIGNATURES = {
     "bzk_msm_g2_table_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "bzk_msm_table_window_count": (_u32, [_vp]),
     "bzk_msm_table_free": (None, [_vp, _vp]),
+    "bzk_mpn_work_decode": (_i32, [_vp, _u64, _u32, C.POINTER(_vp), C.POINTER(_u64)]),
+    "bzk_mpn_work_last_error": (C.c_char_p, []),
+    "bzk_mpn_work_free": (None, [_vp]),
+    "bzk_mpn_work_info": (_i32, [_vp, C.POINTER(_u64)]),
+    "bzk_mpn_work_scalars": (_i32, [_vp, _vp]),
+    "bzk_mpn_work_vk": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_u64)]),
+    "bzk_mpn_work_commitment": (_i32, [_vp, _vp, _vp]),
+    "bzk_mpn_work_synthesize": (_i32, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "bzk_mpn_work_encode": (_i32, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "bzk_mpn_make_work": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_host_scalar_new": (_i32, [_vp, _u32, _vp]),
+    "bzk_zkproof_encode": (_i32, [_vp, _vp]),
+    "bzk_zkproof_decode": (_i32, [_vp, _u64, _vp]),
     "bzk_g1_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
     "bzk_g2_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
 }
@@ -105,6 +118,13 @@ class CsrDesc(C.Structure):
 
 class Assignment(C.Structure):
     _fields_ = [("z", _vp), ("az", _vp), ("bz", _vp), ("cz", _vp), ("n_rows", _u64)]
+
+
+class WorkConfig(C.Structure):  # bzk_mpn_work_config
+    _fields_ = [("log4_deposit_batch", C.c_uint8), ("log4_withdraw_batch", C.c_uint8), ("log4_update_batch", C.c_uint8),
+                ("num_update_batches", _u64), ("num_deposit_batches", _u64), ("num_withdraw_batches", _u64),
+                ("deposit_vk", _vp), ("deposit_vk_len", _u64), ("withdraw_vk", _vp), ("withdraw_vk_len", _u64),
+                ("update_vk", _vp), ("update_vk_len", _u64), ("new_root_state_size", _u64)]
 
 
 class BzkError(RuntimeError):
@@ -477,8 +497,21 @@ class MpnWorld:
     def push_deposit(self, key_index: int, token_id: bytes, amount: int):
         _st(self.lib.bzk_mpn_push_deposit(self.h, key_index, _ptr(token_id), amount), "push_deposit")
 
-    def push_withdraw(self, account: int, token_id: bytes, amount: int, fee_token: bytes, fee: int, fingerprint: bytes):
+    def push_withdraw(self, account: int, token_id: bytes, amount: int, fee_token: bytes, fee: int, fingerprint: bytes | None = None):
+        """fingerprint None: derived from a synthetic L1 payment as the wallet does (the withdrawal can go on the wire)"""
         _st(self.lib.bzk_mpn_push_withdraw(self.h, account, _ptr(token_id), amount, _ptr(fee_token), fee, _ptr(fingerprint)), "push_withdraw")
+
+    def make_work(self, kind: int, vks, reward: int, log4_batches=(1, 1, 1), num_batches=(1, 1, 1), state_size: int = 0) -> "MpnWork":
+        """validator side (`prepare_works`): one work from the queued transactions.  kind 0 deposit / 1 withdraw / 2 update;
+        vks = (deposit, withdraw, update) bincode Groth16VerifyingKey; log4_batches = (deposit, withdraw, update);
+        num_batches = (update, deposit, withdraw) counts of MpnConfig."""
+        keep = [C.create_string_buffer(bytes(v), len(v)) for v in vks]
+        cfg = WorkConfig(log4_batches[0], log4_batches[1], log4_batches[2], num_batches[0], num_batches[1], num_batches[2],
+                         C.cast(keep[0], _vp), len(vks[0]), C.cast(keep[1], _vp), len(vks[1]), C.cast(keep[2], _vp), len(vks[2]),
+                         state_size)
+        h = C.c_void_p()
+        _st(self.lib.bzk_mpn_make_work(self.h, kind, C.byref(cfg), reward, C.byref(h)), "make_work")
+        return MpnWork(h)
 
     def deposit_synthesize(self, log4_batch: int, commitment: bytes, record_matrices=False) -> R1cs:
         h = C.c_void_p()
@@ -495,6 +528,80 @@ class MpnWorld:
         _st(self.lib.bzk_mpn_update_synthesize(self.h, log4_batch, _ptr(commitment), _ptr(fee_token), int(record_matrices),
                                                C.byref(h)), "update_synthesize")
         return R1cs(h)
+
+
+class MpnWork:
+    """One `MpnWork` (src/mpn/mod.rs:263-270): decoded from bincode bytes (worker side) or made from a world (validator side)."""
+    KINDS = ("deposit", "withdraw", "update")
+
+    def __init__(self, handle, consumed: int = 0):
+        self.lib = load_library()
+        self.h = handle
+        self.consumed = consumed
+        info = (_u64 * 12)()
+        _st(self.lib.bzk_mpn_work_info(self.h, info), "work_info")
+        (self.kind, self.log4_tree, self.log4_token_tree, self.log4_batch, self.n_transitions, self.height, self.reward,
+         self.new_root_size, self.num_update_batches, self.num_deposit_batches, self.num_withdraw_batches, self.vk_len) = [int(x) for x in info]
+        sc = C.create_string_buffer(160)
+        _st(self.lib.bzk_mpn_work_scalars(self.h, sc), "work_scalars")
+        self.state, self.aux_data, self.next_state, self.new_root_hash, self.contract_id = [sc.raw[32 * i:32 * i + 32] for i in range(5)]
+
+    @classmethod
+    def decode(cls, data: bytes, flags: int = 0) -> "MpnWork":
+        lib = load_library()
+        h, used = C.c_void_p(), _u64()
+        st = lib.bzk_mpn_work_decode(_ptr(data), len(data), flags, C.byref(h), C.byref(used))
+        if st != 0:
+            raise BzkError(f"work_decode: {lib.bzk_strerror(st).decode()} [{lib.bzk_mpn_work_last_error().decode()}]")
+        return cls(h, used.value)
+
+    def free(self):
+        if self.h:
+            self.lib.bzk_mpn_work_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def vk(self, which: int = -1) -> bytes:
+        n = _u64()
+        _st(self.lib.bzk_mpn_work_vk(self.h, which, None, 0, C.byref(n)), "work_vk")
+        buf = C.create_string_buffer(max(1, n.value))
+        _st(self.lib.bzk_mpn_work_vk(self.h, which, buf, n.value, None), "work_vk")
+        return buf.raw[: n.value]
+
+    def commitment(self, prover_pub: bytes) -> bytes:
+        out = C.create_string_buffer(32)
+        _st(self.lib.bzk_mpn_work_commitment(self.h, _ptr(prover_pub), out), "work_commitment")
+        return out.raw
+
+    def encode(self) -> bytes:
+        n = _u64()
+        _st(self.lib.bzk_mpn_work_encode(self.h, None, 0, C.byref(n)), "work_encode")
+        buf = C.create_string_buffer(max(1, n.value))
+        _st(self.lib.bzk_mpn_work_encode(self.h, buf, n.value, None), "work_encode")
+        return buf.raw[: n.value]
+
+    def synthesize(self, prover_pub: bytes, fee_token: bytes | None = None, threads: int = 0, record_matrices=False) -> R1cs:
+        h = C.c_void_p()
+        _st(self.lib.bzk_mpn_work_synthesize(self.h, _ptr(prover_pub), _ptr(fee_token), threads, int(record_matrices), C.byref(h)),
+            "work_synthesize")
+        return R1cs(h)
+
+
+def zkproof_encode(proof387: bytes) -> bytes:
+    out = C.create_string_buffer(391)
+    _st(load_library().bzk_zkproof_encode(_ptr(proof387), out), "zkproof_encode")
+    return out.raw
+
+
+def zkproof_decode(data: bytes) -> bytes:
+    out = C.create_string_buffer(387)
+    _st(load_library().bzk_zkproof_decode(_ptr(data), len(data), out), "zkproof_decode")
+    return out.raw
 
 
 def mpn_update_empty(L, T, B, commitment, height, state, aux, next_state, fee_token, record_matrices=False) -> R1cs:
@@ -515,6 +622,13 @@ def mpn_circuit_empty(kind, L, T, B, commitment, height, state, aux, next_state,
 def host_poseidon(inp: bytes) -> bytes:
     out = C.create_string_buffer(32)
     _st(load_library().bzk_host_poseidon(_ptr(inp), len(inp) // 32, out), "host_poseidon")
+    return out.raw
+
+
+def host_scalar_new(le_bytes: bytes) -> bytes:
+    """`ZkScalar::new`: little-endian integer mod r -> 32 Montgomery bytes"""
+    out = C.create_string_buffer(32)
+    _st(load_library().bzk_host_scalar_new(_ptr(le_bytes) if le_bytes else None, len(le_bytes), out), "host_scalar_new")
     return out.raw
 
 

@@ -1,0 +1,178 @@
+"""Proving worker for a Bazuka node: the loop the reference's external provers run against
+
+    GET  /bincode/mpn/work      GetMpnWorkRequest{address}             -> GetMpnWorkResponse{works: HashMap<usize, MpnWork>}
+    POST /bincode/mpn/solution  PostMpnSolutionRequest{prover, proofs} -> PostMpnSolutionResponse{accepted}
+    POST /bincode/mpn/worker    PostMpnWorkerRequest{address}          -> PostMpnWorkerResponse{accepted}
+
+(/root/reference/src/node/mod.rs:393-413, src/client/messages.rs:368-396, src/client/mod.rs:428-463; bodies are bincode,
+a GET carries its request in the body too).  A solution is accepted iff `MpnWork::verify` passes with the commitment
+bound to the prover's address and the work's reward (src/mpn/mod.rs:281-295, src/node/api/post_mpn_solution.rs).
+
+Everything that computes is libbzk: `bzk_mpn_work_decode` / `_synthesize` (host C++) and `bzk_groth16_prove` (HIP).
+This module is the plumbing around it: HTTP, the HashMap framing of the two messages, the proving-key cache.  It needs a
+GPU context (`Bzk`); there is no CPU prover to fall back to.
+
+Proving keys: the reference's provers load bellman `Parameters` files produced by the network's setup; this build has no
+reader for that file format yet (bellman is not vendored in the reference), so the key source is a callable
+`params_for(work) -> bzk_params handle` - e.g. `DevSetup`, which generates the CRS on the GPU from the circuit's
+matrices and a given toxic waste, as the reference's dev-mode setup does (src/config/blockchain.rs:355-417).
+"""
+from __future__ import annotations
+
+import http.client
+import os
+import struct
+import time
+
+from . import lib as L
+
+
+# ---- message framing (the maps' payload types are decoded / encoded by libbzk) -------------------------------------
+def work_request(address: bytes) -> bytes:
+    """bincode(GetMpnWorkRequest{address}); Address = ed25519 public key = byte string of 32"""
+    assert len(address) == 32
+    return struct.pack("<Q", 32) + address
+
+
+worker_request = work_request  # PostMpnWorkerRequest has the same single field
+
+
+def parse_work_response(body: bytes, flags: int = 0) -> dict[int, L.MpnWork]:
+    """bincode(GetMpnWorkResponse{works: HashMap<usize, MpnWork>}) -> {work id: MpnWork}"""
+    if len(body) < 8:
+        raise L.BzkError("work response: truncated")
+    (n,) = struct.unpack_from("<Q", body, 0)
+    pos, out = 8, {}
+    for _ in range(n):
+        if len(body) - pos < 8:
+            raise L.BzkError("work response: truncated")
+        (wid,) = struct.unpack_from("<Q", body, pos)
+        w = L.MpnWork.decode(body[pos + 8:], flags)
+        pos += 8 + w.consumed
+        out[wid] = w
+    if pos != len(body):
+        raise L.BzkError(f"work response: {len(body) - pos} trailing bytes")
+    return out
+
+
+def solution_request(prover: bytes, proofs: dict[int, bytes]) -> bytes:
+    """bincode(PostMpnSolutionRequest{prover, proofs: HashMap<usize, ZkProof>}); proofs = {work id: 387 proof bytes}"""
+    assert len(prover) == 32
+    out = [struct.pack("<Q", 32), prover, struct.pack("<Q", len(proofs))]
+    for wid, proof in proofs.items():
+        out += [struct.pack("<Q", wid), L.zkproof_encode(proof)]
+    return b"".join(out)
+
+
+def parse_solution_response(body: bytes) -> int:
+    if len(body) != 8:
+        raise L.BzkError("solution response: expected 8 bytes")
+    return struct.unpack("<Q", body)[0]
+
+
+# ---- proving keys ----------------------------------------------------------------------------------------------------
+class DevSetup:
+    """Proving keys generated on the GPU (bzk_groth16_setup) from the matrices of the all-disabled circuit of the work's
+    shape - the reference's dev-mode CRS (src/config/blockchain.rs:355-417) with caller-supplied toxic waste
+    (tau | alpha | beta | gamma | delta, 5 x 32 Montgomery bytes per circuit kind).  Cached per (kind, L, T, B)."""
+
+    def __init__(self, bzk: L.Bzk, toxic_by_kind: dict[int, bytes]):
+        self.bzk, self.toxic, self.cache = bzk, toxic_by_kind, {}
+
+    def shape_circuit(self, kind: int, L4: int, T4: int, B4: int) -> L.R1cs:
+        z = bytes(32)
+        if kind == 2:
+            return L.mpn_update_empty(L4, T4, B4, z, 0, z, z, z, z, record_matrices=True)
+        return L.mpn_circuit_empty(kind, L4, T4, B4, z, 0, z, z, z, record_matrices=True)
+
+    def keys(self, kind: int, L4: int, T4: int, B4: int):
+        """(params handle, bincode Groth16VerifyingKey) for a circuit shape"""
+        key = (kind, L4, T4, B4)
+        if key not in self.cache:
+            r = self.shape_circuit(kind, L4, T4, B4)
+            csr = [(r.n_constraints, r.view("rp" + w), r.view("col" + w), r.view("val" + w)) for w in "ABC"]
+            self.cache[key] = self.bzk.groth16_setup(csr, r.n_in, r.n_aux, self.toxic[kind])
+            r.free()
+        return self.cache[key]
+
+    def __call__(self, work: L.MpnWork):
+        ph, vk = self.keys(work.kind, work.log4_tree, work.log4_token_tree, work.log4_batch)
+        if vk != work.vk():
+            raise L.BzkError("the work's verifying key is not the one of this worker's proving key")
+        return ph
+
+    def close(self):
+        for ph, _ in self.cache.values():
+            self.bzk.params_free(ph)
+        self.cache = {}
+
+
+# ---- the loop ----------------------------------------------------------------------------------------------------------
+class Worker:
+    def __init__(self, bzk: L.Bzk, address: bytes, node: tuple[str, int], params_for, flags: int = 0, threads: int = 0,
+                 rng=os.urandom, timeout_s: float = 30.0):
+        self.bzk, self.address, self.node, self.params_for = bzk, address, node, params_for
+        self.flags, self.threads, self.rng, self.timeout_s = flags, threads, rng, timeout_s
+        self.stats = {"fetched": 0, "proved": 0, "accepted": 0, "unsat": 0, "synth_s": 0.0, "prove_s": 0.0}
+
+    def _http(self, method: str, path: str, body: bytes) -> bytes:
+        conn = http.client.HTTPConnection(self.node[0], self.node[1], timeout=self.timeout_s)
+        try:
+            conn.request(method, path, body=body, headers={"Content-Type": "application/octet-stream"})
+            resp = conn.getresponse()
+            data = resp.read()
+            if resp.status != 200:
+                raise L.BzkError(f"{method} {path}: HTTP {resp.status}")
+            return data
+        finally:
+            conn.close()
+
+    def register(self) -> bool:
+        body = self._http("POST", "/bincode/mpn/worker", worker_request(self.address))
+        return body == b"\x01"
+
+    def fetch(self) -> dict[int, L.MpnWork]:
+        works = parse_work_response(self._http("GET", "/bincode/mpn/work", work_request(self.address)), self.flags)
+        self.stats["fetched"] += len(works)
+        return works
+
+    def prove(self, work: L.MpnWork) -> bytes | None:
+        """387 proof bytes for the work, or None when the work's witness does not satisfy its circuit (a proof of it
+        could only be rejected by the node)."""
+        t0 = time.perf_counter()
+        r1cs = work.synthesize(self.address, threads=self.threads)
+        t1 = time.perf_counter()
+        self.stats["synth_s"] += t1 - t0
+        if not r1cs.satisfied:
+            self.stats["unsat"] += 1
+            return None
+        ph = self.params_for(work)
+        r, s = L.host_scalar_new(self.rng(64)), L.host_scalar_new(self.rng(64))  # bellman: `E::Fr::random(rng)` twice
+        proof = self.bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
+        self.stats["prove_s"] += time.perf_counter() - t1
+        self.stats["proved"] += 1
+        return proof
+
+    def submit(self, proofs: dict[int, bytes]) -> int:
+        acc = parse_solution_response(self._http("POST", "/bincode/mpn/solution", solution_request(self.address, proofs)))
+        self.stats["accepted"] += acc
+        return acc
+
+    def run_once(self) -> int:
+        """one round: fetch the works assigned to this address, prove them, post the solutions; returns `accepted`"""
+        proofs = {}
+        for wid, work in self.fetch().items():
+            p = self.prove(work)
+            if p is not None:
+                proofs[wid] = p
+        return self.submit(proofs) if proofs else 0
+
+    def run_forever(self, poll_s: float = 1.0, rounds: int | None = None):
+        done = 0
+        while rounds is None or done < rounds:
+            try:
+                self.run_once()
+            except (OSError, L.BzkError) as e:  # node away or a bad payload: keep polling, as a worker daemon does
+                self.stats["last_error"] = str(e)
+            done += 1
+            time.sleep(poll_s)

@@ -224,6 +224,8 @@ int32_t bzk_mpn_update_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t
  * tree (`reveal`, src/zk/groth16/gadgets/reveal/mod.rs:13-61).  `fingerprint` = ContractWithdraw::fingerprint()
  * (src/core/transaction.rs:204-211), taken as an opaque scalar: the L1 payment serialisation is out of scope. */
 int32_t bzk_mpn_push_deposit(bzk_mpn* w, uint64_t key_index, const uint8_t token_id[32], uint64_t amount);
+/* fingerprint NULL: the withdrawal carries a synthetic L1 payment and its fingerprint is derived from it as the wallet does
+ * (src/wallet/tx_builder.rs:376-425); non-NULL: an opaque fingerprint (such a withdrawal cannot be put on the wire) */
 int32_t bzk_mpn_push_withdraw(bzk_mpn* w, uint64_t account_index, const uint8_t token_id[32], uint64_t amount,
                               const uint8_t fee_token[32], uint64_t fee, const uint8_t fingerprint[32]);
 int32_t bzk_mpn_deposit_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t commitment[32], int32_t record_matrices, bzk_r1cs** out);
@@ -244,7 +246,47 @@ int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]);
 const void* bzk_r1cs_data(const bzk_r1cs* r, int32_t which, uint64_t* bytes);
 void bzk_r1cs_free(bzk_r1cs* r);
 /* CPU mirrors of `ZkHasher::hash`, `hash_to_scalar`'s SHA3 and `JubJub::{generate_keys, sign, verify}` */
+/* ---- f-2: the proving worker's wire format ---------------------------------------------------------------------------
+ * `MpnWork` (src/mpn/mod.rs:263-270) as `GET /bincode/mpn/work` delivers it (src/node/mod.rs:393-398,
+ * src/client/messages.rs:368-376) and `ZkProof` (src/zk/mod.rs:646-651) as `POST /bincode/mpn/solution` takes it, both
+ * bincode 1.3.3 with default options.  Layouts: bazuka_amd/csrc/host_bincode.h.  A Rust host that already holds an
+ * `MpnWork` passes `bincode::serialize(&work)`; the worker loop of bazuka_amd/worker.py passes the HTTP body. */
+#define BZK_WORK_SIG_LEN_PREFIXED 1u /* ed25519 signatures inside L1 payments carry a u64 length (ed25519 < 1.3) */
+typedef struct bzk_mpn_work bzk_mpn_work;
+/* decodes ONE MpnWork from the front of `bytes`; *consumed = its encoded length (a response holds several) */
+int32_t bzk_mpn_work_decode(const uint8_t* bytes, uint64_t len, uint32_t flags, bzk_mpn_work** out, uint64_t* consumed);
+const char* bzk_mpn_work_last_error(void); /* why the last decode on this thread failed */
+void bzk_mpn_work_free(bzk_mpn_work* work);
+/* info = kind (0 deposit, 1 withdraw, 2 update), log4_tree, log4_token_tree, log4 batch size of that kind, transitions on
+ * the wire, height, reward, new_root.state_size, mpn_num_{update,deposit,withdraw}_batches, this work's VK byte length */
+int32_t bzk_mpn_work_info(const bzk_mpn_work* work, uint64_t info[12]);
+/* out = state | aux_data | next_state | new_root.state_hash | mpn_contract_id, 32 bytes each */
+int32_t bzk_mpn_work_scalars(const bzk_mpn_work* work, uint8_t out[160]);
+/* bincode(Groth16VerifyingKey) (src/zk/groth16/mod.rs:22-31); which = -1: `MpnWork::vk()`, 0/1/2: deposit/withdraw/update */
+int32_t bzk_mpn_work_vk(const bzk_mpn_work* work, int32_t which, uint8_t* out, uint64_t cap, uint64_t* len);
+/* ZkScalar::new(sha3_256(bincode((prover, reward)))) - the commitment `MpnWork::verify` binds a solution to
+ * (src/mpn/mod.rs:281-295); prover_pub = the worker's 32-byte ed25519 address */
+int32_t bzk_mpn_work_commitment(const bzk_mpn_work* work, const uint8_t prover_pub[32], uint8_t out[32]);
+/* the circuit instance to prove: transitions padded with null ones to 4^batch; fee_token NULL = Ziesha; threads 0 = all */
+int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* work, const uint8_t prover_pub[32], const uint8_t fee_token[32],
+                                int32_t threads, int32_t record_matrices, bzk_r1cs** out);
+int32_t bzk_mpn_work_encode(const bzk_mpn_work* work, uint8_t* out, uint64_t cap, uint64_t* len); /* out NULL: size query */
+/* validator side (`prepare_works`, src/mpn/mod.rs:298-424): one work of the given kind from the world's queued
+ * transactions; the world advances to the work's next_state */
+typedef struct {
+    uint8_t log4_deposit_batch, log4_withdraw_batch, log4_update_batch;
+    uint64_t num_update_batches, num_deposit_batches, num_withdraw_batches;
+    const uint8_t* deposit_vk;  uint64_t deposit_vk_len;  /* bincode(Groth16VerifyingKey) */
+    const uint8_t* withdraw_vk; uint64_t withdraw_vk_len;
+    const uint8_t* update_vk;   uint64_t update_vk_len;
+    uint64_t new_root_state_size; /* ZkCompressedState::state_size: bookkeeping of the node's KV store, passed through */
+} bzk_mpn_work_config;
+int32_t bzk_mpn_make_work(bzk_mpn* w, int32_t kind, const bzk_mpn_work_config* cfg, uint64_t reward, bzk_mpn_work** out);
+int32_t bzk_zkproof_encode(const uint8_t proof[387], uint8_t out[391]); /* ZkProof::Groth16(Box<Groth16Proof>) */
+int32_t bzk_zkproof_decode(const uint8_t* in, uint64_t len, uint8_t proof[387]);
+
 int32_t bzk_host_poseidon(const uint8_t* in, uint32_t arity, uint8_t out[32]);
+int32_t bzk_host_scalar_new(const uint8_t* le_bytes, uint32_t len, uint8_t out[32]); /* ZkScalar::new: LE integer mod r; len <= 64 */
 int32_t bzk_host_sha3_256(const uint8_t* in, uint64_t len, uint8_t out[32]);
 int32_t bzk_host_jubjub_keys(const uint8_t* seed, uint32_t len, uint8_t out[128]); /* pub.x|pub.y|randomness|scalar */
 int32_t bzk_host_jubjub_sign(const uint8_t key[128], const uint8_t msg[32], uint8_t sig_out[96]); /* r.x|r.y|s */

@@ -1,0 +1,61 @@
+"""GPU end-to-end for SURVEY 8f-2: a proving worker against a (mock) Bazuka node.  The node hands out three works - one
+deposit, one withdraw, one update batch over consecutive states, as `prepare_works` does (src/mpn/mod.rs:352-414) - as
+bincode `GetMpnWorkResponse`; the worker (bazuka_amd/worker.py) decodes them with libbzk, synthesizes the circuits with
+the commitment H(prover, reward), proves on the GPU and posts `PostMpnSolutionRequest`; the node accepts a solution iff
+the oracle's pairing check passes for [commitment, height, state, aux_data, next_state] - `MpnWork::verify`."""
+import pytest
+
+from bazuka_amd import lib as L
+from bazuka_amd import worker as W
+from mock_node import MockNode
+from oracle import pyref as pr
+from util import fr_bytes, fr_list
+
+pytestmark = pytest.mark.gpu
+F = pr.fr_to_mont_bytes
+ZIESHA = F(1)
+ALICE = bytes(range(1, 33))
+MALLORY = bytes(range(101, 133))
+
+
+def test_worker_proves_a_block_of_works_and_the_node_accepts(bzk):
+    keys = W.DevSetup(bzk, {k: fr_bytes(fr_list(5, 9000 + k)) for k in range(3)})
+    vks = [keys.keys(k, 3, 3, 1)[1] for k in range(3)]
+    assert len({v for v in vks}) == 3 and all(len(v) == 1460 for v in vks)
+    w = L.MpnWorld(3, 3)
+    for i in range(4):
+        w.add_account(i, b"acct%d" % i, ZIESHA, 10 ** 9)
+    w.add_key(7, b"newcomer")
+    w.set_height(21)
+    blobs, roots = {}, [w.root()]
+    w.push_deposit(0, ZIESHA, 1000)
+    w.push_deposit(7, ZIESHA, 55)
+    blobs[0] = w.make_work(0, vks, 100).encode()
+    roots.append(w.root())
+    w.push_withdraw(1, ZIESHA, 400, ZIESHA, 2)
+    blobs[1] = w.make_work(1, vks, 200).encode()
+    roots.append(w.root())
+    w.push_tx(0, 1, ZIESHA, 1000, ZIESHA, 7)
+    w.push_tx(7, 2, ZIESHA, 5, ZIESHA, 1)      # the account the deposit just created spends
+    w.push_tx(2, 3, ZIESHA, 10, ZIESHA, 0)
+    blobs[2] = w.make_work(2, vks, 300).encode()
+    roots.append(w.root())
+    assert len(set(roots)) == 4
+    node = MockNode(blobs)
+    try:
+        rnd = iter(range(1, 1000))
+        alice = W.Worker(bzk, ALICE, ("127.0.0.1", node.port), keys, rng=lambda n: bytes([next(rnd)]) * n)
+        # a solution is bound to its prover: Mallory re-posting Alice's proofs under her own address gets nothing
+        proofs = {wid: alice.prove(work) for wid, work in alice.fetch().items()}
+        assert all(p is not None and len(p) == 387 for p in proofs.values()) and alice.stats["proved"] == 3
+        mallory = W.Worker(bzk, MALLORY, ("127.0.0.1", node.port), keys)
+        assert mallory.submit(proofs) == 0 and not node.solved
+        # wrong work id (update proof offered for the deposit work): refused; then the honest round
+        assert alice.submit({0: proofs[2]}) == 0
+        assert alice.run_once() == 3
+        assert node.solved == {0: ALICE, 1: ALICE, 2: ALICE}
+        assert alice.fetch() == {} and alice.run_once() == 0     # nothing left to do
+        assert alice.stats["accepted"] == 3 and alice.stats["unsat"] == 0
+    finally:
+        node.close()
+        keys.close()
