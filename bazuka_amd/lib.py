@@ -386,9 +386,11 @@ class Bzk:
         vk bincode bytes = Groth16VerifyingKey)."""
         keep, descs = [], []
         for n_rows, rp, col, val in csr_abc:
-            bufs = [C.create_string_buffer(bytes(x), max(1, len(x))) for x in (rp, col, val)]
+            # bytes are copied into stable buffers; ctypes arrays (R1cs.raw: zero-copy views of the generator's own
+            # arrays - the only option once a matrix passes 2 GiB) are passed by address
+            bufs = [x if isinstance(x, C.Array) else C.create_string_buffer(bytes(x), max(1, len(x))) for x in (rp, col, val)]
             keep.append(bufs)
-            descs.append(CsrDesc(n_rows, *[C.cast(b, C.c_void_p) for b in bufs]))
+            descs.append(CsrDesc(n_rows, *[C.cast(C.addressof(b), C.c_void_p) for b in bufs]))
         h = C.c_void_p()
         vk = C.create_string_buffer(878 + 97 * n_in)
         self._ck(self.lib.bzk_groth16_setup(self.h, C.byref(descs[0]), C.byref(descs[1]), C.byref(descs[2]), n_in, n_aux,
