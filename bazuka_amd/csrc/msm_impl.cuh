@@ -44,6 +44,21 @@ static int msm_pick_c(uint64_t n) {
     return c;
 }
 static int msm_windows_for(int c) { return (256 + c - 1) / c; }  // signed digits need one spare bit
+// Window size of a proof's witness MSMs (flag BZK_F_DEDUP: l, a, b_g1, b_g2) - A/B knob.  By WORK, in units of one mixed
+// addition, an MSM costs W(c) x (n_eff + kappa 2^(c-1)) with W(c) = ceil(256 / c), n_eff ~ 0.6 n distinct scalars after
+// de-duplication and kappa = 4.75 general additions per bucket x 14 / 10 products = 6.65: for the 16-tx Update circuit
+// (n = 0.7 - 0.9 M) that is flat within 7 % from c = 13 to 16, and so is the measurement - pipelined proofs/s 41.3 / 39.7
+// with the plain pick (16), 40.9 - 43.3 with 13 / 14, 38.7 with 15 / 14, run-to-run noise +-1.5
+// (profiles/r01_run48_49_witness_window.txt).  The plain pick therefore stays; env BZK_MSM_C_WIT_G1 / BZK_MSM_C_WIT_G2
+// set a window size for the unsharded witness MSMs of one curve.
+template <class C>
+static int msm_pick_c_witness(uint64_t n, int c_plain) {
+    static const int env_g1 = [] { const char* e = getenv("BZK_MSM_C_WIT_G1"); return e ? atoi(e) : 0; }();
+    static const int env_g2 = [] { const char* e = getenv("BZK_MSM_C_WIT_G2"); return e ? atoi(e) : 0; }();
+    const int env = C::RAW == 192 ? env_g2 : env_g1;
+    (void)n;
+    return env >= 4 && env <= 20 ? env : c_plain;
+}
 
 // ------------------------------------------------------------------------------------------------
 // 1. digits
@@ -648,12 +663,18 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     typedef typename C::Pt Pt;
     typedef XyzzT<F> StdPt;
     result = xyzz_identity<F>();
-    if (n == 0 || w_begin >= w_end) return BZK_OK;
+    if (n == 0 || (w_end >= 0 && w_begin >= w_end)) return BZK_OK;  // w_end < 0: every window (resolved once c is known)
     if (n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
-    const int c = table ? table->c : (ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n));
+    int c = table ? table->c : (ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n));
+    // the work-model pick applies to unsharded calls only: a caller that names a window range counts windows with
+    // bzk_msm_window_count(n), i.e. with the plain pick
+    if (!table && (flags & BZK_F_DEDUP) && w_end < 0 && w_begin == 0 && !(ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20))
+        c = msm_pick_c_witness<C>(n, c);
     const int w_total = msm_windows_for(c);
     const bool folded = table && table->wpl > 1;  // bucket sets [w_begin, w_end) of a folded table, fed by every level
     const int levels = table ? table->levels : 1;
+    if (w_end < 0) w_end = folded ? table->wpl : w_total;
+    if (w_begin >= w_end) return BZK_OK;
     if (w_end > (folded ? table->wpl : w_total)) return BZK_E_ARG;
     if (table && (n > table->n || (uint64_t)levels * table->n >= ((uint64_t)1 << 31))) return BZK_E_ARG;
     const uint32_t half = 1u << (c - 1);
@@ -878,11 +899,7 @@ static int32_t msm_entry_dev(bzk_ctx* ctx, const void* bases, const void* scalar
     if (!ctx || !out || (n && (!bases || !scalars))) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     XyzzT<F> r;
-    if (w_end < 0) {
-        const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n ? n : 1);
-        w_end = msm_windows_for(c);
-    }
-    BZK_TRY(msm_run<C>(ctx, bases, scalars, n, flags, w_begin, w_end, r));
+    BZK_TRY(msm_run<C>(ctx, bases, scalars, n, flags, w_begin, w_end, r));  // w_end < 0: all windows of the c msm_run picks
     PointIO<F>::pack(r, out);
     return BZK_OK;
 }
@@ -955,7 +972,6 @@ static int32_t msm_table_entry(bzk_ctx* ctx, const MsmTable* t, const void* scal
     typedef typename C::HostF F;
     if (!ctx || !t || !out || (n && !scalars)) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
-    if (w_end < 0) w_end = t->wpl > 1 ? t->wpl : t->w_total;
     XyzzT<F> r;
     BZK_TRY(msm_run<C>(ctx, nullptr, scalars, n, flags, w_begin, w_end, r, t));
     PointIO<F>::pack(r, out);
