@@ -299,14 +299,16 @@ class Bzk:
     def msm_window_count(self, n: int) -> int:
         return self.lib.bzk_msm_window_count(n)
 
-    def msm_g1_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False) -> bytes:
+    def msm_g1_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False, dedup=False) -> bytes:
         out = C.create_string_buffer(97)
-        self._ck(self.lib.bzk_msm_g1_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, w0, w1, out), "msm_g1_windows_dev")
+        flags = (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0)
+        self._ck(self.lib.bzk_msm_g1_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, flags, w0, w1, out), "msm_g1_windows_dev")
         return out.raw
 
-    def msm_g2_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False) -> bytes:
+    def msm_g2_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False, dedup=False) -> bytes:
         out = C.create_string_buffer(193)
-        self._ck(self.lib.bzk_msm_g2_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, w0, w1, out), "msm_g2_windows_dev")
+        flags = (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0)
+        self._ck(self.lib.bzk_msm_g2_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, flags, w0, w1, out), "msm_g2_windows_dev")
         return out.raw
 
     def msm_table_build(self, bases, n: int, g2=False, levels: int = 0):

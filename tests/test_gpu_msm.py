@@ -340,3 +340,85 @@ def test_msm_g1_2p24_partition_property(bzk):
     lo = bzk.msm_g1_dev(bases[:h * 96], sc[:h * 32], h)
     hi = bzk.msm_g1_dev(bases[h * 96:], sc[h * 32:], h)
     assert bzk.g1_sum(lo + hi) == whole
+
+
+# ---- every window size, not only the ones the size-based pick happens to choose for the test sizes
+
+@pytest.mark.parametrize("c", [5, 9, 11, 13, 14, 15, 17])
+def test_msm_g1_every_window_size_vs_oracle(co, pr, c, monkeypatch):
+    """BZK_MSM_C (read when a context is created) forces the window size: plain, de-duplicated and window-sharded MSMs
+    equal the oracle for sizes whose automatic pick never reaches most of these c (11 and 13 - 15 were first exercised
+    by the witness-window A/B of run 48, which found a window-count bug the size-based tests could not see)."""
+    from bazuka_amd import Bzk
+    monkeypatch.setenv("BZK_MSM_C", str(c))
+    ctx = Bzk(0)
+    try:
+        n = 20000
+        hb = bytearray(co.g1_bases(91, 0, n, nthreads=co.ncpu()))
+        hb[96:192] = hb[0:96]
+        sc = _witness_like_scalars(n, 100 + c)
+        sc[0] = sc[1] = 0x1234567
+        sc[2], sc[3], sc[4] = pr.R_MOD - 1, 1 << 254, (1 << c) - 1
+        scb = fr_bytes(sc)
+        want = co.msm_g1(bytes(hb), scb, nthreads=co.ncpu())
+        assert ctx.msm_g1(bytes(hb), scb) == want
+        assert ctx.msm_g1(bytes(hb), scb, dedup=True) == want
+        W = ctx.msm_window_count(n)
+        assert W == (256 + c - 1) // c
+        bases, sd = to_dev(bytes(hb)), to_dev(scb)
+        cuts = [0, 1, W // 2, W]
+        parts = b"".join(ctx.msm_g1_windows_dev(bases, sd, n, cuts[i], cuts[i + 1]) for i in range(3))
+        assert ctx.g1_sum(parts) == want
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("c", [7, 12])
+def test_msm_g2_other_window_sizes_vs_oracle(co, pr, c, monkeypatch):
+    from bazuka_amd import Bzk
+    monkeypatch.setenv("BZK_MSM_C", str(c))
+    ctx = Bzk(0)
+    try:
+        n = 4500
+        hb = co.g2_bases(93, 0, n, nthreads=co.ncpu())
+        scb = fr_bytes(_witness_like_scalars(n, 200 + c))
+        want = co.msm_g2(hb, scb, nthreads=co.ncpu())
+        assert ctx.msm_g2(hb, scb) == want
+        assert ctx.msm_g2(hb, scb, dedup=True) == want
+    finally:
+        ctx.close()
+
+
+def test_witness_window_knob_in_a_fresh_process(co):
+    """BZK_MSM_C_WIT_G1 / _G2 (process-wide, read once): the unsharded de-duplicated MSMs run with their own window size and
+    still equal the oracle; a named window range keeps the plain pick (its window count comes from bzk_msm_window_count)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from bazuka_amd import Bzk
+from oracle import coracle as co
+from util import fr_bytes, to_dev
+import random
+rnd = random.Random(5)
+from oracle import pyref as pr
+n = 9000
+sc = [rnd.choice([0, 1, 1, 2, rnd.randrange(1 << 64), rnd.randrange(pr.R_MOD)]) for _ in range(n)]
+scb = fr_bytes(sc)
+ctx = Bzk(0)
+b1 = co.g1_bases(5, 0, n, nthreads=co.ncpu()); b2 = co.g2_bases(5, 0, 3000, nthreads=co.ncpu())
+assert ctx.msm_g1(b1, scb, dedup=True) == co.msm_g1(b1, scb, nthreads=co.ncpu())
+assert ctx.msm_g2(b2, scb[:3000 * 32], dedup=True) == co.msm_g2(b2, scb[:3000 * 32], nthreads=co.ncpu())
+W = ctx.msm_window_count(n)
+d1, ds = to_dev(b1), to_dev(scb)
+parts = ctx.msm_g1_windows_dev(d1, ds, n, 0, W // 2, dedup=True) + ctx.msm_g1_windows_dev(d1, ds, n, W // 2, W, dedup=True)
+assert ctx.g1_sum(parts) == co.msm_g1(b1, scb, nthreads=co.ncpu())
+print("ok")
+''' % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, BZK_MSM_C_WIT_G1="11", BZK_MSM_C_WIT_G2="6")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
