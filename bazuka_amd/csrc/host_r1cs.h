@@ -15,6 +15,7 @@
 // Linear combinations merge duplicate variables (bellman appends; the evaluations are identical).
 #pragma once
 #include <stdexcept>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -85,6 +86,17 @@ struct PinnedPoolAlloc {
         return (T*)p;
     }
     void deallocate(T* p, size_t n) { pinned_pool_give(p, n * sizeof(T)); }
+    // resize() DEFAULT-initialises (no zero fill): the witness arrays of a production circuit are gigabytes that the worker
+    // threads overwrite completely (every slot of a window is accounted for, ConstraintSystem::set_window), and a
+    // single-threaded memset of them was a third of the generator's wall time at 2^24 - 2^26 constraints
+    template <class U>
+    void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new ((void*)p) U;
+    }
+    template <class U, class... Args>
+    void construct(U* p, Args&&... args) {
+        ::new ((void*)p) U(std::forward<Args>(args)...);
+    }
     template <class U>
     bool operator==(const PinnedPoolAlloc<U>&) const { return true; }
     template <class U>

@@ -427,6 +427,7 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
             size_hint_cons = it->second.second;
         }
         // workers write straight into their slice of the final (pinned) arrays: no per-transition buffers, no merge copy
+        const auto ta0 = std::chrono::steady_clock::now();
         const size_t base_aux = cs.aux.size(), base_con = cs.az.size();
         cs.aux.reserve(base_aux + n * size_hint_aux + 4096);
         cs.az.reserve(base_con + n * size_hint_cons + 4096);
@@ -436,6 +437,8 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
         cs.az.resize(base_con + n * size_hint_cons);
         cs.bz.resize(base_con + n * size_hint_cons);
         cs.cz.resize(base_con + n * size_hint_cons);
+        if (getenv("BZK_DEBUG"))
+            fprintf(stderr, "[bzk] witness arrays sized: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - ta0).count());
         std::vector<Fr> state_in(n + 1);
         state_in[0] = state.v;
         for (size_t t = 0; t < n; ++t) state_in[t + 1] = transitions[t].enabled ? transitions[t].state_after.v : state_in[t];
@@ -885,7 +888,25 @@ static void finish_r1cs(bzk_r1cs* r) {
     const size_t n_in = cs.inputs.size(), n_aux = cs.aux.size();
     r->z_bytes.resize((n_in + n_aux) * 32);
     for (size_t i = 0; i < n_in; ++i) memcpy(&r->z_bytes[32 * i], cs.inputs[i].l, 32);
-    for (size_t i = 0; i < n_aux; ++i) memcpy(&r->z_bytes[32 * (n_in + i)], cs.aux[i].l, 32);
+    {
+        // z = inputs | aux: Fr is 32 contiguous bytes, so the aux part is one block copy - split over a few threads once
+        // it is large (1.85 GB for the 1024-tx circuit)
+        uint8_t* dst = r->z_bytes.data() + 32 * n_in;
+        const uint8_t* src = (const uint8_t*)cs.aux.data();
+        const size_t bytes = n_aux * 32;
+        const size_t nt = bytes < ((size_t)64 << 20) ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+        if (nt <= 1) {
+            if (bytes) memcpy(dst, src, bytes);
+        } else {
+            std::vector<std::thread> th;
+            const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+            for (size_t t = 0; t < nt; ++t) {
+                const size_t lo = t * per, hi = std::min(bytes, lo + per);
+                if (lo < hi) th.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+            }
+            for (auto& x : th) x.join();
+        }
+    }
     auto dens = [&](const std::vector<uint8_t>& din, const std::vector<uint8_t>& daux, std::vector<uint8_t>& out) {
         out.assign(n_in + n_aux, 0);
         for (size_t i = 0; i < din.size() && i < n_in; ++i) out[i] = din[i];

@@ -45,6 +45,8 @@ def main(b=4, n_proofs=2, compare=0):
     for k in range(n_proofs):
         if k:
             batch(k)
+            if cur is not r:
+                cur.free()  # hand the pinned witness arrays back to the pool BEFORE the next instance asks for its own
             t0 = time.perf_counter(); cur = w.update_synthesize(b, fr(99), ZIESHA); tw.append(time.perf_counter() - t0)
             assert cur.accepted == n_tx
         z, az, bz, cz = cur.raw("z"), cur.raw("az"), cur.raw("bz"), cur.raw("cz")
