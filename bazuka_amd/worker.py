@@ -176,3 +176,42 @@ class Worker:
                 self.stats["last_error"] = str(e)
             done += 1
             time.sleep(poll_s)
+
+
+def main(argv=None):
+    """python -m bazuka_amd.worker --node 127.0.0.1:8765 --address <64 hex> --dev-toxic <seed>
+    Dev-mode worker: proving keys are generated on the GPU from a toxic-waste seed shared with the node's setup
+    (development networks only - a real network's keys come from its ceremony)."""
+    import argparse
+    import hashlib
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--node", required=True, help="host:port of the Bazuka node")
+    ap.add_argument("--address", required=True, help="this worker's L1 address: 32-byte ed25519 public key, hex")
+    ap.add_argument("--dev-toxic", required=True, help="seed of the dev-mode CRS (tau, alpha, beta, gamma, delta per circuit kind)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--poll", type=float, default=1.0)
+    ap.add_argument("--rounds", type=int, default=None)
+    ap.add_argument("--sig-len-prefixed", action="store_true", help="node built against ed25519 < 1.3 (BZK_WORK_SIG_LEN_PREFIXED)")
+    a = ap.parse_args(argv)
+    host, port = a.node.rsplit(":", 1)
+    address = bytes.fromhex(a.address)
+    if len(address) != 32:
+        ap.error("--address must be 32 bytes of hex")
+
+    def toxic(kind):
+        return b"".join(L.host_scalar_new(hashlib.sha3_256(f"{a.dev_toxic}/{kind}/{i}".encode()).digest() * 2) for i in range(5))
+
+    bzk = L.Bzk(a.device)  # raises without a gfx950 device: there is no CPU prover
+    keys = DevSetup(bzk, {k: toxic(k) for k in range(3)})
+    w = Worker(bzk, address, (host, int(port)), keys, flags=1 if a.sig_len_prefixed else 0)
+    try:
+        w.register()
+        w.run_forever(a.poll, a.rounds)
+    finally:
+        print(w.stats)
+        keys.close()
+        bzk.close()
+
+
+if __name__ == "__main__":
+    main()

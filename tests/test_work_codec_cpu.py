@@ -278,3 +278,46 @@ def test_worker_http_round_trip_against_a_mock_node():
         assert [e[0] for e in node.log] == ["worker", "work", "solution"] and node.log[2][1:] == (PROVER, [4], 0)
     finally:
         node.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_decoder_survives_mutated_payloads(kind):
+    """differential fuzzing of the decoder: random byte flips, truncations and splices of a valid work either decode in
+    BOTH codecs to the same thing or are refused by libbzk - never a crash, never a silent disagreement.  (The schema
+    codec accepts a few inputs libbzk refuses on purpose: keys that do not decompress, proofs of the wrong depth.)"""
+    import random
+    rnd = random.Random(1234 + kind)
+    _, _, work = _make(kind)
+    blob = work.encode()
+    agree = refused = 0
+    for it in range(300):
+        b = bytearray(blob)
+        mode = it % 4
+        if mode == 0:      # flip 1-3 bytes anywhere
+            for _ in range(rnd.randint(1, 3)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:    # overwrite an aligned u64 / u32 (lengths, tags, indices live there)
+            off = rnd.randrange(0, len(b) - 8)
+            b[off:off + 8] = rnd.choice([0, 1, 2, 255, 1 << 31, (1 << 64) - 1]).to_bytes(8, "little")
+        elif mode == 2:    # truncate
+            b = b[:rnd.randrange(len(b))]
+        else:              # splice a chunk from elsewhere
+            a, c = sorted(rnd.randrange(len(b)) for _ in range(2))
+            off = rnd.randrange(len(b))
+            b[off:off + (c - a)] = blob[a:c]
+        b = bytes(b)
+        try:
+            dec = L.MpnWork.decode(b)
+        except L.BzkError:
+            refused += 1
+            continue
+        # accepted: the reference-schema codec must read the same prefix and agree on what it says
+        v, used = B.decode_prefix(B.MpnWork, b)
+        assert used == dec.consumed
+        assert v["public_inputs"]["height"] == dec.height and v["reward"] == dec.reward
+        assert v["public_inputs"]["state"] == dec.state and v["new_root"]["state_hash"] == dec.new_root_hash
+        assert len(v["data"][1]) == dec.n_transitions and ("Deposit", "Withdraw", "Update").index(v["data"][0]) == dec.kind
+        again = L.MpnWork.decode(dec.encode())
+        assert again.encode() == dec.encode()   # encode . decode is idempotent on whatever was accepted
+        agree += 1
+    assert agree > 20 and refused > 20, (agree, refused)
