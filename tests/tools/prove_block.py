@@ -42,6 +42,8 @@ def main(small=False):
         for k in range(3):
             if k:
                 make_batch(k)
+                if cur is not r:
+                    cur.free()  # pinned witness arrays back to the pool before the next instance takes its own
                 t0 = time.perf_counter(); cur = synth(False); tw.append(time.perf_counter() - t0)
             t0 = time.perf_counter()
             proof = ctx.groth16_prove(ph, cur.raw("z"), cur.raw("az"), cur.raw("bz"), cur.raw("cz"), fr(7 + k), fr(9 + k))
