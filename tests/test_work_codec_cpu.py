@@ -17,7 +17,7 @@ F, U = pr.fr_to_mont_bytes, pr.fr_from_mont_bytes
 ZIESHA = F(1)
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REF = json.load(open(os.path.join(G, "reference_vectors.json")))
-VKS = [bytes.fromhex(h) for h in REF["verifying_keys_bincode_hex"]]  # order in the reference: deposit? - used as 3 distinct blobs
+VKS = [bytes.fromhex(h) for h in REF["verifying_keys_bincode_hex"]]  # the reference's three hard-coded keys, used as (deposit, withdraw, update)
 PROVER = bytes(range(1, 33))  # a worker's L1 address (ed25519 public key bytes)
 
 

@@ -41,8 +41,35 @@ def main(seconds=60, seed=1):
     counts = {}
     t_end = time.time() + seconds
     while time.time() < t_end:
-        kind = rnd.choice(("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows"))
+        kind = rnd.choice(("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows", "table", "window_size"))
         counts[kind] = counts.get(kind, 0) + 1
+        if kind in ("table", "window_size"):
+            import torch
+            n = rnd.choice((1, 5, 300, 2000, 6000))
+            bases = co.g1_bases(rnd.randrange(1 << 30), 0, n, nthreads=nt)
+            sc = scalars(rnd, n)
+            want = co.msm_g1(bases, sc, nthreads=nt)
+            db = torch.frombuffer(bytearray(bases), dtype=torch.uint8).cuda(); ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+            if kind == "table":  # static-base tables: full (levels 0) and folded (2..6 levels), bucket-set / level shards
+                tab = ctx.msm_table_build(db, n, levels=rnd.choice((0, 0, 2, 3, 4, 5, 6)))
+                m = rnd.choice((n, max(1, n // 2)))
+                assert ctx.msm_table_run_dev(tab, ds, m) == co.msm_g1(bases[:96 * m], sc[:32 * m], nthreads=nt), (kind, n, m)
+                S = ctx.msm_table_window_count(tab)
+                cut = sorted({0, S, rnd.randrange(S + 1)})
+                parts = b"".join(ctx.msm_table_windows_dev(tab, ds, n, a, b) for a, b in zip(cut, cut[1:]))
+                assert ctx.g1_sum(parts) == want, (kind, n, cut)
+                ctx.msm_table_free(tab)
+            else:  # every window size through a context created under BZK_MSM_C
+                c = rnd.randrange(4, 19)
+                os.environ["BZK_MSM_C"] = str(c)
+                try:
+                    cx = Bzk(0)
+                finally:
+                    del os.environ["BZK_MSM_C"]
+                assert cx.msm_g1_dev(db, ds, n) == want, (kind, n, c)
+                assert cx.msm_g1(bases, sc, dedup=True) == want, (kind, n, c, "dedup")
+                cx.close()
+            continue
         if kind in ("msm_g1", "msm_g2", "windows"):
             g2 = kind == "msm_g2"
             size = 192 if g2 else 96
