@@ -76,8 +76,10 @@ class DevSetup:
     shape - the reference's dev-mode CRS (src/config/blockchain.rs:355-417) with caller-supplied toxic waste
     (tau | alpha | beta | gamma | delta, 5 x 32 Montgomery bytes per circuit kind).  Cached per (kind, L, T, B)."""
 
-    def __init__(self, bzk: L.Bzk, toxic_by_kind: dict[int, bytes]):
-        self.bzk, self.toxic, self.cache = bzk, toxic_by_kind, {}
+    def __init__(self, bzk: L.Bzk, toxic_by_kind: dict[int, bytes], cache_dir: str | None = None):
+        """cache_dir: keep each generated CRS on disk (one file per circuit shape and toxic waste) so that a restarted
+        worker uploads it with bzk_params_load instead of regenerating it (minutes for the production circuits)"""
+        self.bzk, self.toxic, self.cache, self.cache_dir = bzk, toxic_by_kind, {}, cache_dir
 
     def shape_circuit(self, kind: int, L4: int, T4: int, B4: int) -> L.R1cs:
         z = bytes(32)
@@ -89,11 +91,54 @@ class DevSetup:
         """(params handle, bincode Groth16VerifyingKey) for a circuit shape"""
         key = (kind, L4, T4, B4)
         if key not in self.cache:
-            r = self.shape_circuit(kind, L4, T4, B4)
-            csr = [(r.n_constraints, r.view("rp" + w), r.view("col" + w), r.view("val" + w)) for w in "ABC"]
-            self.cache[key] = self.bzk.groth16_setup(csr, r.n_in, r.n_aux, self.toxic[kind])
-            r.free()
+            path = None
+            if self.cache_dir:
+                import hashlib
+                tag = hashlib.sha3_256(self.toxic[kind]).hexdigest()[:16]
+                path = os.path.join(self.cache_dir, f"crs_k{kind}_L{L4}_T{T4}_B{B4}_{tag}.bzkcrs")
+            if path and os.path.exists(path):
+                self.cache[key] = self._load(path)
+            else:
+                r = self.shape_circuit(kind, L4, T4, B4)
+                csr = [(r.n_constraints, r.raw("rp" + w), r.raw("col" + w), r.raw("val" + w)) for w in "ABC"]
+                self.cache[key] = self.bzk.groth16_setup(csr, r.n_in, r.n_aux, self.toxic[kind])
+                if path:
+                    self._save(path, self.cache[key], r)
+                r.free()
         return self.cache[key]
+
+    # file = magic | 5 x u32 (n_in, n_aux, log_m, n_a, n_b) | 9 x (u64 length + bytes): vk(bincode), vk points(870), h, l, a, b_g1,
+    # b_g2, a_density, b_density - the arrays bzk_params_read returns / bzk_params_load takes (include/bzk.h)
+    _MAGIC = b"BZKCRS01"
+
+    def _save(self, path, entry, r):
+        ph, vk = entry
+        a_d, b_d = r.view("a_density"), r.view("b_density")
+        parts = [vk] + [self.bzk.params_read(ph, which) for which in range(6)] + [a_d, b_d]
+        log_m = max(0, (r.n_constraints - 1).bit_length())
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(self._MAGIC + struct.pack("<5I", r.n_in, r.n_aux, log_m, sum(a_d), sum(b_d)))
+            for p in parts:
+                f.write(struct.pack("<Q", len(p)))
+                f.write(p)
+        os.replace(tmp, path)
+
+    def _load(self, path):
+        with open(path, "rb") as f:
+            head = f.read(8 + 20)
+            if head[:8] != self._MAGIC:
+                raise L.BzkError(f"{path}: not a bzk CRS file")
+            n_in, n_aux, log_m, n_a, n_b = struct.unpack("<5I", head[8:])
+            parts = []
+            for _ in range(9):
+                (ln,) = struct.unpack("<Q", f.read(8))
+                parts.append(f.read(ln))
+        vk_bincode, vk_pts, h, l, a, b_g1, b_g2, a_d, b_d = parts
+        ph = self.bzk.params_load({"n_in": n_in, "n_aux": n_aux, "log_m": log_m, "n_a": n_a, "n_b": n_b, "vk": vk_pts, "h": h, "l": l,
+                                   "a": a, "b_g1": b_g1, "b_g2": b_g2, "a_density": a_d, "b_density": b_d})
+        return ph, vk_bincode
 
     def __call__(self, work: L.MpnWork):
         ph, vk = self.keys(work.kind, work.log4_tree, work.log4_token_tree, work.log4_batch)

@@ -59,3 +59,28 @@ def test_worker_proves_a_block_of_works_and_the_node_accepts(bzk):
     finally:
         node.close()
         keys.close()
+
+
+def test_dev_setup_disk_cache_gives_the_same_keys_and_proofs(bzk, tmp_path):
+    """a restarted worker loads its proving key from the cache file (bzk_params_load) instead of regenerating it: same
+    verifying key, and the SAME proof bytes for the same (work, r, s) as the worker that generated the key"""
+    tox = {k: fr_bytes(fr_list(5, 7000 + k)) for k in range(3)}
+    first = W.DevSetup(bzk, tox, cache_dir=str(tmp_path))
+    ph1, vk1 = first.keys(0, 3, 3, 1)
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and files[0].suffix == ".bzkcrs" and files[0].stat().st_size > 1 << 20
+    again = W.DevSetup(bzk, tox, cache_dir=str(tmp_path))
+    ph2, vk2 = again.keys(0, 3, 3, 1)          # from disk
+    assert vk2 == vk1 and ph2.value != ph1.value
+    w = L.MpnWorld(3, 3)
+    w.add_account(0, b"acct0", ZIESHA, 10 ** 9)
+    w.push_deposit(0, ZIESHA, 17)
+    work = L.MpnWork.decode(w.make_work(0, [vk1, vk1, vk1], 5).encode())
+    proofs = []
+    for keys in (first, again):
+        rnd = iter(range(1, 100))
+        wk = W.Worker(bzk, ALICE, ("127.0.0.1", 1), keys, rng=lambda n: bytes([next(rnd)]) * n)
+        proofs.append(wk.prove(work))
+    assert proofs[0] is not None and proofs[0] == proofs[1]
+    first.close()
+    again.close()
