@@ -47,6 +47,17 @@ int hc_fp28_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     st<FpParams>(out, fp28::from28(fp28::mul(fp28::to28(x), fp28::to28(y))));
     return 0;
 }
+// the dedicated square against the product of a value with itself - also on weakly reduced inputs (sums of up to
+// 2^grow terms, i.e. limbs up to ~2^(28 + grow)): returns 0 iff every output LIMB is identical
+int hc_fp28_sqr_equals_mul(const uint8_t* a, int grow, uint8_t* out) {
+    Fp28 x = fp28::to28(ld<FpParams>(a));
+    for (int i = 0; i < grow; ++i) x = fp28::add(x, x);
+    const Fp28 s = fp28::sqr_body(x), m = fp28::mul_body(x, x);
+    int diff = 0;
+    for (int i = 0; i < fp28::N; ++i) diff |= s.l[i] != m.l[i];
+    st<FpParams>(out, fp28::from28(s));
+    return diff;
+}
 int hc_fp28_roundtrip(const uint8_t* a, uint8_t* out) {
     st<FpParams>(out, fp28::from28(fp28::to28(ld<FpParams>(a))));
     return 0;

@@ -136,6 +136,12 @@ def test_reduced_radix_fields_on_host_match_oracle(hc, co, pr):
         out = C.create_string_buffer(48)
         hc.hc_fp28_mul(pr.fp_to_mont_bytes(a), pr.fp_to_mont_bytes(b), out)
         assert out.raw == pr.fp_to_mont_bytes(a * b % pr.P_MOD)
+    # the dedicated square (105 + 196 mads) is limb-identical to mul(a, a) (392 mads), also on weakly reduced inputs
+    for a in pv:
+        for grow in (0, 1, 2):  # limbs up to ~2^30: beyond what the curve formulas feed it (L <= 29.6)
+            out = C.create_string_buffer(48)
+            assert hc.hc_fp28_sqr_equals_mul(pr.fp_to_mont_bytes(a), grow, out) == 0
+            assert out.raw == pr.fp_to_mont_bytes(a * a * 4 ** grow % pr.P_MOD)
     rv = [0, 1, pr.R_MOD - 1, 2 ** 254] + [rnd.randrange(pr.R_MOD) for _ in range(100)]
     for _ in range(200):
         a, b = rnd.choice(rv), rnd.choice(rv)
