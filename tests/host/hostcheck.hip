@@ -122,6 +122,16 @@ int hc_fr29_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     st<FrParams>(out, fr29::from29(fr29::mul(fr29::to29(ld<FrParams>(a)), fr29::to29(ld<FrParams>(b)))));
     return 0;
 }
+// the dedicated square == the product of a value with itself, limb for limb, also on unnormalised inputs (value * 2^grow)
+int hc_fr29_sqr_equals_mul(const uint8_t* a, int grow, uint8_t* out) {
+    Fr29 x = fr29::to29(ld<FrParams>(a));
+    for (int i = 0; i < grow; ++i) x = fr29::add(x, x);
+    const Fr29 s = fr29::sqr_body(x), m = fr29::mul_body(x, x);
+    int diff = 0;
+    for (int i = 0; i < fr29::N; ++i) diff |= s.l[i] != m.l[i];
+    st<FrParams>(out, fr29::from29(s));
+    return diff;
+}
 // one Poseidon hash through the device function; consts = rc then mds in the reference's plain layout, 8 x 32-bit
 // Montgomery (n_consts entries): the sparse-partial-round constants are derived here exactly as the library does
 int hc_poseidon29(const uint8_t* in, int arity, const uint8_t* consts, int n_consts, int rf, int rp, uint8_t* out) {

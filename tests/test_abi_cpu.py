@@ -143,6 +143,11 @@ def test_reduced_radix_fields_on_host_match_oracle(hc, co, pr):
             assert hc.hc_fp28_sqr_equals_mul(pr.fp_to_mont_bytes(a), grow, out) == 0
             assert out.raw == pr.fp_to_mont_bytes(a * a * 4 ** grow % pr.P_MOD)
     rv = [0, 1, pr.R_MOD - 1, 2 ** 254] + [rnd.randrange(pr.R_MOD) for _ in range(100)]
+    for a in rv:  # the Fr29 square (the S-box's x^2 and x^4)
+        for grow in (0, 1):
+            out = C.create_string_buffer(32)
+            assert hc.hc_fr29_sqr_equals_mul(pr.fr_to_mont_bytes(a), grow, out) == 0
+            assert out.raw == pr.fr_to_mont_bytes(a * a * 4 ** grow % pr.R_MOD)
     for _ in range(200):
         a, b = rnd.choice(rv), rnd.choice(rv)
         out = C.create_string_buffer(32)
