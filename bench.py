@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N, help="log2 points per GPU (default 20 = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proofs", action="store_true", help="skip the full Groth16 proofs/s section (N=1 only)")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the informational two-MSMs-in-flight measurement (kernel traces)")
     args = ap.parse_args()
 
     import torch
@@ -295,7 +296,7 @@ def main():
     # what a prover with independent MSMs in flight sees: the latency-bound tail of one MSM (bucket reduction, window
     # sums, read-back, ~1.4 ms) overlaps the accumulation of the other.  `value` above stays the one-at-a-time rate.
     overlapped = None
-    if world == 1:
+    if world == 1 and not args.no_overlap:
         import threading
         ctxs = [Bzk(local_rank) for _ in range(2)]
         outs = [None, None]
