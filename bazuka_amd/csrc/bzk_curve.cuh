@@ -114,6 +114,54 @@ BZK_HD void xyzz_add(XyzzT<F>& acc, const XyzzT<F>& q) {
     acc.ZZZ = F::mul(F::mul(acc.ZZZ, q.ZZZ), PPP);
 }
 
+// acc += *q with q left in memory: each coordinate of q is read where it is used, so only acc and the formula's
+// temporaries occupy registers (peak ~10 field elements instead of ~14 with q resident).  For the G2 tail kernels, where
+// two resident 112-register points plus an addition's temporaries exceed what survives a call to the field product
+// (everything beyond went through scratch memory: 1744 B per lane in msm_reduce).  Same formula and case analysis as
+// xyzz_add; `fence` is a compiler barrier that keeps the loads from being hoisted back to the top.
+template <class F>
+BZK_HD void xyzz_add_mem(XyzzT<F>& acc, const XyzzT<F>* q) {
+    typedef typename F::T T;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BZK_MEM_FENCE() __asm__ volatile("" ::: "memory")
+#else
+#define BZK_MEM_FENCE() ((void)0)
+#endif
+    {
+        const T qzz = q->ZZ;
+        if (F::is_zero(qzz)) return;  // q is the identity
+        if (xyzz_is_identity<F>(acc)) {
+            acc = *q;
+            return;
+        }
+    }
+    BZK_MEM_FENCE();
+    T U1 = F::mul(acc.X, q->ZZ);
+    BZK_MEM_FENCE();
+    T U2 = F::mul(q->X, acc.ZZ);
+    T Pp = F::sub(U2, U1);
+    BZK_MEM_FENCE();
+    T S1 = F::mul(acc.Y, q->ZZZ);
+    BZK_MEM_FENCE();
+    T S2 = F::mul(q->Y, acc.ZZZ);
+    T R = F::sub(S2, S1);
+    if (F::is_zero(Pp)) {
+        if (F::is_zero(R)) acc = xyzz_dbl<F>(acc);
+        else acc = xyzz_identity<F>();
+        return;
+    }
+    T PP = F::sqr(Pp), PPP = F::mul(Pp, PP), Q = F::mul(U1, PP);
+    T X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+    T Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+    acc.X = X3;
+    acc.Y = Y3;
+    BZK_MEM_FENCE();
+    acc.ZZ = F::mul(F::mul(acc.ZZ, q->ZZ), PP);
+    BZK_MEM_FENCE();
+    acc.ZZZ = F::mul(F::mul(acc.ZZZ, q->ZZZ), PPP);
+#undef BZK_MEM_FENCE
+}
+
 template <class F>
 BZK_HD XyzzT<F> xyzz_neg(const XyzzT<F>& p) {
     return {p.X, F::neg(p.Y), p.ZZ, p.ZZZ};

@@ -250,6 +250,19 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
     else partial[t] = acc;
 }
 
+// acc += *q.  G2 (PARK_REDUCE): q stays in memory and is read where the formula uses it - two resident 112-register points
+// plus an addition's temporaries do not survive the calls to the field product, and the tail kernels spilled to scratch
+// memory (fold 368, fold_small 352, reduce 1744, window sums 304 / 352 bytes per lane; now 16 - 80).  G1: by value, as before.
+template <class C>
+__device__ __forceinline__ void add_from(typename C::Pt& acc, const typename C::Pt* q) {
+    if constexpr (C::PARK_REDUCE) {
+        C::add_mem(acc, q);
+    } else {
+        typename C::Pt p = *q;
+        C::add(acc, p);
+    }
+}
+
 static constexpr uint32_t MSM_FOLD_SMALL = 16;  // buckets with at most this many tasks are folded by one lane
 
 // multi-task buckets with few tasks: one lane per bucket (sorted position), serial fold
@@ -267,10 +280,7 @@ __global__ void __launch_bounds__(64) msm_fold_small_kernel(const uint32_t* __re
     if (nt > MSM_FOLD_SMALL) return;
     const Pt* src = partial + tbase[i];
     Pt acc = src[0];
-    for (uint32_t j = 1; j < nt; ++j) {
-        Pt p = src[j];
-        C::add(acc, p);
-    }
+    for (uint32_t j = 1; j < nt; ++j) add_from<C>(acc, &src[j]);  // G2: second operand read from memory where it is used (no scratch)
     buckets[order[i]] = acc;
 }
 
@@ -290,16 +300,13 @@ __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict
     if (nt <= MSM_FOLD_SMALL) return;
     const Pt* src = partial + tbase[i];
     Pt acc = C::identity();
-    for (uint32_t j = threadIdx.x; j < nt; j += 64) {
-        Pt p = src[j];
-        C::add(acc, p);
-    }
+    for (uint32_t j = threadIdx.x; j < nt; j += 64) add_from<C>(acc, &src[j]);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 32; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
-            Pt a = sh[threadIdx.x], b = sh[threadIdx.x + s];
-            C::add(a, b);
+            Pt a = sh[threadIdx.x];
+            add_from<C>(a, &sh[threadIdx.x + s]);
             sh[threadIdx.x] = a;
         }
         __syncthreads();
@@ -320,6 +327,45 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
     const uint32_t w = t / per_win, k = t % per_win;
     const uint32_t lo = k * ch;
     const Pt* b = buckets + (size_t)w * half + lo;
+    if constexpr (C::PARK_REDUCE) {
+        // G2: a point is 112 registers; `run`, `acc` and an addition's temporaries do not survive a call to the field
+        // product together (the compiler spilled 1774 registers, 1744 B of scratch per lane).  Here no point stays in
+        // registers between additions: `run` lives in LDS (28 KB per wavefront), `acc` in this lane's own output slot,
+        // and the second operand of every addition is read from memory where it is used (xyzz_add_mem).
+        __shared__ Pt park[64];
+        Pt* const run_m = &park[threadIdx.x];
+        Pt* const acc_m = &out[t];
+        *run_m = C::identity();
+        *acc_m = C::identity();
+        for (int j = (int)ch - 1; j >= 0; --j) {
+            {
+                Pt r = *run_m;
+                C::add_mem(r, &b[j]);
+                *run_m = r;
+            }
+            __asm__ volatile("" ::: "memory");
+            {
+                Pt a = *acc_m;
+                C::add_mem(a, run_m);
+                *acc_m = a;
+            }
+            __asm__ volatile("" ::: "memory");
+        }
+        if (lo) {
+            Pt m = C::identity();  // lo * run, double-and-add with `run` read from LDS
+            for (int i = 31; i >= 0; --i) {
+                m = C::dbl(m);
+                if ((lo >> i) & 1) C::add_mem(m, run_m);
+                __asm__ volatile("" ::: "memory");
+            }
+            *run_m = m;
+            __asm__ volatile("" ::: "memory");
+            Pt a = *acc_m;
+            C::add_mem(a, run_m);
+            *acc_m = a;
+        }
+        return;
+    }
     Pt run = C::identity(), acc = C::identity();
     for (int j = (int)ch - 1; j >= 0; --j) {
         Pt p = b[j];
@@ -346,8 +392,8 @@ __device__ __forceinline__ typename C::Pt block_tree_sum(typename C::Pt acc, typ
     __syncthreads();
     for (int s = THREADS / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
-            Pt a = sh[threadIdx.x], b = sh[threadIdx.x + s];
-            C::add(a, b);
+            Pt a = sh[threadIdx.x];
+            add_from<C>(a, &sh[threadIdx.x + s]);
             sh[threadIdx.x] = a;
         }
         __syncthreads();
@@ -375,10 +421,7 @@ __global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const typename 
     const uint32_t w = blockIdx.x;
     const Pt* src = partials + (size_t)w * groups;
     Pt acc = C::identity();
-    for (uint32_t i = threadIdx.x; i < groups; i += THREADS) {
-        Pt p = src[i];
-        C::add(acc, p);
-    }
+    for (uint32_t i = threadIdx.x; i < groups; i += THREADS) add_from<C>(acc, &src[i]);
     Pt r = block_tree_sum<C, THREADS>(acc, sh);
     if (threadIdx.x == 0) win_out[w] = C::to_std(r);  // standard 12 x 32-bit XYZZ for the host
 }

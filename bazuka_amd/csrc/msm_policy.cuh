@@ -23,6 +23,7 @@ struct G1Fast {
     static constexpr bool CONVERT_BASES = true;
     static constexpr int WSUM_THREADS = 256;  // 256 x 224 B = 56 KiB LDS
     static constexpr int ACC_OCC = 2;
+    static constexpr bool PARK_REDUCE = false;  // two resident G1 points + temporaries fit the register file
     __device__ static __forceinline__ Pt identity() { return g1x28::identity(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p, bool neg) { g1x28::add_mixed(acc, p, neg); }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { g1x28::add_full(acc, q); }
@@ -92,6 +93,9 @@ struct G2Fast {
         xyzz_add_mixed<Fp2x28Ops>(acc, p);
     }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2x28Ops>(acc, q); }
+    // second operand left in memory (LDS / global): see xyzz_add_mem
+    static constexpr bool PARK_REDUCE = true;
+    __device__ static __forceinline__ void add_mem(Pt& acc, const Pt* q) { xyzz_add_mem<Fp2x28Ops>(acc, q); }
     __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return xyzz_mul_u32<Fp2x28Ops>(p, k); }
     __device__ static __forceinline__ Pt dbl(const Pt& p) { return xyzz_dbl<Fp2x28Ops>(p); }
     __device__ static __forceinline__ DevAff to_dev_affine(const Pt& p) {
