@@ -117,6 +117,39 @@ int hc_g2x28_sum_mixed(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* o
     st_g2(out193, g2x28::to_std(acc));
     return 0;
 }
+// sum_i (+/-) k_i * P_i with EVERY general addition done by xyzz_add_mem (second operand read from memory - what the G2
+// tail kernels use on the device), including the double-and-add of the scalar multiplication; mode 1 adds each term twice
+// through a parked copy (P + P = doubling inside add_mem), mode 2 adds a term and its negation (cancellation -> identity)
+int hc_g2x28_lincomb_mem(const uint8_t* pts, const uint32_t* k, const uint8_t* neg, int n, int mode, uint8_t* out193) {
+    typedef Fp2x28Ops F;
+    G2X28 acc = xyzz_identity<F>();
+    for (int i = 0; i < n; ++i) {
+        G2A28 a = g2x28::affine_to28(ld_g2(pts + 192 * i));
+        if (neg[i]) a.y = F::neg(a.y);
+        G2X28 t = xyzz_identity<F>();
+        xyzz_add_mixed<F>(t, a);
+        G2X28 m = xyzz_identity<F>();
+        for (int b = 31; b >= 0; --b) {
+            m = xyzz_dbl<F>(m);
+            if ((k[i] >> b) & 1) xyzz_add_mem<F>(m, &t);
+        }
+        const G2X28 parked = m;
+        xyzz_add_mem<F>(acc, &parked);               // acc += m  (first term: acc is the identity; k = 0: m is the identity)
+        if (mode == 1) {                              // m + m through add_mem: the doubling branch
+            G2X28 d = parked;
+            xyzz_add_mem<F>(d, &parked);
+            xyzz_add_mem<F>(acc, &d);                 // acc += 2 m   (total 3 m)
+        } else if (mode == 2) {                       // m + (-m) through add_mem: the cancellation branch
+            G2X28 c = parked;
+            const G2X28 minus = xyzz_neg<F>(parked);
+            xyzz_add_mem<F>(c, &minus);
+            if (!xyzz_is_identity<F>(c)) return 1;
+            xyzz_add_mem<F>(acc, &c);                 // adding the identity from memory changes nothing
+        }
+    }
+    st_g2(out193, g2x28::to_std(acc));
+    return 0;
+}
 // Fr in 9 x 29-bit limbs
 int hc_fr29_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     st<FrParams>(out, fr29::from29(fr29::mul(fr29::to29(ld<FrParams>(a)), fr29::to29(ld<FrParams>(b)))));

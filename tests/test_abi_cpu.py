@@ -178,6 +178,15 @@ def test_reduced_radix_curves_on_host_match_oracle(hc, co, pr):
     out2 = C.create_string_buffer(193)
     hc.hc_g2x28_lincomb(b2, (C.c_uint32 * n)(*ks), neg, n, out2)
     assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    # the memory-operand addition of the G2 tail kernels (xyzz_add_mem): same points as xyzz_add, incl. acc / q identity,
+    # P + P (doubling) and P - P (cancellation), with the reduced-radix bound assertions on
+    assert hc.hc_g2x28_lincomb_mem(b2, (C.c_uint32 * n)(*ks), neg, n, 0, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    assert hc.hc_g2x28_lincomb_mem(b2, (C.c_uint32 * n)(*ks), neg, n, 2, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    assert hc.hc_g2x28_lincomb_mem(b2, (C.c_uint32 * n)(*ks), neg, n, 1, out2) == 0
+    sc3 = b"".join((3 * int.from_bytes(sc[32 * i:32 * i + 32], "little") % pr.R_MOD).to_bytes(32, "little") for i in range(n))
+    assert out2.raw == co.msm_g2(b2, sc3, mont=False, naive=True)
     m = 150  # long chains of mixed adds: the weak-reduction bounds must hold indefinitely
     b3 = co.g1_bases(9, 0, m)
     negs = bytes(rnd.randrange(2) for _ in range(m))
