@@ -1,0 +1,1144 @@
+"""TEST INFRASTRUCTURE - second, independent restatement of the reference's R1CS circuits.
+
+Only tests/ may import this module; nothing under bazuka_amd/ does.  It was written from the reference's Rust sources
+line by line - NOT from bazuka_amd/csrc/{mpn.hip, host_r1cs.h} - so that variable numbering, constraint order,
+linear-combination contents, densities and witness values of the product's generator are checked against something
+other than itself ("What's missing" item 1).
+
+Restated here (file:line into /root/reference):
+  gadgets/common/number.rs:10-250    Number (LC + value), mul / compress / is_zero / is_equal / assert_equal[_if_enabled]
+  gadgets/common/uint.rs:14-134      UnsignedInteger alloc / constrain / lt / gt / lte / gte
+  gadgets/common/mux.rs:7-47         mux
+  gadgets/common/boolean.rs:7-39     extract_bool / assert_true / boolean_or
+  gadgets/poseidon/mod.rs:8-95       sbox / full_round / partial_round / product_mds / poseidon
+  gadgets/merkle/mod.rs:21-78        merge_hash_poseidon4 / calc_root_poseidon4 / check_proof_poseidon4
+  gadgets/eddsa/mod.rs:14-280        AllocatedPoint, base_mul, mul_cofactor, verify_eddsa
+  gadgets/reveal/mod.rs:13-61        reveal
+  src/mpn/circuits/update_circuit.rs:49-494, deposit_circuit.rs:47-293, withdraw_circuit.rs:50-413
+  src/crypto/jubjub/curve.rs:19-91   PointAffine add_assign / double / is_on_curve, PointCompressed::decompress
+  src/core/transaction.rs:204-211    ContractWithdraw::fingerprint
+
+bellman 0.14 is NOT under /root/reference (Cargo.toml:29, un-vendored); its primitives are restated from the published
+crate [recalled]: `ConstraintSystem::{alloc, alloc_input, enforce}`, `LinearCombination` (a Vec of (Variable, coeff) that
+APPENDS - it never merges), `AllocatedNum::{alloc, mul, inputize, to_bits_le_strict}`, `AllocatedBit::{alloc,
+alloc_conditionally, and, and_not, nor}`, `Boolean::{and, not}`, and the prover's `eval` (density = "variable appears in
+the LC with a non-zero coefficient"; the reference's circuits contain no cancelling duplicates, which
+tests/test_pycircuit_cpu.py asserts).
+
+Variables are ints while synthesizing: input i -> -(i + 1), aux j -> j; `flat()` maps them to the prover's flat index
+(inputs first, then aux), the convention of oracle/pyref.py's R1CS and of bzk_r1cs_data's `col` arrays.
+"""
+import hashlib
+
+from oracle.pyref import R_MOD, poseidon_params, poseidon_rounds, inv_mod, fr_from_mont_bytes
+
+ONE = -1  # CS::one() = Input(0)
+
+JJ_A = R_MOD - 1
+JJ_D = 19257038036680949359750312669786877991949435402254120286184196891950884077233
+JJ_BASE = (28867639725710769449342053336011988556061781325688749245863888315629457631946, 18)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# native Jubjub pieces the witness closures call (src/crypto/jubjub/curve.rs)
+# ---------------------------------------------------------------------------------------------------------------------
+def pt_is_on_curve(p):  # curve.rs:39-41
+    x, y = p
+    return (y * y - x * x) % R_MOD == (1 + JJ_D * x * x % R_MOD * y * y) % R_MOD
+
+
+def pt_double(p):  # curve.rs:48-57
+    x, y = p
+    xx = inv_mod((JJ_A * x * x + y * y) % R_MOD, R_MOD)
+    yy = inv_mod((2 - JJ_A * x * x - y * y) % R_MOD, R_MOD)
+    return (2 * (x * y % R_MOD * xx) % R_MOD, (y * y - JJ_A * x * x) % R_MOD * yy % R_MOD)
+
+
+def pt_add(p, q):  # curve.rs:19-36 (AddAssign)
+    if p == q:
+        return pt_double(p)
+    (x1, y1), (x2, y2) = p, q
+    k = JJ_D * x1 % R_MOD * x2 % R_MOD * y1 % R_MOD * y2 % R_MOD
+    xx = inv_mod((1 + k) % R_MOD, R_MOD)
+    yy = inv_mod((1 - k) % R_MOD, R_MOD)
+    return ((x1 * y2 + y1 * x2) % R_MOD * xx % R_MOD, (y1 * y2 - JJ_A * x1 * x2) % R_MOD * yy % R_MOD)
+
+
+def _sqrt_fr(a):
+    """A square root in Fr (Tonelli-Shanks, S = 32); which of the two roots is irrelevant to decompress()."""
+    a %= R_MOD
+    if a == 0:
+        return 0
+    assert pow(a, (R_MOD - 1) // 2, R_MOD) == 1, "not a square"
+    s, q = 32, (R_MOD - 1) >> 32
+    z = pow(7, q, R_MOD)  # 7 generates Fr* (src/zk/mod.rs:204), hence a non-residue
+    m, c, t, r = s, z, pow(a, q, R_MOD), pow(a, (q + 1) // 2, R_MOD)
+    while t != 1:
+        i, t2 = 0, t
+        while t2 != 1:
+            t2 = t2 * t2 % R_MOD
+            i += 1
+        b = pow(c, 1 << (m - i - 1), R_MOD)
+        m, c = i, b * b % R_MOD
+        t, r = t * c % R_MOD, r * b % R_MOD
+    return r
+
+
+def pt_decompress(x, odd):  # curve.rs:79-91
+    x2 = x * x % R_MOD
+    y = _sqrt_fr(inv_mod((1 - JJ_D * x2) % R_MOD, R_MOD) * ((1 - JJ_A * x2) % R_MOD))
+    if bool(y & 1) != bool(odd):
+        y = (-y) % R_MOD
+    return (x, y)
+
+
+_BASE_COFACTOR = None
+
+
+def base_cofactor():  # curve.rs:160: BASE.multiply(8)
+    global _BASE_COFACTOR
+    if _BASE_COFACTOR is None:
+        p = JJ_BASE
+        for _ in range(3):
+            p = pt_double(p)
+        _BASE_COFACTOR = p
+    return _BASE_COFACTOR
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bellman: constraint system, linear combinations, AllocatedNum / AllocatedBit / Boolean  [recalled, see header]
+# ---------------------------------------------------------------------------------------------------------------------
+class ConstraintSystem:
+    """Records what bellman's ProvingAssignment and KeypairAssembly both see."""
+
+    def __init__(self):
+        self.inputs = [1]  # input 0 = ONE
+        self.aux = []
+        self.A, self.B, self.C = [], [], []
+
+    def alloc(self, value):
+        self.aux.append(value % R_MOD)
+        return len(self.aux) - 1
+
+    def alloc_input(self, value):
+        self.inputs.append(value % R_MOD)
+        return -len(self.inputs)
+
+    def enforce(self, a, b, c):
+        self.A.append(a)
+        self.B.append(b)
+        self.C.append(c)
+
+    # ---- what the prover / generator derive from the recording
+    @property
+    def n_in(self):
+        return len(self.inputs)
+
+    @property
+    def n_aux(self):
+        return len(self.aux)
+
+    def flat(self, v):
+        return -v - 1 if v < 0 else len(self.inputs) + v
+
+    def z(self):
+        return list(self.inputs) + list(self.aux)
+
+    def rows(self, which, with_input_rows=True):
+        """Rows of matrix 'A' / 'B' / 'C' over flat indices, terms in the order bellman holds them (appended, unmerged).
+        bellman's generator and prover append `input_i * 0 = 0` per input after synthesis."""
+        src = {"A": self.A, "B": self.B, "C": self.C}[which]
+        out = [[(self.flat(v), c % R_MOD) for v, c in lc] for lc in src]
+        if with_input_rows:
+            for i in range(self.n_in):
+                out.append([(i, 1)] if which == "A" else [])
+        return out
+
+    def value_of(self, v):
+        return self.inputs[-v - 1] if v < 0 else self.aux[v]
+
+    def eval_lc(self, lc):
+        return sum(c * self.value_of(v) for v, c in lc) % R_MOD
+
+
+def lc_add_term(lc, coeff, var):  # LinearCombination + (coeff, var): push
+    return lc + [(var, coeff % R_MOD)]
+
+
+def lc_add_lc(lc, other):  # lc + &other
+    return lc + other
+
+
+def lc_sub_lc(lc, other):  # lc - &other
+    return lc + [(v, (-c) % R_MOD) for v, c in other]
+
+
+def lc_add_scaled(lc, coeff, other):  # lc + (coeff, &other)
+    return lc + [(v, c * coeff % R_MOD) for v, c in other]
+
+
+class AllocatedNum:
+    def __init__(self, var, value):
+        self.var, self.value = var, value % R_MOD
+
+    @staticmethod
+    def alloc(cs, value):
+        return AllocatedNum(cs.alloc(value), value)
+
+    def inputize(self, cs):
+        inp = cs.alloc_input(self.value)
+        cs.enforce([(inp, 1)], [(ONE, 1)], [(self.var, 1)])
+
+    def mul(self, cs, other):
+        out = AllocatedNum.alloc(cs, self.value * other.value)
+        cs.enforce([(self.var, 1)], [(other.var, 1)], [(out.var, 1)])
+        return out
+
+    def to_bits_le_strict(self, cs):
+        """bellman gadgets/num.rs `to_bits_le_strict`: bits of self, proven <= r - 1 by walking r - 1 from the top."""
+        a, b = self.value, R_MOD - 1
+        result = []
+        last_run, current_run = None, []
+        found_one = False
+        for i in range(255, -1, -1):
+            b_bit, a_bit = (b >> i) & 1, (a >> i) & 1
+            found_one = found_one or bool(b_bit)
+            if not found_one:
+                assert a_bit == 0
+                continue
+            if b_bit:
+                bit = AllocatedBit.alloc(cs, a_bit)
+                current_run.append(bit)
+                result.append(bit)
+            else:
+                if current_run:
+                    if last_run is not None:
+                        current_run.append(last_run)
+                    cur = None
+                    for v in current_run:  # kary_and
+                        cur = v if cur is None else AllocatedBit.and_(cs, cur, v)
+                    last_run = cur
+                    current_run = []
+                bit = AllocatedBit.alloc_conditionally(cs, a_bit, last_run)
+                result.append(bit)
+        assert not current_run
+        lc, coeff = [], 1
+        for bit in reversed(result):
+            lc = lc_add_term(lc, coeff, bit.var)
+            coeff = coeff * 2 % R_MOD
+        lc = lc_add_term(lc, -1, self.var)
+        cs.enforce([], [], lc)
+        return [Boolean.is_(bit) for bit in reversed(result)]
+
+
+class AllocatedBit:
+    def __init__(self, var, value):
+        self.var, self.value = var, int(bool(value))
+
+    @staticmethod
+    def alloc(cs, value):
+        var = cs.alloc(1 if value else 0)
+        cs.enforce([(ONE, 1), (var, R_MOD - 1)], [(var, 1)], [])
+        return AllocatedBit(var, value)
+
+    @staticmethod
+    def alloc_conditionally(cs, value, must_be_false):
+        var = cs.alloc(1 if value else 0)
+        cs.enforce([(ONE, 1), (must_be_false.var, R_MOD - 1), (var, R_MOD - 1)], [(var, 1)], [])
+        return AllocatedBit(var, value)
+
+    @staticmethod
+    def and_(cs, a, b):
+        out = AllocatedBit(cs.alloc(a.value & b.value), a.value & b.value)
+        cs.enforce([(a.var, 1)], [(b.var, 1)], [(out.var, 1)])
+        return out
+
+    @staticmethod
+    def and_not(cs, a, b):
+        val = a.value & (1 - b.value)
+        out = AllocatedBit(cs.alloc(val), val)
+        cs.enforce([(a.var, 1)], [(ONE, 1), (b.var, R_MOD - 1)], [(out.var, 1)])
+        return out
+
+    @staticmethod
+    def nor(cs, a, b):
+        val = (1 - a.value) & (1 - b.value)
+        out = AllocatedBit(cs.alloc(val), val)
+        cs.enforce([(ONE, 1), (a.var, R_MOD - 1)], [(ONE, 1), (b.var, R_MOD - 1)], [(out.var, 1)])
+        return out
+
+
+class Boolean:
+    """kind: 'is' (bit), 'not' (bit), 'const' (value)"""
+
+    def __init__(self, kind, bit=None, const=None):
+        self.kind, self.bit, self.const = kind, bit, const
+
+    @staticmethod
+    def is_(bit):
+        return Boolean("is", bit)
+
+    def not_(self):
+        if self.kind == "const":
+            return Boolean("const", const=not self.const)
+        return Boolean("not" if self.kind == "is" else "is", self.bit)
+
+    @staticmethod
+    def and_(cs, a, b):
+        if a.kind == "const":
+            return b if a.const else Boolean("const", const=False)
+        if b.kind == "const":
+            return a if b.const else Boolean("const", const=False)
+        if a.kind == "is" and b.kind == "not":
+            return Boolean.is_(AllocatedBit.and_not(cs, a.bit, b.bit))
+        if a.kind == "not" and b.kind == "is":
+            return Boolean.is_(AllocatedBit.and_not(cs, b.bit, a.bit))
+        if a.kind == "not" and b.kind == "not":
+            return Boolean.is_(AllocatedBit.nor(cs, a.bit, b.bit))
+        return Boolean.is_(AllocatedBit.and_(cs, a.bit, b.bit))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gadgets/common
+# ---------------------------------------------------------------------------------------------------------------------
+class Number:  # number.rs:10-11: (LinearCombination, Option<value>)
+    def __init__(self, lc, value):
+        self.lc, self.value = lc, value % R_MOD
+
+    def add_constant(self, num):  # number.rs:19-22
+        return Number(lc_add_term(self.lc, num, ONE), self.value + num)
+
+    def add_num(self, coeff, num):  # number.rs:23-30
+        return Number(lc_add_term(self.lc, coeff, num.var), num.value * coeff + self.value)
+
+    @staticmethod
+    def constant(v):  # number.rs:31-36
+        return Number([(ONE, v % R_MOD)], v)
+
+    @staticmethod
+    def zero():
+        return Number([], 0)
+
+    @staticmethod
+    def one():
+        return Number([(ONE, 1)], 1)
+
+    @staticmethod
+    def of(x):
+        """the `From` impls, number.rs:214-250"""
+        if isinstance(x, Number):
+            return x
+        if isinstance(x, (AllocatedNum, AllocatedBit)):
+            return Number([(x.var, 1)], x.value)
+        if isinstance(x, UnsignedInteger):
+            return Number(list(x.num.lc), x.num.value)
+        raise TypeError(type(x))
+
+    @staticmethod
+    def scaled(coeff, num):  # From<(BellmanFr, AllocatedNum)>
+        return Number([(num.var, coeff % R_MOD)], num.value * coeff)
+
+    def __add__(self, other):  # number.rs:179-188
+        return Number(lc_add_lc(self.lc, other.lc), self.value + other.value)
+
+    def add_scaled(self, coeff, other):  # number.rs:190-201
+        return Number(lc_add_scaled(self.lc, coeff, other.lc), self.value + coeff * other.value)
+
+    def __sub__(self, other):  # number.rs:203-212
+        return Number(lc_sub_lc(self.lc, other.lc), self.value - other.value)
+
+    def mul(self, cs, other):  # number.rs:50-67
+        out = AllocatedNum.alloc(cs, self.value * other.value)
+        cs.enforce(list(self.lc), list(other.lc), [(out.var, 1)])
+        return out
+
+    def compress(self, cs):  # number.rs:68-73
+        return self.mul(cs, Number.one())
+
+    def is_zero(self, cs):  # number.rs:76-111
+        is_zero = AllocatedBit.alloc(cs, self.value == 0)
+        inv = AllocatedNum.alloc(cs, 0 if self.value == 0 else inv_mod(self.value, R_MOD))
+        cs.enforce(lc_sub_lc([], self.lc), [(inv.var, 1)], [(is_zero.var, 1), (ONE, R_MOD - 1)])
+        cs.enforce([(is_zero.var, 1)], list(self.lc), [])
+        return Boolean.is_(is_zero)
+
+    def is_equal(self, cs, other):  # number.rs:113-119
+        return (self - other).is_zero(cs)
+
+    def assert_equal(self, cs, other):  # number.rs:121-128
+        cs.enforce(list(self.lc), [(ONE, 1)], list(other.lc))
+
+    def assert_equal_if_enabled(self, cs, enabled, other):  # number.rs:130-177
+        if enabled.kind == "is":
+            e = enabled.bit
+            eis = cs.alloc(self.value if e.value else 0)
+            cs.enforce([(e.var, 1)], list(self.lc), [(eis, 1)])
+            cs.enforce([(e.var, 1)], list(other.lc), [(eis, 1)])
+        elif enabled.kind == "not":
+            raise NotImplementedError
+        elif enabled.const:
+            self.assert_equal(cs, other)
+
+
+def extract_bool(b):  # boolean.rs:7-20
+    if b.kind == "is":
+        return Number.of(b.bit)
+    if b.kind == "not":
+        return Number.one() - Number.of(b.bit)
+    return Number.one() if b.const else Number.zero()
+
+
+def assert_true(cs, b):  # boolean.rs:22-24
+    extract_bool(b).assert_equal(cs, Number.one())
+
+
+def boolean_or(cs, a, b):  # boolean.rs:34-39
+    return Boolean.and_(cs, a.not_(), b.not_()).not_()
+
+
+def mux(cs, select, a, b):  # mux.rs:7-47
+    if select.kind == "is":
+        s = select.bit
+        ret = AllocatedNum.alloc(cs, b.value if s.value else a.value)
+        cs.enforce(lc_sub_lc(list(a.lc), b.lc), [(s.var, 1)], lc_add_term(list(a.lc), -1, ret.var))
+        return ret
+    if select.kind == "not":
+        ns = select.bit
+        ret = AllocatedNum.alloc(cs, a.value if ns.value else b.value)
+        cs.enforce(lc_sub_lc(list(b.lc), a.lc), [(ns.var, 1)], lc_add_term(list(b.lc), -1, ret.var))
+        return ret
+    raise NotImplementedError
+
+
+class UnsignedInteger:  # uint.rs
+    def __init__(self, bits, num):
+        self.bits, self.num = bits, num
+
+    @staticmethod
+    def alloc(cs, val, bits):  # uint.rs:31-38
+        return UnsignedInteger.constrain(cs, Number.of(AllocatedNum.alloc(cs, val)), bits)
+
+    @staticmethod
+    def alloc_64(cs, val):
+        return UnsignedInteger.alloc(cs, val, 64)
+
+    @staticmethod
+    def constrain(cs, num, num_bits):  # uint.rs:66-91
+        bits, coeff, all_ = [], 1, []
+        for i in range(num_bits):
+            bit = AllocatedBit.alloc(cs, (num.value >> i) & 1)
+            all_ = lc_add_term(all_, coeff, bit.var)
+            bits.append(bit)
+            coeff = coeff * 2 % R_MOD
+        cs.enforce(all_, [(ONE, 1)], list(num.lc))
+        return UnsignedInteger(bits, num)
+
+    def lt(self, cs, other):  # uint.rs:94-109
+        assert len(self.bits) == len(other.bits)
+        n = len(self.bits)
+        sub = (self.num - other.num).add_constant(pow(2, n + 1, R_MOD))
+        sub_bits = UnsignedInteger.constrain(cs, sub, n + 2)
+        return Boolean.is_(sub_bits.bits[n])
+
+    def gt(self, cs, other):
+        return other.lt(cs, self)
+
+    def lte(self, cs, other):
+        return self.gt(cs, other).not_()
+
+    def gte(self, cs, other):
+        return self.lt(cs, other).not_()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gadgets/poseidon
+# ---------------------------------------------------------------------------------------------------------------------
+def _sbox(cs, a):  # poseidon/mod.rs:8-15
+    a2 = a.mul(cs, a)
+    a4 = a2.mul(cs, a2)
+    return a.mul(cs, Number.of(a4))
+
+
+def _product_mds(vals, mds):  # poseidon/mod.rs:55-64
+    out = []
+    for j in range(len(vals)):
+        acc = Number.zero()
+        for k in range(len(vals)):
+            acc = acc.add_scaled(mds[j][k], vals[k])
+        out.append(acc)
+    return out
+
+
+def poseidon_gadget(cs, vals):  # poseidon/mod.rs:66-95
+    elems = [Number.zero()] + [Number.of(v) for v in vals]
+    t = len(elems)
+    rc, mds = poseidon_params(t)
+    r_f, r_p = poseidon_rounds(t)
+    off = 0
+
+    def full(elems, off):
+        elems = [e.add_constant(rc[off + i]) for i, e in enumerate(elems)]
+        elems = [Number.of(_sbox(cs, e)) for e in elems]
+        return _product_mds(elems, mds)
+
+    def partial(elems, off):
+        elems = [e.add_constant(rc[off + i]) for i, e in enumerate(elems)]
+        elems[0] = Number.of(_sbox(cs, elems[0]))
+        for i in range(1, t):
+            elems[i] = Number.of(elems[i].compress(cs))
+        return _product_mds(elems, mds)
+
+    for _ in range(r_f // 2):
+        elems = full(elems, off)
+        off += t
+    for _ in range(r_p):
+        elems = partial(elems, off)
+        off += t
+    for _ in range(r_f // 2):
+        elems = full(elems, off)
+        off += t
+    return elems[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gadgets/merkle
+# ---------------------------------------------------------------------------------------------------------------------
+def _merge_hash_poseidon4(cs, s0, s1, v, p):  # merkle/mod.rs:21-51
+    b0, b1 = Boolean.is_(s0), Boolean.is_(s1)
+    and_ = Boolean.and_(cs, b0, b1)
+    or_ = boolean_or(cs, b0, b1)
+    p0, p1, p2 = (Number.of(x) for x in p)
+    v0 = mux(cs, or_, v, p0)
+    v1p = mux(cs, b0, p0, v)
+    v1 = mux(cs, b1, Number.of(v1p), p1)
+    v2p = mux(cs, b0, v, p2)
+    v2 = mux(cs, b1, p1, Number.of(v2p))
+    v3 = mux(cs, and_, p2, v)
+    return poseidon_gadget(cs, [v0, v1, v2, v3])
+
+
+def calc_root_poseidon4(cs, index, val, proof):  # merkle/mod.rs:53-65
+    assert len(index.bits) == 2 * len(proof)
+    curr = val
+    for lvl, p in enumerate(proof):
+        curr = _merge_hash_poseidon4(cs, index.bits[2 * lvl], index.bits[2 * lvl + 1], curr, p)
+    return curr
+
+
+def check_proof_poseidon4(cs, enabled, index, val, proof, root):  # merkle/mod.rs:67-78
+    new_root = calc_root_poseidon4(cs, index, val, proof)
+    root.assert_equal_if_enabled(cs, enabled, new_root)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gadgets/eddsa
+# ---------------------------------------------------------------------------------------------------------------------
+class AllocatedPoint:
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+    def value(self):
+        return (self.x.value, self.y.value)
+
+    @staticmethod
+    def alloc(cs, pt):  # eddsa/mod.rs:31-42
+        return AllocatedPoint(AllocatedNum.alloc(cs, pt[0]), AllocatedNum.alloc(cs, pt[1]))
+
+    def is_null(self, cs):  # eddsa/mod.rs:44-51
+        xz = Number.of(self.x).is_zero(cs)
+        yz = Number.of(self.y).is_zero(cs)
+        return Boolean.and_(cs, xz, yz)
+
+    def is_equal(self, cs, other):  # eddsa/mod.rs:53-63
+        xe = Number.of(self.x).is_equal(cs, Number.of(other.x))
+        ye = Number.of(self.y).is_equal(cs, Number.of(other.y))
+        return Boolean.and_(cs, xe, ye)
+
+    def assert_on_curve(self, cs, enabled):  # eddsa/mod.rs:65-76
+        x2 = self.x.mul(cs, self.x)
+        y2 = self.y.mul(cs, self.y)
+        x2y2 = x2.mul(cs, y2)
+        lhs = Number.of(y2) - Number.of(x2)
+        rhs = Number.scaled(JJ_D, x2y2) + Number.one()
+        lhs.assert_equal_if_enabled(cs, enabled, rhs)
+
+    def add_const(self, cs, b):  # eddsa/mod.rs:78-123
+        a = self.value()
+        s = (0, 0) if (not pt_is_on_curve(a) or not pt_is_on_curve(b)) else pt_add(a, b)
+        sum_ = AllocatedPoint.alloc(cs, s)
+        bx, by = b
+        dbb = JJ_D * bx % R_MOD * by % R_MOD
+        common = self.x.mul(cs, self.y)
+        cs.enforce([(ONE, 1), (common.var, dbb)], [(sum_.x.var, 1)], [(self.x.var, by), (self.y.var, bx)])
+        cs.enforce([(ONE, 1), (common.var, (-dbb) % R_MOD)], [(sum_.y.var, 1)],
+                   [(self.y.var, by), (self.x.var, (-(JJ_A * bx)) % R_MOD)])
+        return sum_
+
+    def add(self, cs, other):  # eddsa/mod.rs:125-172
+        a, b = self.value(), other.value()
+        s = (0, 0) if (not pt_is_on_curve(a) or not pt_is_on_curve(b)) else pt_add(a, b)
+        sum_ = AllocatedPoint.alloc(cs, s)
+        common = self.x.mul(cs, other.x).mul(cs, self.y).mul(cs, other.y)
+        x_1 = self.x.mul(cs, other.y)
+        x_2 = self.y.mul(cs, other.x)
+        cs.enforce([(ONE, 1), (common.var, JJ_D)], [(sum_.x.var, 1)], [(x_1.var, 1), (x_2.var, 1)])
+        y_1 = self.y.mul(cs, other.y)
+        y_2 = self.x.mul(cs, other.x)
+        cs.enforce([(ONE, 1), (common.var, (-JJ_D) % R_MOD)], [(sum_.y.var, 1)], [(y_1.var, 1), (y_2.var, (-JJ_A) % R_MOD)])
+        return sum_
+
+    def mul(self, cs, b):  # eddsa/mod.rs:174-202
+        bits = list(reversed(b.to_bits_le_strict(cs)))
+        result = AllocatedPoint(mux(cs, bits[0], Number.zero(), Number.of(self.x)),
+                                mux(cs, bits[0], Number.constant(1), Number.of(self.y)))
+        for bit in bits[1:]:
+            result = result.add(cs, result)
+            rpb = result.add(cs, self)
+            rx = mux(cs, bit, Number.of(result.x), Number.of(rpb.x))
+            ry = mux(cs, bit, Number.of(result.y), Number.of(rpb.y))
+            result = AllocatedPoint(rx, ry)
+        return result
+
+
+def base_mul(cs, base, b):  # eddsa/mod.rs:205-236
+    bits = list(reversed(b.to_bits_le_strict(cs)))
+    result = AllocatedPoint(mux(cs, bits[0], Number.zero(), Number.constant(base[0])),
+                            mux(cs, bits[0], Number.constant(1), Number.constant(base[1])))
+    for bit in bits[1:]:
+        result = result.add(cs, result)
+        rpb = result.add_const(cs, base)
+        rx = mux(cs, bit, Number.of(result.x), Number.of(rpb.x))
+        ry = mux(cs, bit, Number.of(result.y), Number.of(rpb.y))
+        result = AllocatedPoint(rx, ry)
+    return result
+
+
+def _mul_cofactor(cs, point):  # eddsa/mod.rs:239-247
+    pnt = point.add(cs, point)
+    pnt = pnt.add(cs, pnt)
+    return pnt.add(cs, pnt)
+
+
+def verify_eddsa(cs, enabled, pk, msg, sig_r, sig_s):  # eddsa/mod.rs:249-280
+    h = poseidon_gadget(cs, [sig_r.x, sig_r.y, pk.x, pk.y, msg]).compress(cs)
+    sb = base_mul(cs, base_cofactor(), sig_s)
+    r_plus_ha = pk.mul(cs, h)
+    r_plus_ha = r_plus_ha.add(cs, sig_r)
+    r_plus_ha = _mul_cofactor(cs, r_plus_ha)
+    Number.of(r_plus_ha.x).assert_equal_if_enabled(cs, enabled, Number.of(sb.x))
+    Number.of(r_plus_ha.y).assert_equal_if_enabled(cs, enabled, Number.of(sb.y))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gadgets/reveal
+# ---------------------------------------------------------------------------------------------------------------------
+def reveal(cs, model, state):  # reveal/mod.rs:13-61; model = "scalar" | ("struct", [models]) | ("list", log4, model)
+    if model == "scalar":
+        assert isinstance(state, Number)
+        return state
+    if model[0] == "struct":
+        vals = [reveal(cs, ft, fv) for ft, fv in zip(model[1], state)]
+        return poseidon_gadget(cs, vals)
+    _, log4_size, item = model
+    leaves = [reveal(cs, item, state[i]) for i in range(1 << (2 * log4_size))]
+    while len(leaves) != 1:
+        leaves = [poseidon_gadget(cs, leaves[i:i + 4]) for i in range(0, len(leaves), 4)]
+    return leaves[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the value side of the reference's types, as tests/bincode_ref.py decodes them off the wire
+# ---------------------------------------------------------------------------------------------------------------------
+def sc(b):
+    """ZkScalar blob (32 B Montgomery, serde of the newtype: src/zk/mod.rs:202-206) -> canonical int"""
+    return fr_from_mont_bytes(b) if isinstance(b, (bytes, bytearray)) else int(b)
+
+
+def contract_id(cid):  # src/zk/mod.rs:280-288
+    kind, payload = cid
+    if kind == "Null":
+        return 0
+    if kind == "Ziesha":
+        return 1
+    return sc(payload)
+
+
+def affine(p):
+    return (sc(p["x"]), sc(p["y"]))
+
+
+def decompress(pk):
+    return pt_decompress(sc(pk["x"]), pk["odd"])
+
+
+def _proof(p):
+    return [[sc(b[0:32]), sc(b[32:64]), sc(b[64:96])] for b in p]
+
+
+def _alloc_proof(cs, p):
+    return [[AllocatedNum.alloc(cs, b[0]), AllocatedNum.alloc(cs, b[1]), AllocatedNum.alloc(cs, b[2])] for b in _proof(p)]
+
+
+def withdraw_fingerprint(payment, encode_contract_withdraw):
+    """ContractWithdraw::fingerprint (src/core/transaction.rs:204-211): sha3-256 of the bincode of the payment with calldata
+    zeroed, as a little-endian integer mod r."""
+    unsigned = dict(payment)
+    unsigned["calldata"] = bytes(32)
+    return int.from_bytes(hashlib.sha3_256(encode_contract_withdraw(unsigned)).digest(), "little") % R_MOD
+
+
+def _header(cs, commitment, height, state, aux_data, next_state, fee_token=None):
+    """update_circuit.rs:55-76 / deposit_circuit.rs:52-70 / withdraw_circuit.rs:54-72"""
+    commitment_wit = AllocatedNum.alloc(cs, commitment)
+    commitment_wit.inputize(cs)
+    height_wit = AllocatedNum.alloc(cs, height)
+    height_wit.inputize(cs)
+    state_wit = AllocatedNum.alloc(cs, state)
+    state_wit.inputize(cs)
+    accepted_fee_token = AllocatedNum.alloc(cs, fee_token) if fee_token is not None else None
+    aux_wit = AllocatedNum.alloc(cs, aux_data)
+    aux_wit.inputize(cs)
+    claimed = AllocatedNum.alloc(cs, next_state)
+    claimed.inputize(cs)
+    return state_wit, accepted_fee_token, aux_wit, claimed
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# src/mpn/circuits/update_circuit.rs:49-494
+# ---------------------------------------------------------------------------------------------------------------------
+def update_circuit(log4_tree, log4_token_tree, commitment, height, state, aux_data, next_state, fee_token, transitions):
+    cs = ConstraintSystem()
+    L, T = log4_tree, log4_token_tree
+    state_wit, accepted_fee_token, aux_wit, claimed_next_state_wit = _header(cs, commitment, height, state, aux_data, next_state,
+                                                                             fee_token)
+    fee_sum = Number.zero()
+    for tr in transitions:
+        tx = tr["tx"]
+        enabled_wit = Boolean.is_(AllocatedBit.alloc(cs, tr["enabled"]))
+        tx_src_token_index_wit = UnsignedInteger.alloc(cs, tr["src_token_index"], 2 * T)
+        tx_src_fee_token_index_wit = UnsignedInteger.alloc(cs, tr["src_fee_token_index"], 2 * T)
+        tx_dst_token_index_wit = UnsignedInteger.alloc(cs, tr["dst_token_index"], 2 * T)
+        src_tx_nonce_wit = AllocatedNum.alloc(cs, tr["src_before"]["tx_nonce"])
+        src_withdraw_nonce_wit = AllocatedNum.alloc(cs, tr["src_before"]["withdraw_nonce"])
+        src_addr_wit = AllocatedPoint.alloc(cs, affine(tr["src_before"]["address"]))
+        src_addr_wit.assert_on_curve(cs, enabled_wit)
+        src_before_balances_hash = AllocatedNum.alloc(cs, sc(tr["src_before_balances_hash"]))
+        dst_before_balances_hash = AllocatedNum.alloc(cs, sc(tr["dst_before_balances_hash"]))
+
+        src_token_id_wit = AllocatedNum.alloc(cs, contract_id(tr["src_before_balance"]["token_id"]))
+        src_balance_wit = UnsignedInteger.alloc_64(cs, tr["src_before_balance"]["amount"])
+        src_token_balance_hash_wit = poseidon_gadget(cs, [src_token_id_wit, src_balance_wit])
+
+        src_fee_token_id_wit = AllocatedNum.alloc(cs, contract_id(tr["src_before_fee_balance"]["token_id"]))
+        src_fee_balance_wit = UnsignedInteger.alloc_64(cs, tr["src_before_fee_balance"]["amount"])
+        src_fee_token_balance_hash_wit = poseidon_gadget(cs, [src_fee_token_id_wit, src_fee_balance_wit])
+
+        src_balance_proof_wits = _alloc_proof(cs, tr["src_balance_proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_src_token_index_wit, src_token_balance_hash_wit, src_balance_proof_wits,
+                              Number.of(src_before_balances_hash))
+
+        tx_amount_wit = UnsignedInteger.alloc_64(cs, tx["amount"]["amount"])
+        tx_fee_wit = UnsignedInteger.alloc_64(cs, tx["fee"]["amount"])
+
+        new_token_balance_hash_wit = poseidon_gadget(
+            cs, [src_token_id_wit, Number.of(src_balance_wit) - Number.of(tx_amount_wit)])
+        balance_middle_root = calc_root_poseidon4(cs, tx_src_token_index_wit, new_token_balance_hash_wit, src_balance_proof_wits)
+
+        src_fee_balance_proof_wits = _alloc_proof(cs, tr["src_fee_balance_proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_src_fee_token_index_wit, src_fee_token_balance_hash_wit,
+                              src_fee_balance_proof_wits, balance_middle_root)
+
+        new_fee_token_balance_hash_wit = poseidon_gadget(
+            cs, [src_fee_token_id_wit, Number.of(src_fee_balance_wit) - Number.of(tx_fee_wit)])
+        src_balance_final_root = calc_root_poseidon4(cs, tx_src_fee_token_index_wit, new_fee_token_balance_hash_wit,
+                                                     src_fee_balance_proof_wits)
+
+        tx_nonce_wit = AllocatedNum.alloc(cs, tx["nonce"])
+        tx_src_index_wit = UnsignedInteger.alloc(cs, tr["src_index"], 2 * L)
+        tx_amount_token_id_wit = AllocatedNum.alloc(cs, contract_id(tx["amount"]["token_id"]))
+        tx_fee_token_id_wit = AllocatedNum.alloc(cs, contract_id(tx["fee"]["token_id"]))
+
+        Number.of(accepted_fee_token).assert_equal_if_enabled(cs, enabled_wit, Number.of(tx_fee_token_id_wit))
+        Number.of(src_token_id_wit).assert_equal(cs, Number.of(tx_amount_token_id_wit))
+        Number.of(src_fee_token_id_wit).assert_equal(cs, Number.of(tx_fee_token_id_wit))
+
+        src_hash_wit = poseidon_gadget(cs, [src_tx_nonce_wit, src_withdraw_nonce_wit, src_addr_wit.x, src_addr_wit.y,
+                                            src_before_balances_hash])
+
+        dst_token_id_wit = AllocatedNum.alloc(cs, contract_id(tr["dst_before_balance"]["token_id"]))
+        dst_balance_wit = AllocatedNum.alloc(cs, tr["dst_before_balance"]["amount"])
+        dst_token_balance_hash_wit = poseidon_gadget(cs, [dst_token_id_wit, Number.of(dst_balance_wit)])
+        new_dst_token_balance_hash_wit = poseidon_gadget(
+            cs, [tx_amount_token_id_wit, Number.of(dst_balance_wit) + Number.of(tx_amount_wit)])
+
+        dst_balance_proof_wits = _alloc_proof(cs, tr["dst_balance_proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_dst_token_index_wit, dst_token_balance_hash_wit, dst_balance_proof_wits,
+                              Number.of(dst_before_balances_hash))
+        dst_balance_final_root = calc_root_poseidon4(cs, tx_dst_token_index_wit, new_dst_token_balance_hash_wit,
+                                                     dst_balance_proof_wits)
+
+        src_proof_wits = _alloc_proof(cs, tr["src_proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_src_index_wit, src_hash_wit, src_proof_wits, Number.of(state_wit))
+
+        new_src_tx_nonce_wit = Number.of(src_tx_nonce_wit) + Number.constant(1)
+        new_src_hash_wit = poseidon_gadget(cs, [new_src_tx_nonce_wit, src_withdraw_nonce_wit, src_addr_wit.x, src_addr_wit.y,
+                                                src_balance_final_root])
+        middle_root_wit = calc_root_poseidon4(cs, tx_src_index_wit, new_src_hash_wit, src_proof_wits)
+
+        tx_dst_addr_wit = AllocatedPoint.alloc(cs, decompress(tx["dst_pub_key"]))
+        tx_dst_addr_wit.assert_on_curve(cs, enabled_wit)
+        tx_dst_index_wit = UnsignedInteger.alloc(cs, tr["dst_index"], 2 * L)
+        dst_tx_nonce_wit = AllocatedNum.alloc(cs, tr["dst_before"]["tx_nonce"])
+        dst_withdraw_nonce_wit = AllocatedNum.alloc(cs, tr["dst_before"]["withdraw_nonce"])
+        dst_addr_wit = AllocatedPoint.alloc(cs, affine(tr["dst_before"]["address"]))
+
+        dst_hash_wit = poseidon_gadget(cs, [dst_tx_nonce_wit, dst_withdraw_nonce_wit, dst_addr_wit.x, dst_addr_wit.y,
+                                            dst_before_balances_hash])
+        dst_proof_wits = _alloc_proof(cs, tr["dst_proof"])
+
+        is_dst_null = dst_addr_wit.is_null(cs)
+        is_dst_and_tx_dst_equal = dst_addr_wit.is_equal(cs, tx_dst_addr_wit)
+        addr_valid = boolean_or(cs, is_dst_null, is_dst_and_tx_dst_equal)
+        assert_true(cs, addr_valid)
+
+        check_proof_poseidon4(cs, enabled_wit, tx_dst_index_wit, dst_hash_wit, dst_proof_wits, middle_root_wit)
+
+        new_dst_hash_wit = poseidon_gadget(cs, [dst_tx_nonce_wit, dst_withdraw_nonce_wit, tx_dst_addr_wit.x, tx_dst_addr_wit.y,
+                                                dst_balance_final_root])
+        next_state_wit = calc_root_poseidon4(cs, tx_dst_index_wit, new_dst_hash_wit, dst_proof_wits)
+        state_wit = mux(cs, enabled_wit, Number.of(state_wit), next_state_wit)
+
+        tx_balance_plus_fee_64 = UnsignedInteger.constrain(cs, Number.of(tx_amount_wit) + Number.of(tx_fee_wit), 64)
+        is_lte = tx_balance_plus_fee_64.lte(cs, src_balance_wit)
+        assert_true(cs, is_lte)
+
+        Number.of(tx_nonce_wit).assert_equal_if_enabled(cs, enabled_wit, Number.of(src_tx_nonce_wit) + Number.constant(1))
+
+        final_fee = mux(cs, enabled_wit, Number.zero(), Number.of(tx_fee_wit))
+        fee_sum = fee_sum.add_num(1, final_fee)
+
+        tx_hash_wit = poseidon_gadget(cs, [tx_nonce_wit, tx_dst_addr_wit.x, tx_dst_addr_wit.y, tx_amount_token_id_wit,
+                                           tx_amount_wit, tx_fee_token_id_wit, tx_fee_wit])
+        tx_sig_r_wit = AllocatedPoint.alloc(cs, affine(tx["sig"]["r"]))
+        tx_sig_r_wit.assert_on_curve(cs, enabled_wit)
+        tx_sig_s_wit = AllocatedNum.alloc(cs, sc(tx["sig"]["s"]))
+        verify_eddsa(cs, enabled_wit, src_addr_wit, tx_hash_wit, tx_sig_r_wit, tx_sig_s_wit)
+
+    fee_sum_and_token_hash = poseidon_gadget(cs, [accepted_fee_token, fee_sum])
+    cs.enforce([(aux_wit.var, 1)], [(ONE, 1)], list(fee_sum_and_token_hash.lc))
+    cs.enforce([(state_wit.var, 1)], [(ONE, 1)], [(claimed_next_state_wit.var, 1)])
+    return cs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# src/mpn/circuits/deposit_circuit.rs:47-293
+# ---------------------------------------------------------------------------------------------------------------------
+def deposit_circuit(log4_tree, log4_token_tree, log4_batch, commitment, height, state, aux_data, next_state, transitions):
+    cs = ConstraintSystem()
+    L, T = log4_tree, log4_token_tree
+    state_wit, _, aux_wit, claimed_next_state_wit = _header(cs, commitment, height, state, aux_data, next_state)
+    state_model = ("list", log4_batch, ("struct", ["scalar"] * 4))
+
+    tx_wits, children = [], []
+    for tr in transitions:
+        tx = tr["tx"]
+        enabled = AllocatedBit.alloc(cs, tr["enabled"])
+        token_id = AllocatedNum.alloc(cs, contract_id(tx["payment"]["amount"]["token_id"]))
+        amount = UnsignedInteger.alloc_64(cs, tx["payment"]["amount"]["amount"])
+        pub_key = AllocatedPoint.alloc(cs, decompress(tx["mpn_address"]))
+        tx_wits.append((Boolean.is_(enabled), token_id, amount, pub_key))
+        pub_key_hash = poseidon_gadget(cs, [pub_key.x, pub_key.y])
+        calldata = mux(cs, Boolean.is_(enabled), Number.zero(), pub_key_hash)
+        children.append([Number.of(enabled), Number.of(token_id), Number.of(amount), Number.of(calldata)])
+    tx_root = reveal(cs, state_model, children)
+    cs.enforce([(aux_wit.var, 1)], [(ONE, 1)], list(tx_root.lc))
+
+    for tr, (enabled_wit, tx_token_id_wit, tx_amount_wit, tx_pub_key_wit) in zip(transitions, tx_wits):
+        tx_index_wit = UnsignedInteger.alloc(cs, tr["account_index"], 2 * L)
+        tx_token_index_wit = UnsignedInteger.alloc(cs, tr["token_index"], 2 * T)
+        tx_pub_key_wit.assert_on_curve(cs, enabled_wit)
+
+        src_tx_nonce_wit = AllocatedNum.alloc(cs, tr["before"]["tx_nonce"])
+        src_withdraw_nonce_wit = AllocatedNum.alloc(cs, tr["before"]["withdraw_nonce"])
+        src_addr_wit = AllocatedPoint.alloc(cs, affine(tr["before"]["address"]))
+        src_balances_hash_wit = AllocatedNum.alloc(cs, sc(tr["before_balances_hash"]))
+        src_token_id_wit = AllocatedNum.alloc(cs, contract_id(tr["before_balance"]["token_id"]))
+        src_balance_wit = AllocatedNum.alloc(cs, tr["before_balance"]["amount"])
+        src_token_balance_hash_wit = poseidon_gadget(cs, [src_token_id_wit, src_balance_wit])
+
+        src_balance_proof_wits = _alloc_proof(cs, tr["balance_proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_token_index_wit, src_token_balance_hash_wit, src_balance_proof_wits,
+                              Number.of(src_balances_hash_wit))
+
+        src_hash_wit = poseidon_gadget(cs, [src_tx_nonce_wit, src_withdraw_nonce_wit, src_addr_wit.x, src_addr_wit.y,
+                                            src_balances_hash_wit])
+        proof_wits = _alloc_proof(cs, tr["proof"])
+
+        is_src_token_id_null = Number.of(src_token_id_wit).is_zero(cs)
+        is_src_token_id_and_tx_token_id_equal = Number.of(src_token_id_wit).is_equal(cs, Number.of(tx_token_id_wit))
+        token_id_valid = boolean_or(cs, is_src_token_id_null, is_src_token_id_and_tx_token_id_equal)
+        assert_true(cs, token_id_valid)
+
+        is_src_addr_null = src_addr_wit.is_null(cs)
+        is_src_and_tx_pub_key_equal = src_addr_wit.is_equal(cs, tx_pub_key_wit)
+        addr_valid = boolean_or(cs, is_src_addr_null, is_src_and_tx_pub_key_equal)
+        assert_true(cs, addr_valid)
+
+        check_proof_poseidon4(cs, enabled_wit, tx_index_wit, src_hash_wit, proof_wits, Number.of(state_wit))
+
+        src_balance_lc = Number.of(src_balance_wit)
+        tx_amount_lc = Number.of(tx_amount_wit)
+        new_balances_hash_wit = poseidon_gadget(cs, [tx_token_id_wit, src_balance_lc + tx_amount_lc])
+        new_balances_hash_wit = calc_root_poseidon4(cs, tx_token_index_wit, new_balances_hash_wit, src_balance_proof_wits)
+
+        new_hash_wit = poseidon_gadget(cs, [src_tx_nonce_wit, src_withdraw_nonce_wit, tx_pub_key_wit.x, tx_pub_key_wit.y,
+                                            new_balances_hash_wit])
+        next_state_wit = calc_root_poseidon4(cs, tx_index_wit, new_hash_wit, proof_wits)
+        state_wit = mux(cs, enabled_wit, Number.of(state_wit), next_state_wit)
+
+    cs.enforce([(state_wit.var, 1)], [(ONE, 1)], [(claimed_next_state_wit.var, 1)])
+    return cs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# src/mpn/circuits/withdraw_circuit.rs:50-413
+# ---------------------------------------------------------------------------------------------------------------------
+def withdraw_circuit(log4_tree, log4_token_tree, log4_batch, commitment, height, state, aux_data, next_state, transitions,
+                     encode_contract_withdraw):
+    cs = ConstraintSystem()
+    L, T = log4_tree, log4_token_tree
+    state_wit, _, aux_wit, claimed_next_state_wit = _header(cs, commitment, height, state, aux_data, next_state)
+    state_model = ("list", log4_batch, ("struct", ["scalar"] * 7))
+
+    tx_wits, children = [], []
+    for tr in transitions:
+        tx = tr["tx"]
+        enabled = AllocatedBit.alloc(cs, tr["enabled"])
+        amount_token_id = AllocatedNum.alloc(cs, contract_id(tx["payment"]["amount"]["token_id"]))
+        amount = UnsignedInteger.alloc_64(cs, tx["payment"]["amount"]["amount"])
+        fee_token_id = AllocatedNum.alloc(cs, contract_id(tx["payment"]["fee"]["token_id"]))
+        fee = UnsignedInteger.alloc_64(cs, tx["payment"]["fee"]["amount"])
+        fingerprint = AllocatedNum.alloc(
+            cs, withdraw_fingerprint(tx["payment"], encode_contract_withdraw) if tr["enabled"] else 0)
+        pub_key = AllocatedPoint.alloc(cs, decompress(tx["mpn_address"]))
+        nonce = AllocatedNum.alloc(cs, tx["mpn_withdraw_nonce"])
+        sig_r = AllocatedPoint.alloc(cs, affine(tx["mpn_sig"]["r"]))
+        sig_s = AllocatedNum.alloc(cs, sc(tx["mpn_sig"]["s"]))
+        tx_wits.append((Boolean.is_(enabled), amount_token_id, amount, fee_token_id, fee, fingerprint, pub_key, nonce, sig_r,
+                        sig_s))
+        calldata_hash = poseidon_gadget(cs, [pub_key.x, pub_key.y, nonce, sig_r.x, sig_r.y, sig_s])
+        calldata = mux(cs, Boolean.is_(enabled), Number.zero(), calldata_hash)
+        children.append([Number.of(enabled), Number.of(amount_token_id), Number.of(amount), Number.of(fee_token_id),
+                         Number.of(fee), Number.of(fingerprint), Number.of(calldata)])
+    tx_root = reveal(cs, state_model, children)
+    cs.enforce([(aux_wit.var, 1)], [(ONE, 1)], list(tx_root.lc))
+
+    for tr, (enabled_wit, tx_amount_token_id_wit, tx_amount_wit, tx_fee_token_id_wit, tx_fee_wit, fingerprint_wit,
+             tx_pub_key_wit, tx_nonce_wit, tx_sig_r_wit, tx_sig_s_wit) in zip(transitions, tx_wits):
+        tx_index_wit = UnsignedInteger.alloc(cs, tr["account_index"], 2 * L)
+        tx_token_index_wit = UnsignedInteger.alloc(cs, tr["token_index"], 2 * T)
+        tx_fee_token_index_wit = UnsignedInteger.alloc(cs, tr["fee_token_index"], 2 * T)
+
+        tx_pub_key_wit.assert_on_curve(cs, enabled_wit)
+        tx_hash_wit = poseidon_gadget(cs, [fingerprint_wit, tx_nonce_wit])
+        tx_sig_r_wit.assert_on_curve(cs, enabled_wit)
+        verify_eddsa(cs, enabled_wit, tx_pub_key_wit, tx_hash_wit, tx_sig_r_wit, tx_sig_s_wit)
+
+        src_tx_nonce_wit = AllocatedNum.alloc(cs, tr["before"]["tx_nonce"])
+        src_withdraw_nonce_wit = AllocatedNum.alloc(cs, tr["before"]["withdraw_nonce"])
+        src_addr_wit = AllocatedPoint.alloc(cs, affine(tr["before"]["address"]))
+        src_addr_wit.assert_on_curve(cs, enabled_wit)
+
+        src_balances_before_token_hash_wit = AllocatedNum.alloc(cs, sc(tr["before_token_hash"]))
+        src_token_id_wit = AllocatedNum.alloc(cs, contract_id(tr["before_token_balance"]["token_id"]))
+        Number.of(src_token_id_wit).assert_equal(cs, Number.of(tx_amount_token_id_wit))
+        src_balance_wit = AllocatedNum.alloc(cs, tr["before_token_balance"]["amount"])
+        src_token_balance_hash_wit = poseidon_gadget(cs, [src_token_id_wit, src_balance_wit])
+        src_token_balance_proof_wits = _alloc_proof(cs, tr["token_balance_proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_token_index_wit, src_token_balance_hash_wit, src_token_balance_proof_wits,
+                              Number.of(src_balances_before_token_hash_wit))
+        new_token_balance_hash_wit = poseidon_gadget(
+            cs, [src_token_id_wit, Number.of(src_balance_wit) - Number.of(tx_amount_wit)])
+        balance_middle_root = calc_root_poseidon4(cs, tx_token_index_wit, new_token_balance_hash_wit,
+                                                  src_token_balance_proof_wits)
+
+        src_fee_token_id_wit = AllocatedNum.alloc(cs, contract_id(tr["before_fee_balance"]["token_id"]))
+        Number.of(src_fee_token_id_wit).assert_equal(cs, Number.of(tx_fee_token_id_wit))
+        src_fee_balance_wit = AllocatedNum.alloc(cs, tr["before_fee_balance"]["amount"])
+        src_fee_token_balance_hash_wit = poseidon_gadget(cs, [src_fee_token_id_wit, src_fee_balance_wit])
+        src_fee_token_balance_proof_wits = _alloc_proof(cs, tr["fee_balance_proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_fee_token_index_wit, src_fee_token_balance_hash_wit,
+                              src_fee_token_balance_proof_wits, balance_middle_root)
+        new_fee_token_balance_hash_wit = poseidon_gadget(
+            cs, [src_fee_token_id_wit, Number.of(src_fee_balance_wit) - Number.of(tx_fee_wit)])
+
+        src_hash_wit = poseidon_gadget(cs, [src_tx_nonce_wit, src_withdraw_nonce_wit, src_addr_wit.x, src_addr_wit.y,
+                                            src_balances_before_token_hash_wit])
+        proof_wits = _alloc_proof(cs, tr["proof"])
+        check_proof_poseidon4(cs, enabled_wit, tx_index_wit, src_hash_wit, proof_wits, Number.of(state_wit))
+
+        Number.of(tx_nonce_wit).assert_equal_if_enabled(cs, enabled_wit,
+                                                        Number.of(src_withdraw_nonce_wit) + Number.constant(1))
+
+        balance_final_root = calc_root_poseidon4(cs, tx_fee_token_index_wit, new_fee_token_balance_hash_wit,
+                                                 src_fee_token_balance_proof_wits)
+        new_hash_wit = poseidon_gadget(cs, [src_tx_nonce_wit, Number.of(src_withdraw_nonce_wit) + Number.constant(1),
+                                            tx_pub_key_wit.x, tx_pub_key_wit.y, balance_final_root])
+        next_state_wit = calc_root_poseidon4(cs, tx_index_wit, new_hash_wit, proof_wits)
+        state_wit = mux(cs, enabled_wit, Number.of(state_wit), next_state_wit)
+
+    cs.enforce([(state_wit.var, 1)], [(ONE, 1)], [(claimed_next_state_wit.var, 1)])
+    return cs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# what bellman's prover derives from a synthesized instance (groth16/prover.rs `eval` + ProvingAssignment) [recalled]
+# ---------------------------------------------------------------------------------------------------------------------
+def evaluations(cs):
+    """(az, bz, cz) per constraint incl. the trailing input rows; (a_density, b_density) over flat indices as bellman
+    tracks them: a variable counts when it appears in an A (resp. B) row with a non-zero coefficient - per TERM, so a pair
+    of cancelling duplicate terms would still count (none exist in these circuits).  bellman tracks a_aux_density,
+    b_input_density and b_aux_density; a_input is FullDensity (every input's `a` base is used)."""
+    z = cs.z()
+    n = len(z)
+    a_d, b_d = [0] * n, [0] * n
+    out = []
+    for which, dens in (("A", a_d), ("B", b_d), ("C", None)):
+        col = []
+        for row in cs.rows(which):
+            acc = 0
+            for v, c in row:
+                if c:
+                    acc += c * z[v]
+                    if dens is not None:
+                        dens[v] = 1
+            col.append(acc % R_MOD)
+        out.append(col)
+    return out[0], out[1], out[2], a_d, b_d
+
+
+def canonical_rows(rows):
+    """Duplicate terms of a row summed, order of first appearance kept, zero sums kept out."""
+    out = []
+    for row in rows:
+        acc = {}
+        for v, c in row:
+            acc[v] = (acc.get(v, 0) + c) % R_MOD
+        out.append([(v, c) for v, c in acc.items() if c])
+    return out
+
+
+def has_cancelling_duplicates(rows):
+    for row in rows:
+        acc, seen = {}, set()
+        for v, c in row:
+            if c:
+                seen.add(v)
+            acc[v] = (acc.get(v, 0) + c) % R_MOD
+        if any(acc[v] == 0 for v in seen):
+            return True
+    return False
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `::null(L, T)` transitions (src/mpn/mod.rs:438-452, 470-487, 513-537) in the shape tests/bincode_ref.py decodes: every
+# field `Default::default()` - ContractId::Null (src/core/transaction.rs:66-70), zero scalars, (0, false) compressed keys,
+# (0, 0) affine points, empty token maps - with all-zero Merkle proofs of the right depth
+# ---------------------------------------------------------------------------------------------------------------------
+_Z32 = bytes(32)
+_NULL_MONEY = {"token_id": ("Null", None), "amount": 0}
+_NULL_PK = {"x": _Z32, "odd": False}
+_NULL_PT = {"x": _Z32, "y": _Z32}
+_NULL_SIG = {"r": _NULL_PT, "s": _Z32}
+_NULL_ACCOUNT = {"tx_nonce": 0, "withdraw_nonce": 0, "address": _NULL_PT, "tokens": {}}
+
+
+def _null_proof(depth):
+    return [bytes(96)] * depth
+
+
+def null_update_transition(L, T):
+    tx = {"nonce": 0, "src_pub_key": _NULL_PK, "dst_pub_key": _NULL_PK, "amount": _NULL_MONEY, "fee": _NULL_MONEY, "sig": _NULL_SIG}
+    return {"enabled": False, "tx": tx, "src_before": _NULL_ACCOUNT, "src_before_balances_hash": _Z32,
+            "src_before_balance": _NULL_MONEY, "src_before_fee_balance": _NULL_MONEY, "src_proof": _null_proof(L), "src_index": 0,
+            "src_token_index": 0, "src_balance_proof": _null_proof(T), "src_fee_token_index": 0,
+            "src_fee_balance_proof": _null_proof(T), "dst_before": _NULL_ACCOUNT, "dst_before_balances_hash": _Z32,
+            "dst_before_balance": _NULL_MONEY, "dst_proof": _null_proof(L), "dst_index": 0, "dst_token_index": 0,
+            "dst_balance_proof": _null_proof(T)}
+
+
+def null_deposit_transition(L, T):
+    payment = {"memo": "", "contract_id": ("Null", None), "deposit_circuit_id": 0, "calldata": _Z32, "src": bytes(32),
+               "amount": _NULL_MONEY, "fee": _NULL_MONEY, "nonce": 0, "sig": None}
+    return {"enabled": False, "tx": {"mpn_address": _NULL_PK, "payment": payment}, "before": _NULL_ACCOUNT,
+            "before_balances_hash": _Z32, "before_balance": _NULL_MONEY, "proof": _null_proof(L), "account_index": 0,
+            "token_index": 0, "balance_proof": _null_proof(T)}
+
+
+def null_withdraw_transition(L, T):
+    payment = {"memo": "", "contract_id": ("Null", None), "withdraw_circuit_id": 0, "calldata": _Z32, "dst": bytes(32),
+               "amount": _NULL_MONEY, "fee": _NULL_MONEY}
+    tx = {"mpn_address": _NULL_PK, "mpn_withdraw_nonce": 0, "mpn_sig": _NULL_SIG, "payment": payment}
+    return {"enabled": False, "tx": tx, "before": _NULL_ACCOUNT, "before_token_balance": _NULL_MONEY,
+            "before_fee_balance": _NULL_MONEY, "proof": _null_proof(L), "account_index": 0, "token_index": 0,
+            "token_balance_proof": _null_proof(T), "before_token_hash": _Z32, "fee_token_index": 0,
+            "fee_balance_proof": _null_proof(T)}
+
+
+def circuit_of_work(work, commitment, fee_token=1, encode_contract_withdraw=None):
+    """The circuit instance a prover builds for a decoded `MpnWork` (tests/bincode_ref.py dict): transitions padded with
+    `::null` to 4^batch, public inputs [commitment, height, state, aux_data, next_state] (the external prover's side of
+    src/mpn/mod.rs:263-295; fee_token = the accepted fee token, Ziesha on the network: src/mpn/mod.rs:156-158, 400)."""
+    c, pi = work["config"], work["public_inputs"]
+    L, T = c["log4_tree_size"], c["log4_token_tree_size"]
+    kind, trs = work["data"]
+    args = (sc(commitment), pi["height"], sc(pi["state"]), sc(pi["aux_data"]), sc(pi["next_state"]))
+    if kind == "Update":
+        n = 1 << (2 * c["log4_update_batch_size"])
+        trs = list(trs) + [null_update_transition(L, T)] * (n - len(trs))
+        return update_circuit(L, T, *args, fee_token, trs)
+    if kind == "Deposit":
+        B = c["log4_deposit_batch_size"]
+        trs = list(trs) + [null_deposit_transition(L, T)] * ((1 << (2 * B)) - len(trs))
+        return deposit_circuit(L, T, B, *args, trs)
+    B = c["log4_withdraw_batch_size"]
+    trs = list(trs) + [null_withdraw_transition(L, T)] * ((1 << (2 * B)) - len(trs))
+    return withdraw_circuit(L, T, B, *args, trs, encode_contract_withdraw)
+
+
+def first_unsatisfied(cs):
+    """index of the first constraint with <A,z> * <B,z> != <C,z>, or -1 (what `verify_proof` accepting a proof of this
+    instance is equivalent to in the reference's gadget tests)"""
+    az, bz, cz, _, _ = evaluations(cs)
+    for i, (a, b, c) in enumerate(zip(az, bz, cz)):
+        if (a * b - c) % R_MOD:
+            return i
+    return -1
+
+
+def csr_bytes(cs, which):
+    """(val, col, row_ptr) of matrix `which` in the byte layout of bzk_r1cs_data views 6-14: duplicate terms summed, first
+    appearance order, 32-B Montgomery values, u32 flat columns, u32 row pointers, input rows appended."""
+    import struct
+    from oracle.pyref import fr_to_mont_bytes
+    can = canonical_rows(cs.rows(which))
+    val = b"".join(fr_to_mont_bytes(c) for row in can for _, c in row)
+    col = b"".join(struct.pack("<I", v) for row in can for v, _ in row)
+    rp, acc = [0], 0
+    for row in can:
+        acc += len(row)
+        rp.append(acc)
+    return val, col, struct.pack("<%dI" % len(rp), *rp)
+
+
+def all_views(cs):
+    """the 15 arrays of bzk_r1cs_data, by the names bazuka_amd.lib.R1cs.VIEWS uses"""
+    from oracle.pyref import fr_to_mont_bytes
+    az, bz, cz, a_d, b_d = evaluations(cs)
+    out = {"z": b"".join(fr_to_mont_bytes(x) for x in cs.z())}
+    for name, colv in (("az", az), ("bz", bz), ("cz", cz)):
+        out[name] = b"".join(fr_to_mont_bytes(x) for x in colv)
+    out["a_density"], out["b_density"] = bytes(a_d), bytes(b_d)
+    for which in "ABC":
+        out["val" + which], out["col" + which], out["rp" + which] = csr_bytes(cs, which)
+    return out
