@@ -40,6 +40,7 @@ struct bzk_ctx {
     std::vector<bzk_ctx*> lanes;
     bool no_coop = false;  // env BZK_NO_COOP=1: never use the cooperative (8 lanes per node) Poseidon kernel (A/B runs)
     bool timing = false;  // env BZK_TIMING=1: host-side phase timings of bzk_groth16_prove on stderr
+    hipEvent_t ev_z = nullptr;  // "assignment staged" event of bzk_groth16_prove: created on first use, destroyed with the ctx
 };
 
 #define BZK_HIP(ctx, call)                                                                  \

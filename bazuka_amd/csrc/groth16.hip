@@ -218,12 +218,32 @@ int32_t bzk_groth16_h_dev(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_
     return groth16_h(ctx, a, b, c, log_m);
 }
 
+static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
+                                  uint8_t proof[387]);
+
 int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
                           uint8_t proof[387]) {
     if (!ctx || !p || !asg || !r32 || !s32 || !proof || !asg->z || !asg->az || !asg->bz || !asg->cz) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
+    const int32_t st = groth16_prove_impl(ctx, p, asg, r32, s32, proof);
+    if (st != BZK_OK) {
+        // the caller frees (re-uses) the assignment arrays as soon as this returns: no copy out of them may still be in
+        // flight, on the main stream or on a lane
+        (void)hipStreamSynchronize(ctx->stream);
+        for (bzk_ctx* c : ctx->lanes) (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+    }
+    return st;
+}
+
+static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
+                                  uint8_t proof[387]) {
     const uint64_t m = (uint64_t)1 << p->log_m, nv = (uint64_t)p->n_in + p->n_aux;
     if (asg->n_rows > m) return BZK_E_ARG;
+    if (asg->n_vars != nv) {  // an R1CS of another circuit shape than the CRS: refuse instead of reading past `z`
+        ctx->last_error = "groth16_prove: assignment has " + std::to_string(asg->n_vars) + " variables, the parameters " + std::to_string(nv);
+        return BZK_E_ARG;
+    }
     // Schedule: the five MSMs are independent, and each ends in a latency-bound tail (bucket reduction, window
     // sums, 97-byte read-back) that leaves most CUs idle.  They run on separate lanes (stream + workspace each,
     // one host thread per lane) so that one MSM's tail overlaps another's accumulation; l, a, b only need z, so
@@ -239,8 +259,8 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
         BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_a + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->a_idx, p->n_a, (Fr*)p->d_sa);
     if (p->n_b)
         BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_b + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->b_idx, p->n_b, (Fr*)p->d_sb);
-    hipEvent_t z_ready;
-    BZK_HIP(ctx, hipEventCreateWithFlags(&z_ready, hipEventDisableTiming));
+    if (!ctx->ev_z) BZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
+    const hipEvent_t z_ready = ctx->ev_z;
     BZK_HIP(ctx, hipEventRecord(z_ready, ctx->stream));
     for (int i = 0; i < 3; ++i) BZK_HIP(ctx, hipStreamWaitEvent(lane[i]->stream, z_ready, 0));
     const auto t1 = clk::now();
@@ -308,7 +328,6 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
     const auto t3 = clk::now();
     if (!serial)
         for (auto& t : th) t.join();
-    (void)hipEventDestroy(z_ready);
     const auto t4 = clk::now();
     if (st_main != BZK_OK) return st_main;
     for (int i = 0; i < 3; ++i)

@@ -75,7 +75,14 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
         s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w;
         s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
     }
-    if (mont) s = fe_from_mont<FrParams>(s);
+    if (mont) {
+        s = fe_from_mont<FrParams>(s);
+    } else {
+        // BZK_F_CANONICAL input is not range-checked by the caller: the signed recoding below drops the carry out of the top
+        // window, which is only safe below 2^255, so bring any 256-bit value under r first (2^256 < 3 r; r P = O)
+        fe_reduce_once<FrParams>(s);
+        fe_reduce_once<FrParams>(s);
+    }
     const uint32_t half = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
     // table mode (table_stride != 0): the table holds level j = 2^(c wpl j) P_i, window w = j * wpl + w' feeds bucket set

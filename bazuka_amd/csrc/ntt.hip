@@ -18,6 +18,8 @@
 
 #include "bzk_field.cuh"
 #include "bzk_fr29.cuh"
+#include <mutex>
+
 #include "bzk_internal.h"
 
 namespace bzk {
@@ -342,12 +344,13 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
     }
     const int d = inverse ? 1 : 0;
     const uint32_t tile_max = ntt_tile_elems();
-    static bool lds_attr_set = false;  // tiles above 64 KiB of dynamic LDS need the opt-in
-    if (!lds_attr_set) {
+    // tiles above 64 KiB of dynamic LDS need the opt-in; the attribute is per DEVICE, so remember it per device id (a process
+    // may hold contexts on several GPUs, and prover slots call this from concurrent threads)
+    static std::once_flag lds_attr_once[64];
+    std::call_once(lds_attr_once[ctx->device & 63], [] {
         (void)hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        lds_attr_set = true;
-    }
+    });
     uint64_t S = n;
     for (int k = 0; k < T->nb; ++k) {
         const int b = T->b[k];

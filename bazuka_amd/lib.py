@@ -117,7 +117,7 @@ class CsrDesc(C.Structure):
 
 
 class Assignment(C.Structure):
-    _fields_ = [("z", _vp), ("az", _vp), ("bz", _vp), ("cz", _vp), ("n_rows", _u64)]
+    _fields_ = [("z", _vp), ("az", _vp), ("bz", _vp), ("cz", _vp), ("n_rows", _u64), ("n_vars", _u64)]
 
 
 class WorkConfig(C.Structure):  # bzk_mpn_work_config
@@ -371,7 +371,9 @@ class Bzk:
     def groth16_prove(self, ph, z, az, bz, cz, r: bytes, s: bytes) -> bytes:
         """z / az / bz / cz: bytes or zero-copy ctypes views (R1cs.raw) - passed by address, never copied here."""
         keep = [x if not isinstance(x, bytearray) else bytes(x) for x in (z, az, bz, cz)]
-        asg = Assignment(*[_ptr(x) for x in keep], len(az) // 32)
+        if not (len(az) == len(bz) == len(cz)) or len(az) % 32 or len(z) % 32:
+            raise BzkError(f"groth16_prove: z / az / bz / cz lengths {len(z)}, {len(az)}, {len(bz)}, {len(cz)}")
+        asg = Assignment(*[_ptr(x) for x in keep], len(az) // 32, len(z) // 32)  # libbzk checks n_vars against the params
         out = C.create_string_buffer(387)
         self._ck(self.lib.bzk_groth16_prove(self.h, ph, C.byref(asg), _ptr(r), _ptr(s), out), "groth16_prove")
         return out.raw
@@ -551,10 +553,15 @@ class MpnWork:
         self.state, self.aux_data, self.next_state, self.new_root_hash, self.contract_id = [sc.raw[32 * i:32 * i + 32] for i in range(5)]
 
     @classmethod
-    def decode(cls, data: bytes, flags: int = 0) -> "MpnWork":
+    def decode(cls, data, flags: int = 0, offset: int = 0) -> "MpnWork":
+        """decodes the work at data[offset:] (bytes or a ctypes buffer) without slicing - a response holds several works"""
         lib = load_library()
         h, used = C.c_void_p(), _u64()
-        st = lib.bzk_mpn_work_decode(_ptr(data), len(data), flags, C.byref(h), C.byref(used))
+        if offset < 0 or offset > len(data):
+            raise BzkError("work_decode: offset out of range")
+        base = _ptr(data)
+        at = C.c_void_p((base.value or 0) + offset) if offset else base
+        st = lib.bzk_mpn_work_decode(at, len(data) - offset, flags, C.byref(h), C.byref(used))
         if st != 0:
             raise BzkError(f"work_decode: {lib.bzk_strerror(st).decode()} [{lib.bzk_mpn_work_last_error().decode()}]")
         return cls(h, used.value)

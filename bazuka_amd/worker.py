@@ -47,7 +47,7 @@ def parse_work_response(body: bytes, flags: int = 0) -> dict[int, L.MpnWork]:
         if len(body) - pos < 8:
             raise L.BzkError("work response: truncated")
         (wid,) = struct.unpack_from("<Q", body, pos)
-        w = L.MpnWork.decode(body[pos + 8:], flags)
+        w = L.MpnWork.decode(body, flags, offset=pos + 8)  # by offset: no re-slicing of a multi-MB response per work
         pos += 8 + w.consumed
         out[wid] = w
     if pos != len(body):
@@ -130,12 +130,27 @@ class DevSetup:
             head = f.read(8 + 20)
             if head[:8] != self._MAGIC:
                 raise L.BzkError(f"{path}: not a bzk CRS file")
+            if len(head) != 28:
+                raise L.BzkError(f"{path}: truncated header")
             n_in, n_aux, log_m, n_a, n_b = struct.unpack("<5I", head[8:])
+            if log_m > 28 or n_in == 0:
+                raise L.BzkError(f"{path}: implausible header")
+            # the file is a cache, not an input format: still, nothing in it is trusted before it reaches bzk_params_load
+            want = [878 + 97 * n_in, 870, 96 * ((1 << log_m) - 1), 96 * n_aux, 96 * n_a, 96 * n_b, 192 * n_b, n_in + n_aux, n_in + n_aux]
             parts = []
-            for _ in range(9):
-                (ln,) = struct.unpack("<Q", f.read(8))
-                parts.append(f.read(ln))
+            for k in range(9):
+                raw = f.read(8)
+                if len(raw) != 8 or struct.unpack("<Q", raw)[0] != want[k]:
+                    raise L.BzkError(f"{path}: part {k} has the wrong length for (n_in, n_aux, log_m, n_a, n_b)")
+                part = f.read(want[k])
+                if len(part) != want[k]:
+                    raise L.BzkError(f"{path}: truncated")
+                parts.append(part)
+            if f.read(1):
+                raise L.BzkError(f"{path}: trailing bytes")
         vk_bincode, vk_pts, h, l, a, b_g1, b_g2, a_d, b_d = parts
+        if sum(a_d) != n_a or sum(b_d) != n_b or max(a_d + b_d, default=0) > 1:
+            raise L.BzkError(f"{path}: density maps do not match n_a / n_b")
         ph = self.bzk.params_load({"n_in": n_in, "n_aux": n_aux, "log_m": log_m, "n_a": n_a, "n_b": n_b, "vk": vk_pts, "h": h, "l": l,
                                    "a": a, "b_g1": b_g1, "b_g2": b_g2, "a_density": a_d, "b_density": b_d})
         return ph, vk_bincode
@@ -217,7 +232,8 @@ class Worker:
         while rounds is None or done < rounds:
             try:
                 self.run_once()
-            except (OSError, L.BzkError) as e:  # node away or a bad payload: keep polling, as a worker daemon does
+            except (OSError, L.BzkError, http.client.HTTPException, struct.error) as e:
+                # node away, a short read (IncompleteRead) or a bad payload: keep polling, as a worker daemon does
                 self.stats["last_error"] = str(e)
             done += 1
             time.sleep(poll_s)

@@ -163,6 +163,8 @@ typedef struct {
     const uint8_t* bz;
     const uint8_t* cz;
     uint64_t n_rows;             /* number of constraints incl. bellman's n_in trailing `input*0=0` rows */
+    uint64_t n_vars;             /* scalars behind `z`: must equal the params' n_in + n_aux, else BZK_E_ARG (an assignment
+                                    of another circuit shape is refused, never read out of bounds) */
 } bzk_assignment;
 /* uploads the CRS to HBM once (host pointers in the descriptor are not retained) */
 int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* desc, bzk_params** out);

@@ -86,3 +86,19 @@ def test_gpu_setup_matches_oracle_crs(bzk, co, pr, n_mul):
     r, s = fr_bytes(fr_list(2, 8))[:32], fr_bytes(fr_list(2, 8))[32:]
     assert bzk.groth16_prove(ph, zb, az, bz, cz, r, s) == co.groth16_prove(want, zb, az, bz, cz, r, s, nthreads=co.ncpu())
     bzk.params_free(ph)
+
+
+def test_prove_refuses_an_assignment_of_another_circuit_shape(bzk, co, pr):
+    """bzk_assignment carries n_vars; a witness of another circuit than the CRS is BZK_E_ARG, never an
+    out-of-bounds read of `z` or a silently wrong proof"""
+    from bazuka_amd.lib import BzkError
+    r1, params, zb, az, bz, cz = _setup(co, pr, 100, 4242)
+    r, s = fr_bytes(fr_list(2, 5))[:32], fr_bytes(fr_list(2, 5))[32:]
+    ph = bzk.params_load(params)
+    for bad_z in (zb[:-32], zb + bytes(32), zb[:32]):
+        with pytest.raises(BzkError, match="bad argument"):
+            bzk.groth16_prove(ph, bad_z, az, bz, cz, r, s)
+    with pytest.raises(BzkError):
+        bzk.groth16_prove(ph, zb, az, bz[:-32], cz, r, s)      # ragged evaluation vectors: refused by the driver
+    assert bzk.groth16_prove(ph, zb, az, bz, cz, r, s) == co.groth16_prove(params, zb, az, bz, cz, r, s)  # ctx still healthy
+    bzk.params_free(ph)

@@ -422,3 +422,28 @@ print("ok")
     env = dict(os.environ, BZK_MSM_C_WIT_G1="11", BZK_MSM_C_WIT_G2="6")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("c", [0, 4, 8, 13, 16])
+def test_msm_canonical_scalars_at_and_above_r(co, pr, c, monkeypatch):
+    """BZK_F_CANONICAL input is not range-checked by callers; values in [r, 2^256) are taken mod r (r P = O) for
+    every window size, including c | 256 (4, 8, 16) where the signed recoding has no spare top bit"""
+    from bazuka_amd import Bzk
+    if c:
+        monkeypatch.setenv("BZK_MSM_C", str(c))
+    ctx = Bzk(0)
+    try:
+        n = 64
+        bases = co.g1_bases(91, 0, n)
+        small = [5, 0, 1, pr.R_MOD - 1] + fr_list(n - 4, 17)
+        big = [v + (pr.R_MOD if v + pr.R_MOD < (1 << 256) else 0) for v in small]
+        big[0] = 5 + 2 * pr.R_MOD
+        big[1] = (1 << 256) - 1                      # all ones
+        small[1] = ((1 << 256) - 1) % pr.R_MOD
+        assert all(b < (1 << 256) for b in big) and sum(b >= (1 << 255) for b in big) > 10
+        want = co.msm_g1(bases, fr_bytes(small, mont=False), mont=False)
+        raw = b"".join(b.to_bytes(32, "little") for b in big)
+        assert ctx.msm_g1(bases, raw, canonical=True) == want
+        assert ctx.msm_g1(bases, fr_bytes(small, mont=False), canonical=True) == want
+    finally:
+        ctx.close()

@@ -321,3 +321,60 @@ def test_decoder_survives_mutated_payloads(kind):
         assert again.encode() == dec.encode()   # encode . decode is idempotent on whatever was accepted
         agree += 1
     assert agree > 20 and refused > 20, (agree, refused)
+
+
+def test_crs_cache_file_is_validated_before_it_reaches_libbzk(tmp_path):
+    """DevSetup._load checks every part length against (n_in, n_aux, log_m, n_a, n_b) and the density maps against
+    n_a / n_b; a damaged cache file is a BzkError, not a short buffer handed to bzk_params_load"""
+    import struct
+    from bazuka_amd import worker as W
+
+    class FakeBzk:  # records what would be uploaded; no GPU on this path
+        def params_load(self, d):
+            self.loaded = d
+            return "handle"
+
+    n_in, n_aux, log_m = 2, 5, 3
+    a_d, b_d = bytes([1, 0, 1, 1, 0, 0, 1]), bytes([0, 1, 0, 0, 1, 0, 0])
+    n_a, n_b = sum(a_d), sum(b_d)
+    parts = [bytes(878 + 97 * n_in), bytes(870), bytes(96 * 7), bytes(96 * n_aux), bytes(96 * n_a), bytes(96 * n_b), bytes(192 * n_b), a_d, b_d]
+
+    def write(path, parts, head=(n_in, n_aux, log_m, n_a, n_b), tail=b""):
+        with open(path, "wb") as f:
+            f.write(W.DevSetup._MAGIC + struct.pack("<5I", *head))
+            for p in parts:
+                f.write(struct.pack("<Q", len(p)) + p)
+            f.write(tail)
+
+    ds = W.DevSetup(FakeBzk(), {})
+    good = tmp_path / "good.bzkcrs"
+    write(good, parts)
+    assert ds._load(str(good))[0] == "handle" and ds.bzk.loaded["n_a"] == n_a
+    for name, kw in (("short_part", dict(parts=parts[:2] + [bytes(96 * 6)] + parts[3:])),
+                     ("wrong_counts", dict(parts=parts, head=(n_in, n_aux, log_m, n_a + 1, n_b))),
+                     ("density", dict(parts=parts[:7] + [bytes([1, 1, 1, 1, 1, 0, 1]), b_d])),
+                     ("density_value", dict(parts=parts[:7] + [bytes([2, 0, 1, 1, 0, 0, 0]), b_d])),
+                     ("trailing", dict(parts=parts, tail=b"x")),
+                     ("log_m", dict(parts=parts, head=(n_in, n_aux, 40, n_a, n_b)))):
+        bad = tmp_path / (name + ".bzkcrs")
+        write(bad, **kw)
+        with pytest.raises(L.BzkError):
+            ds._load(str(bad))
+    trunc = tmp_path / "trunc.bzkcrs"
+    trunc.write_bytes(good.read_bytes()[:-10])
+    with pytest.raises(L.BzkError):
+        ds._load(str(trunc))
+
+
+def test_work_response_is_parsed_by_offset():
+    """several works in one response body are decoded in place (no per-work re-slicing of the body)"""
+    import struct
+    from bazuka_amd import worker as W
+    blobs = [_make(k)[2].encode() for k in (0, 1, 2)]
+    body = struct.pack("<Q", 3) + b"".join(struct.pack("<Q", 10 + i) + b for i, b in enumerate(blobs))
+    works = W.parse_work_response(body)
+    assert sorted(works) == [10, 11, 12] and [works[10 + i].encode() for i in range(3)] == blobs
+    with pytest.raises(L.BzkError):
+        W.parse_work_response(body + b"\\0")
+    with pytest.raises(L.BzkError):
+        W.parse_work_response(body[:-5])
