@@ -41,6 +41,10 @@ struct bzk_ctx {
     bool no_coop = false;  // env BZK_NO_COOP=1: never use the cooperative (8 lanes per node) Poseidon kernel (A/B runs)
     bool timing = false;  // env BZK_TIMING=1: host-side phase timings of bzk_groth16_prove on stderr
     hipEvent_t ev_z = nullptr;  // "assignment staged" event of bzk_groth16_prove: created on first use, destroyed with the ctx
+    // side stream of one MSM call: work that the bucket pipeline does not depend on until the accumulation (the per-call base
+    // conversion) runs here beside digits / sort; fork / join through the two events.  Created on first use.
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 #define BZK_HIP(ctx, call)                                                                  \

@@ -143,6 +143,12 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
         if (p) (void)hipFree(p);
     bzk::ntt_free_tables(ctx);
     if (ctx->ev_z) (void)hipEventDestroy(ctx->ev_z);
+    if (ctx->aux) {
+        (void)hipStreamSynchronize(ctx->aux);
+        (void)hipStreamDestroy(ctx->aux);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

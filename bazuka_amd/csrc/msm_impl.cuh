@@ -164,6 +164,50 @@ static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3b. counting sort of the (bucket, point) pairs through global atomics - an EXPERIMENT (BZK_MSM_CSORT=1), measured and
+// rejected in round 2.  The pairs only have to be GROUPED by bucket (a bucket sum does not depend on the order of its points
+// and the affine result of the MSM is canonical), so instead of a radix sort of 20-bit keys:
+//   msm_hist     count[key]++                 one 4-byte atomic per pair into a 2 MB table
+//   scan         start = exclusive sum(count)
+//   msm_scatter  vals_s[start[key] + cursor[key]++] = val
+// Measured (profiles/r02_run2_csort_ab.txt): device-scope atomics to random addresses run at ~27 G/s on MI355X (they are
+// resolved beyond the per-XCD L2): hist 0.62 ms + scatter 0.85 ms at 2^20 points against 0.43 + 0.05 ms for rocPRIM's
+// radix sort + msm_offsets; 2^24: 20.1 ms against 6.5 ms.  The radix sort stays the default.
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) msm_hist_kernel(const uint32_t* __restrict__ keys, uint64_t len, uint32_t nb,
+                                                              uint32_t* __restrict__ count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const uint32_t k = keys[i];
+    if (k < nb) atomicAdd(&count[k], 1u);
+}
+
+static __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                 uint64_t len, uint32_t nb, const uint32_t* __restrict__ start,
+                                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ vals_s) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const uint32_t k = keys[i];
+    if (k >= nb) return;
+    const uint32_t pos = start[k] + atomicAdd(&cursor[k], 1u);
+    vals_s[pos] = vals[i];
+}
+
+static __global__ void __launch_bounds__(256) msm_iota_clamp_kernel(const uint32_t* __restrict__ count, uint32_t* __restrict__ iota,
+                                                                    uint32_t* __restrict__ ckey, uint32_t nb) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nb) return;
+    const uint32_t c = count[g];
+    iota[g] = g;
+    ckey[g] = c < 65535u ? c : 65535u;
+}
+
+static bool msm_use_csort() {
+    static const bool on = [] { const char* e = getenv("BZK_MSM_CSORT"); return e && atoi(e) != 0; }();
+    return on;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 4b. base conversion to the policy's internal form (G1: 14 x 28-bit limbs); one pass per call
 // ------------------------------------------------------------------------------------------------
 template <class C>
@@ -211,11 +255,16 @@ __global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restr
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t MSM_SEG_MAX = 256;  // longest serial run of mixed adds one lane executes
 
-static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* __restrict__ count_sorted, uint32_t nb, uint32_t seg,
+// buckets arrive ordered by min(count, 65535) (two 8-bit radix passes instead of four over the full count width: buckets
+// beyond 65535 entries are cut into tasks of <= 256 anyway, their mutual order does not matter); the true counts are
+// gathered through the order here
+static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order,
+                                                               uint32_t nb, uint32_t seg, uint32_t* __restrict__ count_sorted,
                                                                uint32_t* __restrict__ ntask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
-    const uint32_t c = count_sorted[i];
+    const uint32_t c = count[order[i]];
+    count_sorted[i] = c;
     ntask[i] = c <= seg ? 1u : (c + seg - 1) / seg;  // empty buckets keep one task (writes the identity)
 }
 
@@ -656,18 +705,22 @@ struct BucketArrays {
 template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
                                  uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
-                                 bool group_sums = false) {
-    BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
-    BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
-    BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
-    BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, nb);
+                                 bool group_sums = false, bool have_counts = false) {
+    if (!have_counts) {  // boundaries from a sorted key list (keys_s == nullptr with have_counts: A.start / A.count are filled)
+        BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
+        BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
+        BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
+        BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, nb);
+    }
+    // clamped population keys: A.ntask holds them until msm_ntask overwrites it, A.tbase receives the (unused) sorted keys
+    BZK_LAUNCH(ctx, "msm_iota_clamp", msm_iota_clamp_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.iota, A.ntask, nb);
     {
         ProfScope ps(ctx, "msm_sort_buckets");
         size_t t = tmp;
-        hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, A.count, A.count_s, A.iota, A.order, (size_t)nb, 0, bits_for(len), ctx->stream);
+        hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 16, ctx->stream);
         if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
     }
-    BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count_s, nb, seg, A.ntask);
+    BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.order, nb, seg, A.count_s, A.ntask);
     {
         ProfScope ps(ctx, "msm_scan_tasks");
         size_t t = tmp;
@@ -697,6 +750,45 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     return BZK_OK;
 }
 
+
+// side stream of a call (bzk_ctx::aux): lazily created; `false` = run everything on the main stream
+static bool msm_aux_ready(bzk_ctx* ctx) {
+    static const bool off = [] { const char* e = getenv("BZK_MSM_NO_AUX"); return e && atoi(e) != 0; }();
+    if (off) return false;
+    if (ctx->aux) return true;
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (s) (void)hipStreamDestroy(s);
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        return false;
+    }
+    ctx->aux = s; ctx->ev_fork = a; ctx->ev_join = b;
+    return true;
+}
+// the main stream waits for the side stream's work of this call exactly once - at the first consumer or, failing that, when the
+// call returns (the workspace must not be re-used or freed under a conversion that is still running)
+struct AuxJoin {
+    bzk_ctx* ctx;
+    bool pending = false;
+    explicit AuxJoin(bzk_ctx* c) : ctx(c) {}
+    void join() {
+        if (pending) {
+            (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+            pending = false;
+        }
+    }
+    ~AuxJoin() { join(); }
+};
+template <class C>
+static int32_t msm_convert_launch(bzk_ctx* ctx, const void* bases_raw, uint64_t n, typename C::DevAff* conv) {
+    auto k_conv = msm_convert_bases_kernel<C>;
+    BZK_LAUNCH(ctx, "msm_convert_bases", k_conv, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, bases_raw, n, conv);
+    return BZK_OK;
+}
 
 // Computes sum over windows [w_begin, w_end) of 2^(c w) S_w into `result` (host XYZZ, standard limbs).
 struct MsmTable {
@@ -814,10 +906,24 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     StdPt* win_out = cur.take<StdPt>(w_total);
     const void* bases = table ? table->data : bases_raw;
     typename C::DevAff* conv = nullptr;
+    AuxJoin aux(ctx);
     if (C::CONVERT_BASES && !table) {
         conv = cur.take<typename C::DevAff>(n + m_max);
-        auto k_conv = msm_convert_bases_kernel<C>;
-        BZK_LAUNCH(ctx, "msm_convert_bases", k_conv, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, bases_raw, n, conv);
+        // the conversion is not needed before the first accumulation: it runs on the side stream beside digits / sort
+        if (msm_aux_ready(ctx) && hipEventRecord(ctx->ev_fork, ctx->stream) == hipSuccess &&
+            hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0) == hipSuccess) {
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->aux;  // BZK_LAUNCH / ProfScope work on ctx->stream
+            const int32_t st = msm_convert_launch<C>(ctx, bases_raw, n, conv);
+            const hipError_t e = hipEventRecord(ctx->ev_join, ctx->aux);
+            ctx->stream = main_stream;
+            aux.pending = true;
+            if (st != BZK_OK) return st;
+            if (e != hipSuccess) { ctx->last_error = "aux join event"; return BZK_E_DEVICE; }
+        } else {
+            (void)hipGetLastError();
+            BZK_TRY(msm_convert_launch<C>(ctx, bases_raw, n, conv));
+        }
         bases = conv;
     }
     uint64_t* hkey = nullptr;
@@ -881,6 +987,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                    (const uint32_t*)didx_s, (const uint32_t*)head, (const uint32_t*)mhead, (const uint32_t*)gid_ex, (const uint32_t*)mid_ex,
                    n, 0xffffffffu, key2, scal2, rep, gof);
         if (M) {
+            aux.join();
             BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true));
             static const uint32_t K = [] {  // sums per lane of the batched inversion (env BZK_DEDUP_K for A/B runs)
                 const char* e = getenv("BZK_DEDUP_K");
@@ -907,13 +1014,28 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
                    mont, c, folded ? levels * table->wpl : w_total, wb, wc, (uint32_t)(table ? table->n : 0), table ? table->wpl : 1,
                    (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
-        {
+        const bool csort = msm_use_csort();
+        if (csort) {
+            const unsigned gl = (unsigned)((len + 255) / 256);
+            BZK_HIP(ctx, hipMemsetAsync(BA.count, 0, (size_t)nb * 4, ctx->stream));
+            BZK_HIP(ctx, hipMemsetAsync(BA.ntask, 0, (size_t)nb * 4, ctx->stream));  // per-bucket cursor of the scatter (re-used as ntask later)
+            BZK_LAUNCH(ctx, "msm_hist", msm_hist_kernel, dim3(gl), dim3(256), 0, (const uint32_t*)keys, len, nb, BA.count);
+            {
+                ProfScope ps(ctx, "msm_scan_buckets");
+                size_t t = tmp;
+                hipError_t e = rocprim::exclusive_scan(tmp_buf, t, BA.count, BA.start, 0u, (size_t)nb, rocprim::plus<uint32_t>(), ctx->stream);
+                if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
+            }
+            BZK_LAUNCH(ctx, "msm_scatter", msm_scatter_kernel, dim3(gl), dim3(256), 0, (const uint32_t*)keys, (const uint32_t*)vals, len, nb,
+                       (const uint32_t*)BA.start, BA.ntask, vals_s);
+        } else {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
             hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, keys, keys_s, vals, vals_s, (size_t)len, 0, bits_for(nb), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
-        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp));
+        aux.join();
+        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, csort));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);

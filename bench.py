@@ -28,6 +28,13 @@ LOG_N = 20
 # tools/ubench_int "Fp28 lib mul", profiles/r01_ubench_int.txt.  10 products per XYZZ mixed add.
 FP_MUL_PEAK_G = 76.2
 MULS_PER_MIXED_ADD = 10
+# integer multiply-adds actually issued by one XYZZ mixed addition: 8 products of 394 v_mad_u64_u32 + 2 squares of 301
+# (profiles/r01_run56_fp28_square.txt), against the measured v_mad_u64_u32 ceiling of the whole chip (profiles/r01_ubench_int.txt)
+MADS_PER_MIXED_ADD = 8 * 394 + 2 * 301
+MAD_PEAK_T = 31.4
+# G2: 8 Fp2 products (3 Fp products each) + 2 Fp2 squares (2 Fp products each)
+FP_MULS_PER_G2_MIXED_ADD = 8 * 3 + 2 * 2
+PROOF_ALG_BYTES = 1.24e9  # MSM 481 MB (G1) + 203 MB (G2) + 7 NTTs x 67 MB + vectors 87 MB per 2^20-class proof
 SEED = 0x42415A554B41
 HBM_PEAK_GBS = 8000.0
 
@@ -40,17 +47,37 @@ def _fr(x: int) -> bytes:
     return (x * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little")
 
 
+MSM_KERNEL_SOURCES = ("msm_impl.cuh", "msm_policy.cuh", "msm_g1.hip", "bzk_fp28.cuh", "bzk_curve.cuh", "bzk_field.cuh")
+
+
+def msm_source_stamp():
+    """sha256 over the sources the MSM kernels are built from: a PMC measurement is only quoted for the build it was taken on
+    (the GPU box has no .git, so the stamp is a content hash, not a commit id)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in MSM_KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "bazuka_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(log_n):
-    """HBM bytes per msm_accumulate launch from the committed PMC passes of this same command
-    (profiles/r01_pmc_traffic.json, written by tools/pmc_traffic.py from two rocprofv3 --pmc runs; counters cannot
-    be collected from inside the timed process).  None when no measurement of this configuration is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if log_n != LOG_N or not os.path.exists(path):
-        return None
-    try:
-        return json.load(open(path))["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        return None
+    """HBM-side bytes per msm_accumulate launch from the committed PMC passes of this same command (profiles/*pmc_traffic.json,
+    written by tools/pmc_traffic.py from two rocprofv3 --pmc runs: counters cannot be collected from inside the timed process).
+    The newest file whose source stamp equals the current MSM sources is used; a measurement of another build is refused
+    (returns None plus the reason) instead of being quoted for kernels it was not taken on."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True)
+    if log_n != LOG_N or not cands:
+        return None, "no PMC measurement of this configuration on file"
+    stamp = msm_source_stamp()
+    for path in cands:
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("source_stamp") == stamp:
+            return doc["traffic_bytes_per_launch"], os.path.basename(path)
+    return None, f"stale: no profiles/*pmc_traffic*.json carries source stamp {stamp} (re-run tools/runs/pmc passes)"
 
 
 def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: int = 16, cpu_baseline: bool = False):
@@ -203,6 +230,86 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     return out
 
 
+def other_configs_section(ctx, dev):
+    """BASELINE.json's other single-GPU configurations and the proof's remaining kernels, timed by the driver's own run
+    (VERDICT r1 item 3): inputs resident in HBM, best of 3 after one warm-up, plus the HIP-event time of the dominant kernel and
+    the algorithmic-byte roofline of SURVEY 8d.  Parity of each is the job of tests/test_gpu_fullsize.py."""
+    import torch
+
+    def rand_fr(cnt, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        t = torch.randint(0, 256, (cnt, 32), dtype=torch.uint8, device=dev, generator=g)
+        t[:, 31] &= 0x3F
+        return t.contiguous()
+
+    def timeit(fn, reps=3):
+        fn()
+        ctx.sync()
+        best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            fn()
+            ctx.sync()
+            best = min(best, time.perf_counter() - t)
+        return best * 1e3
+
+    def kernels(fn):
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        fn()
+        ctx.sync()
+        d = {k: round(v[1], 4) for k, v in ctx.prof_dump().items() if v[1] > 0.02}
+        ctx.prof_enable(False)
+        return d
+
+    def hbm(alg_bytes, ms):
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6)}
+
+    out = {}
+    # configs[4]: 2^24-leaf 4-ary Poseidon tree (5 592 405 arity-4 hashes); 32 B per leaf read + 32 B per node written
+    n = 1 << 24
+    leaves = rand_fr(n, 24)
+    ms = timeit(lambda: ctx.merkle4_root_dev(leaves, 12))
+    hashes = (n - 1) // 3
+    out["tree_2p24"] = {"workload": "BASELINE configs[4]: 4-ary Poseidon re-hash of a 2^24-leaf ZkState tree", "ms": round(ms, 3),
+                        "Mhash_per_s": round(hashes / ms / 1e3, 2), "roofline": hbm(32.0 * n + 32.0 * hashes, ms),
+                        "alu": {"fr_products_per_hash_sparse": 1184, "note": "integer-ALU bound: 9 x 29-bit Fr, sparse partial rounds"},
+                        "kernel_ms": kernels(lambda: ctx.merkle4_root_dev(leaves, 12))}
+    del leaves
+    # NTT (a4): 64 B per element per transform in one HBM round trip (SURVEY 8d), coset forward = the h stage's variant
+    for lg in (20, 24):
+        d = rand_fr(1 << lg, lg)
+        ms = timeit(lambda: ctx.ntt_dev(d, lg, False, True))
+        out[f"ntt_2p{lg}"] = {"ms": round(ms, 4), "roofline": hbm(64.0 * (1 << lg), ms),
+                              "alu": {"fr_products": (lg * (1 << lg)) // 2, "G_per_s": round(lg * (1 << lg) / 2 / ms / 1e6, 2), "peak": 162.9,
+                                      "peak_source": "Fr29 product as dependent calls, profiles/r01_ubench_int.txt"}}
+        del d
+    a, b, c = rand_fr(1 << 20, 1), rand_fr(1 << 20, 2), rand_fr(1 << 20, 3)
+    ms = timeit(lambda: ctx.groth16_h_dev(a, b, c, 20))
+    out["h_stage_2p20"] = {"what": "3 iNTT + 3 coset NTT + pointwise (a b - c) / Z + 1 inverse coset NTT", "ms": round(ms, 3),
+                           "roofline": hbm(7 * 64.0 * (1 << 20) + 128.0 * (1 << 20), ms)}
+    del a, b, c
+    # G2 MSM (a6): 224 algorithmic bytes per (point, scalar) pair
+    n = 1 << 20
+    bases = torch.empty(n * 192, dtype=torch.uint8, device=dev)
+    ctx.g2_synth_bases_dev(SEED, 0, n, bases)
+    sc = rand_fr(n, 2020)
+    ms = timeit(lambda: ctx.msm_g2_dev(bases, sc, n), reps=2)
+    km = kernels(lambda: ctx.msm_g2_dev(bases, sc, n))
+    acc = km.get("msm_accumulate", 0.0)
+    sec = {"ms": round(ms, 3), "Mpt_per_s": round(n / ms / 1e3, 2), "kernel_ms": km}
+    if acc:
+        W = ctx.msm_window_count(n)
+        sec["roofline"] = dict(hbm(224.0 * n, acc), kernel="msm_accumulate<G2>", avg_launch_ms=round(acc, 4))
+        g = n * W * FP_MULS_PER_G2_MIXED_ADD / (acc * 1e-3) / 1e9
+        sec["alu"] = {"achieved": round(g, 2), "peak": 60.1, "unit": "G Fp-mul/s", "frac": round(g / 60.1, 4),
+                      "peak_source": "library product at 1 wave/SIMD (the G2 kernel's occupancy), profiles/r01_ubench_int.txt"}
+    out["msm_g2_2p20"] = sec
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +319,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proofs", action="store_true", help="skip the full Groth16 proofs/s section (N=1 only)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the informational two-MSMs-in-flight measurement (kernel traces)")
+    ap.add_argument("--no-others", action="store_true", help="skip the tree / NTT / h-stage / G2 sections (N=1 only)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): 2^log-n points PER GPU; strong: 2^log-n-total points for the whole job (SURVEY 8d C4 reading (i))")
+    ap.add_argument("--log-n-total", type=int, default=24, help="log2 points of the whole job in --scaling strong (24 or 26)")
     args = ap.parse_args()
 
     import torch
@@ -241,7 +352,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     ctx = Bzk(local_rank, torch.cuda.current_stream().cuda_stream)
-    n = (1 << args.log_n) * world  # whole-job points; every rank holds all of them (CRS is replicated)
+    # whole-job points; every rank holds all of them (the CRS is static and replicated).  weak: per-GPU work constant in N;
+    # strong: the job is fixed (2^24 / 2^26 points) and a rank's share of the windows shrinks with N
+    n = (1 << args.log_n_total) if args.scaling == "strong" else (1 << args.log_n) * world
     bases = torch.empty(n * 96, dtype=torch.uint8, device=dev)
     ctx.g1_synth_bases_dev(SEED, 0, n, bases)
     g = torch.Generator(device=dev).manual_seed(SEED & 0x7FFFFFFF)
@@ -334,16 +447,21 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: 2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU "
-                               f"(bases k_i*G, uniform scalars, resident in HBM)",
+        "config": {"workload": (f"BASELINE configs[1]: 2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU "
+                                f"(bases k_i*G, uniform scalars, resident in HBM)") if args.scaling == "weak" else
+                               (f"BASELINE configs[3] reading (i): ONE 2^{args.log_n_total}-point G1 MSM for the whole job, window-sharded "
+                                f"over the ranks (bases k_i*G, uniform scalars, replicated in HBM)"),
                    "points_total": n, "windows": W, "window_range_this_rank": [w0, w1],
                    "parallelism": "single-gpu" if world == 1 else f"window-sharded x{world} + RCCL all-gather of partial sums"},
         "proofs_per_sec": None,
     }
+    if world > 1:  # what the collective layer actually saw
+        out["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                             "exchange": "one all-gather of 97-byte partial sums per MSM + device-side fold"}
     if dry:
         out["dryrun"] = f"ranks share GPUs, exchange over {dry}: NOT a measurement"
     # Second half of the metric: full Groth16 proofs/s.  Every rank proves its own batches (replicas).
@@ -368,7 +486,8 @@ def main():
             achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                               "traffic": _pmc_traffic(args.log_n), "avg_launch_ms": round(per_launch_ms, 4),
+                               "traffic": _pmc_traffic(args.log_n)[0], "traffic_source": _pmc_traffic(args.log_n)[1],
+                               "avg_launch_ms": round(per_launch_ms, 4),
                                "note": "integer-ALU bound (381-bit Montgomery carry chains); HBM fraction is "
                                        "structurally ~1e-3, see DESIGN.md"}
             pairs = n * (w1 - w0)  # one mixed add per (point, window) pair (zero digits skipped: ~2^-16 of them)
@@ -376,6 +495,11 @@ def main():
             out["roofline"]["alu"] = {"achieved": round(gmul, 2), "peak": FP_MUL_PEAK_G, "unit": "G Fp-mul/s",
                                       "frac": round(gmul / FP_MUL_PEAK_G, 4),
                                       "peak_source": "tools/ubench_int.hip, library product as dependent calls (profiles/)"}
+            tmad = pairs * MADS_PER_MIXED_ADD / (per_launch_ms * 1e-3) / 1e12
+            out["roofline"]["alu_mad"] = {"achieved": round(tmad, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s",
+                                          "frac": round(tmad / MAD_PEAK_T, 4),
+                                          "how": f"{MADS_PER_MIXED_ADD} mads issued per mixed add (8 x 394 + 2 x 301) against the "
+                                                 "micro-benchmarked instruction ceiling (profiles/r01_ubench_int.txt)"}
         out["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}
         if overlapped:
             out["two_msms_in_flight"] = overlapped
@@ -392,6 +516,16 @@ def main():
                                    "sample": f"the full 2^{args.log_n}-point MSM of this run, 1 run, "
                                              f"window-per-thread Pippenger (bellman-equivalent), {dt:.2f} s",
                                    "parity": "bit-exact (97-byte affine result)"}
+        if world == 1 and not args.no_others:
+            try:
+                out["other_configs"] = other_configs_section(ctx, dev)
+            except Exception as e:  # the headline line must still be printed
+                out["other_configs"] = {"error": repr(e)}
+        if proofs is not None and isinstance(proofs.get("proofs_per_s_pipelined"), float):
+            gbs = PROOF_ALG_BYTES * proofs["proofs_per_s_pipelined"] / 1e9
+            proofs["proof_roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(gbs / HBM_PEAK_GBS, 6),
+                                        "alg_bytes_per_proof": PROOF_ALG_BYTES, "note": "SURVEY 8d: 1.24 GB of compulsory traffic per 2^20-class proof"}
         if proofs is not None:
             out["proofs"] = proofs
             if world == 1:

@@ -79,6 +79,15 @@ if __name__ == "__main__":
             run("g1", 20, {"BZK_MSM_C": "16", "BZK_MSM_CHUNK": str(ch)})
         for lg in (16, 18, 22, 24):
             run("g1", lg)
+    if what in ("r2csort",):  # round 2: counting sort vs radix sort of the pairs, side-stream base conversion
+        for lg in (20, 22, 24):
+            for cs in ("1", "0"):
+                run("g1", lg, {"BZK_MSM_CSORT": cs})
+        run("g1", 20, {"BZK_MSM_NO_AUX": "1"})
+        run("g1", 18); run("g1", 16)
+        for cs in ("1", "0"):
+            run("g2", 20, {"BZK_MSM_CSORT": cs})
+        run("g1win", 23)
     if what in ("occ",):
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
