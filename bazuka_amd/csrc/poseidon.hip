@@ -529,6 +529,56 @@ __global__ void __launch_bounds__(256) tree4_prove_kernel(const Fr* __restrict__
         if (j != cur) out[t * 3 + s++] = nodes[off + j];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-resident MPN account state (second half; bzk_mpn_tree_*): the production state model
+//     List{L, Struct{tx_nonce, withdraw_nonce, pub_x, pub_y, List{T, Struct{token_id, balance}}}}   src/mpn/mod.rs:218-241
+// as `KvStoreStateManager::{get,set}_mpn_account / prove` see it (src/zk/state/mod.rs:93-264, 310-420), kept in HBM:
+//   * the account level is the dense heap-order tree above (bzk_tree4) over the account LEAF HASHES
+//     H5(nonce, wnonce, x, y, tokens_root) - 46 GB at the production depth L = 15;
+//   * account CONTENTS exist only for populated accounts, in a slot pool (the dense form of 4^15 accounts x 4^3 token
+//     slots would be 4.5 TB): per slot the four cells, the 4^T (token_id, balance) pairs and the token sub-tree as levels
+//     of a forest - level k holds cap x 4^k hashes, node (slot, i) at slot 4^k + i, so "parent = index >> 2" holds across
+//     the whole forest and one launch re-hashes a level for all touched accounts.  Slot 0 is the default (empty) account.
+// The account-index -> slot map lives on the host side of the handle (an unordered_map): kernels get slot lists.
+// ------------------------------------------------------------------------------------------------
+// in5[a] = cells[slot_a][0..3], token_root[slot_a]
+__global__ void __launch_bounds__(256) mpn_leaf_inputs_kernel(const Fr* __restrict__ cells, const Fr* __restrict__ tok_root,
+                                                              const uint64_t* __restrict__ slots, uint64_t n, Fr* __restrict__ in5) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 5) return;
+    const uint64_t a = t / 5, j = t % 5;
+    const uint64_t s = slots[a];
+    in5[t] = j < 4 ? cells[s * 4 + j] : tok_root[s];
+}
+// out record of account a: nonce, wnonce, x, y, tokens_root, then 4^T x (token_id, balance)
+__global__ void __launch_bounds__(256) mpn_get_kernel(const Fr* __restrict__ cells, const Fr* __restrict__ tok, const Fr* __restrict__ tok_root,
+                                                      const uint64_t* __restrict__ slots, uint64_t n, uint32_t rec, uint32_t tslots,
+                                                      Fr* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * rec) return;
+    const uint64_t a = t / rec, j = t % rec;
+    const uint64_t s = slots[a];
+    out[t] = j < 4 ? cells[s * 4 + j] : j == 4 ? tok_root[s] : tok[s * 2 * tslots + (j - 5)];
+}
+struct ForestLevels {
+    const Fr* lvl[9];
+};
+// token-level `prove`: out[(q * T + layer) * 3 + s] = s-th sibling (index order, self skipped) at forest depth T - layer
+__global__ void __launch_bounds__(256) mpn_prove_token_kernel(ForestLevels F, uint32_t T, const uint64_t* __restrict__ gidx, uint64_t n,
+                                                              Fr* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * T) return;
+    const uint64_t q = t / T;
+    const uint32_t layer = (uint32_t)(t % T);
+    const uint32_t depth = T - layer;
+    const uint64_t cur = gidx[q] >> (2 * layer);
+    const uint64_t base = cur & ~(uint64_t)3;
+    const Fr* L = F.lvl[depth];
+    int s = 0;
+    for (uint64_t j = base; j < base + 4; ++j)
+        if (j != cur) out[t * 3 + s++] = L[j];
+}
+
 }  // namespace bzk
 
 using namespace bzk;
@@ -766,6 +816,282 @@ int32_t bzk_tree4_node(bzk_ctx* ctx, const bzk_tree4* t, uint32_t depth, uint64_
     if (!ctx || !t || !out || depth > t->log4 || index >= ((uint64_t)1 << (2 * depth))) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     BZK_HIP(ctx, hipMemcpyAsync(out, t->nodes + tree4_off(depth) + index, 32, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+// ---- device-resident MPN account state (kernels and layout: see above) -------------------------------------------------
+}  // extern "C"
+#include <unordered_map>
+struct bzk_mpn_tree {
+    uint32_t L = 0, T = 0;
+    uint64_t cap = 0, used = 1;  // slot 0 = the default account
+    bzk_tree4* acct = nullptr;
+    Fr* cells = nullptr;         // cap x 4
+    Fr* tok = nullptr;           // cap x 4^T x 2
+    Fr* tl[9] = {};              // token forest: tl[k] = cap x 4^k hashes (k = 0: the accounts' tokens_root)
+    std::unordered_map<uint64_t, uint64_t> slot_of;
+};
+namespace {
+// re-hash, level by level, exactly the parents with a changed child.  lvl[d] = array of depth d (d = 0 .. depth_leaf);
+// `leaf_idx`: sorted unique indices at depth_leaf whose values were already written.
+int32_t rehash_paths(bzk_ctx* ctx, Fr* const* lvl, int depth_leaf, int depth_top, const std::vector<uint64_t>& leaf_idx) {
+    if (leaf_idx.empty() || depth_leaf <= depth_top) return BZK_OK;
+    const void* consts;
+    int rf, rp;
+    BZK_TRY(poseidon_consts_dev(ctx, 5, &consts, &rf, &rp));
+    std::vector<uint64_t> all, level_off, level_cnt;
+    std::vector<uint64_t> parents(leaf_idx);
+    for (int k = depth_leaf - 1; k >= depth_top; --k) {
+        for (auto& p : parents) p >>= 2;
+        parents.erase(std::unique(parents.begin(), parents.end()), parents.end());
+        level_off.push_back(all.size());
+        level_cnt.push_back(parents.size());
+        all.insert(all.end(), parents.begin(), parents.end());
+    }
+    uint64_t* d_idx = nullptr;
+    BZK_HIP(ctx, hipMalloc((void**)&d_idx, all.size() * 8));  // not the ctx workspace: the caller's staging lives there
+    hipError_t e = hipMemcpyAsync(d_idx, all.data(), all.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    int32_t st = e == hipSuccess ? BZK_OK : BZK_E_DEVICE;
+    auto level = [&](int k, size_t lv) -> int32_t {
+        const uint64_t np = level_cnt[lv];
+        if (np <= COOP_MAX_NODES && !ctx->no_coop) {
+            BZK_LAUNCH(ctx, "tree4_rehash_coop", poseidon29_coop5_kernel, dim3((unsigned)((np + 7) / 8)), dim3(64), 0, (const Fr*)lvl[k + 1], np,
+                       (const uint64_t*)(d_idx + level_off[lv]), (const Fr29*)consts, rf, rp, lvl[k]);
+        } else {
+            BZK_LAUNCH(ctx, "tree4_rehash", tree4_rehash_kernel, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, (const Fr*)lvl[k + 1], lvl[k],
+                       (const uint64_t*)(d_idx + level_off[lv]), np, (const Fr29*)consts, rf, rp);
+        }
+        return BZK_OK;
+    };
+    size_t lv = 0;
+    for (int k = depth_leaf - 1; k >= depth_top && st == BZK_OK; --k, ++lv) st = level(k, lv);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == BZK_OK) st = BZK_E_DEVICE;  // `all` is pageable host memory
+    (void)hipFree(d_idx);
+    return st;
+}
+struct DevBuf {  // scoped device staging
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int32_t alloc(bzk_ctx* ctx, size_t bytes) {
+        if (hipMalloc(&p, bytes ? bytes : 32) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->last_error = "mpn_tree: staging allocation failed";
+            return BZK_E_ALLOC;
+        }
+        return BZK_OK;
+    }
+};
+}  // namespace
+extern "C" {
+
+int32_t bzk_mpn_tree_create(bzk_ctx* ctx, uint32_t log4_tree, uint32_t log4_token_tree, uint64_t capacity, bzk_mpn_tree** out) {
+    if (!ctx || !out || log4_tree == 0 || log4_tree > 15 || log4_token_tree == 0 || log4_token_tree > 8 || capacity == 0) return BZK_E_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    bzk_mpn_tree* t = new (std::nothrow) bzk_mpn_tree();
+    if (!t) return BZK_E_ALLOC;
+    t->L = log4_tree;
+    t->T = log4_token_tree;
+    t->cap = capacity + 1;
+    const uint64_t ts = (uint64_t)1 << (2 * t->T);
+    auto fail = [&](int32_t st) {
+        bzk_mpn_tree_free(ctx, t);
+        return st;
+    };
+    if (hipMalloc((void**)&t->cells, t->cap * 4 * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&t->tok, t->cap * ts * 2 * sizeof(Fr)) != hipSuccess)
+        return fail(BZK_E_ALLOC);
+    for (uint32_t k = 0; k <= t->T; ++k)
+        if (hipMalloc((void**)&t->tl[k], (t->cap << (2 * k)) * sizeof(Fr)) != hipSuccess) return fail(BZK_E_ALLOC);
+    // defaults (`compress_default`, src/zk/mod.rs:401-423): zero cells, H2(0, 0) token leaves, the default chain above them
+    if (hipMemsetAsync(t->cells, 0, t->cap * 4 * sizeof(Fr), ctx->stream) != hipSuccess ||
+        hipMemsetAsync(t->tok, 0, t->cap * ts * 2 * sizeof(Fr), ctx->stream) != hipSuccess)
+        return fail(BZK_E_DEVICE);
+    ZkScalar z2[2] = {ZkScalar::zero(), ZkScalar::zero()};
+    ZkScalar d = poseidon_hash(z2, 2);
+    for (int k = (int)t->T; k >= 0; --k) {
+        const uint64_t cnt = t->cap << (2 * k);
+        hipLaunchKernelGGL(tree4_fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, t->tl[k], cnt, d.v);
+        if (hipGetLastError() != hipSuccess) return fail(BZK_E_DEVICE);
+        if (k > 0) {
+            ZkScalar c[4] = {d, d, d, d};
+            d = poseidon_hash(c, 4);
+        }
+    }
+    ZkScalar leaf_in[5] = {ZkScalar::zero(), ZkScalar::zero(), ZkScalar::zero(), ZkScalar::zero(), d};
+    const ZkScalar leaf = poseidon_hash(leaf_in, 5);
+    const int32_t st = bzk_tree4_create(ctx, t->L, nullptr, (const uint8_t*)leaf.v.l, &t->acct);
+    if (st != BZK_OK) return fail(st);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(BZK_E_DEVICE);
+    *out = t;
+    return BZK_OK;
+}
+
+void bzk_mpn_tree_free(bzk_ctx* ctx, bzk_mpn_tree* t) {
+    if (!t) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (t->acct) bzk_tree4_free(ctx, t->acct);
+    if (t->cells) (void)hipFree(t->cells);
+    if (t->tok) (void)hipFree(t->tok);
+    for (auto& p : t->tl)
+        if (p) (void)hipFree(p);
+    delete t;
+}
+
+int32_t bzk_mpn_tree_root(bzk_ctx* ctx, const bzk_mpn_tree* t, uint8_t root[32]) {
+    if (!ctx || !t) return BZK_E_ARG;
+    return bzk_tree4_root(ctx, t->acct, root);
+}
+
+uint64_t bzk_mpn_tree_accounts(const bzk_mpn_tree* t) { return t ? t->used - 1 : 0; }
+
+// Batched `set_mpn_account` (src/zk/state/mod.rs:158-208): account a := (cells[a], its token slots tok_index[tok_off[a] ..
+// tok_off[a+1]) := tok_vals).  As in the reference, token slots that are not named keep their contents.
+int32_t bzk_mpn_tree_set_accounts(bzk_ctx* ctx, bzk_mpn_tree* t, const uint64_t* idx, const uint8_t* cells, const uint64_t* tok_off,
+                                  const uint64_t* tok_index, const uint8_t* tok_vals, uint64_t n) {
+    if (!ctx || !t || (n && (!idx || !cells || !tok_off))) return BZK_E_ARG;
+    if (n == 0) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n_acct = (uint64_t)1 << (2 * t->L), ts = (uint64_t)1 << (2 * t->T);
+    const uint64_t m = tok_off[n];
+    if (m && (!tok_index || !tok_vals)) return BZK_E_ARG;
+    // validation before anything is changed
+    uint64_t fresh = 0;
+    {
+        std::vector<uint64_t> seen(idx, idx + n);
+        std::sort(seen.begin(), seen.end());
+        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end() || seen.back() >= n_acct) return BZK_E_ARG;
+        for (uint64_t a = 0; a < n; ++a) {
+            if (tok_off[a] > tok_off[a + 1] || tok_off[a + 1] > m) return BZK_E_ARG;
+            std::vector<uint64_t> ti(tok_index + tok_off[a], tok_index + tok_off[a + 1]);
+            std::sort(ti.begin(), ti.end());
+            if (std::adjacent_find(ti.begin(), ti.end()) != ti.end() || (!ti.empty() && ti.back() >= ts)) return BZK_E_ARG;
+            if (!t->slot_of.count(idx[a])) ++fresh;
+        }
+    }
+    if (t->used + fresh > t->cap) {
+        ctx->last_error = "mpn_tree: account pool exhausted";
+        return BZK_E_ALLOC;
+    }
+    std::vector<uint64_t> slots(n), cell_pos(n * 4), tok_pos(m * 2), g(m);
+    for (uint64_t a = 0; a < n; ++a) {
+        auto it = t->slot_of.find(idx[a]);
+        const uint64_t s = it != t->slot_of.end() ? it->second : (t->slot_of[idx[a]] = t->used++);
+        slots[a] = s;
+        for (int j = 0; j < 4; ++j) cell_pos[a * 4 + j] = s * 4 + j;
+        for (uint64_t q = tok_off[a]; q < tok_off[a + 1]; ++q) {
+            g[q] = s * ts + tok_index[q];
+            tok_pos[2 * q] = 2 * g[q];
+            tok_pos[2 * q + 1] = 2 * g[q] + 1;
+        }
+    }
+    // staging: positions, values, intermediate hashes
+    DevBuf d_pos, d_val, d_h;
+    const size_t pos_cnt = std::max<size_t>(n * 4, m * 2);
+    BZK_TRY(d_pos.alloc(ctx, pos_cnt * 8));
+    BZK_TRY(d_val.alloc(ctx, std::max<size_t>(n * 5, m * 2) * sizeof(Fr)));
+    BZK_TRY(d_h.alloc(ctx, std::max<size_t>(n, m) * sizeof(Fr)));
+    // 1. cells
+    BZK_HIP(ctx, hipMemcpyAsync(d_pos.p, cell_pos.data(), n * 4 * 8, hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(d_val.p, cells, n * 4 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    BZK_LAUNCH(ctx, "mpn_scatter_cells", tree4_scatter_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, t->cells,
+               (const uint64_t*)d_pos.p, (const Fr*)d_val.p, n * 4);
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffers are re-used below
+    if (m) {
+        // 2. token slots, their H2 leaf hashes, the token sub-trees of the touched accounts
+        BZK_HIP(ctx, hipMemcpyAsync(d_pos.p, tok_pos.data(), m * 2 * 8, hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(d_val.p, tok_vals, m * 2 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        BZK_LAUNCH(ctx, "mpn_scatter_tokens", tree4_scatter_kernel, dim3((unsigned)((m * 2 + 255) / 256)), dim3(256), 0, t->tok,
+                   (const uint64_t*)d_pos.p, (const Fr*)d_val.p, m * 2);
+        BZK_TRY(poseidon_launch(ctx, d_val.p, 2, m, d_h.p));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(d_pos.p, g.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+        BZK_LAUNCH(ctx, "mpn_scatter_token_hashes", tree4_scatter_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, t->tl[t->T],
+                   (const uint64_t*)d_pos.p, (const Fr*)d_h.p, m);
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> gs(g);
+        std::sort(gs.begin(), gs.end());
+        BZK_TRY(rehash_paths(ctx, t->tl, (int)t->T, 0, gs));
+    }
+    // 3. account leaves H5(nonce, wnonce, x, y, tokens_root) and the account tree above them
+    BZK_HIP(ctx, hipMemcpyAsync(d_pos.p, slots.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    BZK_LAUNCH(ctx, "mpn_leaf_inputs", mpn_leaf_inputs_kernel, dim3((unsigned)((n * 5 + 255) / 256)), dim3(256), 0, (const Fr*)t->cells,
+               (const Fr*)t->tl[0], (const uint64_t*)d_pos.p, n, (Fr*)d_val.p);
+    BZK_TRY(poseidon_launch(ctx, d_val.p, 5, n, d_h.p));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::pair<uint64_t, uint64_t>> order(n);  // (account index, position): the tree update wants sorted indices
+    for (uint64_t a = 0; a < n; ++a) order[a] = {idx[a], a};
+    std::sort(order.begin(), order.end());
+    std::vector<uint64_t> sidx(n), perm(n);
+    for (uint64_t a = 0; a < n; ++a) { sidx[a] = order[a].first; perm[a] = order[a].second; }
+    BZK_HIP(ctx, hipMemcpyAsync(d_pos.p, idx, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    Fr* leaves = t->acct->nodes + tree4_off(t->L);
+    BZK_LAUNCH(ctx, "mpn_scatter_leaves", tree4_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, leaves, (const uint64_t*)d_pos.p,
+               (const Fr*)d_h.p, n);
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<Fr*> lvl(t->L + 1);
+    for (uint32_t k = 0; k <= t->L; ++k) lvl[k] = t->acct->nodes + tree4_off(k);
+    return rehash_paths(ctx, lvl.data(), (int)t->L, 0, sidx);
+}
+
+// Batched `get_mpn_account` (src/zk/state/mod.rs:93-137): per account 5 + 2 * 4^T scalars - tx_nonce, withdraw_nonce, pub_x,
+// pub_y, tokens_root (= `MpnAccount::tokens_hash`, the before_balances_hash of the transitions), then (token_id, balance) of
+// every token slot.  Accounts that were never set read as the default account (all zero, default tokens_root).
+int32_t bzk_mpn_tree_get_accounts(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint64_t* idx, uint64_t n, uint8_t* out) {
+    if (!ctx || !t || (n && (!idx || !out))) return BZK_E_ARG;
+    if (n == 0) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n_acct = (uint64_t)1 << (2 * t->L), ts = (uint64_t)1 << (2 * t->T);
+    const uint32_t rec = (uint32_t)(5 + 2 * ts);
+    std::vector<uint64_t> slots(n);
+    for (uint64_t a = 0; a < n; ++a) {
+        if (idx[a] >= n_acct) return BZK_E_ARG;
+        auto it = t->slot_of.find(idx[a]);
+        slots[a] = it == t->slot_of.end() ? 0 : it->second;
+    }
+    DevBuf d_s, d_o;
+    BZK_TRY(d_s.alloc(ctx, n * 8));
+    BZK_TRY(d_o.alloc(ctx, n * rec * sizeof(Fr)));
+    BZK_HIP(ctx, hipMemcpyAsync(d_s.p, slots.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    BZK_LAUNCH(ctx, "mpn_get", mpn_get_kernel, dim3((unsigned)((n * rec + 255) / 256)), dim3(256), 0, (const Fr*)t->cells, (const Fr*)t->tok,
+               (const Fr*)t->tl[0], (const uint64_t*)d_s.p, n, rec, (uint32_t)ts, (Fr*)d_o.p);
+    BZK_HIP(ctx, hipMemcpyAsync(out, d_o.p, n * rec * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+// `prove(tree_loc = [], index)`: L sibling triples per account (the src_proof / dst_proof / proof of the transitions)
+int32_t bzk_mpn_tree_prove(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint64_t* idx, uint64_t n, uint8_t* out) {
+    if (!ctx || !t) return BZK_E_ARG;
+    return bzk_tree4_prove(ctx, t->acct, idx, n, out);
+}
+
+// `prove(tree_loc = [account, 4], token_index)`: T sibling triples (the *_balance_proof of the transitions)
+int32_t bzk_mpn_tree_prove_token(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint64_t* account_idx, const uint64_t* token_idx, uint64_t n,
+                                 uint8_t* out) {
+    if (!ctx || !t || (n && (!account_idx || !token_idx || !out))) return BZK_E_ARG;
+    if (n == 0) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n_acct = (uint64_t)1 << (2 * t->L), ts = (uint64_t)1 << (2 * t->T);
+    std::vector<uint64_t> g(n);
+    for (uint64_t a = 0; a < n; ++a) {
+        if (account_idx[a] >= n_acct || token_idx[a] >= ts) return BZK_E_ARG;
+        auto it = t->slot_of.find(account_idx[a]);
+        g[a] = (it == t->slot_of.end() ? 0 : it->second) * ts + token_idx[a];
+    }
+    const uint64_t cells = n * t->T;
+    DevBuf d_g, d_o;
+    BZK_TRY(d_g.alloc(ctx, n * 8));
+    BZK_TRY(d_o.alloc(ctx, cells * 3 * sizeof(Fr)));
+    BZK_HIP(ctx, hipMemcpyAsync(d_g.p, g.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ForestLevels F;
+    for (int k = 0; k < 9; ++k) F.lvl[k] = t->tl[k];
+    BZK_LAUNCH(ctx, "mpn_prove_token", mpn_prove_token_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, F, t->T,
+               (const uint64_t*)d_g.p, n, (Fr*)d_o.p);
+    BZK_HIP(ctx, hipMemcpyAsync(out, d_o.p, cells * 3 * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BZK_OK;
 }

@@ -46,6 +46,10 @@ SIGNATURES = {
     "bzk_params_load": (_i32, [_vp, _vp, C.POINTER(_vp)]),
     "bzk_params_free": (None, [_vp, _vp]),
     "bzk_groth16_prove": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "bzk_bellman_params_info": (_i32, [_vp, _u64, C.POINTER(_u64)]),
+    "bzk_bellman_params_decode": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
+    "bzk_bellman_params_encode": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64)]),
+    "bzk_params_load_bellman": (_i32, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, C.POINTER(_vp), _vp, _u64]),
     "bzk_params_read": (_i32, [_vp, _vp, _i32, _vp, _u64, C.POINTER(_u64)]),
     "bzk_groth16_setup": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, C.POINTER(_vp), _vp, _u64]),
     "bzk_groth16_h_dev": (_i32, [_vp, _vp, _vp, _vp, _u32]),
@@ -63,6 +67,14 @@ SIGNATURES = {
     "bzk_tree4_update": (_i32, [_vp, _vp, _vp, _vp, _u64]),
     "bzk_tree4_prove": (_i32, [_vp, _vp, _vp, _u64, _vp]),
     "bzk_tree4_node": (_i32, [_vp, _vp, _u32, _u64, _vp]),
+    "bzk_mpn_tree_create": (_i32, [_vp, _u32, _u32, _u64, C.POINTER(_vp)]),
+    "bzk_mpn_tree_free": (None, [_vp, _vp]),
+    "bzk_mpn_tree_root": (_i32, [_vp, _vp, _vp]),
+    "bzk_mpn_tree_accounts": (_u64, [_vp]),
+    "bzk_mpn_tree_set_accounts": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
+    "bzk_mpn_tree_get_accounts": (_i32, [_vp, _vp, _vp, _u64, _vp]),
+    "bzk_mpn_tree_prove": (_i32, [_vp, _vp, _vp, _u64, _vp]),
+    "bzk_mpn_tree_prove_token": (_i32, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "bzk_mpn_push_deposit": (_i32, [_vp, _u64, _vp, _u64]),
     "bzk_mpn_push_withdraw": (_i32, [_vp, _u64, _vp, _u64, _vp, _u64, _vp]),
     "bzk_mpn_deposit_synthesize": (_i32, [_vp, _u32, _vp, _i32, C.POINTER(_vp)]),
@@ -353,6 +365,62 @@ class Bzk:
         self._ck(self.lib.bzk_g2_sum(_ptr(packed), len(packed) // 193, out), "g2_sum")
         return out.raw
 
+    # ---- device-resident MPN account state
+    def mpn_tree_create(self, log4_tree: int, log4_token_tree: int, capacity: int):
+        h = C.c_void_p()
+        self._ck(self.lib.bzk_mpn_tree_create(self.h, log4_tree, log4_token_tree, capacity, C.byref(h)), "mpn_tree_create")
+        return h
+
+    def mpn_tree_free(self, tree):
+        self.lib.bzk_mpn_tree_free(self.h, tree)
+
+    def mpn_tree_root(self, tree) -> bytes:
+        out = C.create_string_buffer(32)
+        self._ck(self.lib.bzk_mpn_tree_root(self.h, tree, out), "mpn_tree_root")
+        return out.raw
+
+    def mpn_tree_set_accounts(self, tree, accounts):
+        """accounts: list of (index, (nonce, wnonce, x, y) as 4 x 32 B Montgomery, {token slot: (token_id 32 B, balance 32 B)})"""
+        n = len(accounts)
+        idx = (_u64 * max(1, n))(*[a[0] for a in accounts])
+        cells = b"".join(b"".join(a[1]) for a in accounts)
+        off, tix, tv = [0], [], []
+        for a in accounts:
+            for slot, (tid, bal) in a[2].items():
+                tix.append(slot)
+                tv.append(tid + bal)
+            off.append(len(tix))
+        offs = (_u64 * (n + 1))(*off)
+        tixs = (_u64 * max(1, len(tix)))(*tix)
+        tvb = b"".join(tv)
+        self._ck(self.lib.bzk_mpn_tree_set_accounts(self.h, tree, idx, _ptr(cells), offs, tixs, _ptr(tvb), n), "mpn_tree_set_accounts")
+
+    def mpn_tree_get_accounts(self, tree, indices, log4_token_tree: int) -> list:
+        """per account: dict(cells = 4 scalars, tokens_root, tokens = {slot: (token_id, balance)} for non-zero token ids)"""
+        n, ts = len(indices), 4 ** log4_token_tree
+        rec = 5 + 2 * ts
+        out = C.create_string_buffer(max(1, n * rec * 32))
+        self._ck(self.lib.bzk_mpn_tree_get_accounts(self.h, tree, (_u64 * max(1, n))(*indices), n, out), "mpn_tree_get_accounts")
+        res = []
+        for a in range(n):
+            sc = [out.raw[32 * (a * rec + j):32 * (a * rec + j + 1)] for j in range(rec)]
+            toks = {i: (sc[5 + 2 * i], sc[6 + 2 * i]) for i in range(ts) if sc[5 + 2 * i] != bytes(32)}
+            res.append({"cells": sc[:4], "tokens_root": sc[4], "tokens": toks})
+        return res
+
+    def mpn_tree_prove(self, tree, indices, log4_tree: int) -> bytes:
+        n = len(indices)
+        out = C.create_string_buffer(max(1, n * log4_tree * 96))
+        self._ck(self.lib.bzk_mpn_tree_prove(self.h, tree, (_u64 * max(1, n))(*indices), n, out), "mpn_tree_prove")
+        return out.raw[: n * log4_tree * 96]
+
+    def mpn_tree_prove_token(self, tree, accounts, slots, log4_token_tree: int) -> bytes:
+        n = len(accounts)
+        out = C.create_string_buffer(max(1, n * log4_token_tree * 96))
+        self._ck(self.lib.bzk_mpn_tree_prove_token(self.h, tree, (_u64 * max(1, n))(*accounts), (_u64 * max(1, n))(*slots), n, out),
+                 "mpn_tree_prove_token")
+        return out.raw[: n * log4_token_tree * 96]
+
     # ---- Groth16
     def params_load(self, params: dict):
         """params: dict with n_in, n_aux, log_m, n_a, n_b and byte strings vk(870), h, l, a, b_g1, b_g2,
@@ -364,6 +432,14 @@ class Bzk:
         h = C.c_void_p()
         self._ck(self.lib.bzk_params_load(self.h, C.byref(d), C.byref(h)), "params_load")
         return h
+
+    def params_load_bellman(self, blob: bytes, n_in: int, n_aux: int, a_density: bytes, b_density: bytes):
+        """bellman `Parameters::write` bytes + the circuit shape's density maps -> (params handle, bincode Groth16VerifyingKey)"""
+        h = C.c_void_p()
+        vk = C.create_string_buffer(878 + 97 * n_in)
+        self._ck(self.lib.bzk_params_load_bellman(self.h, _ptr(blob), len(blob), n_in, n_aux, _ptr(a_density), _ptr(b_density), C.byref(h),
+                                                  vk, len(vk)), "params_load_bellman")
+        return h, vk.raw
 
     def params_free(self, ph):
         self.lib.bzk_params_free(self.h, ph)
@@ -601,6 +677,33 @@ class MpnWork:
         _st(self.lib.bzk_mpn_work_synthesize(self.h, _ptr(prover_pub), _ptr(fee_token), threads, int(record_matrices), C.byref(h)),
             "work_synthesize")
         return R1cs(h)
+
+
+def bellman_params_decode(blob: bytes, threads: int = 0) -> dict:
+    """bellman `Parameters::write` bytes -> dict(vk (870 packed), ic (97 B each), h, l, a, b_g1 (raw 96 B), b_g2 (raw 192 B), counts)"""
+    lib = load_library()
+    info = (_u64 * 7)()
+    _st(lib.bzk_bellman_params_info(_ptr(blob), len(blob), info), "bellman_params_info")
+    n_ic, n_h, n_l, n_a, n_b1, n_b2, used = [int(x) for x in info]
+    bufs = {k: C.create_string_buffer(max(1, sz)) for k, sz in dict(vk=870, ic=97 * n_ic, h=96 * n_h, l=96 * n_l, a=96 * n_a, b_g1=96 * n_b1,
+                                                                     b_g2=192 * n_b2).items()}
+    _st(lib.bzk_bellman_params_decode(_ptr(blob), len(blob), bufs["vk"], bufs["ic"], bufs["h"], bufs["l"], bufs["a"], bufs["b_g1"],
+                                      bufs["b_g2"], threads), "bellman_params_decode")
+    sizes = dict(vk=870, ic=97 * n_ic, h=96 * n_h, l=96 * n_l, a=96 * n_a, b_g1=96 * n_b1, b_g2=192 * n_b2)
+    out = {k: v.raw[: sizes[k]] for k, v in bufs.items()}
+    out.update(n_ic=n_ic, n_h=n_h, n_l=n_l, n_a=n_a, n_b_g1=n_b1, n_b_g2=n_b2, consumed=used)
+    return out
+
+
+def bellman_params_encode(vk870: bytes, ic: bytes, h: bytes, l: bytes, a: bytes, b_g1: bytes, b_g2: bytes) -> bytes:
+    lib = load_library()
+    n = _u64()
+    args = (_ptr(vk870), _ptr(ic), len(ic) // 97, _ptr(h), len(h) // 96, _ptr(l), len(l) // 96, _ptr(a), len(a) // 96, _ptr(b_g1), _ptr(b_g2),
+            len(b_g1) // 96)
+    _st(lib.bzk_bellman_params_encode(*args, None, 0, C.byref(n)), "bellman_params_encode")
+    buf = C.create_string_buffer(n.value)
+    _st(lib.bzk_bellman_params_encode(*args, buf, n.value, None), "bellman_params_encode")
+    return buf.raw
 
 
 def zkproof_encode(proof387: bytes) -> bytes:

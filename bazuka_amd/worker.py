@@ -167,6 +167,37 @@ class DevSetup:
         self.cache = {}
 
 
+class BellmanKeys:
+    """Proving keys of a real network: bellman `Parameters` files (the format the reference's external prover loads,
+    README.md:26-28), one per circuit kind.  The file does not carry the density maps (bellman's prover derives them from the
+    circuit), so they come from the all-disabled circuit of the work's shape; bzk_params_load_bellman checks every array
+    length of the file against them.  `__call__(work)` returns the params handle like DevSetup."""
+
+    def __init__(self, bzk: L.Bzk, path_by_kind: dict[int, str]):
+        self.bzk, self.paths, self.cache = bzk, path_by_kind, {}
+
+    def keys(self, kind: int, L4: int, T4: int, B4: int):
+        key = (kind, L4, T4, B4)
+        if key not in self.cache:
+            r = DevSetup.shape_circuit(None, kind, L4, T4, B4)
+            with open(self.paths[kind], "rb") as f:
+                blob = f.read()
+            self.cache[key] = self.bzk.params_load_bellman(blob, r.n_in, r.n_aux, r.view("a_density"), r.view("b_density"))
+            r.free()
+        return self.cache[key]
+
+    def __call__(self, work: L.MpnWork):
+        ph, vk = self.keys(work.kind, work.log4_tree, work.log4_token_tree, work.log4_batch)
+        if vk != work.vk():
+            raise L.BzkError("the work's verifying key is not the one inside this worker's parameter file")
+        return ph
+
+    def close(self):
+        for ph, _ in self.cache.values():
+            self.bzk.params_free(ph)
+        self.cache = {}
+
+
 # ---- the loop ----------------------------------------------------------------------------------------------------------
 class Worker:
     def __init__(self, bzk: L.Bzk, address: bytes, node: tuple[str, int], params_for, flags: int = 0, threads: int = 0,
@@ -248,7 +279,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=main.__doc__)
     ap.add_argument("--node", required=True, help="host:port of the Bazuka node")
     ap.add_argument("--address", required=True, help="this worker's L1 address: 32-byte ed25519 public key, hex")
-    ap.add_argument("--dev-toxic", required=True, help="seed of the dev-mode CRS (tau, alpha, beta, gamma, delta per circuit kind)")
+    ap.add_argument("--dev-toxic", help="seed of the dev-mode CRS (tau, alpha, beta, gamma, delta per circuit kind)")
+    ap.add_argument("--params", nargs=3, metavar=("DEPOSIT", "WITHDRAW", "UPDATE"),
+                    help="bellman `Parameters` files of the network's three circuits (instead of --dev-toxic)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--poll", type=float, default=1.0)
     ap.add_argument("--rounds", type=int, default=None)
@@ -263,7 +296,9 @@ def main(argv=None):
         return b"".join(L.host_scalar_new(hashlib.sha3_256(f"{a.dev_toxic}/{kind}/{i}".encode()).digest() * 2) for i in range(5))
 
     bzk = L.Bzk(a.device)  # raises without a gfx950 device: there is no CPU prover
-    keys = DevSetup(bzk, {k: toxic(k) for k in range(3)})
+    if bool(a.dev_toxic) == bool(a.params):
+        ap.error("exactly one of --dev-toxic / --params")
+    keys = BellmanKeys(bzk, dict(enumerate(a.params))) if a.params else DevSetup(bzk, {k: toxic(k) for k in range(3)})
     w = Worker(bzk, address, (host, int(port)), keys, flags=1 if a.sig_len_prefixed else 0)
     try:
         w.register()

@@ -102,6 +102,30 @@ int32_t bzk_tree4_update(bzk_ctx* ctx, bzk_tree4* tree, const uint64_t* indices,
 int32_t bzk_tree4_prove(bzk_ctx* ctx, const bzk_tree4* tree, const uint64_t* indices, uint64_t n, uint8_t* out);
 int32_t bzk_tree4_node(bzk_ctx* ctx, const bzk_tree4* tree, uint32_t depth, uint64_t index, uint8_t out[32]);
 
+/* Device-resident MPN ACCOUNT STATE (second half): the production state model
+ *   List{log4_tree, Struct{tx_nonce, withdraw_nonce, pub_x, pub_y, List{log4_token_tree, Struct{token_id, balance}}}}
+ * (`MpnConfig::state_model`, src/mpn/mod.rs:218-241) with the batched forms of `KvStoreStateManager::set_mpn_account`
+ * (src/zk/state/mod.rs:158-208), `get_mpn_account` (93-137) and `prove` (218-264).  The account level is a dense tree of leaf
+ * hashes H5(nonce, wnonce, x, y, tokens_root) in HBM (46 GB at log4_tree = 15); account contents and token sub-trees exist for
+ * populated accounts only (`capacity` of them; BZK_E_ALLOC beyond).  All scalars: 32-byte Montgomery.
+ *   set_accounts : n DISTINCT accounts; cells = n x 4 scalars (nonce, withdraw nonce, x, y); account a's token updates are
+ *                  entries tok_off[a] .. tok_off[a+1] of tok_index (slot < 4^log4_token_tree, distinct per account) and
+ *                  tok_vals (token_id, balance); slots not named keep their contents, as in the reference
+ *   get_accounts : per account 5 + 2 * 4^T scalars: the 4 cells, tokens_root (`MpnAccount::tokens_hash`), then every token slot
+ *   prove        : log4_tree sibling triples per account (the transitions' `proof` / `src_proof` / `dst_proof`)
+ *   prove_token  : log4_token_tree sibling triples per (account, token slot) (the `*_balance_proof`s) */
+typedef struct bzk_mpn_tree bzk_mpn_tree;
+int32_t bzk_mpn_tree_create(bzk_ctx* ctx, uint32_t log4_tree, uint32_t log4_token_tree, uint64_t capacity, bzk_mpn_tree** out);
+void    bzk_mpn_tree_free(bzk_ctx* ctx, bzk_mpn_tree* tree);
+int32_t bzk_mpn_tree_root(bzk_ctx* ctx, const bzk_mpn_tree* tree, uint8_t root[32]);
+uint64_t bzk_mpn_tree_accounts(const bzk_mpn_tree* tree);
+int32_t bzk_mpn_tree_set_accounts(bzk_ctx* ctx, bzk_mpn_tree* tree, const uint64_t* indices, const uint8_t* cells, const uint64_t* tok_off,
+                                  const uint64_t* tok_index, const uint8_t* tok_vals, uint64_t n);
+int32_t bzk_mpn_tree_get_accounts(bzk_ctx* ctx, const bzk_mpn_tree* tree, const uint64_t* indices, uint64_t n, uint8_t* out);
+int32_t bzk_mpn_tree_prove(bzk_ctx* ctx, const bzk_mpn_tree* tree, const uint64_t* indices, uint64_t n, uint8_t* out);
+int32_t bzk_mpn_tree_prove_token(bzk_ctx* ctx, const bzk_mpn_tree* tree, const uint64_t* account_indices, const uint64_t* token_indices,
+                                 uint64_t n, uint8_t* out);
+
 /* ---- K3: radix-2 NTT over Fr -----------------------------------------------------------------
  * bellman 0.14 `EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}` (third-party crate; reached
  * from `create_random_proof`, src/mpn/circuits/test.rs:135,175,215).  In place, natural order in and
@@ -172,6 +196,26 @@ void bzk_params_free(bzk_ctx* ctx, bzk_params* params);
 /* r, s: Montgomery scalars (the prover's blinding factors; bellman draws them from the rng) */
 int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* params, const bzk_assignment* asg, const uint8_t r[32],
                           const uint8_t s[32], uint8_t proof_out[387]);
+/* bellman's `groth16::Parameters<Bls12>` file format (third-party crate; the proving keys a real network ships and its
+ * external prover loads, README.md:26-28; dev networks generate theirs in memory, src/config/blockchain.rs:355-417):
+ *   Parameters::write = VerifyingKey::write | u32-BE n, h.. | u32-BE n, l.. | u32-BE n, a.. | u32-BE n, b_g1.. | u32-BE n, b_g2..
+ * with `to_uncompressed` points (48-byte big-endian canonical coordinates, G2 as c1 | c0, flag bits in byte 0).  Host code.
+ *   info   : lengths of ic, h, l, a, b_g1, b_g2 and the bytes consumed
+ *   decode : -> vk870 (packed alpha_g1 | beta_g1 | beta_g2 | gamma_g2 | delta_g1 | delta_g2), ic (packed 97 B each), raw
+ *            Montgomery h / l / a / b_g1 (96 B) and b_g2 (192 B); canonical-range and on-curve checks, infinity refused in
+ *            the queries as `Parameters::read` does; threads 0 = all cores
+ *   encode : the inverse; out NULL = size query
+ *   bzk_params_load_bellman : parse + upload for a prover.  The file does not say which variables the a / b queries belong
+ *            to (bellman derives that from the circuit): pass the density maps of the circuit shape (bzk_r1cs_data views 4, 5
+ *            of the empty circuit); every length is checked against them.  vk_out (optional): bincode(Groth16VerifyingKey). */
+int32_t bzk_bellman_params_info(const uint8_t* bytes, uint64_t len, uint64_t info[7]);
+int32_t bzk_bellman_params_decode(const uint8_t* bytes, uint64_t len, uint8_t* vk870, uint8_t* ic, uint8_t* h, uint8_t* l, uint8_t* a,
+                                  uint8_t* b_g1, uint8_t* b_g2, int32_t threads);
+int32_t bzk_bellman_params_encode(const uint8_t vk870[870], const uint8_t* ic, uint64_t n_ic, const uint8_t* h, uint64_t n_h, const uint8_t* l,
+                                  uint64_t n_l, const uint8_t* a, uint64_t n_a, const uint8_t* b_g1, const uint8_t* b_g2, uint64_t n_b,
+                                  uint8_t* out, uint64_t cap, uint64_t* size_out);
+int32_t bzk_params_load_bellman(bzk_ctx* ctx, const uint8_t* bytes, uint64_t len, uint32_t n_in, uint32_t n_aux, const uint8_t* a_density,
+                                const uint8_t* b_density, bzk_params** out, uint8_t* vk_out, uint64_t vk_cap);
 /* reads a CRS component back (tests): which = 0 vk (870 B), 1 h, 2 l, 3 a, 4 b_g1, 5 b_g2 */
 int32_t bzk_params_read(bzk_ctx* ctx, const bzk_params* params, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out);
 

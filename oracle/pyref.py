@@ -712,3 +712,33 @@ def jj_verify(pub, msg: int, sig) -> bool:
         return False
     h = poseidon([rr[0], rr[1], pub[0], pub[1], msg])
     return jj_add(jj_mul(pub, h), rr) == jj_mul(JJ_BASE, s)
+
+
+# --------------------------------------------------------------------------------------------------
+# bellman `groth16::Parameters<Bls12>::write` [recalled: bellman 0.14 groth16/mod.rs, bls12_381 0.8 `to_uncompressed`] - the
+# oracle's WRITER of the proving-key file format, for round-trip tests of the product's reader (bzk_bellman_params_*).
+# Points: 48-byte big-endian canonical coordinates; G2 = x.c1 | x.c0 | y.c1 | y.c0; infinity = 0x40 then zeros.
+# --------------------------------------------------------------------------------------------------
+def g1_uncompressed(p) -> bytes:
+    if p is None:
+        return b"\x40" + bytes(95)
+    return p[0].to_bytes(48, "big") + p[1].to_bytes(48, "big")
+
+
+def g2_uncompressed(p) -> bytes:
+    if p is None:
+        return b"\x40" + bytes(191)
+    (x0, x1), (y0, y1) = p
+    return x1.to_bytes(48, "big") + x0.to_bytes(48, "big") + y1.to_bytes(48, "big") + y0.to_bytes(48, "big")
+
+
+def bellman_params_bytes(vk, h, l, a, b_g1, b_g2) -> bytes:
+    """vk: dict(alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2, ic) of affine points (ints; None = infinity);
+    h, l, a, b_g1: lists of G1 points; b_g2: list of G2 points."""
+    out = [g1_uncompressed(vk["alpha_g1"]), g1_uncompressed(vk["beta_g1"]), g2_uncompressed(vk["beta_g2"]), g2_uncompressed(vk["gamma_g2"]),
+           g1_uncompressed(vk["delta_g1"]), g2_uncompressed(vk["delta_g2"]), len(vk["ic"]).to_bytes(4, "big")]
+    out += [g1_uncompressed(p) for p in vk["ic"]]
+    for arr, enc in ((h, g1_uncompressed), (l, g1_uncompressed), (a, g1_uncompressed), (b_g1, g1_uncompressed), (b_g2, g2_uncompressed)):
+        out.append(len(arr).to_bytes(4, "big"))
+        out += [enc(p) for p in arr]
+    return b"".join(out)

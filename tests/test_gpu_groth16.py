@@ -102,3 +102,36 @@ def test_prove_refuses_an_assignment_of_another_circuit_shape(bzk, co, pr):
         bzk.groth16_prove(ph, zb, az, bz[:-32], cz, r, s)      # ragged evaluation vectors: refused by the driver
     assert bzk.groth16_prove(ph, zb, az, bz, cz, r, s) == co.groth16_prove(params, zb, az, bz, cz, r, s)  # ctx still healthy
     bzk.params_free(ph)
+
+
+def test_bellman_parameters_file_round_trip_through_the_prover(bzk, co, pr):
+    """a CRS written in bellman's `Parameters` format (here: the GPU-generated one, encoded by libbzk and
+    cross-checked against the oracle writer on the small case of tests/test_bellman_params_cpu.py) loads through
+    bzk_params_load_bellman and proves the same bytes; the vk it returns is the bincode `Groth16VerifyingKey`."""
+    from bazuka_amd import lib as L
+    from bazuka_amd.lib import BzkError
+    r1 = synth_r1cs(1500, seed=99)
+    csr = _csr_bytes(co, r1)
+    tox = fr_bytes(fr_list(5, 4321))
+    ph, vkb = bzk.groth16_setup(csr, r1["n_in"], r1["n_aux"], tox)
+    A, B, Cm = r1cs_to_csr(co, r1)
+    nv = r1["n_in"] + r1["n_aux"]
+    a_d, b_d = co.r1cs_density(A, nv), co.r1cs_density(B, nv)
+    parts = [bzk.params_read(ph, which) for which in range(6)]
+    ic = vkb[878:]
+    blob = L.bellman_params_encode(parts[0], ic, *parts[1:])
+    ph2, vkb2 = bzk.params_load_bellman(blob, r1["n_in"], r1["n_aux"], a_d, b_d)
+    assert vkb2 == vkb
+    zb = fr_bytes(r1["z"])
+    az, bz, cz = co.r1cs_eval(A, B, Cm, zb, nthreads=co.ncpu())
+    r, s = fr_bytes(fr_list(2, 8))[:32], fr_bytes(fr_list(2, 8))[32:]
+    p1 = bzk.groth16_prove(ph, zb, az, bz, cz, r, s)
+    assert bzk.groth16_prove(ph2, zb, az, bz, cz, r, s) == p1
+    assert pr.groth16_verify(pr.vk_from_bytes(vkb2), r1["z"][1:r1["n_in"]], pr.proof_from_bytes(p1))
+    # a key of another circuit shape is refused by its lengths, not loaded
+    with pytest.raises(BzkError, match="bad argument"):
+        bzk.params_load_bellman(blob, r1["n_in"], r1["n_aux"] - 1, a_d[:-1], b_d[:-1])
+    with pytest.raises(BzkError, match="bad argument"):
+        bzk.params_load_bellman(blob[:-7], r1["n_in"], r1["n_aux"], a_d, b_d)
+    bzk.params_free(ph)
+    bzk.params_free(ph2)

@@ -247,3 +247,18 @@ def test_witness_mode_equals_tracking_mode_for_all_three_circuits():
         assert a.satisfied and b.satisfied and (a.n_aux, a.n_constraints) == (b.n_aux, b.n_constraints)
         for name in ("z", "az", "bz", "cz"):
             assert a.view(name) == b.view(name), name
+
+
+def test_host_state_root_equals_state_manager_restatement():
+    """the witness builder's sparse account state (bzk_mpn_*) against tests/pystate.py (src/zk/state/mod.rs restated):
+    same root for the same accounts, at a small and at the production depth"""
+    import random
+    from pystate import PyMpnState
+    for L4, T4, n in ((4, 2, 9), (15, 3, 6)):
+        rnd = random.Random(L4)
+        w, py = L.MpnWorld(L4, T4), PyMpnState(L4, T4)
+        assert w.root() == F(py.root())
+        for i, idx in enumerate(rnd.sample(range(4 ** L4), n)):
+            pub = w.add_account(idx, b"acct%d" % i, F(7 + i), 500 + i)
+            py.set_account(idx, [0, 0, U(pub[:32]), U(pub[32:])], {0: (7 + i, 500 + i)})
+            assert w.root() == F(py.root())
