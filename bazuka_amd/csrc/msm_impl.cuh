@@ -319,7 +319,9 @@ __device__ __forceinline__ void add_from(typename C::Pt& acc, const typename C::
     }
 }
 
-static constexpr uint32_t MSM_FOLD_SMALL = 16;  // buckets with at most this many tasks are folded by one lane
+// buckets with at most this many tasks are folded by one lane; more: one workgroup, tree over the partial sums.  2 since round 2
+// (was 16): a serial fold of up to 15 general additions is a 0.23 ms (G1) / 1 ms (G2) dependency chain, the tree at most 4 deep
+static constexpr uint32_t MSM_FOLD_SMALL = 2;
 
 // multi-task buckets with few tasks: one lane per bucket (sorted position), serial fold
 template <class C>
@@ -991,7 +993,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true));
             static const uint32_t K = [] {  // sums per lane of the batched inversion (env BZK_DEDUP_K for A/B runs)
                 const char* e = getenv("BZK_DEDUP_K");
-                const int v = e ? atoi(e) : 16;
+                const int v = e ? atoi(e) : 8;
                 return (uint32_t)(v < 4 ? 4 : (v > 256 ? 256 : v));
             }();
             auto k_aff = dedup_affine_kernel<C>;

@@ -58,6 +58,15 @@ int hc_fp28_sqr_equals_mul(const uint8_t* a, int grow, uint8_t* out) {
     st<FpParams>(out, fp28::from28(s));
     return diff;
 }
+// binary-GCD inversion against the Fermat inversion, on a weakly reduced input (2^grow a); 0 iff the canonical results agree.
+// *iters_needed (optional): outer iterations after which gcd_inv_plain's `a` reached 0 (re-run with a counting copy)
+int hc_fp28_inv_gcd(const uint8_t* a, int grow, uint8_t* out) {
+    Fp28 x = fp28::to28(ld<FpParams>(a));
+    for (int i = 0; i < grow; ++i) x = fp28::add(x, x);
+    const Fp r1 = fp28::from28(fp28::inv_gcd(x)), r2 = fp28::from28(fp28::inv_fermat(x));
+    st<FpParams>(out, r1);
+    return r1.equals(r2) ? 0 : 1;
+}
 int hc_fp28_roundtrip(const uint8_t* a, uint8_t* out) {
     st<FpParams>(out, fp28::from28(fp28::to28(ld<FpParams>(a))));
     return 0;
