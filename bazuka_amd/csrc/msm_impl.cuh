@@ -164,35 +164,11 @@ static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3b. counting sort of the (bucket, point) pairs through global atomics - an EXPERIMENT (BZK_MSM_CSORT=1), measured and
-// rejected in round 2.  The pairs only have to be GROUPED by bucket (a bucket sum does not depend on the order of its points
-// and the affine result of the MSM is canonical), so instead of a radix sort of 20-bit keys:
-//   msm_hist     count[key]++                 one 4-byte atomic per pair into a 2 MB table
-//   scan         start = exclusive sum(count)
-//   msm_scatter  vals_s[start[key] + cursor[key]++] = val
-// Measured (profiles/r02_run2_csort_ab.txt): device-scope atomics to random addresses run at ~27 G/s on MI355X (they are
-// resolved beyond the per-XCD L2): hist 0.62 ms + scatter 0.85 ms at 2^20 points against 0.43 + 0.05 ms for rocPRIM's
-// radix sort + msm_offsets; 2^24: 20.1 ms against 6.5 ms.  The radix sort stays the default.
+// 3b. (round 2, removed again) counting sort of the pairs through GLOBAL atomics - count[key]++ / scan / scatter with a per-bucket
+// cursor: measured 0.62 ms + 0.85 ms at 2^20 points against 0.43 + 0.05 ms for rocPRIM's radix sort + msm_offsets (device-scope
+// atomics to random addresses run at ~27 G/s on MI355X, they are resolved beyond the per-XCD L2); 2^24: 20.1 ms against 6.5 ms
+// (profiles/r02_run2_csort_ab.txt).
 // ------------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256) msm_hist_kernel(const uint32_t* __restrict__ keys, uint64_t len, uint32_t nb,
-                                                              uint32_t* __restrict__ count) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    const uint32_t k = keys[i];
-    if (k < nb) atomicAdd(&count[k], 1u);
-}
-
-static __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                                 uint64_t len, uint32_t nb, const uint32_t* __restrict__ start,
-                                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ vals_s) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    const uint32_t k = keys[i];
-    if (k >= nb) return;
-    const uint32_t pos = start[k] + atomicAdd(&cursor[k], 1u);
-    vals_s[pos] = vals[i];
-}
-
 static __global__ void __launch_bounds__(256) msm_iota_clamp_kernel(const uint32_t* __restrict__ count, uint32_t* __restrict__ iota,
                                                                     uint32_t* __restrict__ ckey, uint32_t nb) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,8 +178,105 @@ static __global__ void __launch_bounds__(256) msm_iota_clamp_kernel(const uint32
     ckey[g] = c < 65535u ? c : 65535u;
 }
 
-static bool msm_use_csort() {
-    static const bool on = [] { const char* e = getenv("BZK_MSM_CSORT"); return e && atoi(e) != 0; }();
+// ------------------------------------------------------------------------------------------------
+// 3c. two-pass LDS partition of the (bucket, point) pairs instead of the radix sort of 20-bit keys (three streaming passes
+// over 8-byte pairs, then a pass for the bucket boundaries) - an EXPERIMENT of round 2 (BZK_MSM_PSORT=1), parity-green but
+// not faster: 0.56 ms against 0.47 ms at 2^20 points, 3.1 against 1.7 ms at 2^22, 12.5 against 6.7 ms at 2^24
+// (profiles/r02_run6_psort_ab.txt).  The tile scatter is the slow part (0.32 ms for 268 MB at 2^20): 16 384 pairs spread
+// over 2 048 bins leave 32-byte runs per bin, i.e. uncoalesced 4-byte stores; rocPRIM's onesweep orders a tile in LDS
+// before it writes.  The radix sort stays the default.  The pairs only have to be GROUPED by bucket:
+//   pass A  coarse bins of 256 buckets (key >> 8): per tile of 16 384 pairs a histogram in LDS (msm_part_hist), one scan over
+//           [bin][tile], then the tile is scattered with LDS cursors (msm_part_scatter) - LDS atomics, no global ones
+//   pass B  one workgroup per coarse bin (~8 k pairs at 2^20 points): histogram of the low 8 key bits in LDS gives the 256
+//           bucket boundaries (start / count written directly: msm_offsets / msm_count disappear), second sweep places the
+//           point indices (the bin's ~32 KB output region stays in L2)
+// Bytes moved: 67 MB + 268 MB + 134 MB (+ 134 MB from L2) + 67 MB at 2^20 points against ~0.95 GB for the radix sort.
+// Order inside a bucket is not deterministic (LDS atomics); a bucket sum does not depend on it and the MSM result is a
+// canonical affine point.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t PART_TILE = 16384;       // pairs per workgroup in pass A
+static constexpr uint32_t PART_MAX_BINS = 8192;    // 32 KB of LDS counters
+
+static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const uint32_t* __restrict__ keys, uint64_t len, uint32_t nb, uint32_t nbins,
+                                                                   uint32_t ntiles, uint32_t* __restrict__ tile_hist) {
+    extern __shared__ uint32_t sh_hist[];
+    for (uint32_t b = threadIdx.x; b < nbins; b += 256) sh_hist[b] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * PART_TILE;
+    for (uint32_t j = threadIdx.x; j < PART_TILE; j += 256) {
+        const uint64_t i = base + j;
+        if (i < len) {
+            const uint32_t k = keys[i];
+            if (k < nb) atomicAdd(&sh_hist[k >> 8], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += 256) tile_hist[(size_t)b * ntiles + blockIdx.x] = sh_hist[b];
+}
+
+static __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                      uint64_t len, uint32_t nb, uint32_t nbins, uint32_t ntiles,
+                                                                      const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ keys_p,
+                                                                      uint32_t* __restrict__ vals_p) {
+    extern __shared__ uint32_t sh_cur[];
+    for (uint32_t b = threadIdx.x; b < nbins; b += 256) sh_cur[b] = tile_off[(size_t)b * ntiles + blockIdx.x];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * PART_TILE;
+    for (uint32_t j = threadIdx.x; j < PART_TILE; j += 256) {
+        const uint64_t i = base + j;
+        if (i < len) {
+            const uint32_t k = keys[i];
+            if (k < nb) {
+                const uint32_t pos = atomicAdd(&sh_cur[k >> 8], 1u);
+                keys_p[pos] = k;
+                vals_p[pos] = vals[i];
+            }
+        }
+    }
+}
+
+// one workgroup per coarse bin: its pairs are [tile_off[bin * ntiles], tile_off[(bin + 1) * ntiles]) (`total` closes the last bin)
+static __global__ void __launch_bounds__(256) msm_part_bin_kernel(const uint32_t* __restrict__ keys_p, const uint32_t* __restrict__ vals_p,
+                                                                  uint32_t nb, uint32_t nbins, uint32_t ntiles, const uint32_t* __restrict__ tile_off,
+                                                                  const uint32_t* __restrict__ total, uint32_t* __restrict__ start,
+                                                                  uint32_t* __restrict__ count, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t hist[256], excl[256], cur[256];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x;
+    const uint32_t lo = tile_off[(size_t)bin * ntiles];
+    const uint32_t hi = bin + 1 < nbins ? tile_off[(size_t)(bin + 1) * ntiles] : *total;
+    hist[t] = 0;
+    cur[t] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + t; i < hi; i += 256) atomicAdd(&hist[keys_p[i] & 255u], 1u);
+    __syncthreads();
+    if (t < 64) {  // exclusive scan of 256 counters by one wavefront: 4 per lane + a shuffle scan of the lane sums
+        const uint32_t a0 = hist[4 * t], a1 = hist[4 * t + 1], a2 = hist[4 * t + 2], a3 = hist[4 * t + 3];
+        const uint32_t sum = a0 + a1 + a2 + a3;
+        uint32_t inc = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+            if ((int)t >= d) inc += o;
+        }
+        const uint32_t ex = inc - sum;
+        excl[4 * t] = ex;
+        excl[4 * t + 1] = ex + a0;
+        excl[4 * t + 2] = ex + a0 + a1;
+        excl[4 * t + 3] = ex + a0 + a1 + a2;
+    }
+    __syncthreads();
+    const uint32_t bucket = bin * 256 + t;
+    if (bucket < nb) {
+        start[bucket] = lo + excl[t];
+        count[bucket] = hist[t];
+    }
+    for (uint32_t i = lo + t; i < hi; i += 256) {
+        const uint32_t j = keys_p[i] & 255u;
+        vals_out[lo + excl[j] + atomicAdd(&cur[j], 1u)] = vals_p[i];
+    }
+}
+
+static bool msm_use_psort() {
+    static const bool on = [] { const char* e = getenv("BZK_MSM_PSORT"); return e && atoi(e) != 0; }();
     return on;
 }
 
@@ -319,23 +392,32 @@ __device__ __forceinline__ void add_from(typename C::Pt& acc, const typename C::
     }
 }
 
-// buckets with at most this many tasks are folded by one lane; more: one workgroup, tree over the partial sums.  2 since round 2
-// (was 16): a serial fold of up to 15 general additions is a 0.23 ms (G1) / 1 ms (G2) dependency chain, the tree at most 4 deep
-static constexpr uint32_t MSM_FOLD_SMALL = 2;
+// Multi-task buckets: with at most `thr` tasks one lane folds the partial sums serially, with more a 64-lane workgroup does
+// (strided pass + LDS tree).  thr depends on HOW MANY partial sums there are beyond one per bucket (read on the device from the
+// task table, uniform over the grid):
+//   few (< 65 536: uniform scalars up to ~2^22 points, witnesses)  thr = 2  - latency regime: a serial fold of up to 15 general
+//        additions is a 0.23 ms (G1) / 1 ms (G2) dependency chain, the tree is at most 4 deep (round 2)
+//   many (2^24 points: every bucket holds ~512 entries = 2 - 3 tasks) thr = 16 - throughput regime: a workgroup per bucket
+//        would spend 64 lanes and six barriers on two additions (6.9 ms at 2^24, profiles/r02_run6_psort_ab.txt)
+static constexpr uint32_t MSM_FOLD_SMALL = 2, MSM_FOLD_SMALL_BULK = 16, MSM_FOLD_BULK_FROM = 65536;
+__device__ __forceinline__ uint32_t msm_fold_threshold(const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ ntask, uint32_t nb) {
+    const uint32_t extra = tbase[nb - 1] + ntask[nb - 1] - nb;  // partial sums beyond one per bucket
+    return extra >= MSM_FOLD_BULK_FROM ? MSM_FOLD_SMALL_BULK : MSM_FOLD_SMALL;
+}
 
 // multi-task buckets with few tasks: one lane per bucket (sorted position), serial fold
 template <class C>
 __global__ void __launch_bounds__(64) msm_fold_small_kernel(const uint32_t* __restrict__ count_sorted,
                                                             const uint32_t* __restrict__ order, const uint32_t* __restrict__ tbase,
-                                                            uint32_t n_pos, uint32_t seg, const typename C::Pt* __restrict__ partial,
-                                                            typename C::Pt* __restrict__ buckets) {
+                                                            const uint32_t* __restrict__ ntask, uint32_t nb, uint32_t n_pos, uint32_t seg,
+                                                            const typename C::Pt* __restrict__ partial, typename C::Pt* __restrict__ buckets) {
     typedef typename C::Pt Pt;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pos) return;
     const uint32_t cnt = count_sorted[i];
     if (cnt <= seg) return;
     const uint32_t nt = (cnt + seg - 1) / seg;
-    if (nt > MSM_FOLD_SMALL) return;
+    if (nt > msm_fold_threshold(tbase, ntask, nb)) return;
     const Pt* src = partial + tbase[i];
     Pt acc = src[0];
     for (uint32_t j = 1; j < nt; ++j) add_from<C>(acc, &src[j]);  // G2: second operand read from memory where it is used (no scratch)
@@ -345,8 +427,8 @@ __global__ void __launch_bounds__(64) msm_fold_small_kernel(const uint32_t* __re
 // heavily populated buckets: one 64-lane workgroup per bucket: lanes stride over the partial sums, LDS tree
 template <class C>
 __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ order,
-                                                      const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t seg,
-                                                      const typename C::Pt* __restrict__ partial,
+                                                      const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ ntask, uint32_t nb,
+                                                      uint32_t seg, const typename C::Pt* __restrict__ partial,
                                                       typename C::Pt* __restrict__ buckets) {
     typedef typename C::Pt Pt;
     __shared__ Pt sh[64];
@@ -355,7 +437,7 @@ __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict
     const uint32_t cnt = count_sorted[i];
     if (cnt <= seg) return;  // wave-uniform: whole workgroup leaves
     const uint32_t nt = (cnt + seg - 1) / seg;
-    if (nt <= MSM_FOLD_SMALL) return;
+    if (nt <= msm_fold_threshold(tbase, ntask, nb)) return;
     const Pt* src = partial + tbase[i];
     Pt acc = C::identity();
     for (uint32_t j = threadIdx.x; j < nt; j += 64) add_from<C>(acc, &src[j]);
@@ -746,9 +828,9 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     // len / (seg * MSM_FOLD_SMALL) can need the workgroup-wide fold
     const uint32_t n_pos = (uint32_t)std::min<uint64_t>(nb, len / seg + 1);
     const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * MSM_FOLD_SMALL) + 1);
-    BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, A.count_s, A.order, A.tbase, nb, seg, A.partial, buckets);
-    BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, A.count_s, A.order, A.tbase, n_pos, seg, A.partial,
-               buckets);
+    BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, seg, A.partial, buckets);
+    BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_pos, seg,
+               A.partial, buckets);
     return BZK_OK;
 }
 
@@ -837,6 +919,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const uint32_t m_max = dedup ? (uint32_t)(n / 2 + 1) : 0;  // group sums: at most n / 2 groups of >= 2 members
     const uint32_t nb_alloc = std::max(nb_max, m_max);
 
+    // [coarse bin][tile] counters of the LDS partition (+ 1 closing cell): histogram and its scan
+    const size_t part_cap = (size_t)((nb_max + 255) / 256) * (size_t)((len_max + PART_TILE - 1) / PART_TILE) + 1;
     // rocPRIM temp sizes
     size_t tmp1 = 0, tmp2 = 0, tmp3 = 0, tmp4 = 0;
     {
@@ -846,7 +930,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_alloc, 0, bits_for(len_max), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
-        e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)std::max<uint64_t>(nb_alloc, dedup ? n : 0), rocprim::plus<uint32_t>(),
+        e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)std::max<uint64_t>(std::max<uint64_t>(nb_alloc, part_cap), dedup ? n : 0), rocprim::plus<uint32_t>(),
                                     ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         if (dedup) {
@@ -885,6 +969,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (dedup) {
         total += 2 * ws_pad(n * 8) + 9 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
     }
+    total += 2 * ws_pad(part_cap * 4);
     total += ws_pad(tmp) + 8192;
     BZK_TRY(ws_reserve(ctx, total));
     BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(StdPt) + 64));
@@ -950,6 +1035,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         pref = cur.take<typename C::Fld>(m_max);
     }
     void* tmp_buf = cur.take<char>(tmp);
+    uint32_t* part_hist = cur.take<uint32_t>(part_cap);
+    uint32_t* part_off = cur.take<uint32_t>(part_cap);
 
     uint64_t n_eff = n;
     const void* scal_eff = scalars;
@@ -1016,20 +1103,29 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
                    mont, c, folded ? levels * table->wpl : w_total, wb, wc, (uint32_t)(table ? table->n : 0), table ? table->wpl : 1,
                    (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
-        const bool csort = msm_use_csort();
-        if (csort) {
-            const unsigned gl = (unsigned)((len + 255) / 256);
-            BZK_HIP(ctx, hipMemsetAsync(BA.count, 0, (size_t)nb * 4, ctx->stream));
-            BZK_HIP(ctx, hipMemsetAsync(BA.ntask, 0, (size_t)nb * 4, ctx->stream));  // per-bucket cursor of the scatter (re-used as ntask later)
-            BZK_LAUNCH(ctx, "msm_hist", msm_hist_kernel, dim3(gl), dim3(256), 0, (const uint32_t*)keys, len, nb, BA.count);
+        const uint32_t nbins = (nb + 255) / 256;
+        const uint32_t ntiles = (uint32_t)((len + PART_TILE - 1) / PART_TILE);
+        const bool psort = msm_use_psort() && len >= (1u << 18) && nbins <= PART_MAX_BINS &&
+                           (uint64_t)nbins * ntiles + 1 <= part_cap;
+        const uint32_t* vals_grouped = vals_s;
+        if (psort) {
+            const size_t cells = (size_t)nbins * ntiles;
+            BZK_LAUNCH(ctx, "msm_part_hist", msm_part_hist_kernel, dim3(ntiles), dim3(256), nbins * 4, (const uint32_t*)keys, len, nb, nbins, ntiles,
+                       part_hist);
             {
-                ProfScope ps(ctx, "msm_scan_buckets");
+                ProfScope ps(ctx, "msm_part_scan");
                 size_t t = tmp;
-                hipError_t e = rocprim::exclusive_scan(tmp_buf, t, BA.count, BA.start, 0u, (size_t)nb, rocprim::plus<uint32_t>(), ctx->stream);
+                // one extra cell behind the last (bin, tile) receives the number of non-sentinel pairs: the end of the last bin
+                BZK_HIP(ctx, hipMemsetAsync(part_hist + cells, 0, 4, ctx->stream));
+                hipError_t e = rocprim::exclusive_scan(tmp_buf, t, part_hist, part_off, 0u, cells + 1, rocprim::plus<uint32_t>(), ctx->stream);
                 if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
             }
-            BZK_LAUNCH(ctx, "msm_scatter", msm_scatter_kernel, dim3(gl), dim3(256), 0, (const uint32_t*)keys, (const uint32_t*)vals, len, nb,
-                       (const uint32_t*)BA.start, BA.ntask, vals_s);
+            BZK_LAUNCH(ctx, "msm_part_scatter", msm_part_scatter_kernel, dim3(ntiles), dim3(256), nbins * 4, (const uint32_t*)keys,
+                       (const uint32_t*)vals, len, nb, nbins, ntiles, (const uint32_t*)part_off, keys_s, vals_s);
+            // pass B writes the grouped point indices over `vals` (free once the scatter has read it)
+            BZK_LAUNCH(ctx, "msm_part_bin", msm_part_bin_kernel, dim3(nbins), dim3(256), 0, (const uint32_t*)keys_s, (const uint32_t*)vals_s, nb, nbins,
+                       ntiles, (const uint32_t*)part_off, (const uint32_t*)(part_off + cells), BA.start, BA.count, vals);
+            vals_grouped = vals;
         } else {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
@@ -1037,7 +1133,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         aux.join();
-        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, csort));
+        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_grouped, len, nb, seg, BA, buckets, tmp_buf, tmp, false, psort));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);

@@ -88,6 +88,13 @@ if __name__ == "__main__":
         for cs in ("1", "0"):
             run("g2", 20, {"BZK_MSM_CSORT": cs})
         run("g1win", 23)
+    if what in ("r2psort",):  # round 2: LDS two-pass partition vs rocPRIM radix sort of the pairs
+        for lg in (20, 22, 24, 18):
+            for ps in ("1", "0"):
+                run("g1", lg, {"BZK_MSM_PSORT": ps})
+        for ps in ("1", "0"):
+            run("g2", 20, {"BZK_MSM_PSORT": ps})
+        run("g1win", 23)
     if what in ("occ",):
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
