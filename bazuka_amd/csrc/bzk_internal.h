@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,7 @@ struct bzk_ctx {
     bool own_stream = false;
     std::string last_error;
     bool prof = false;
+    std::string prof_only;  // non-empty: only launches whose label contains it get event pairs (bzk_prof_filter)
     std::vector<bzk_prof_rec> recs;
     // grow-only scratch buffer reused across calls
     void* ws = nullptr;
@@ -94,7 +96,7 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     const char* name;
     ProfScope(bzk_ctx* c, const char* n) : ctx(c), name(n) {
-        if (ctx->prof) {
+        if (ctx->prof && (ctx->prof_only.empty() || strstr(n, ctx->prof_only.c_str()))) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
             (void)hipEventRecord(a, ctx->stream);

@@ -66,6 +66,7 @@ bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
     }
     bzk_ctx* c = ctx->lanes[i];
     c->prof = ctx->prof;
+    c->prof_only = ctx->prof_only;
     c->debug = ctx->debug;
     c->timing = ctx->timing;
     c->msm_c_override = ctx->msm_c_override;
@@ -198,6 +199,13 @@ int32_t bzk_d2h(bzk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
 int32_t bzk_prof_enable(bzk_ctx* ctx, int32_t on) {
     if (!ctx) return BZK_E_ARG;
     ctx->prof = on != 0;
+    return BZK_OK;
+}
+
+int32_t bzk_prof_filter(bzk_ctx* ctx, const char* substr) {
+    if (!ctx) return BZK_E_ARG;
+    ctx->prof_only = substr ? substr : "";
+    for (bzk_ctx* c : ctx->lanes) c->prof_only = ctx->prof_only;
     return BZK_OK;
 }
 

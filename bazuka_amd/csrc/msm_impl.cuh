@@ -29,6 +29,22 @@
 
 namespace bzk {
 
+// rocPRIM configuration for the bucket-population sort (524 288 keys of 16 bits at 2^20 points).  Below 2^20 items the library
+// picks its merge sort (device_radix_sort.hpp: merge_sort_limit = 1 M): 0.125 ms.  With the limit lowered and 8-bit onesweep passes
+// (the gfx942 tuning for 4-byte keys and values) the same sort takes two passes: 0.076 ms (profiles/r02_run9_sort_config_ab.txt).
+// The same explicit configuration changes nothing for the 16.7 M-pair sort (0.426 vs 0.430 ms: the library's own choice is
+// equivalent there) and the 8-byte-key variant made the de-duplication sort slower (0.20 -> 0.25 - 0.32 ms), so both keep
+// rocPRIM's defaults.
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 8,
+                                                                       rocprim::block_radix_rank_algorithm::match>,
+                                   65536>
+    SortCfg32;  // 4-byte keys, 4-byte values
+static bool msm_tuned_sort() {  // BZK_MSM_SORT_DEFAULT=1: rocPRIM's own (untuned) configuration, for A/B runs
+    static const bool on = [] { const char* e = getenv("BZK_MSM_SORT_DEFAULT"); return !(e && atoi(e) != 0); }();
+    return on;
+}
+
 // ------------------------------------------------------------------------------------------------
 // parameters
 // ------------------------------------------------------------------------------------------------
@@ -179,106 +195,12 @@ static __global__ void __launch_bounds__(256) msm_iota_clamp_kernel(const uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3c. two-pass LDS partition of the (bucket, point) pairs instead of the radix sort of 20-bit keys (three streaming passes
-// over 8-byte pairs, then a pass for the bucket boundaries) - an EXPERIMENT of round 2 (BZK_MSM_PSORT=1), parity-green but
-// not faster: 0.56 ms against 0.47 ms at 2^20 points, 3.1 against 1.7 ms at 2^22, 12.5 against 6.7 ms at 2^24
-// (profiles/r02_run6_psort_ab.txt).  The tile scatter is the slow part (0.32 ms for 268 MB at 2^20): 16 384 pairs spread
-// over 2 048 bins leave 32-byte runs per bin, i.e. uncoalesced 4-byte stores; rocPRIM's onesweep orders a tile in LDS
-// before it writes.  The radix sort stays the default.  The pairs only have to be GROUPED by bucket:
-//   pass A  coarse bins of 256 buckets (key >> 8): per tile of 16 384 pairs a histogram in LDS (msm_part_hist), one scan over
-//           [bin][tile], then the tile is scattered with LDS cursors (msm_part_scatter) - LDS atomics, no global ones
-//   pass B  one workgroup per coarse bin (~8 k pairs at 2^20 points): histogram of the low 8 key bits in LDS gives the 256
-//           bucket boundaries (start / count written directly: msm_offsets / msm_count disappear), second sweep places the
-//           point indices (the bin's ~32 KB output region stays in L2)
-// Bytes moved: 67 MB + 268 MB + 134 MB (+ 134 MB from L2) + 67 MB at 2^20 points against ~0.95 GB for the radix sort.
-// Order inside a bucket is not deterministic (LDS atomics); a bucket sum does not depend on it and the MSM result is a
-// canonical affine point.
+// 3c. (round 2, removed again) two-pass LDS partition of the pairs instead of the radix sort: coarse bins of 256 buckets per
+// 16 k-pair tile with LDS cursors, then one workgroup per bin producing the bucket boundaries directly.  Measured on the c = 16
+// sizes: 0.56 ms against 0.47 ms at 2^20 points, 3.1 against 1.7 ms at 2^22, 12.5 against 6.7 ms at 2^24
+// (profiles/r02_run6_psort_ab.txt) - the tile scatter leaves 32-byte runs per bin (uncoalesced 4-byte stores) where onesweep
+// orders a tile in LDS before it writes; a c = 15 case later disagreed with the oracle.  Slower and not clean: gone.
 // ------------------------------------------------------------------------------------------------
-static constexpr uint32_t PART_TILE = 16384;       // pairs per workgroup in pass A
-static constexpr uint32_t PART_MAX_BINS = 8192;    // 32 KB of LDS counters
-
-static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const uint32_t* __restrict__ keys, uint64_t len, uint32_t nb, uint32_t nbins,
-                                                                   uint32_t ntiles, uint32_t* __restrict__ tile_hist) {
-    extern __shared__ uint32_t sh_hist[];
-    for (uint32_t b = threadIdx.x; b < nbins; b += 256) sh_hist[b] = 0;
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * PART_TILE;
-    for (uint32_t j = threadIdx.x; j < PART_TILE; j += 256) {
-        const uint64_t i = base + j;
-        if (i < len) {
-            const uint32_t k = keys[i];
-            if (k < nb) atomicAdd(&sh_hist[k >> 8], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nbins; b += 256) tile_hist[(size_t)b * ntiles + blockIdx.x] = sh_hist[b];
-}
-
-static __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                                      uint64_t len, uint32_t nb, uint32_t nbins, uint32_t ntiles,
-                                                                      const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ keys_p,
-                                                                      uint32_t* __restrict__ vals_p) {
-    extern __shared__ uint32_t sh_cur[];
-    for (uint32_t b = threadIdx.x; b < nbins; b += 256) sh_cur[b] = tile_off[(size_t)b * ntiles + blockIdx.x];
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * PART_TILE;
-    for (uint32_t j = threadIdx.x; j < PART_TILE; j += 256) {
-        const uint64_t i = base + j;
-        if (i < len) {
-            const uint32_t k = keys[i];
-            if (k < nb) {
-                const uint32_t pos = atomicAdd(&sh_cur[k >> 8], 1u);
-                keys_p[pos] = k;
-                vals_p[pos] = vals[i];
-            }
-        }
-    }
-}
-
-// one workgroup per coarse bin: its pairs are [tile_off[bin * ntiles], tile_off[(bin + 1) * ntiles]) (`total` closes the last bin)
-static __global__ void __launch_bounds__(256) msm_part_bin_kernel(const uint32_t* __restrict__ keys_p, const uint32_t* __restrict__ vals_p,
-                                                                  uint32_t nb, uint32_t nbins, uint32_t ntiles, const uint32_t* __restrict__ tile_off,
-                                                                  const uint32_t* __restrict__ total, uint32_t* __restrict__ start,
-                                                                  uint32_t* __restrict__ count, uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t hist[256], excl[256], cur[256];
-    const uint32_t bin = blockIdx.x, t = threadIdx.x;
-    const uint32_t lo = tile_off[(size_t)bin * ntiles];
-    const uint32_t hi = bin + 1 < nbins ? tile_off[(size_t)(bin + 1) * ntiles] : *total;
-    hist[t] = 0;
-    cur[t] = 0;
-    __syncthreads();
-    for (uint32_t i = lo + t; i < hi; i += 256) atomicAdd(&hist[keys_p[i] & 255u], 1u);
-    __syncthreads();
-    if (t < 64) {  // exclusive scan of 256 counters by one wavefront: 4 per lane + a shuffle scan of the lane sums
-        const uint32_t a0 = hist[4 * t], a1 = hist[4 * t + 1], a2 = hist[4 * t + 2], a3 = hist[4 * t + 3];
-        const uint32_t sum = a0 + a1 + a2 + a3;
-        uint32_t inc = sum;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-            if ((int)t >= d) inc += o;
-        }
-        const uint32_t ex = inc - sum;
-        excl[4 * t] = ex;
-        excl[4 * t + 1] = ex + a0;
-        excl[4 * t + 2] = ex + a0 + a1;
-        excl[4 * t + 3] = ex + a0 + a1 + a2;
-    }
-    __syncthreads();
-    const uint32_t bucket = bin * 256 + t;
-    if (bucket < nb) {
-        start[bucket] = lo + excl[t];
-        count[bucket] = hist[t];
-    }
-    for (uint32_t i = lo + t; i < hi; i += 256) {
-        const uint32_t j = keys_p[i] & 255u;
-        vals_out[lo + excl[j] + atomicAdd(&cur[j], 1u)] = vals_p[i];
-    }
-}
-
-static bool msm_use_psort() {
-    static const bool on = [] { const char* e = getenv("BZK_MSM_PSORT"); return e && atoi(e) != 0; }();
-    return on;
-}
 
 // ------------------------------------------------------------------------------------------------
 // 4b. base conversion to the policy's internal form (G1: 14 x 28-bit limbs); one pass per call
@@ -801,7 +723,9 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     {
         ProfScope ps(ctx, "msm_sort_buckets");
         size_t t = tmp;
-        hipError_t e = rocprim::radix_sort_pairs_desc(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 16, ctx->stream);
+        hipError_t e = msm_tuned_sort()
+                           ? rocprim::radix_sort_pairs_desc<SortCfg32>(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 16, ctx->stream)
+                           : rocprim::radix_sort_pairs_desc(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 16, ctx->stream);
         if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
     }
     BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.order, nb, seg, A.count_s, A.ntask);
@@ -919,18 +843,20 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const uint32_t m_max = dedup ? (uint32_t)(n / 2 + 1) : 0;  // group sums: at most n / 2 groups of >= 2 members
     const uint32_t nb_alloc = std::max(nb_max, m_max);
 
-    // [coarse bin][tile] counters of the LDS partition (+ 1 closing cell): histogram and its scan
-    const size_t part_cap = (size_t)((nb_max + 255) / 256) * (size_t)((len_max + PART_TILE - 1) / PART_TILE) + 1;
     // rocPRIM temp sizes
     size_t tmp1 = 0, tmp2 = 0, tmp3 = 0, tmp4 = 0;
     {
         uint32_t* nul = nullptr;
         uint64_t* nul64 = nullptr;
+        // both configurations are sized for (the A/B switch is read once per process, the workspace is grow-only)
+        size_t q = 0;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp1, nul, nul, nul, nul, (size_t)len_max, 0, bits_for(nb_max), ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         e = rocprim::radix_sort_pairs_desc(nullptr, tmp2, nul, nul, nul, nul, (size_t)nb_alloc, 0, bits_for(len_max), ctx->stream);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs_desc<SortCfg32>(nullptr, q, nul, nul, nul, nul, (size_t)nb_alloc, 0, 16, ctx->stream);
+        tmp2 = std::max(tmp2, q);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
-        e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)std::max<uint64_t>(std::max<uint64_t>(nb_alloc, part_cap), dedup ? n : 0), rocprim::plus<uint32_t>(),
+        e = rocprim::exclusive_scan(nullptr, tmp3, nul, nul, 0u, (size_t)std::max<uint64_t>(nb_alloc, dedup ? n : 0), rocprim::plus<uint32_t>(),
                                     ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         if (dedup) {
@@ -969,7 +895,6 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (dedup) {
         total += 2 * ws_pad(n * 8) + 9 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
     }
-    total += 2 * ws_pad(part_cap * 4);
     total += ws_pad(tmp) + 8192;
     BZK_TRY(ws_reserve(ctx, total));
     BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(StdPt) + 64));
@@ -1035,8 +960,6 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         pref = cur.take<typename C::Fld>(m_max);
     }
     void* tmp_buf = cur.take<char>(tmp);
-    uint32_t* part_hist = cur.take<uint32_t>(part_cap);
-    uint32_t* part_off = cur.take<uint32_t>(part_cap);
 
     uint64_t n_eff = n;
     const void* scal_eff = scalars;
@@ -1103,37 +1026,14 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
                    mont, c, folded ? levels * table->wpl : w_total, wb, wc, (uint32_t)(table ? table->n : 0), table ? table->wpl : 1,
                    (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
-        const uint32_t nbins = (nb + 255) / 256;
-        const uint32_t ntiles = (uint32_t)((len + PART_TILE - 1) / PART_TILE);
-        const bool psort = msm_use_psort() && len >= (1u << 18) && nbins <= PART_MAX_BINS &&
-                           (uint64_t)nbins * ntiles + 1 <= part_cap;
-        const uint32_t* vals_grouped = vals_s;
-        if (psort) {
-            const size_t cells = (size_t)nbins * ntiles;
-            BZK_LAUNCH(ctx, "msm_part_hist", msm_part_hist_kernel, dim3(ntiles), dim3(256), nbins * 4, (const uint32_t*)keys, len, nb, nbins, ntiles,
-                       part_hist);
-            {
-                ProfScope ps(ctx, "msm_part_scan");
-                size_t t = tmp;
-                // one extra cell behind the last (bin, tile) receives the number of non-sentinel pairs: the end of the last bin
-                BZK_HIP(ctx, hipMemsetAsync(part_hist + cells, 0, 4, ctx->stream));
-                hipError_t e = rocprim::exclusive_scan(tmp_buf, t, part_hist, part_off, 0u, cells + 1, rocprim::plus<uint32_t>(), ctx->stream);
-                if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
-            }
-            BZK_LAUNCH(ctx, "msm_part_scatter", msm_part_scatter_kernel, dim3(ntiles), dim3(256), nbins * 4, (const uint32_t*)keys,
-                       (const uint32_t*)vals, len, nb, nbins, ntiles, (const uint32_t*)part_off, keys_s, vals_s);
-            // pass B writes the grouped point indices over `vals` (free once the scatter has read it)
-            BZK_LAUNCH(ctx, "msm_part_bin", msm_part_bin_kernel, dim3(nbins), dim3(256), 0, (const uint32_t*)keys_s, (const uint32_t*)vals_s, nb, nbins,
-                       ntiles, (const uint32_t*)part_off, (const uint32_t*)(part_off + cells), BA.start, BA.count, vals);
-            vals_grouped = vals;
-        } else {
+        {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
             hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, keys, keys_s, vals, vals_s, (size_t)len, 0, bits_for(nb), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         aux.join();
-        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_grouped, len, nb, seg, BA, buckets, tmp_buf, tmp, false, psort));
+        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "bzk_h2d": (_i32, [_vp, _vp, _vp, _u64]),
     "bzk_d2h": (_i32, [_vp, _vp, _vp, _u64]),
     "bzk_prof_enable": (_i32, [_vp, _i32]),
+    "bzk_prof_filter": (_i32, [_vp, C.c_char_p]),
     "bzk_prof_reset": (_i32, [_vp]),
     "bzk_prof_query": (_i32, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
     "bzk_prof_dump": (_i32, [_vp, _vp, _u64]),
@@ -206,6 +207,10 @@ class Bzk:
         self._ck(self.lib.bzk_sync(self.h), "sync")
 
     # ---- profiling
+    def prof_filter(self, substr: str | None):
+        """event pairs only around launches whose label contains `substr` (None: every launch)"""
+        self._ck(self.lib.bzk_prof_filter(self.h, substr.encode() if substr else None), "prof_filter")
+
     def prof_enable(self, on=True):
         self._ck(self.lib.bzk_prof_enable(self.h, int(on)), "prof_enable")
 

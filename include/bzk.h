@@ -61,6 +61,10 @@ int32_t bzk_d2h(bzk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t byte
 
 /* per-kernel timing with HIP events on the ctx stream (used by bench.py for `roofline.achieved`) */
 int32_t bzk_prof_enable(bzk_ctx* ctx, int32_t on);
+/* restrict the event pairs to launches whose label contains `substr` (NULL: every launch).  Timing every launch costs two event
+ * creations per kernel (~0.25 ms per 2^20-point MSM with its ~25 launches); bench.py times only the dominant kernel inside its
+ * timed region */
+int32_t bzk_prof_filter(bzk_ctx* ctx, const char* substr);
 int32_t bzk_prof_reset(bzk_ctx* ctx);
 /* sums over launches whose kernel label == name; synchronises the stream */
 int32_t bzk_prof_query(bzk_ctx* ctx, const char* name, uint64_t* launches, double* total_ms);

@@ -447,45 +447,3 @@ def test_msm_canonical_scalars_at_and_above_r(co, pr, c, monkeypatch):
         assert ctx.msm_g1(bases, fr_bytes(small, mont=False), canonical=True) == want
     finally:
         ctx.close()
-
-
-def test_experimental_lds_partition_is_parity_green_in_a_fresh_process(co):
-    """BZK_MSM_PSORT=1 (process-wide, read once): the two-pass LDS partition of the pairs - measured slower than the radix sort and
-    therefore off by default (profiles/r02_run6_psort_ab.txt) - must still give the oracle's bytes: 2^19 uniform points (the
-    partition needs >= 2^18 pairs), skewed witness-like scalars with de-duplication off and on, and a window range"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import torch
-from bazuka_amd import Bzk
-from oracle import coracle as co
-from util import rand_scalars_bytes, to_dev, dev_bytes
-import numpy as np
-ctx = Bzk(0)
-n = 1 << 19
-bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(3, 0, n, bases)
-hb = dev_bytes(bases)
-scb = bytearray(rand_scalars_bytes(n, 19))
-want = co.msm_g1(hb, bytes(scb), nthreads=co.ncpu())
-ctx.prof_enable(True); ctx.prof_reset()
-assert ctx.msm_g1_dev(bases, to_dev(bytes(scb)), n) == want
-assert "msm_part_bin" in ctx.prof_dump(), "the partition path did not run"
-one = (1 * ((1 << 256) %% 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001)).to_bytes(32, "little")
-for i in range(0, n, 7):
-    scb[32 * i:32 * i + 32] = one            # 1/7 of the scalars equal 1: one bucket of window 0 holds 75 k points
-sk = to_dev(bytes(scb))
-want = co.msm_g1(hb, bytes(scb), nthreads=co.ncpu())
-assert ctx.msm_g1_dev(bases, sk, n) == want
-assert ctx.msm_g1_dev(bases, sk, n, dedup=True) == want
-W = ctx.msm_window_count(n)
-parts = ctx.msm_g1_windows_dev(bases, sk, n, 0, 5) + ctx.msm_g1_windows_dev(bases, sk, n, 5, W)
-assert ctx.g1_sum(parts) == want
-print("ok")
-''' % (root, os.path.join(root, "tests"))
-    env = dict(os.environ, BZK_MSM_PSORT="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

@@ -88,6 +88,13 @@ if __name__ == "__main__":
         for cs in ("1", "0"):
             run("g2", 20, {"BZK_MSM_CSORT": cs})
         run("g1win", 23)
+    if what in ("r2sortcfg",):  # round 2: rocPRIM with the explicit 8-bit onesweep configuration vs its untuned gfx950 fallback (4 bits, merge sort)
+        for lg in (20, 22, 24, 16):
+            for d in ("0", "1"):
+                run("g1", lg, {"BZK_MSM_SORT_DEFAULT": d})
+        for d in ("0", "1"):
+            run("g2", 20, {"BZK_MSM_SORT_DEFAULT": d})
+        run("g1win", 23)
     if what in ("r2psort",):  # round 2: LDS two-pass partition vs rocPRIM radix sort of the pairs
         for lg in (20, 22, 24, 18):
             for ps in ("1", "0"):
