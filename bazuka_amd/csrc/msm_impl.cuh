@@ -602,7 +602,12 @@ static int bits_for(uint64_t v) {
 // element; grouping is by a 64-bit hash sort with a full 256-bit comparison of sorted neighbours (a hash collision
 // can only split a group, never merge two).
 // ------------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256) dedup_hash_kernel(const U128* __restrict__ scalars, uint64_t n, uint64_t* __restrict__ hkey,
+// 32-bit sort keys since round 2 (were 64): a collision of two DIFFERENT scalars only interleaves two groups in the sorted order
+// and thereby splits them (the neighbour comparison is on all 256 bits), i.e. costs a little de-duplication - n^2 / 2^33 pairs:
+// ~130 at the 0.9 M values of a 16-tx circuit, ~30 k of 14 M at the production size - while the sort drops from 8-byte keys and
+// eight 8-bit passes to 4-byte keys and four (the four de-duplication sorts of a 256-tx proof took 105 ms of its 260,
+// profiles/r02_run10_production.txt)
+static __global__ void __launch_bounds__(256) dedup_hash_kernel(const U128* __restrict__ scalars, uint64_t n, uint32_t* __restrict__ hkey,
                                                                 uint32_t* __restrict__ idx) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -616,8 +621,9 @@ static __global__ void __launch_bounds__(256) dedup_hash_kernel(const U128* __re
         h = (h ^ l[k]) * 0xBF58476D1CE4E5B9ull;
         h ^= h >> 29;
     }
-    if (h == ~0ull) h = ~0ull - 1;
-    hkey[i] = any ? h : ~0ull;  // zero scalars sort to the end and are dropped
+    uint32_t h32 = (uint32_t)(h ^ (h >> 32));
+    if (h32 == ~0u) h32 = ~0u - 1;
+    hkey[i] = any ? h32 : ~0u;  // zero scalars sort to the end and are dropped
     idx[i] = (uint32_t)i;
 }
 
@@ -627,12 +633,12 @@ __device__ __forceinline__ bool dedup_same(const U128* __restrict__ scalars, uin
 }
 
 // head[i]: sorted position i starts a group of equal non-zero scalars; mhead[i]: ... of at least two members
-static __global__ void __launch_bounds__(256) dedup_heads_kernel(const U128* __restrict__ scalars, const uint64_t* __restrict__ hkey_s,
+static __global__ void __launch_bounds__(256) dedup_heads_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict__ hkey_s,
                                                                  const uint32_t* __restrict__ idx_s, uint64_t n, uint32_t* __restrict__ head,
                                                                  uint32_t* __restrict__ mhead) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool alive = hkey_s[i] != ~0ull;
+    const bool alive = hkey_s[i] != ~0u;
     bool h = false, m = false;
     if (alive) {
         h = i == 0 || hkey_s[i - 1] != hkey_s[i] || !dedup_same(scalars, idx_s[i - 1], idx_s[i]);
@@ -644,7 +650,7 @@ static __global__ void __launch_bounds__(256) dedup_heads_kernel(const U128* __r
 
 // per sorted position: the bucket key of the group-sum accumulation (multi-member groups only) and, at group heads,
 // the compacted scalar, its base index (`rep`: the original base, or n + m for the m-th group sum) and gof[m] = g
-static __global__ void __launch_bounds__(256) dedup_assign_kernel(const U128* __restrict__ scalars, const uint64_t* __restrict__ hkey_s,
+static __global__ void __launch_bounds__(256) dedup_assign_kernel(const U128* __restrict__ scalars, const uint32_t* __restrict__ hkey_s,
                                                                   const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ head,
                                                                   const uint32_t* __restrict__ mhead, const uint32_t* __restrict__ gid_ex,
                                                                   const uint32_t* __restrict__ mid_ex, uint64_t n, uint32_t sentinel,
@@ -652,7 +658,7 @@ static __global__ void __launch_bounds__(256) dedup_assign_kernel(const U128* __
                                                                   uint32_t* __restrict__ rep, uint32_t* __restrict__ gof) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool alive = hkey_s[i] != ~0ull;
+    const bool alive = hkey_s[i] != ~0u;
     const bool h = head[i] != 0, m = mhead[i] != 0;
     const bool member = alive && (m || !h);  // belongs to a group of >= 2
     key2[i] = member ? mid_ex[i] + mhead[i] - 1 : sentinel;
@@ -847,7 +853,6 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     size_t tmp1 = 0, tmp2 = 0, tmp3 = 0, tmp4 = 0;
     {
         uint32_t* nul = nullptr;
-        uint64_t* nul64 = nullptr;
         // both configurations are sized for (the A/B switch is read once per process, the workspace is grow-only)
         size_t q = 0;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp1, nul, nul, nul, nul, (size_t)len_max, 0, bits_for(nb_max), ctx->stream);
@@ -860,7 +865,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                                     ctx->stream);
         if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         if (dedup) {
-            e = rocprim::radix_sort_pairs(nullptr, tmp4, nul64, nul64, nul, nul, (size_t)n, 0, 64, ctx->stream);
+            e = rocprim::radix_sort_pairs(nullptr, tmp4, nul, nul, nul, nul, (size_t)n, 0, 32, ctx->stream);
             if (e != hipSuccess) { ctx->last_error = "rocprim size query"; return BZK_E_DEVICE; }
         }
     }
@@ -893,7 +898,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     total += ws_pad((size_t)w_total * sizeof(StdPt));
     if (C::CONVERT_BASES && !table) total += ws_pad((size_t)(n + m_max) * sizeof(typename C::DevAff));
     if (dedup) {
-        total += 2 * ws_pad(n * 8) + 9 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
+        total += 11 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
     }
     total += ws_pad(tmp) + 8192;
     BZK_TRY(ws_reserve(ctx, total));
@@ -938,15 +943,14 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         }
         bases = conv;
     }
-    uint64_t* hkey = nullptr;
-    uint64_t* hkey_s = nullptr;
+    uint32_t *hkey = nullptr, *hkey_s = nullptr;
     uint32_t *didx = nullptr, *didx_s = nullptr, *head = nullptr, *mhead = nullptr, *gid_ex = nullptr, *mid_ex = nullptr, *key2 = nullptr,
              *rep = nullptr, *gof = nullptr;
     U128* scal2 = nullptr;
     typename C::Fld* pref = nullptr;
     if (dedup) {
-        hkey = cur.take<uint64_t>(n);
-        hkey_s = cur.take<uint64_t>(n);
+        hkey = cur.take<uint32_t>(n);
+        hkey_s = cur.take<uint32_t>(n);
         didx = cur.take<uint32_t>(n);
         didx_s = cur.take<uint32_t>(n);
         head = cur.take<uint32_t>(n);
@@ -969,10 +973,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         {
             ProfScope ps(ctx, "dedup_sort");
             size_t t = tmp;
-            hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, hkey, hkey_s, didx, didx_s, (size_t)n, 0, 64, ctx->stream);
+            hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, hkey, hkey_s, didx, didx_s, (size_t)n, 0, 32, ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("dedup sort: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
-        BZK_LAUNCH(ctx, "dedup_heads", dedup_heads_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, (const uint64_t*)hkey_s,
+        BZK_LAUNCH(ctx, "dedup_heads", dedup_heads_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, (const uint32_t*)hkey_s,
                    (const uint32_t*)didx_s, n, head, mhead);
         {
             ProfScope ps(ctx, "dedup_scan");
@@ -995,7 +999,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         if (ctx->timing) fprintf(stderr, "[bzk] dedup: n %llu -> %u distinct non-zero scalars, %u groups of >= 2\n", (unsigned long long)n, G, M);
         if (G == 0) return BZK_OK;  // every scalar is zero
         if (M > m_max) { ctx->last_error = "dedup: group count out of range"; return BZK_E_INTERNAL; }
-        BZK_LAUNCH(ctx, "dedup_assign", dedup_assign_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, (const uint64_t*)hkey_s,
+        BZK_LAUNCH(ctx, "dedup_assign", dedup_assign_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, (const uint32_t*)hkey_s,
                    (const uint32_t*)didx_s, (const uint32_t*)head, (const uint32_t*)mhead, (const uint32_t*)gid_ex, (const uint32_t*)mid_ex,
                    n, 0xffffffffu, key2, scal2, rep, gof);
         if (M) {

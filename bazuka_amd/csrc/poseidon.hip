@@ -499,6 +499,10 @@ __global__ void __launch_bounds__(256) tree4_fill_kernel(Fr* __restrict__ dst, u
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = v;
 }
+__global__ void __launch_bounds__(256) tree4_iota_kernel(uint64_t* __restrict__ dst, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = i;
+}
 __global__ void __launch_bounds__(256) tree4_scatter_kernel(Fr* __restrict__ level, const uint64_t* __restrict__ idx,
                                                             const Fr* __restrict__ vals, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1092,6 +1096,51 @@ int32_t bzk_mpn_tree_prove_token(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint
     BZK_LAUNCH(ctx, "mpn_prove_token", mpn_prove_token_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, F, t->T,
                (const uint64_t*)d_g.p, n, (Fr*)d_o.p);
     BZK_HIP(ctx, hipMemcpyAsync(out, d_o.p, cells * 3 * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+
+// `ZkStateModel::compress` (src/zk/mod.rs:392-423, `ZkStateBuilder::compress` src/zk/state/mod.rs) for a DENSE state of the MPN shape
+// List{L, Struct{S, S, S, S, List{T, Struct{S, S}}}} resident in HBM - BASELINE configs[4]'s secondary instance (4^9
+// accounts x (64 H2 + 21 H4 + 1 H5)).  cells_dev: 4^L x 4 scalars (nonce, withdraw nonce, x, y); tokens_dev: 4^L x 4^T x 2 scalars
+// (token id, balance).  Every level is one dense launch: H2 over all token slots, T levels of H4, H5 per account, L levels of H4.
+int32_t bzk_mpn_state_compress_dev(bzk_ctx* ctx, uint32_t log4_tree, uint32_t log4_token_tree, const void* cells_dev, const void* tokens_dev,
+                                   uint8_t root[32]) {
+    if (!ctx || !cells_dev || !tokens_dev || !root || log4_tree == 0 || log4_tree > 12 || log4_token_tree == 0 || log4_token_tree > 8)
+        return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n_acct = (uint64_t)1 << (2 * log4_tree), ts = (uint64_t)1 << (2 * log4_token_tree);
+    if (n_acct * ts > ((uint64_t)1 << 32)) return BZK_E_ARG;
+    // workspace: two ping-pong hash buffers of n_acct * ts scalars, the H5 inputs (n_acct x 5) and the account tree's nodes
+    const uint64_t n_nodes = tree4_off(log4_tree);
+    BZK_TRY(ws_reserve(ctx, 2 * ws_pad(n_acct * ts * sizeof(Fr)) + ws_pad(n_acct * 5 * sizeof(Fr)) + ws_pad((n_acct + n_nodes) * sizeof(Fr)) + 1024));
+    WsCursor cur(ctx->ws);
+    Fr* h0 = cur.take<Fr>(n_acct * ts);
+    Fr* h1 = cur.take<Fr>(n_acct * ts);
+    Fr* in5 = cur.take<Fr>(n_acct * 5);
+    Fr* leaves = cur.take<Fr>(n_acct);
+    Fr* nodes = cur.take<Fr>(n_nodes ? n_nodes : 1);
+    BZK_TRY(poseidon_launch(ctx, tokens_dev, 2, n_acct * ts, h0));                                  // Struct{token, balance}
+    Fr *src = h0, *dst = h1;
+    for (int k = (int)log4_token_tree - 1; k >= 0; --k) {                                          // List{T, ..}: per-account sub-trees
+        BZK_TRY(poseidon_launch(ctx, src, 4, n_acct << (2 * k), dst));
+        std::swap(src, dst);
+    }
+    // account a: H5(cells[a][0..3], token root a); slot = account index in the dense layout
+    {
+        uint64_t* ident = (uint64_t*)dst;  // the free ping-pong buffer holds the identity slot list for the gather kernel
+        hipLaunchKernelGGL(tree4_iota_kernel, dim3((unsigned)((n_acct + 255) / 256)), dim3(256), 0, ctx->stream, ident, n_acct);
+        BZK_LAUNCH(ctx, "mpn_leaf_inputs", mpn_leaf_inputs_kernel, dim3((unsigned)((n_acct * 5 + 255) / 256)), dim3(256), 0, (const Fr*)cells_dev,
+                   (const Fr*)src, (const uint64_t*)ident, n_acct, in5);
+    }
+    BZK_TRY(poseidon_launch(ctx, in5, 5, n_acct, leaves));
+    const Fr* child = leaves;
+    for (int k = (int)log4_tree - 1; k >= 0; --k) {
+        Fr* out = nodes + tree4_off(k);
+        BZK_TRY(poseidon_launch(ctx, child, 4, (uint64_t)1 << (2 * k), out));
+        child = out;
+    }
+    BZK_HIP(ctx, hipMemcpyAsync(root, nodes, 32, hipMemcpyDeviceToHost, ctx->stream));
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BZK_OK;
 }

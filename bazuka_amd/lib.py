@@ -51,6 +51,7 @@ SIGNATURES = {
     "bzk_bellman_params_decode": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "bzk_bellman_params_encode": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64)]),
     "bzk_params_load_bellman": (_i32, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, C.POINTER(_vp), _vp, _u64]),
+    "bzk_groth16_verify": (_i32, [_vp, _u64, _vp, _u32, _vp]),
     "bzk_params_read": (_i32, [_vp, _vp, _i32, _vp, _u64, C.POINTER(_u64)]),
     "bzk_groth16_setup": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, C.POINTER(_vp), _vp, _u64]),
     "bzk_groth16_h_dev": (_i32, [_vp, _vp, _vp, _vp, _u32]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "bzk_tree4_update": (_i32, [_vp, _vp, _vp, _vp, _u64]),
     "bzk_tree4_prove": (_i32, [_vp, _vp, _vp, _u64, _vp]),
     "bzk_tree4_node": (_i32, [_vp, _vp, _u32, _u64, _vp]),
+    "bzk_mpn_state_compress_dev": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),
     "bzk_mpn_tree_create": (_i32, [_vp, _u32, _u32, _u64, C.POINTER(_vp)]),
     "bzk_mpn_tree_free": (None, [_vp, _vp]),
     "bzk_mpn_tree_root": (_i32, [_vp, _vp, _vp]),
@@ -371,6 +373,12 @@ class Bzk:
         return out.raw
 
     # ---- device-resident MPN account state
+    def mpn_state_compress_dev(self, log4_tree: int, log4_token_tree: int, cells, tokens) -> bytes:
+        """root of a dense MPN-shaped state in device memory: cells = 4^L x 4 scalars, tokens = 4^L x 4^T x 2 scalars"""
+        out = C.create_string_buffer(32)
+        self._ck(self.lib.bzk_mpn_state_compress_dev(self.h, log4_tree, log4_token_tree, _ptr(cells), _ptr(tokens), out), "mpn_state_compress_dev")
+        return out.raw
+
     def mpn_tree_create(self, log4_tree: int, log4_token_tree: int, capacity: int):
         h = C.c_void_p()
         self._ck(self.lib.bzk_mpn_tree_create(self.h, log4_tree, log4_token_tree, capacity, C.byref(h)), "mpn_tree_create")
@@ -709,6 +717,14 @@ def bellman_params_encode(vk870: bytes, ic: bytes, h: bytes, l: bytes, a: bytes,
     buf = C.create_string_buffer(n.value)
     _st(lib.bzk_bellman_params_encode(*args, buf, n.value, None), "bellman_params_encode")
     return buf.raw
+
+
+def groth16_verify(vk_bincode: bytes, inputs: bytes, proof387: bytes) -> bool:
+    """host-side `groth16_verify` (src/zk/groth16/mod.rs:67-121): inputs = n x 32 B Montgomery scalars"""
+    st = load_library().bzk_groth16_verify(_ptr(vk_bincode), len(vk_bincode), _ptr(inputs), len(inputs) // 32, _ptr(proof387))
+    if st < 0:
+        raise BzkError(f"groth16_verify: {load_library().bzk_strerror(st).decode()}")
+    return st == 1
 
 
 def zkproof_encode(proof387: bytes) -> bytes:

@@ -201,10 +201,12 @@ class BellmanKeys:
 # ---- the loop ----------------------------------------------------------------------------------------------------------
 class Worker:
     def __init__(self, bzk: L.Bzk, address: bytes, node: tuple[str, int], params_for, flags: int = 0, threads: int = 0,
-                 rng=os.urandom, timeout_s: float = 30.0):
+                 rng=os.urandom, timeout_s: float = 30.0, self_check: bool = False):
+        """self_check: verify every proof on the host with the work's own verifying key before posting it (bzk_groth16_verify =
+        the check the node will run, src/mpn/mod.rs:281-295; ~20 ms of one core per proof) - a proof that fails is not posted"""
         self.bzk, self.address, self.node, self.params_for = bzk, address, node, params_for
-        self.flags, self.threads, self.rng, self.timeout_s = flags, threads, rng, timeout_s
-        self.stats = {"fetched": 0, "proved": 0, "accepted": 0, "unsat": 0, "synth_s": 0.0, "prove_s": 0.0}
+        self.flags, self.threads, self.rng, self.timeout_s, self.self_check = flags, threads, rng, timeout_s, self_check
+        self.stats = {"fetched": 0, "proved": 0, "accepted": 0, "unsat": 0, "self_check_failed": 0, "synth_s": 0.0, "prove_s": 0.0}
 
     def _http(self, method: str, path: str, body: bytes) -> bytes:
         conn = http.client.HTTPConnection(self.node[0], self.node[1], timeout=self.timeout_s)
@@ -242,6 +244,11 @@ class Worker:
         proof = self.bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
         self.stats["prove_s"] += time.perf_counter() - t1
         self.stats["proved"] += 1
+        if self.self_check:
+            inputs = bytes(r1cs.raw("z")[32:32 * r1cs.n_in])   # [commitment, height, state, aux_data, next_state]
+            if not L.groth16_verify(work.vk(), inputs, proof):
+                self.stats["self_check_failed"] += 1
+                return None
         return proof
 
     def submit(self, proofs: dict[int, bytes]) -> int:
@@ -285,6 +292,7 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--poll", type=float, default=1.0)
     ap.add_argument("--rounds", type=int, default=None)
+    ap.add_argument("--self-check", action="store_true", help="verify every proof on the host (pairing check) before posting it")
     ap.add_argument("--sig-len-prefixed", action="store_true", help="node built against ed25519 < 1.3 (BZK_WORK_SIG_LEN_PREFIXED)")
     a = ap.parse_args(argv)
     host, port = a.node.rsplit(":", 1)
@@ -299,7 +307,7 @@ def main(argv=None):
     if bool(a.dev_toxic) == bool(a.params):
         ap.error("exactly one of --dev-toxic / --params")
     keys = BellmanKeys(bzk, dict(enumerate(a.params))) if a.params else DevSetup(bzk, {k: toxic(k) for k in range(3)})
-    w = Worker(bzk, address, (host, int(port)), keys, flags=1 if a.sig_len_prefixed else 0)
+    w = Worker(bzk, address, (host, int(port)), keys, flags=1 if a.sig_len_prefixed else 0, self_check=a.self_check)
     try:
         w.register()
         w.run_forever(a.poll, a.rounds)

@@ -187,7 +187,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     # the latency-bound tails of one proof (bucket reduction, window sums, batched inversions) overlap the
     # throughput-bound bucket accumulation of the other.
     from bazuka_amd import Bzk
-    n_slots = max(1, int(os.environ.get("BZK_BENCH_SLOTS", "3")))
+    n_slots = max(1, int(os.environ.get("BZK_BENCH_SLOTS", "4")))
     slots = [(ctx, ph)]
     for _ in range(n_slots - 1):
         cx = Bzk(ctx.device)
@@ -278,6 +278,15 @@ def other_configs_section(ctx, dev):
                         "alu": {"fr_products_per_hash_sparse": 1184, "note": "integer-ALU bound: 9 x 29-bit Fr, sparse partial rounds"},
                         "kernel_ms": kernels(lambda: ctx.merkle4_root_dev(leaves, 12))}
     del leaves
+    # configs[4], secondary instance: the MPN-shaped state - 4^9 accounts x (64 H2 + 21 H4 + 1 H5) + the account tree
+    n_acct, ts = 1 << 18, 64
+    cells, toks = rand_fr(n_acct * 4, 9), rand_fr(n_acct * ts * 2, 93)
+    ms = timeit(lambda: ctx.mpn_state_compress_dev(9, 3, cells, toks))
+    hashes = n_acct * (ts + (ts - 1) // 3 + 1) + (n_acct - 1) // 3
+    out["mpn_state_4p9_accounts"] = {"workload": "BASELINE configs[4] secondary: compress of a dense List{9, Struct{S,S,S,S,List{3,Struct{S,S}}}} state (262 144 accounts)",
+                                     "ms": round(ms, 3), "Mhash_per_s": round(hashes / ms / 1e3, 2), "hashes": hashes,
+                                     "roofline": hbm(32.0 * n_acct * (4 + 2 * ts) + 32.0 * hashes, ms)}
+    del cells, toks
     # NTT (a4): 64 B per element per transform in one HBM round trip, coset forward = the h stage's variant
     for lg in (20, 24):
         d = rand_fr(1 << lg, lg)

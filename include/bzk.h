@@ -118,6 +118,10 @@ int32_t bzk_tree4_node(bzk_ctx* ctx, const bzk_tree4* tree, uint32_t depth, uint
  *   get_accounts : per account 5 + 2 * 4^T scalars: the 4 cells, tokens_root (`MpnAccount::tokens_hash`), then every token slot
  *   prove        : log4_tree sibling triples per account (the transitions' `proof` / `src_proof` / `dst_proof`)
  *   prove_token  : log4_token_tree sibling triples per (account, token slot) (the `*_balance_proof`s) */
+/* `ZkStateModel::compress` of a DENSE MPN-shaped state resident in HBM (BASELINE configs[4], secondary instance): cells_dev = 4^L x 4
+ * scalars, tokens_dev = 4^L x 4^T x 2 scalars; one dense launch per level (H2 token slots, T x H4, H5 per account, L x H4). L <= 12. */
+int32_t bzk_mpn_state_compress_dev(bzk_ctx* ctx, uint32_t log4_tree, uint32_t log4_token_tree, const void* cells_dev, const void* tokens_dev,
+                                   uint8_t root[32]);
 typedef struct bzk_mpn_tree bzk_mpn_tree;
 int32_t bzk_mpn_tree_create(bzk_ctx* ctx, uint32_t log4_tree, uint32_t log4_token_tree, uint64_t capacity, bzk_mpn_tree** out);
 void    bzk_mpn_tree_free(bzk_ctx* ctx, bzk_mpn_tree* tree);
@@ -220,6 +224,11 @@ int32_t bzk_bellman_params_encode(const uint8_t vk870[870], const uint8_t* ic, u
                                   uint8_t* out, uint64_t cap, uint64_t* size_out);
 int32_t bzk_params_load_bellman(bzk_ctx* ctx, const uint8_t* bytes, uint64_t len, uint32_t n_in, uint32_t n_aux, const uint8_t* a_density,
                                 const uint8_t* b_density, bzk_params** out, uint8_t* vk_out, uint64_t vk_cap);
+/* `groth16_verify` (src/zk/groth16/mod.rs:67-121; bellman `verify_proof`): host code, no GPU.  vk = bincode(Groth16VerifyingKey)
+ * (870 + 8 + 97 n bytes, n = n_inputs + 1); inputs = n_inputs Montgomery scalars (the reference passes commitment, height, state,
+ * aux_data, next_state).  Returns 1 (verifies), 0 (does not - incl. malformed or off-curve points, for which the reference returns
+ * false), negative on bad arguments.  ~20 ms on one core. */
+int32_t bzk_groth16_verify(const uint8_t* vk, uint64_t vk_len, const uint8_t* inputs, uint32_t n_inputs, const uint8_t proof[387]);
 /* reads a CRS component back (tests): which = 0 vk (870 B), 1 h, 2 l, 3 a, 4 b_g1, 5 b_g2 */
 int32_t bzk_params_read(bzk_ctx* ctx, const bzk_params* params, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out);
 

@@ -121,3 +121,36 @@ def test_production_depth_same_root_and_proofs_as_the_witness_builders_state(bzk
         assert bzk.mpn_tree_root(tree) == work["public_inputs"]["next_state"] == w.root()
     finally:
         bzk.mpn_tree_free(tree)
+
+
+@pytest.mark.parametrize("L4,T4", [(3, 2), (4, 1), (2, 3)])
+def test_dense_state_compress_equals_restatement_and_device_tree(bzk, L4, T4):
+    """bzk_mpn_state_compress_dev = `ZkStateModel::compress` of a fully populated MPN-shaped state (BASELINE configs[4], secondary
+    instance): root == the state manager restatement == the device-resident tree after setting every account"""
+    import torch
+    from util import to_dev
+    rnd = random.Random(100 * L4 + T4)
+    n_acct, ts = 4 ** L4, 4 ** T4
+    py = PyMpnState(L4, T4)
+    cells, toks, batch = [], [], []
+    for a in range(n_acct):
+        c = [rnd.randrange(1 << 32), rnd.randrange(1 << 32), rnd.randrange(pr.R_MOD), rnd.randrange(pr.R_MOD)]
+        t = {s: (rnd.randrange(pr.R_MOD), rnd.randrange(1 << 64)) if rnd.random() < 0.7 else (0, 0) for s in range(ts)}
+        py.set_account(a, c, t)
+        cells += [F(x) for x in c]
+        for s in range(ts):
+            toks += [F(t[s][0]), F(t[s][1])]
+        batch.append((a, [F(x) for x in c], {s: (F(t[s][0]), F(t[s][1])) for s in range(ts)}))
+    root = bzk.mpn_state_compress_dev(L4, T4, to_dev(b"".join(cells)), to_dev(b"".join(toks)))
+    assert root == F(py.root())
+    tree = bzk.mpn_tree_create(L4, T4, n_acct)
+    try:
+        bzk.mpn_tree_set_accounts(tree, batch)
+        assert bzk.mpn_tree_root(tree) == root
+    finally:
+        bzk.mpn_tree_free(tree)
+    # the empty dense state is the default chain
+    z = torch.zeros(n_acct * 4 * 32, dtype=torch.uint8, device="cuda")
+    zt = torch.zeros(n_acct * ts * 2 * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    assert bzk.mpn_state_compress_dev(L4, T4, z, zt) == F(PyMpnState(L4, T4).root())

@@ -44,7 +44,8 @@ def test_worker_proves_a_block_of_works_and_the_node_accepts(bzk):
     node = MockNode(blobs)
     try:
         rnd = iter(range(1, 1000))
-        alice = W.Worker(bzk, ALICE, ("127.0.0.1", node.port), keys, rng=lambda n: bytes([next(rnd)]) * n)
+        # self_check: every proof passes the product's own host-side groth16_verify (the node's check) before it is posted
+        alice = W.Worker(bzk, ALICE, ("127.0.0.1", node.port), keys, rng=lambda n: bytes([next(rnd)]) * n, self_check=True)
         # a solution is bound to its prover: Mallory re-posting Alice's proofs under her own address gets nothing
         proofs = {wid: alice.prove(work) for wid, work in alice.fetch().items()}
         assert all(p is not None and len(p) == 387 for p in proofs.values()) and alice.stats["proved"] == 3
@@ -55,7 +56,14 @@ def test_worker_proves_a_block_of_works_and_the_node_accepts(bzk):
         assert alice.run_once() == 3
         assert node.solved == {0: ALICE, 1: ALICE, 2: ALICE}
         assert alice.fetch() == {} and alice.run_once() == 0     # nothing left to do
-        assert alice.stats["accepted"] == 3 and alice.stats["unsat"] == 0
+        assert alice.stats["accepted"] == 3 and alice.stats["unsat"] == 0 and alice.stats["self_check_failed"] == 0
+        # the product verifier and the mock node's oracle pairing check agree on every posted proof, and it binds the prover:
+        # Alice's proof fails under Mallory's commitment
+        for wid, blob in blobs.items():
+            wk = L.MpnWork.decode(blob)
+            ok_inputs = wk.commitment(ALICE) + pr.fr_to_mont_bytes(wk.height) + wk.state + wk.aux_data + wk.next_state
+            bad_inputs = wk.commitment(MALLORY) + ok_inputs[32:]
+            assert L.groth16_verify(wk.vk(), ok_inputs, proofs[wid]) and not L.groth16_verify(wk.vk(), bad_inputs, proofs[wid])
     finally:
         node.close()
         keys.close()

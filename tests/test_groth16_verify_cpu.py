@@ -1,0 +1,76 @@
+"""Row a8 in the product: bzk_groth16_verify (host C++, bazuka_amd/csrc/host_pairing.hip) = `groth16_verify`
+(src/zk/groth16/mod.rs:67-121) against the oracle's Python verifier on oracle-made proofs (C++ oracle setup + prove on the CPU):
+same verdict on a valid proof, a wrong public input, a tampered proof, swapped proof elements, an off-curve point; the reference's
+own acceptance case - the empty 4-slot Update circuit with inputs [456, 0, 123, H2(1, 0), 123] (src/mpn/circuits/test.rs:117-149)."""
+import time
+
+import pytest
+
+from bazuka_amd import lib as L
+from oracle import pyref as pr
+from util import fr_bytes, fr_list, log2_ceil, r1cs_to_csr, synth_r1cs
+
+F = pr.fr_to_mont_bytes
+
+
+def _vk_bytes(params):
+    return params["vk"] + (len(params["ic"]) // 97).to_bytes(8, "little") + params["ic"]
+
+
+@pytest.mark.parametrize("n_mul,n_in", [(40, 3), (300, 6)])
+def test_same_verdict_as_the_oracle_verifier(co, n_mul, n_in):
+    r1 = synth_r1cs(n_mul, n_in=n_in, seed=500 + n_mul)
+    A, B, Cm = r1cs_to_csr(co, r1)
+    params = co.groth16_setup(A, B, Cm, r1["n_in"], r1["n_aux"], log2_ceil(len(r1["rows"])), fr_bytes(fr_list(5, 77)))
+    zb = fr_bytes(r1["z"])
+    az, bz, cz = co.r1cs_eval(A, B, Cm, zb)
+    rs = fr_bytes(fr_list(2, 9))
+    proof = co.groth16_prove(params, zb, az, bz, cz, rs[:32], rs[32:])
+    vkb = _vk_bytes(params)
+    vk = pr.vk_from_bytes(vkb)
+    pub = r1["z"][1:n_in]
+    inputs = fr_bytes(pub)
+    t0 = time.perf_counter()
+    assert L.groth16_verify(vkb, inputs, proof) is True
+    dt = time.perf_counter() - t0
+    assert pr.groth16_verify(vk, pub, pr.proof_from_bytes(proof))
+    cases = {
+        "wrong input": (vkb, fr_bytes([pub[0] + 1] + pub[1:]), proof),
+        "a and c swapped": (vkb, inputs, proof[290:387] + proof[97:290] + proof[0:97]),
+        "tampered c.x": (vkb, inputs, proof[:290] + bytes([proof[290] ^ 1]) + proof[291:]),      # off the curve
+        "identity a": (vkb, inputs, pr.g1_to_bytes(None) + proof[97:]),
+        "fewer inputs": (vkb, inputs[:-32], proof),
+    }
+    for name, (v, i, p) in cases.items():
+        assert L.groth16_verify(v, i, p) is False, name
+    # a DIFFERENT valid proof of the same statement (other r, s) also verifies; negating a and b together does too (e(-A, -B) = e(A, B))
+    rs2 = fr_bytes(fr_list(2, 10))
+    assert L.groth16_verify(vkb, inputs, co.groth16_prove(params, zb, az, bz, cz, rs2[:32], rs2[32:]))
+    a, b = pr.g1_from_bytes(proof[:97]), pr.g2_from_bytes(proof[97:290])
+    neg = pr.g1_to_bytes((a[0], (-a[1]) % pr.P_MOD)) + pr.g2_to_bytes((b[0], ((-b[1][0]) % pr.P_MOD, (-b[1][1]) % pr.P_MOD))) + proof[290:]
+    assert L.groth16_verify(vkb, inputs, neg) and pr.groth16_verify(vk, pub, pr.proof_from_bytes(neg))
+    assert dt < 2.0
+
+
+def test_the_references_own_acceptance_case(co):
+    """src/mpn/circuits/test.rs:117-149: MpnCircuit::empty(3, 3, 1) with commitment 456, height 0, state = next_state = 123,
+    aux = H2(fee_token Ziesha = 1, fee sum 0): proved on the CPU oracle, accepted by the product verifier"""
+    aux = pr.poseidon([1, 0])
+    r = L.mpn_update_empty(3, 3, 1, F(456), 0, F(123), F(aux), F(123), F(1), record_matrices=True)
+    assert r.satisfied
+    csr = [co.CsrHolder(r.n_constraints, list(memoryview(r.view("rp" + w)).cast("I")), list(memoryview(r.view("col" + w)).cast("I")), r.view("val" + w))
+           for w in "ABC"]
+    params = co.groth16_setup(*csr, r.n_in, r.n_aux, 17, fr_bytes(fr_list(5, 123)), nthreads=co.ncpu())
+    z = r.view("z")
+    rs = fr_bytes(fr_list(2, 11))
+    proof = co.groth16_prove(params, z, r.view("az"), r.view("bz"), r.view("cz"), rs[:32], rs[32:], nthreads=co.ncpu())
+    vkb = _vk_bytes(params)
+    inputs = F(456) + F(0) + F(123) + F(aux) + F(123)
+    assert z[32:192] == inputs
+    assert L.groth16_verify(vkb, inputs, proof)
+    assert not L.groth16_verify(vkb, F(456) + F(1) + F(123) + F(aux) + F(123), proof)   # another height
+    # the three hard-coded verifying keys of the reference decode (src/config/blockchain.rs:32-37): a proof for another key is refused
+    import json, os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for hexvk in json.load(open(os.path.join(G, "reference_vectors.json")))["verifying_keys_bincode_hex"]:
+        assert L.groth16_verify(bytes.fromhex(hexvk), inputs, proof) is False
