@@ -415,8 +415,9 @@ class Bzk:
         out = C.create_string_buffer(max(1, n * rec * 32))
         self._ck(self.lib.bzk_mpn_tree_get_accounts(self.h, tree, (_u64 * max(1, n))(*indices), n, out), "mpn_tree_get_accounts")
         res = []
+        raw = out.raw  # ONE copy of the buffer (`.raw` copies on every access)
         for a in range(n):
-            sc = [out.raw[32 * (a * rec + j):32 * (a * rec + j + 1)] for j in range(rec)]
+            sc = [raw[32 * (a * rec + j):32 * (a * rec + j + 1)] for j in range(rec)]
             toks = {i: (sc[5 + 2 * i], sc[6 + 2 * i]) for i in range(ts) if sc[5 + 2 * i] != bytes(32)}
             res.append({"cells": sc[:4], "tokens_root": sc[4], "tokens": toks})
         return res
