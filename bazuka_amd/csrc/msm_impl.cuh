@@ -3,18 +3,22 @@
 // Replaces bellman 0.14 `multiexp` (third-party crate behind `create_random_proof`,
 // /root/reference/src/mpn/circuits/test.rs:135) - the h / l / a / b_g1 / b_g2 queries of a proof.
 //
-// Pipeline (all on the ctx stream, data stays in HBM):
+// Pipeline (on the ctx stream unless noted, data stays in HBM):
+//   0. msm_convert     raw 96-byte bases -> internal 112-byte form, on the call's SIDE stream (joined before step 5)
 //   1. msm_digits      one lane per scalar: Montgomery -> canonical, signed c-bit window recoding,
 //                      emits (bucket key, point index | sign) pairs, window-major => coalesced stores
 //   2. radix sort      rocPRIM pair sort by bucket key (HBM-bound streaming passes)
 //   3. msm_offsets     bucket boundaries from the sorted keys
-//   4. size sort       buckets ordered by population (descending) so the 64 lanes of a wavefront
-//                      run equally long accumulation loops (no lane idles behind a long bucket)
-//   5. msm_accumulate  one lane per bucket: gathers its affine points (6 x 16 B loads each) and
-//                      folds them with XYZZ mixed adds                      <-- dominant kernel
+//   4. size sort       buckets ordered by population (descending, on 16-bit clamped counts) so the 64 lanes of a
+//                      wavefront run equally long accumulation loops; task table (runs of <= seg entries)
+//   5. msm_accumulate  one lane per TASK: gathers its affine points (7 x 16 B loads each) and folds them with XYZZ
+//                      mixed adds                                           <-- dominant kernel
+//      msm_fold*       partial sums of multi-task buckets (regime picked on the device, see msm_fold_threshold)
 //   6. msm_reduce      per chunk of CH buckets: running-sum  sum (b+1) B_b  (+ chunk offset)
-//   7. msm_window_sum  per window: LDS tree over the chunk results
+//   7. msm_window_sum  per window: LDS trees over the chunk results
 //   8. host            Horner over <= 32 window sums, to affine, pack
+// With BZK_F_DEDUP (section 8) equal scalars are merged first: 32-bit hash sort, group sums through steps 4 - 5, batched
+// to-affine with the binary-GCD inversion, then the pipeline above over the distinct scalars.
 // MFMA is not used anywhere: the arithmetic is 32-bit integer carry chains.
 #pragma once
 #include <string.h>
@@ -717,13 +721,11 @@ struct BucketArrays {
 template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
                                  uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
-                                 bool group_sums = false, bool have_counts = false) {
-    if (!have_counts) {  // boundaries from a sorted key list (keys_s == nullptr with have_counts: A.start / A.count are filled)
-        BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
-        BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
-        BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
-        BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, nb);
-    }
+                                 bool group_sums = false) {
+    BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
+    BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
+    BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
+    BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, nb);
     // clamped population keys: A.ntask holds them until msm_ntask overwrites it, A.tbase receives the (unused) sorted keys
     BZK_LAUNCH(ctx, "msm_iota_clamp", msm_iota_clamp_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.iota, A.ntask, nb);
     {
