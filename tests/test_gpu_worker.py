@@ -92,3 +92,38 @@ def test_dev_setup_disk_cache_gives_the_same_keys_and_proofs(bzk, tmp_path):
     assert proofs[0] is not None and proofs[0] == proofs[1]
     first.close()
     again.close()
+
+
+def test_worker_with_bellman_parameter_files(bzk, tmp_path):
+    """a network ships its proving keys as bellman `Parameters` files: the worker loads them (worker.BellmanKeys ->
+    bzk_params_load_bellman with the density maps of the circuit shape), proves a work, the node's pairing check accepts; a file of
+    another circuit kind is refused by its lengths / verifying key instead of producing a proof nobody accepts"""
+    dev = W.DevSetup(bzk, {k: fr_bytes(fr_list(5, 9100 + k)) for k in range(3)})
+    paths, vks = {}, []
+    for kind in range(3):
+        ph, vk = dev.keys(kind, 3, 3, 1)
+        vks.append(vk)
+        parts = [bzk.params_read(ph, which) for which in range(6)]
+        path = tmp_path / f"kind{kind}.params"
+        path.write_bytes(L.bellman_params_encode(parts[0], vk[878:], *parts[1:]))
+        paths[kind] = str(path)
+    w = L.MpnWorld(3, 3)
+    for i in range(3):
+        w.add_account(i, b"acct%d" % i, ZIESHA, 10 ** 9)
+    w.set_height(5)
+    w.push_tx(0, 1, ZIESHA, 77, ZIESHA, 2)
+    w.push_tx(1, 2, ZIESHA, 5, ZIESHA, 0)
+    blobs = {4: w.make_work(2, vks, 900).encode()}
+    node = MockNode(blobs)
+    keys = W.BellmanKeys(bzk, paths)
+    try:
+        alice = W.Worker(bzk, ALICE, ("127.0.0.1", node.port), keys, self_check=True)
+        assert alice.run_once() == 1 and node.solved == {4: ALICE} and alice.stats["self_check_failed"] == 0
+        # the deposit key offered for the update circuit: array lengths do not fit the shape
+        wrong = W.BellmanKeys(bzk, {2: paths[0]})
+        with pytest.raises(L.BzkError):
+            wrong(L.MpnWork.decode(blobs[4]))
+    finally:
+        node.close()
+        keys.close()
+        dev.close()
