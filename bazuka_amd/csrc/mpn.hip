@@ -1423,6 +1423,20 @@ int32_t bzk_mpn_work_commitment(const bzk_mpn_work* h, const uint8_t prover_pub[
     return BZK_OK;
 }
 
+// `MpnWork::verify(prover, proof)` (src/mpn/mod.rs:281-295): groth16_verify under the work's key with the public inputs
+// [H(prover, reward), height, state, aux_data, next_state].  1 = accepted, 0 = refused, negative = bad arguments.  Host code.
+int32_t bzk_mpn_work_verify(const bzk_mpn_work* h, const uint8_t prover_pub[32], const uint8_t proof[387]) {
+    if (!h || !prover_pub || !proof) return BZK_E_ARG;
+    uint8_t in[160];
+    mpn_work_commitment(prover_pub, h->w.reward).to_bytes(in);
+    ZkScalar::from_u64(h->w.height).to_bytes(in + 32);
+    h->w.state.to_bytes(in + 64);
+    h->w.aux_data.to_bytes(in + 96);
+    h->w.next_state.to_bytes(in + 128);
+    const std::vector<uint8_t>& vk = h->w.vk();
+    return bzk_groth16_verify(vk.data(), vk.size(), in, 5, proof);
+}
+
 int32_t bzk_mpn_work_encode(const bzk_mpn_work* h, uint8_t* out, uint64_t cap, uint64_t* len) {
     if (!h) return BZK_E_ARG;
     try {

@@ -111,6 +111,7 @@ SIGNATURES = {
     "bzk_mpn_work_scalars": (_i32, [_vp, _vp]),
     "bzk_mpn_work_vk": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_u64)]),
     "bzk_mpn_work_commitment": (_i32, [_vp, _vp, _vp]),
+    "bzk_mpn_work_verify": (_i32, [_vp, _vp, _vp]),
     "bzk_mpn_work_synthesize": (_i32, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "bzk_mpn_work_encode": (_i32, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "bzk_mpn_make_work": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_vp)]),
@@ -678,6 +679,13 @@ class MpnWork:
         out = C.create_string_buffer(32)
         _st(self.lib.bzk_mpn_work_commitment(self.h, _ptr(prover_pub), out), "work_commitment")
         return out.raw
+
+    def verify(self, prover_pub: bytes, proof387: bytes) -> bool:
+        """`MpnWork::verify` (src/mpn/mod.rs:281-295), on the host"""
+        st = self.lib.bzk_mpn_work_verify(self.h, _ptr(prover_pub), _ptr(proof387))
+        if st < 0:
+            raise BzkError(f"work_verify: {self.lib.bzk_strerror(st).decode()}")
+        return st == 1
 
     def encode(self) -> bytes:
         n = _u64()

@@ -245,8 +245,7 @@ class Worker:
         self.stats["prove_s"] += time.perf_counter() - t1
         self.stats["proved"] += 1
         if self.self_check:
-            inputs = bytes(r1cs.raw("z")[32:32 * r1cs.n_in])   # [commitment, height, state, aux_data, next_state]
-            if not L.groth16_verify(work.vk(), inputs, proof):
+            if not work.verify(self.address, proof):   # MpnWork::verify: the node's own acceptance test
                 self.stats["self_check_failed"] += 1
                 return None
         return proof

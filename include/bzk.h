@@ -326,6 +326,8 @@ int32_t bzk_mpn_work_vk(const bzk_mpn_work* work, int32_t which, uint8_t* out, u
 /* ZkScalar::new(sha3_256(bincode((prover, reward)))) - the commitment `MpnWork::verify` binds a solution to
  * (src/mpn/mod.rs:281-295); prover_pub = the worker's 32-byte ed25519 address */
 int32_t bzk_mpn_work_commitment(const bzk_mpn_work* work, const uint8_t prover_pub[32], uint8_t out[32]);
+/* `MpnWork::verify(prover, proof)` (src/mpn/mod.rs:281-295) on the host: 1 accepted / 0 refused / negative bad arguments */
+int32_t bzk_mpn_work_verify(const bzk_mpn_work* work, const uint8_t prover_pub[32], const uint8_t proof[387]);
 /* the circuit instance to prove: transitions padded with null ones to 4^batch; fee_token NULL = Ziesha; threads 0 = all */
 int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* work, const uint8_t prover_pub[32], const uint8_t fee_token[32],
                                 int32_t threads, int32_t record_matrices, bzk_r1cs** out);

@@ -64,6 +64,7 @@ def test_worker_proves_a_block_of_works_and_the_node_accepts(bzk):
             ok_inputs = wk.commitment(ALICE) + pr.fr_to_mont_bytes(wk.height) + wk.state + wk.aux_data + wk.next_state
             bad_inputs = wk.commitment(MALLORY) + ok_inputs[32:]
             assert L.groth16_verify(wk.vk(), ok_inputs, proofs[wid]) and not L.groth16_verify(wk.vk(), bad_inputs, proofs[wid])
+            assert wk.verify(ALICE, proofs[wid]) and not wk.verify(MALLORY, proofs[wid])
     finally:
         node.close()
         keys.close()

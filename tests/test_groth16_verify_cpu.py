@@ -74,3 +74,32 @@ def test_the_references_own_acceptance_case(co):
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     for hexvk in json.load(open(os.path.join(G, "reference_vectors.json")))["verifying_keys_bincode_hex"]:
         assert L.groth16_verify(bytes.fromhex(hexvk), inputs, proof) is False
+
+
+def test_mpn_work_verify_binds_the_prover(co):
+    """bzk_mpn_work_verify = `MpnWork::verify` (src/mpn/mod.rs:281-295): a deposit work proved on the CPU oracle against an oracle-made key is
+    accepted for its prover and refused for another address, another work, a tampered proof"""
+    ZIESHA = F(1)
+    alice, mallory = bytes(range(1, 33)), bytes(range(101, 133))
+    shape = L.mpn_circuit_empty(0, 3, 3, 1, bytes(32), 0, bytes(32), bytes(32), bytes(32), record_matrices=True)
+    csr = [co.CsrHolder(shape.n_constraints, list(memoryview(shape.view("rp" + w)).cast("I")), list(memoryview(shape.view("col" + w)).cast("I")),
+                        shape.view("val" + w)) for w in "ABC"]
+    params = co.groth16_setup(*csr, shape.n_in, shape.n_aux, 16, fr_bytes(fr_list(5, 321)), nthreads=co.ncpu())
+    vkb = _vk_bytes(params)
+    w = L.MpnWorld(3, 3)
+    w.add_account(0, b"acct0", ZIESHA, 10 ** 9)
+    w.add_key(5, b"newcomer")
+    w.set_height(3)
+    w.push_deposit(0, ZIESHA, 10)
+    w.push_deposit(5, ZIESHA, 20)
+    work = L.MpnWork.decode(w.make_work(0, [vkb, vkb, vkb], 77).encode())
+    r = work.synthesize(alice)
+    assert r.satisfied
+    rs = fr_bytes(fr_list(2, 12))
+    proof = co.groth16_prove(params, r.view("z"), r.view("az"), r.view("bz"), r.view("cz"), rs[:32], rs[32:], nthreads=co.ncpu())
+    assert work.verify(alice, proof) is True
+    assert work.verify(mallory, proof) is False                       # the commitment binds the proof to its prover
+    assert work.verify(alice, proof[:100] + bytes([proof[100] ^ 1]) + proof[101:]) is False
+    w.push_deposit(0, ZIESHA, 11)
+    other = L.MpnWork.decode(w.make_work(0, [vkb, vkb, vkb], 77).encode())
+    assert other.verify(alice, proof) is False                        # another state transition
