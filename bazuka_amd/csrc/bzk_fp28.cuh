@@ -670,6 +670,53 @@ BZK_HD void add_full(G1X28& acc, const G1X28& q) {  // add-2008-s
     acc.ZZZ = mul(mul(acc.ZZZ, q.ZZZ), PPP);
 }
 
+// acc += *q with q left in memory (LDS or global): every coordinate of q is read where the formula uses it, so only acc and the
+// formula's temporaries stay in registers.  For msm_reduce: with `run` / `acc` / the loaded bucket all resident the kernel needs 354
+// registers (one wave per SIMD, 180 of them parked in accumulation registers); in this form it fits the 256-register budget of two
+// waves per SIMD and can share a SIMD with an accumulate wave of another MSM.  Same formula and case analysis as add_full.
+BZK_HD void add_mem(G1X28& acc, const G1X28* q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BZK_G1_FENCE() __asm__ volatile("" ::: "memory")
+#else
+#define BZK_G1_FENCE() ((void)0)
+#endif
+    {
+        const Fp28 qzz = q->ZZ;
+        if (limbs_all_zero(qzz)) return;  // q is the identity
+        if (is_identity(acc)) {
+            acc = *q;
+            return;
+        }
+    }
+    BZK_G1_FENCE();
+    Fp28 U1 = mul(acc.X, q->ZZ);
+    BZK_G1_FENCE();
+    Fp28 U2 = mul(q->X, acc.ZZ);
+    Fp28 Pp = sub<3>(U2, U1);
+    BZK_G1_FENCE();
+    Fp28 S1 = mul(acc.Y, q->ZZZ);
+    BZK_G1_FENCE();
+    Fp28 S2 = mul(q->Y, acc.ZZZ);
+    Fp28 R = sub<3>(S2, S1);  // k 5
+    Fp28 PP = sqr(Pp);
+    if (mulout_is_zero(PP)) {
+        Fp28 RR = sqr(R);
+        if (mulout_is_zero(RR)) acc = dbl(acc);
+        else acc = identity();
+        return;
+    }
+    Fp28 PPP = mul(Pp, PP), Q = mul(U1, PP), RR = sqr(R);
+    Fp28 X3 = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));
+    Fp28 Y3 = norm(sub<3>(mul(R, sub<12>(Q, X3)), mul(S1, PPP)));
+    acc.X = X3;
+    acc.Y = Y3;
+    BZK_G1_FENCE();
+    acc.ZZ = mul(mul(acc.ZZ, q->ZZ), PP);
+    BZK_G1_FENCE();
+    acc.ZZZ = mul(mul(acc.ZZZ, q->ZZZ), PPP);
+#undef BZK_G1_FENCE
+}
+
 BZK_HD G1X28 mul_u32(const G1X28& p, uint32_t k) {
     G1X28 r = identity();
     for (int i = 31; i >= 0; --i) {

@@ -23,7 +23,16 @@ struct G1Fast {
     static constexpr bool CONVERT_BASES = true;
     static constexpr int WSUM_THREADS = 256;  // 256 x 224 B = 56 KiB LDS
     static constexpr int ACC_OCC = 2;
-    static constexpr bool PARK_REDUCE = false;  // two resident G1 points + temporaries fit the register file
+#ifndef BZK_G1_PARK_REDUCE
+#define BZK_G1_PARK_REDUCE 0
+#endif
+    // 1: msm_reduce / folds / window sums keep ONE point in registers and read the second operand from memory (as G2 always does):
+    // msm_reduce drops from 354 registers (one wave per SIMD) to 256 (two per SIMD; it could share a SIMD with an accumulate wave of
+    // another MSM).  Built and MEASURED in round 2, no gain: msm_reduce 0.65 -> 0.68 ms at 2^20 and 0.63 -> 0.97 ms
+    // at 2^22 / 2^24, inside a proof 0.66 - 0.71 -> 0.70 - 1.05 ms, pipelined proofs/s unchanged (profiles/r02_run16_g1_park_reduce.txt):
+    // the kernel is bound by its products, and the register-resident form issues fewer loads.  0 (default): both points resident.
+    static constexpr bool PARK_REDUCE = BZK_G1_PARK_REDUCE != 0;
+    __device__ static __forceinline__ void add_mem(Pt& acc, const Pt* q) { g1x28::add_mem(acc, q); }
     __device__ static __forceinline__ Pt identity() { return g1x28::identity(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p, bool neg) { g1x28::add_mixed(acc, p, neg); }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { g1x28::add_full(acc, q); }
