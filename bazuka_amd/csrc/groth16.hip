@@ -27,6 +27,10 @@ struct bzk_params {
     void *h, *l, *a, *b_g1, *b_g2;      // device CRS
     uint32_t *a_idx, *b_idx;            // device: variable index of each dense entry
     void *d_z, *d_a, *d_b, *d_c, *d_sa, *d_sb;  // device scratch sized for this circuit
+    // static-base table of the h query (built on the first proof): the h bases never change and their scalars are never
+    // de-duplicated, so all windows can share one bucket set at a window size of ~log2 m (fewer windows = fewer additions)
+    bzk_msm_table* h_table;
+    bool h_table_tried;
 };
 
 namespace bzk {
@@ -130,6 +134,7 @@ void bzk_params_free(bzk_ctx* ctx, bzk_params* p) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
+    if (p->h_table) bzk_msm_table_free(ctx, p->h_table);
     void* bufs[] = {p->h, p->l, p->a, p->b_g1, p->b_g2, p->a_idx, p->b_idx, p->d_z, p->d_a, p->d_b, p->d_c, p->d_sa, p->d_sb};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -248,6 +253,19 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
     // sums, 97-byte read-back) that leaves most CUs idle.  They run on separate lanes (stream + workspace each,
     // one host thread per lane) so that one MSM's tail overlaps another's accumulation; l, a, b only need z, so
     // they start while az/bz/cz are still being copied and the h polynomial is computed on the main stream.
+    // h-query table: 2^16 .. 2^21 domains (13 levels x 112 B x m: 1.5 GB at 2^20, 3 GB at 2^21 - the production 2^24 domain would
+    // need 24 GB per prover slot and keeps the per-call pipeline); env BZK_PROVE_H_TABLE=0 switches it off (A/B runs)
+    if (!p->h_table_tried) {
+        p->h_table_tried = true;
+        static const bool want = [] { const char* e = getenv("BZK_PROVE_H_TABLE"); return !e || atoi(e) != 0; }();
+        if (want && p->log_m >= 16 && p->log_m <= 21) {
+            const uint32_t c = p->log_m > 20 ? 20u : p->log_m;
+            if (bzk_msm_g1_table_build_c(ctx, p->h, m - 1, c, &p->h_table) != BZK_OK) {
+                p->h_table = nullptr;  // not enough memory: the per-call pipeline works without it
+                (void)hipGetLastError();
+            }
+        }
+    }
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     bzk_ctx* lane[3];
@@ -321,6 +339,7 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
                 BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
         }
         BZK_TRY(groth16_h(ctx, p->d_a, p->d_b, p->d_c, p->log_m));
+        if (p->h_table) return bzk_msm_g1_table_run_dev(ctx, p->h_table, p->d_a, m - 1, 0, pH);
         return bzk_msm_g1_dev(ctx, p->h, p->d_a, m - 1, 0, pH);
     };
     const auto t2 = clk::now();

@@ -50,6 +50,12 @@ int32_t bzk_msm_g1_table_build_levels(bzk_ctx* ctx, const void* bases_dev, uint6
     if (out) *out = (bzk_msm_table*)t;
     return st;
 }
+int32_t bzk_msm_g1_table_build_c(bzk_ctx* ctx, const void* bases_dev, uint64_t n, uint32_t c, bzk_msm_table** out) {
+    MsmTable* t = nullptr;
+    int32_t st = msm_table_build<G1Fast>(ctx, bases_dev, n, &t, 0, (int)c);
+    if (out) *out = (bzk_msm_table*)t;
+    return st;
+}
 int32_t bzk_msm_g1_table_run_dev(bzk_ctx* ctx, const bzk_msm_table* table, const void* scalars_dev, uint64_t n, uint32_t flags,
                                  uint8_t out[97]) {
     return msm_table_entry<G1Fast>(ctx, (const MsmTable*)table, scalars_dev, n, flags, 0, -1, out);

@@ -203,7 +203,7 @@ static __global__ void __launch_bounds__(256) msm_iota_clamp_kernel(const uint32
 // 16 k-pair tile with LDS cursors, then one workgroup per bin producing the bucket boundaries directly.  Measured on the c = 16
 // sizes: 0.56 ms against 0.47 ms at 2^20 points, 3.1 against 1.7 ms at 2^22, 12.5 against 6.7 ms at 2^24
 // (profiles/r02_run6_psort_ab.txt) - the tile scatter leaves 32-byte runs per bin (uncoalesced 4-byte stores) where onesweep
-// orders a tile in LDS before it writes; a c = 15 case later disagreed with the oracle.  Slower and not clean: gone.
+// orders a tile in LDS before it writes.  Slower: gone.
 // ------------------------------------------------------------------------------------------------
 
 // ------------------------------------------------------------------------------------------------
@@ -1100,7 +1100,7 @@ static int32_t msm_entry_host(bzk_ctx* ctx, const uint8_t* bases, const uint8_t*
 }
 
 template <class C>
-static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, MsmTable** out, int levels_req = 0) {
+static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, MsmTable** out, int levels_req = 0, int c_req = 0) {
     if (!ctx || !out || !bases_raw || n == 0 || levels_req < 0) return BZK_E_ARG;
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
@@ -1109,6 +1109,7 @@ static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, 
         int v = atoi(e);
         if (v >= 4 && v <= 20) c = v;
     }
+    if (c_req >= 4 && c_req <= 22) c = c_req;  // explicit window size (a full table affords c ~ log2 n: the buckets are shared by all windows)
     const int w_total = msm_windows_for(c);
     // levels_req = 0 (or >= W): full table, one level per window; otherwise windows per level = ceil(W / levels_req)
     // and only as many levels as that leaves non-empty

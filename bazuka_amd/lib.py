@@ -95,6 +95,7 @@ SIGNATURES = {
     "bzk_host_jubjub_verify": (_i32, [_vp, _vp, _vp]),
     "bzk_msm_g1_table_build": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
     "bzk_msm_g2_table_build": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_msm_g1_table_build_c": (_i32, [_vp, _vp, _u64, _u32, C.POINTER(_vp)]),
     "bzk_msm_g1_table_build_levels": (_i32, [_vp, _vp, _u64, _u32, C.POINTER(_vp)]),
     "bzk_msm_g2_table_build_levels": (_i32, [_vp, _vp, _u64, _u32, C.POINTER(_vp)]),
     "bzk_msm_table_levels": (_u32, [_vp]),
@@ -331,6 +332,12 @@ class Bzk:
         self._ck(self.lib.bzk_msm_g2_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, flags, w0, w1, out), "msm_g2_windows_dev")
         return out.raw
 
+    def msm_table_build_c(self, bases, n: int, c: int):
+        """full G1 table with an explicit window size"""
+        h = C.c_void_p()
+        self._ck(self.lib.bzk_msm_g1_table_build_c(self.h, _ptr(bases), n, c, C.byref(h)), "msm_table_build_c")
+        return h
+
     def msm_table_build(self, bases, n: int, g2=False, levels: int = 0):
         """levels = 0: full table (one level per window); levels = L: folded table (see include/bzk.h)"""
         h = C.c_void_p()
@@ -496,10 +503,13 @@ class Bzk:
         self._ck(self.lib.bzk_groth16_h_dev(self.h, _ptr(a), _ptr(b), _ptr(c), log_m), "groth16_h_dev")
 
     def g1_synth_bases_dev(self, seed: int, start: int, n: int, out):
+        # test / bench helper: synchronised, so that a caller reading `out` through another stream (torch) cannot race the kernel
         self._ck(self.lib.bzk_g1_synth_bases_dev(self.h, seed, start, n, _ptr(out)), "g1_synth_bases_dev")
+        self.sync()
 
     def g2_synth_bases_dev(self, seed: int, start: int, n: int, out):
         self._ck(self.lib.bzk_g2_synth_bases_dev(self.h, seed, start, n, _ptr(out)), "g2_synth_bases_dev")
+        self.sync()
 
 
 # --------------------------------------------------------------------------------------------------

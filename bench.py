@@ -316,6 +316,17 @@ def other_configs_section(ctx, dev):
         sec["alu"] = {"achieved": round(g, 2), "peak": 60.1, "unit": "G Fp-mul/s", "frac": round(g / 60.1, 4),
                       "peak_source": "library product at 1 wave/SIMD (the G2 kernel's occupancy), profiles/r01_ubench_int.txt"}
     out["msm_g2_2p20"] = sec
+    # static bases (a Groth16 CRS is static): full table at c = 20 - 13 windows sharing one bucket set, no host Horner.  Informational:
+    # `value` of the headline stays the per-call pipeline on raw bases
+    gb = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+    ctx.g1_synth_bases_dev(SEED, 0, n, gb)
+    tab = ctx.msm_table_build_c(gb, n, 20)
+    ms = timeit(lambda: ctx.msm_table_run_dev(tab, sc, n))
+    same = ctx.msm_table_run_dev(tab, sc, n) == ctx.msm_g1_dev(gb, sc, n)
+    out["msm_g1_2p20_static_table"] = {"what": "2^20-point G1 MSM over a precomputed table 2^(20 w) P_i (13 levels, 1.5 GB): 13 additions per point instead of 16",
+                                       "ms": round(ms, 3), "Mpt_per_s": round(n / ms / 1e3, 2), "same_bytes_as_per_call_pipeline": same,
+                                       "kernel_ms": kernels(lambda: ctx.msm_table_run_dev(tab, sc, n))}
+    ctx.msm_table_free(tab)
     return out
 
 

@@ -360,6 +360,10 @@ int32_t bzk_host_jubjub_verify(const uint8_t pub_xy[64], const uint8_t msg[32], 
 typedef struct bzk_msm_table bzk_msm_table;
 int32_t bzk_msm_g1_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_table** out);
 int32_t bzk_msm_g2_table_build(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_table** out);
+/* full table with an explicit window size c (4 .. 22): every window shares one set of 2^(c-1) buckets, so c can grow to ~log2 n -
+ * fewer windows, i.e. fewer additions per point: 2^20 points, c = 20: 13 levels (1.5 GB), 3.93 ms against 4.32 ms for the per-call
+ * pipeline on raw bases (profiles/r02_run17_static_tables.txt).  What bzk_groth16_prove uses for the (static) h query. */
+int32_t bzk_msm_g1_table_build_c(bzk_ctx* ctx, const void* bases_dev, uint64_t n, uint32_t c, bzk_msm_table** out);
 /* folded table: `levels` L < W levels tab[j][i] = 2^(c wpl j) * base_i, wpl = ceil(W / L): windows j * wpl + w' share bucket
  * set w' - the same number of point additions, 1 / L of the buckets to reduce, L x the base memory (levels = 0 or >= W: the
  * full table).  For a folded table the `windows` range of *_table_windows_dev selects bucket sets [w_begin, w_end) of the

@@ -447,3 +447,24 @@ def test_msm_canonical_scalars_at_and_above_r(co, pr, c, monkeypatch):
         assert ctx.msm_g1(bases, fr_bytes(small, mont=False), canonical=True) == want
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("log_n,c", [(14, 14), (16, 16), (16, 19)])
+def test_msm_g1_full_table_with_explicit_window(bzk, co, log_n, c):
+    """bzk_msm_g1_table_build_c: a full static-base table whose window size is chosen by the caller (all windows share one bucket
+    set, so c ~ log2 n pays) - what bzk_groth16_prove builds for the h query: same bytes as the per-call pipeline and the oracle, for a
+    prefix of the bases too; witness-like scalars (skew inside the single bucket set)"""
+    n = 1 << log_n
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(500 + c, 0, n, bases)
+    hb = dev_bytes(bases)
+    tab = bzk.msm_table_build_c(bases, n, c)
+    try:
+        assert bzk.msm_table_window_count(tab) == (256 + c - 1) // c
+        for m, seed in ((n, 1), (n - 777, 2)):
+            scb = rand_scalars_bytes(m, seed) if seed == 1 else fr_bytes(_witness_like_scalars(m, 50 + c))
+            want = co.msm_g1(hb[: 96 * m], scb, nthreads=co.ncpu())
+            assert bzk.msm_table_run_dev(tab, to_dev(scb), m) == want
+            assert bzk.msm_g1_dev(bases, to_dev(scb), m) == want
+    finally:
+        bzk.msm_table_free(tab)
