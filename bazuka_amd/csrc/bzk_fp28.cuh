@@ -159,6 +159,64 @@ BZK_HD Fp28 sqr_body(const Fp28& a) {
     return r;
 }
 
+// ---- a b - c d with ONE Montgomery reduction (the Y coordinate of every addition formula is such a difference): the second
+// product is accumulated against the non-underflowing negation  6p - d  (d normalised, value < 6p), so the 28 columns only ever
+// grow: 2 x 196 + 196 multiply-adds instead of 2 x 392, and the result is a product output (normalised, k = 2) where the
+// two-product form needed sub<3> + norm.  Needs  14 (2^(La+Lb) + 2^(Lc+29) + 2^56) < 2^64  and  ka kb + 6 kc <= 2048.
+// Inlined (four operands = 56 argument registers do not fit the 32 of a call): used once, in the accumulation's mixed addition.
+BZK_HD Fp28 mul_sub2_body(const Fp28& a, const Fp28& b, const Fp28& cc, const Fp28& d) {
+    uint32_t nd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+        assert(D6.v[i] >= d.l[i]);
+#endif
+        nd[i] = D6.v[i] - d.l[i];
+    }
+#if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    {
+        uint32_t ma = 0, mb = 0, mc = 0, md = 0;
+        for (int i = 0; i < N; ++i) {
+            if (a.l[i] > ma) ma = a.l[i];
+            if (b.l[i] > mb) mb = b.l[i];
+            if (cc.l[i] > mc) mc = cc.l[i];
+            if (nd[i] > md) md = nd[i];
+        }
+        const unsigned __int128 worst = (unsigned __int128)14 * ma * mb + (unsigned __int128)14 * mc * md + (unsigned __int128)14 * MASK * MASK +
+                                        ((unsigned __int128)1 << 40);
+        assert(worst < ((unsigned __int128)1 << 64));
+    }
+#endif
+    uint64_t c[2 * N];
+#pragma unroll
+    for (int k = 0; k < 2 * N; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)cc.l[i] * nd[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P.v[j];
+        c[i + 1] += c[i] >> W;
+    }
+    Fp28 r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+        c[k + 1] += c[k] >> W;
+        r.l[k - N] = (uint32_t)c[k] & MASK;
+    }
+    r.l[N - 1] = (uint32_t)c[2 * N - 1];
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // one resident copy of the product per kernel image: by-value arguments travel in VGPRs
 // The product is a real call (I-cache: see the header).  The operands travel as four-lane VECTOR arguments, not
@@ -587,6 +645,9 @@ struct G1X28 {
 
 namespace g1x28 {
 using namespace fp28;
+#ifndef BZK_G1_FUSED_Y
+#define BZK_G1_FUSED_Y 1  // 0: Y3 of the mixed addition as two reduced products (A/B builds)
+#endif
 
 BZK_HD G1X28 identity() { return {zero(), one(), zero(), zero()}; }
 BZK_HD bool is_identity(const G1X28& p) { return limbs_all_zero(p.ZZ); }
@@ -638,11 +699,14 @@ BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q) {
     }
     Fp28 PPP = mul(Pp, PP), Q = mul(acc.X, PP), RR = sqr(R);
     Fp28 X3 = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));             // k 11
-    Fp28 Y3 = norm(sub<3>(mul(R, sub<12>(Q, X3)), mul(acc.Y, PPP)));   // k 5
-    acc.X = X3;
-    acc.Y = Y3;
     acc.ZZ = mul(acc.ZZ, PP);
     acc.ZZZ = mul(acc.ZZZ, PPP);
+#if BZK_G1_FUSED_Y
+    acc.Y = mul_sub2_body(R, sub<12>(Q, X3), PPP, acc.Y);              // R (Q - X3) - Y PPP, one reduction; k 2
+#else
+    acc.Y = norm(sub<3>(mul(R, sub<12>(Q, X3)), mul(acc.Y, PPP)));     // k 5
+#endif
+    acc.X = X3;
 }
 
 BZK_HD void add_full(G1X28& acc, const G1X28& q) {  // add-2008-s

@@ -71,6 +71,7 @@ bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
     c->timing = ctx->timing;
     c->msm_c_override = ctx->msm_c_override;
     c->msm_chunk_override = ctx->msm_chunk_override;
+    c->msm_reduce2 = ctx->msm_reduce2;
     return c;
 }
 
@@ -122,6 +123,7 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     }
     if (const char* e = getenv("BZK_MSM_C")) ctx->msm_c_override = atoi(e);
     if (const char* e = getenv("BZK_MSM_CHUNK")) ctx->msm_chunk_override = atoi(e);
+    if (const char* e = getenv("BZK_MSM_REDUCE2")) ctx->msm_reduce2 = atoi(e);
     if (const char* e = getenv("BZK_DEBUG")) ctx->debug = atoi(e) != 0;
     if (const char* e = getenv("BZK_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char* e = getenv("BZK_NO_COOP")) ctx->no_coop = atoi(e) != 0;

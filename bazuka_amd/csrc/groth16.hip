@@ -289,7 +289,10 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
     // timings for profiling; the lanes otherwise overlap and stretch each other's intervals)
     // the witness MSMs (l, a, b_g1, b_g2) run on de-duplicated scalars: half of a Groth16 assignment is repeats
     // (msm_impl.cuh section 8); env BZK_PROVE_NODEDUP=1 switches that off for A/B measurements
-    static const uint32_t wflags = (getenv("BZK_PROVE_NODEDUP") && atoi(getenv("BZK_PROVE_NODEDUP")) != 0) ? 0u : BZK_F_DEDUP;
+    // BZK_F_THROUGHPUT: the five MSMs overlap each other and the neighbouring proofs of a pipelined prover, so the forms with
+    // less arithmetic beat those with the shortest chain (env BZK_PROVE_LATENCY=1 switches the hint off for A/B measurements)
+    static const uint32_t tflag = (getenv("BZK_PROVE_LATENCY") && atoi(getenv("BZK_PROVE_LATENCY")) != 0) ? 0u : BZK_F_THROUGHPUT;
+    static const uint32_t wflags = ((getenv("BZK_PROVE_NODEDUP") && atoi(getenv("BZK_PROVE_NODEDUP")) != 0) ? 0u : BZK_F_DEDUP) | tflag;
     static const bool serial = getenv("BZK_PROVE_SERIAL") && atoi(getenv("BZK_PROVE_SERIAL")) != 0;
     std::thread th[3];
     auto job0 = [&] {
@@ -339,8 +342,8 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
                 BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
         }
         BZK_TRY(groth16_h(ctx, p->d_a, p->d_b, p->d_c, p->log_m));
-        if (p->h_table) return bzk_msm_g1_table_run_dev(ctx, p->h_table, p->d_a, m - 1, 0, pH);
-        return bzk_msm_g1_dev(ctx, p->h, p->d_a, m - 1, 0, pH);
+        if (p->h_table) return bzk_msm_g1_table_run_dev(ctx, p->h_table, p->d_a, m - 1, tflag, pH);
+        return bzk_msm_g1_dev(ctx, p->h, p->d_a, m - 1, tflag, pH);
     };
     const auto t2 = clk::now();
     st_main = main_part();

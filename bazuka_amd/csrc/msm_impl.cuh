@@ -383,9 +383,15 @@ __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // 6. chunked running-sum reduction:  out[t] = sum_{j<CH} (lo + j + 1) * B[w][lo + j]
 // ------------------------------------------------------------------------------------------------
+//    Two-level form (tot != nullptr): the chunk offset is NOT multiplied in per lane.  Level 1 writes  B_k = sum_j (j+1) S[lo+j]  and
+//    the chunk total T_k; the offsets  sum_k (ch k) T_k = ch * sum_k k T_k  are the same problem on per_win = half / ch "buckets"
+//    T_1 .. T_{per_win-1} (stored shifted by one, the last slot = identity), solved by a second launch of this kernel with
+//    post_dbl = log2 ch doublings of its result.  2 + 4.75/8 general additions per bucket instead of 4.75 (the 15-bit double-and-add
+//    per chunk is 60 % of the one-level work) for a chain of 16 + 41 instead of 41: a THROUGHPUT form, for calls that overlap others.
 template <class C>
 __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __restrict__ buckets, uint32_t half, uint32_t ch,
-                                                        uint32_t n_chunks_total, typename C::Pt* __restrict__ out) {
+                                                        uint32_t n_chunks_total, typename C::Pt* __restrict__ out, uint32_t out_stride,
+                                                        uint32_t out_off, typename C::Pt* __restrict__ tot, uint32_t post_dbl) {
     typedef typename C::Pt Pt;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_chunks_total) return;
@@ -393,6 +399,8 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
     const uint32_t w = t / per_win, k = t % per_win;
     const uint32_t lo = k * ch;
     const Pt* b = buckets + (size_t)w * half + lo;
+    const size_t o = (size_t)w * out_stride + out_off + k;
+    Pt* const tot_slot = tot ? tot + (size_t)w * per_win + (k ? k - 1 : per_win - 1) : nullptr;
     if constexpr (C::PARK_REDUCE) {
         // G2: a point is 112 registers; `run`, `acc` and an addition's temporaries do not survive a call to the field
         // product together (the compiler spilled 1774 registers, 1744 B of scratch per lane).  Here no point stays in
@@ -400,7 +408,7 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
         // and the second operand of every addition is read from memory where it is used (xyzz_add_mem).
         __shared__ Pt park[64];
         Pt* const run_m = &park[threadIdx.x];
-        Pt* const acc_m = &out[t];
+        Pt* const acc_m = &out[o];
         *run_m = C::identity();
         *acc_m = C::identity();
         for (int j = (int)ch - 1; j >= 0; --j) {
@@ -417,6 +425,10 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
             }
             __asm__ volatile("" ::: "memory");
         }
+        if (tot_slot) {
+            *tot_slot = k ? *run_m : C::identity();
+            return;
+        }
         if (lo) {
             Pt m = C::identity();  // lo * run, double-and-add with `run` read from LDS
             for (int i = 31; i >= 0; --i) {
@@ -430,6 +442,12 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
             C::add_mem(a, run_m);
             *acc_m = a;
         }
+        if (post_dbl) {
+            __asm__ volatile("" ::: "memory");
+            Pt a = *acc_m;
+            for (uint32_t d = 0; d < post_dbl; ++d) a = C::dbl(a);
+            *acc_m = a;
+        }
         return;
     }
     Pt run = C::identity(), acc = C::identity();
@@ -438,11 +456,17 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
         C::add(run, p);
         C::add(acc, run);
     }
+    if (tot_slot) {
+        out[o] = acc;
+        *tot_slot = k ? run : C::identity();
+        return;
+    }
     if (lo) {
         Pt m = C::mul_u32(run, lo);
         C::add(acc, m);
     }
-    out[t] = acc;
+    for (uint32_t d = 0; d < post_dbl; ++d) acc = C::dbl(acc);
+    out[o] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -840,6 +864,11 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (ch > half) ch = half;
     while (half % ch) --ch;
     const uint32_t per_win = half / ch;
+    // two-level bucket reduction (see msm_reduce_kernel): ctx->msm_reduce2 > 0 forces it, < 0 forbids it, 0 = the caller's hint
+    // BZK_F_THROUGHPUT (set by bzk_groth16_prove for its overlapping MSMs)
+    const uint32_t ch2 = std::min<uint32_t>(8u, per_win);
+    const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && (flags & BZK_F_THROUGHPUT)));
+    const uint32_t per_win_out = two_level ? per_win + per_win / ch2 : per_win;  // chunk results per window handed to the window sums
     const bool dedup = (flags & BZK_F_DEDUP) && C::CONVERT_BASES && !table && n >= 4096 && n < ((uint64_t)1 << 30);
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
@@ -895,8 +924,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     total += 7 * ws_pad((size_t)nb_alloc * 4);        // start, count, count_sorted, iota, order, ntask, tbase
     total += ws_pad((size_t)t_cap * sizeof(Pt));      // per-task partial sums (multi-task buckets only)
     total += ws_pad((size_t)nb_alloc * sizeof(Pt));   // buckets
-    total += ws_pad((size_t)group * per_win * sizeof(Pt));
-    total += ws_pad(((size_t)group * (per_win / C::WSUM_THREADS + 1)) * sizeof(Pt));
+    total += ws_pad((size_t)group * per_win_out * sizeof(Pt));
+    if (two_level) total += ws_pad((size_t)group * per_win * sizeof(Pt));
+    total += ws_pad(((size_t)group * (per_win_out / C::WSUM_THREADS + 1)) * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(StdPt));
     if (C::CONVERT_BASES && !table) total += ws_pad((size_t)(n + m_max) * sizeof(typename C::DevAff));
     if (dedup) {
@@ -920,8 +950,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     BA.tbase = cur.take<uint32_t>(nb_alloc);
     BA.partial = cur.take<Pt>(t_cap);
     Pt* buckets = cur.take<Pt>(nb_alloc);
-    Pt* chunk_out = cur.take<Pt>((size_t)group * per_win);
-    Pt* wpart = cur.take<Pt>((size_t)group * (per_win / C::WSUM_THREADS + 1));
+    Pt* chunk_out = cur.take<Pt>((size_t)group * per_win_out);
+    Pt* chunk_tot = two_level ? cur.take<Pt>((size_t)group * per_win) : nullptr;
+    Pt* wpart = cur.take<Pt>((size_t)group * (per_win_out / C::WSUM_THREADS + 1));
     StdPt* win_out = cur.take<StdPt>(w_total);
     const void* bases = table ? table->data : bases_raw;
     typename C::DevAff* conv = nullptr;
@@ -1042,12 +1073,23 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
-        BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out);
+        if (two_level) {
+            int lg = 0;
+            while ((1u << lg) < ch) ++lg;
+            const uint32_t n_chunks2 = (uint32_t)n_red_win * (per_win / ch2);
+            BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out, per_win_out, 0u,
+                       chunk_tot, 0u);
+            BZK_LAUNCH(ctx, "msm_reduce_l2", k_red, dim3((n_chunks2 + 63) / 64), dim3(64), 0, (const Pt*)chunk_tot, per_win, ch2, n_chunks2,
+                       chunk_out, per_win_out, per_win, (Pt*)nullptr, (uint32_t)lg);
+        } else {
+            BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out, per_win, 0u,
+                       (Pt*)nullptr, 0u);
+        }
         constexpr int WT = C::WSUM_THREADS;
-        const uint32_t groups = (per_win + WT - 1) / WT;
+        const uint32_t groups = (per_win_out + WT - 1) / WT;
         auto k_wp = msm_window_partial_kernel<C, WT>;
         auto k_ws = msm_window_sum_kernel<C, WT>;
-        BZK_LAUNCH(ctx, "msm_window_partial", k_wp, dim3((unsigned)n_red_win * groups), dim3(WT), 0, chunk_out, per_win, groups, wpart);
+        BZK_LAUNCH(ctx, "msm_window_partial", k_wp, dim3((unsigned)n_red_win * groups), dim3(WT), 0, chunk_out, per_win_out, groups, wpart);
         BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_out);
         BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)n_red_win * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));

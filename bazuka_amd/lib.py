@@ -9,6 +9,13 @@ LIB_PATH = os.path.join(_HERE, "libbzk.so")
 
 BZK_F_CANONICAL = 1
 BZK_F_DEDUP = 2
+BZK_F_THROUGHPUT = 4
+
+
+def _flags(canonical=False, dedup=False, throughput=False) -> int:
+    return (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0) | (BZK_F_THROUGHPUT if throughput else 0)
+
+
 _lib = None
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/bzk.h
@@ -254,16 +261,16 @@ class Bzk:
         self._ck(self.lib.bzk_ntt(self.h, buf, log_n, int(inverse), int(coset)), "ntt")
         return buf.raw
 
-    def msm_g1(self, bases: bytes, scalars: bytes, canonical=False, dedup=False) -> bytes:
+    def msm_g1(self, bases: bytes, scalars: bytes, canonical=False, dedup=False, throughput=False) -> bytes:
         n = len(scalars) // 32
         out = C.create_string_buffer(97)
-        self._ck(self.lib.bzk_msm_g1(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g1")
+        self._ck(self.lib.bzk_msm_g1(self.h, _ptr(bases), _ptr(scalars), n, _flags(canonical, dedup, throughput), out), "msm_g1")
         return out.raw
 
-    def msm_g2(self, bases: bytes, scalars: bytes, canonical=False, dedup=False) -> bytes:
+    def msm_g2(self, bases: bytes, scalars: bytes, canonical=False, dedup=False, throughput=False) -> bytes:
         n = len(scalars) // 32
         out = C.create_string_buffer(193)
-        self._ck(self.lib.bzk_msm_g2(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g2")
+        self._ck(self.lib.bzk_msm_g2(self.h, _ptr(bases), _ptr(scalars), n, _flags(canonical, dedup, throughput), out), "msm_g2")
         return out.raw
 
     # ---- device-pointer forms (x = torch tensor / int device address)
@@ -278,14 +285,14 @@ class Bzk:
     def ntt_dev(self, data, log_n: int, inverse=False, coset=False):
         self._ck(self.lib.bzk_ntt_dev(self.h, _ptr(data), log_n, int(inverse), int(coset)), "ntt_dev")
 
-    def msm_g1_dev(self, bases, scalars, n: int, canonical=False, dedup=False) -> bytes:
+    def msm_g1_dev(self, bases, scalars, n: int, canonical=False, dedup=False, throughput=False) -> bytes:
         out = C.create_string_buffer(97)
-        self._ck(self.lib.bzk_msm_g1_dev(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g1_dev")
+        self._ck(self.lib.bzk_msm_g1_dev(self.h, _ptr(bases), _ptr(scalars), n, _flags(canonical, dedup, throughput), out), "msm_g1_dev")
         return out.raw
 
-    def msm_g2_dev(self, bases, scalars, n: int, canonical=False, dedup=False) -> bytes:
+    def msm_g2_dev(self, bases, scalars, n: int, canonical=False, dedup=False, throughput=False) -> bytes:
         out = C.create_string_buffer(193)
-        self._ck(self.lib.bzk_msm_g2_dev(self.h, _ptr(bases), _ptr(scalars), n, (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0), out), "msm_g2_dev")
+        self._ck(self.lib.bzk_msm_g2_dev(self.h, _ptr(bases), _ptr(scalars), n, _flags(canonical, dedup, throughput), out), "msm_g2_dev")
         return out.raw
 
     # ---- device-resident 4-ary tree
@@ -320,15 +327,15 @@ class Bzk:
     def msm_window_count(self, n: int) -> int:
         return self.lib.bzk_msm_window_count(n)
 
-    def msm_g1_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False, dedup=False) -> bytes:
+    def msm_g1_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False, dedup=False, throughput=False) -> bytes:
         out = C.create_string_buffer(97)
-        flags = (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0)
+        flags = _flags(canonical, dedup, throughput)
         self._ck(self.lib.bzk_msm_g1_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, flags, w0, w1, out), "msm_g1_windows_dev")
         return out.raw
 
-    def msm_g2_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False, dedup=False) -> bytes:
+    def msm_g2_windows_dev(self, bases, scalars, n: int, w0: int, w1: int, canonical=False, dedup=False, throughput=False) -> bytes:
         out = C.create_string_buffer(193)
-        flags = (BZK_F_CANONICAL if canonical else 0) | (BZK_F_DEDUP if dedup else 0)
+        flags = _flags(canonical, dedup, throughput)
         self._ck(self.lib.bzk_msm_g2_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, flags, w0, w1, out), "msm_g2_windows_dev")
         return out.raw
 
@@ -352,10 +359,10 @@ class Bzk:
     def msm_table_levels(self, table) -> int:
         return self.lib.bzk_msm_table_levels(table)
 
-    def msm_table_run_dev(self, table, scalars, n: int, g2=False, canonical=False) -> bytes:
+    def msm_table_run_dev(self, table, scalars, n: int, g2=False, canonical=False, throughput=False) -> bytes:
         out = C.create_string_buffer(193 if g2 else 97)
         fn = self.lib.bzk_msm_g2_table_run_dev if g2 else self.lib.bzk_msm_g1_table_run_dev
-        self._ck(fn(self.h, table, _ptr(scalars), n, BZK_F_CANONICAL if canonical else 0, out), "msm_table_run")
+        self._ck(fn(self.h, table, _ptr(scalars), n, _flags(canonical, False, throughput), out), "msm_table_run")
         return out.raw
 
     def msm_table_windows_dev(self, table, scalars, n: int, w0: int, w1: int, g2=False, canonical=False) -> bytes:

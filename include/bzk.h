@@ -40,6 +40,9 @@ extern "C" {
 #define BZK_F_CANONICAL 1u  /* scalars are canonical integers instead of Montgomery limbs */
 #define BZK_F_DEDUP 2u      /* MSM entries: the scalar vector repeats itself (a Groth16 witness): bases of equal scalars
                              * are summed once before the bucket phase, zero scalars dropped.  Same result. */
+#define BZK_F_THROUGHPUT 4u /* MSM entries: this call overlaps other device work (the five MSMs of a proof): prefer the
+                             * forms that do less arithmetic over those with the shortest dependency chain (two-level
+                             * bucket reduction).  Same result. */
 
 typedef struct bzk_ctx bzk_ctx;
 

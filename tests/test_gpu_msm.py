@@ -468,3 +468,35 @@ def test_msm_g1_full_table_with_explicit_window(bzk, co, log_n, c):
             assert bzk.msm_g1_dev(bases, to_dev(scb), m) == want
     finally:
         bzk.msm_table_free(tab)
+
+
+@pytest.mark.parametrize("log_n", [13, 16])
+def test_msm_two_level_reduce_same_bytes(bzk, co, log_n):
+    """BZK_F_THROUGHPUT (what bzk_groth16_prove passes for its five overlapping MSMs): the bucket reduction in its two-level
+    form - chunk sums B_k and totals T_k first, then the chunk offsets sum_k k T_k as a second, 8x smaller reduction - is the
+    same group element as the one-level form and the oracle: G1 and G2, uniform and witness-like (de-duplicated) scalars, a
+    window range, and the shared bucket set of a full table (per_win = 2^(c-1) / 8 chunks in one 'window')"""
+    n = (1 << log_n) - 3
+    g1 = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    g2 = torch.empty(n * 192, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(900 + log_n, 0, n, g1)
+    bzk.g2_synth_bases_dev(901 + log_n, 0, n, g2)
+    h1, h2 = dev_bytes(g1), dev_bytes(g2)
+    for seed, dedup in ((1, False), (2, True)):
+        scb = rand_scalars_bytes(n, seed) if not dedup else fr_bytes(_witness_like_scalars(n, 70 + log_n))
+        sc = to_dev(scb)
+        want1 = co.msm_g1(h1, scb, nthreads=co.ncpu())
+        want2 = co.msm_g2(h2, scb, nthreads=co.ncpu())
+        assert bzk.msm_g1_dev(g1, sc, n, dedup=dedup, throughput=True) == want1
+        assert bzk.msm_g1_dev(g1, sc, n, dedup=dedup) == want1
+        assert bzk.msm_g2_dev(g2, sc, n, dedup=dedup, throughput=True) == want2
+    scb = rand_scalars_bytes(n, 5)
+    sc = to_dev(scb)
+    W = bzk.msm_window_count(n)
+    parts = [bzk.msm_g1_windows_dev(g1, sc, n, 0, W // 2, throughput=True), bzk.msm_g1_windows_dev(g1, sc, n, W // 2, W, throughput=True)]
+    assert bzk.g1_sum(b"".join(parts)) == co.msm_g1(h1, scb, nthreads=co.ncpu())
+    tab = bzk.msm_table_build_c(g1, n, log_n)
+    try:
+        assert bzk.msm_table_run_dev(tab, sc, n, throughput=True) == co.msm_g1(h1, scb, nthreads=co.ncpu())
+    finally:
+        bzk.msm_table_free(tab)
