@@ -85,7 +85,7 @@ static int msm_pick_c_witness(uint64_t n, int c_plain) {
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __restrict__ scalars, uint64_t n, int mont, int c,
                                                          int w_total, int w_begin, int w_cnt, uint32_t table_stride, int table_wpl,
-                                                         const uint32_t* __restrict__ rep, uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ rep, int wiv, uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ vals) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -138,6 +138,12 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
             if (table_stride) {
                 keys[o] = d ? (d - 1) : nb;
                 vals[o] = ((uint32_t)w * table_stride + (uint32_t)i) | (neg << 31);
+            } else if (wiv) {
+                // window-in-value form: the sort key is the bucket WITHIN its window (c - 1 bits + the sentinel: one radix pass
+                // fewer than w * half + d), the window rides in bits 27..30 of the value.  The pairs are emitted window-major and
+                // the radix sort is stable, so the runs of (bucket, window) are still contiguous: msm_offsets_wiv finds them
+                keys[o] = d ? (d - 1) : half;
+                vals[o] = (rep ? rep[i] : (uint32_t)i) | (lw << 27) | (neg << 31);
             } else {
                 keys[o] = d ? lw * half + (d - 1) : nb;
                 vals[o] = (rep ? rep[i] : (uint32_t)i) | (neg << 31);
@@ -172,6 +178,29 @@ static __global__ void __launch_bounds__(256) msm_offsets_kernel(const uint32_t*
     if (k >= nb) return;
     if (i == 0 || keys[i - 1] != k) start[k] = (uint32_t)i;
     if (i + 1 == len || keys[i + 1] != k) endx[k] = (uint32_t)(i + 1);
+}
+
+// window-in-value form (see msm_digits): key = bucket within the window, window = bits 27..30 of the value
+static __global__ void __launch_bounds__(256) msm_offsets_wiv_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                              uint64_t len, uint32_t half, uint32_t* __restrict__ start,
+                                                              uint32_t* __restrict__ endx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    // a boundary between positions i - 1 and i closes the run of i - 1 and opens the run of i: two loads per array instead of three
+    const uint32_t k = keys[i];
+    const uint32_t w = (vals[i] >> 27) & 15u;
+    const uint32_t g = w * half + k;
+    if (i == 0) {
+        if (k < half) start[g] = 0;
+    } else {
+        const uint32_t kp = keys[i - 1];
+        const uint32_t wp = (vals[i - 1] >> 27) & 15u;
+        if (kp != k || wp != w) {
+            if (k < half) start[g] = (uint32_t)i;
+            if (kp < half) endx[wp * half + kp] = (uint32_t)i;
+        }
+    }
+    if (i + 1 == len && k < half) endx[g] = (uint32_t)len;
 }
 
 // count[g] = end[g] - start[g] (in place over `endx`), iota[g] = g
@@ -274,7 +303,7 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t t_max,
                                                              uint32_t seg, typename C::Pt* __restrict__ buckets,
-                                                             typename C::Pt* __restrict__ partial) {
+                                                             typename C::Pt* __restrict__ partial, uint32_t vmask) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= t_max) return;
     // last sorted position i with tbase[i] <= t
@@ -298,7 +327,7 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
     typename C::Pt acc = C::identity();
     for (uint32_t j = 0; j < len; ++j) {
         const uint32_t v = vals[s + j];
-        typename C::DevAff p = C::load(bases, v & 0x7fffffffu);
+        typename C::DevAff p = C::load(bases, v & vmask);
         C::add_mixed(acc, p, (v >> 31) != 0);
     }
     if (cnt <= seg) buckets[g] = acc;
@@ -745,10 +774,16 @@ struct BucketArrays {
 template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
                                  uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
-                                 bool group_sums = false) {
+                                 bool group_sums = false, uint32_t wiv_half = 0) {
     BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
     BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
-    BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
+    const uint32_t vmask = wiv_half ? 0x07ffffffu : 0x7fffffffu;
+    if (wiv_half) {
+        BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_wiv_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, vals_s, len, wiv_half,
+                   A.start, A.count);
+    } else {
+        BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
+    }
     BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, nb);
     // clamped population keys: A.ntask holds them until msm_ntask overwrites it, A.tbase receives the (unused) sorted keys
     BZK_LAUNCH(ctx, "msm_iota_clamp", msm_iota_clamp_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.iota, A.ntask, nb);
@@ -775,10 +810,10 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     auto k_fold_small = msm_fold_small_kernel<C>;
     if (group_sums) {
         BZK_LAUNCH(ctx, "dedup_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
-                   nb, t_max, seg, buckets, A.partial);
+                   nb, t_max, seg, buckets, A.partial, vmask);
     } else {
         BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
-                   nb, t_max, seg, buckets, A.partial);
+                   nb, t_max, seg, buckets, A.partial, vmask);
     }
     // only sorted positions < len / seg can hold a multi-task bucket; of those only the first
     // len / (seg * MSM_FOLD_SMALL) can need the workgroup-wide fold
@@ -1054,6 +1089,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     }
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;
+    // window-in-value pairs (msm_digits): per-window bucket sets of up to 16 windows per pass over fewer than 2^27 bases
+    static const bool wiv_off = [] { const char* e = getenv("BZK_MSM_NO_WIV"); return e && atoi(e) != 0; }();
+    const bool wiv = !wiv_off && !table && group <= 16 && (uint64_t)n + m_max < ((uint64_t)1 << 27);
     std::vector<StdPt> wsum((size_t)(w_end - w_begin));
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
@@ -1062,15 +1100,15 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         const int n_red_win = (table && !folded) ? 1 : wc;  // bucket sets to reduce
         BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
                    mont, c, folded ? levels * table->wpl : w_total, wb, wc, (uint32_t)(table ? table->n : 0), table ? table->wpl : 1,
-                   (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
+                   (const uint32_t*)(dedup ? rep : nullptr), wiv ? 1 : 0, keys, vals);
         {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
-            hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, keys, keys_s, vals, vals_s, (size_t)len, 0, bits_for(nb), ctx->stream);
+            hipError_t e = rocprim::radix_sort_pairs(tmp_buf, t, keys, keys_s, vals, vals_s, (size_t)len, 0, bits_for(wiv ? half : nb), ctx->stream);
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         aux.join();
-        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp));
+        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, wiv ? half : 0u));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         if (two_level) {

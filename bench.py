@@ -25,12 +25,14 @@ sys.path.insert(0, ROOT)
 
 LOG_N = 20
 # micro-benchmarked peak of the library's own Fp product (chains of dependent calls, all CUs busy):
-# tools/ubench_int "Fp28 lib mul", profiles/r01_ubench_int.txt.  10 products per XYZZ mixed add.
+# tools/ubench_int "Fp28 lib mul", profiles/r01_ubench_int.txt.  An XYZZ mixed add is 8 products + 2 squares; since round 2 its Y
+# coordinate R (Q - X3) - Y PPP is two multiplications under ONE Montgomery reduction (fp28::mul_sub2_body) = 1.5 products
 FP_MUL_PEAK_G = 76.2
-MULS_PER_MIXED_ADD = 10
-# integer multiply-adds actually issued by one XYZZ mixed addition: 8 products of 394 v_mad_u64_u32 + 2 squares of 301
-# (profiles/r01_run56_fp28_square.txt), against the measured v_mad_u64_u32 ceiling of the whole chip (profiles/r01_ubench_int.txt)
-MADS_PER_MIXED_ADD = 8 * 394 + 2 * 301
+MULS_PER_MIXED_ADD = 9.5
+# integer multiply-adds actually issued by one XYZZ mixed addition: 6 products of 394 v_mad_u64_u32 + 2 squares of 301
+# (profiles/r01_run56_fp28_square.txt) + the fused Y (2 x 196 + 196 + 2), against the measured v_mad_u64_u32 ceiling of the whole
+# chip (profiles/r01_ubench_int.txt)
+MADS_PER_MIXED_ADD = 6 * 394 + 2 * 301 + (3 * 196 + 2)
 MAD_PEAK_T = 31.4
 # G2: 8 Fp2 products (3 Fp products each) + 2 Fp2 squares (2 Fp products each)
 FP_MULS_PER_G2_MIXED_ADD = 8 * 3 + 2 * 2
@@ -531,7 +533,7 @@ def main():
             tmad = pairs * MADS_PER_MIXED_ADD / (per_launch_ms * 1e-3) / 1e12
             out["roofline"]["alu_mad"] = {"achieved": round(tmad, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s",
                                           "frac": round(tmad / MAD_PEAK_T, 4),
-                                          "how": f"{MADS_PER_MIXED_ADD} mads issued per mixed add (8 x 394 + 2 x 301) against the "
+                                          "how": f"{MADS_PER_MIXED_ADD} mads issued per mixed add (6 x 394 + 2 x 301 + 590 for the fused Y) against the "
                                                  "micro-benchmarked instruction ceiling (profiles/r01_ubench_int.txt)"}
         out["kernel_ms_per_step"] = {k: round(v[1] / n_break, 4) for k, v in sorted(prof_all.items())}
         out["kernel_ms_per_step_how"] = f"{n_break} extra untimed steps with every launch instrumented (HIP events)"
