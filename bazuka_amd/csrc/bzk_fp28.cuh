@@ -217,6 +217,65 @@ BZK_HD Fp28 mul_sub2_body(const Fp28& a, const Fp28& b, const Fp28& cc, const Fp
     return r;
 }
 
+// ---- a0 b0 + a1 b1 + a2 b2 + a3 b3 with ONE reduction: a component of  R T - Y PPP  over Fp2 (the G2 mixed addition), the signs
+// carried by non-underflowing negations of one factor.  Needs  14 (sum_i 2^(Lai+Lbi) + 2^56) < 2^64  and  sum_i kai kbi <= 2048.
+BZK_HD Fp28 mul4_body(const Fp28& a0, const Fp28& b0, const Fp28& a1, const Fp28& b1, const Fp28& a2, const Fp28& b2, const Fp28& a3,
+                      const Fp28& b3) {
+#if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    {
+        const Fp28* o[8] = {&a0, &b0, &a1, &b1, &a2, &b2, &a3, &b3};
+        unsigned __int128 worst = (unsigned __int128)14 * MASK * MASK + ((unsigned __int128)1 << 40);
+        for (int t = 0; t < 4; ++t) {
+            uint32_t ma = 0, mb = 0;
+            for (int i = 0; i < N; ++i) {
+                if (o[2 * t]->l[i] > ma) ma = o[2 * t]->l[i];
+                if (o[2 * t + 1]->l[i] > mb) mb = o[2 * t + 1]->l[i];
+            }
+            worst += (unsigned __int128)14 * ma * mb;
+        }
+        assert(worst < ((unsigned __int128)1 << 64));
+    }
+#endif
+    uint64_t c[2 * N];
+#pragma unroll
+    for (int k = 0; k < 2 * N; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)a0.l[i] * b0.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)a1.l[i] * b1.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)a2.l[i] * b2.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)a3.l[i] * b3.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P.v[j];
+        c[i + 1] += c[i] >> W;
+    }
+    Fp28 r;
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+        c[k + 1] += c[k] >> W;
+        r.l[k - N] = (uint32_t)c[k] & MASK;
+    }
+    r.l[N - 1] = (uint32_t)c[2 * N - 1];
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // one resident copy of the product per kernel image: by-value arguments travel in VGPRs
 // The product is a real call (I-cache: see the header).  The operands travel as four-lane VECTOR arguments, not
@@ -804,6 +863,67 @@ BZK_HD G1Xyzz to_std(const G1X28& p) {
 typedef AffineT<Fp2x28Ops> G2A28;  // 224 B
 typedef XyzzT<Fp2x28Ops> G2X28;    // 448 B
 namespace g2x28 {
+#ifndef BZK_G2_FAST_MIXED
+#define BZK_G2_FAST_MIXED 1  // 0: the accumulation uses the generic xyzz_add_mixed<Fp2x28Ops> (A/B builds)
+#endif
+// acc += q (q affine, never the identity; neg_q: add -q) with STATIC bounds instead of the generic code's uniform "reduce every sum and
+// difference below 3p" (16 quotient-estimate reductions per mixed addition; here 2) and with the Y coordinate's two Fp2 products under
+// one reduction per component (mul4_body).  Invariants of the accumulator: X, Y components normalised and < 3p; ZZ, ZZZ outputs of
+// Fp2x28Ops::mul / sqr (c0 < 5p, c1 < 8p, normalised); identity <=> every ZZ limb zero (the only way an accumulator becomes the
+// identity is the explicit assignment below; a non-identity point has ZZ != 0 mod p).  The results satisfy the generic discipline
+// (every component < 8p), so the tail kernels consume them unchanged.  Bounds (k = value < k p; all operands of a product normalised
+// unless noted):
+//   U2 = q.x ZZ: (8 + 8)(5 + 8) = 208, S2 = q.y ZZZ: (12 + 12)(13) = 312 -> (5, 8)     Pp = U2 - X, R = S2 - Y : sub<3> + norm, k <= 11
+//   PP, RR = squares: (c0 + c1)(c0 - c1) with sub<12> (k 11 < 12): (22)(23) = 506 <= 2048; 2 c0 c1 -> (2, 4)
+//   PPP = Pp PP: (22)(6);  Q = X PP: (6)(6);  X3 = RR - PPP - 2 Q: three sub<12> (limbs < 2^30.8, k <= 40) + reduce -> < 3p
+//   T = Q - X3: sub<3> + norm, k <= 11
+//   Y3.re = R0 T0 + (12p - R1) T1 + (3p - Y0) PPP0 + Y1 PPP1      (121 + 132 + 15 + 24 = 292 <= 2048; columns 14 * 7 * 2^56 < 2^64)
+//   Y3.im = R0 T1 + R1 T0 + (3p - Y0) PPP1 + (3p - Y1) PPP0       (121 + 121 + 24 + 15)                       -> product outputs, k 2
+BZK_HD void add_mixed(XyzzT<Fp2x28Ops>& acc, const AffineT<Fp2x28Ops>& q_in, bool neg_q) {
+    using namespace fp28;
+    typedef Fp2x28Ops F;
+    // q: components normalised and < 8p - converted bases are product outputs (< 2p), table entries and the group sums of the
+    // de-duplication come out of Fp2 products (c0 < 5p, c1 < 8p)
+    AffineT<Fp2x28Ops> q = q_in;
+    if (neg_q) q.y = {norm(sub<12>(zero(), q.y.c0)), norm(sub<12>(zero(), q.y.c1))};  // 12p - y, k 12
+    if (limbs_all_zero(acc.ZZ.c0) && limbs_all_zero(acc.ZZ.c1)) {
+        acc = {{reduce(q.x.c0), reduce(q.x.c1)}, {reduce(q.y.c0), reduce(q.y.c1)}, F::one(), F::one()};  // X, Y < 3p (once per run)
+        return;
+    }
+    const Fp2x28 U2 = F::mul(q.x, acc.ZZ), S2 = F::mul(q.y, acc.ZZZ);
+    const Fp2x28 Pp = {norm(sub<3>(U2.c0, acc.X.c0)), norm(sub<3>(U2.c1, acc.X.c1))};
+    const Fp2x28 R = {norm(sub<3>(S2.c0, acc.Y.c0)), norm(sub<3>(S2.c1, acc.Y.c1))};
+    Fp2x28 PP;
+    PP.c0 = mul(add(Pp.c0, Pp.c1), sub<12>(Pp.c0, Pp.c1));
+    {
+        const Fp28 m = mul(Pp.c0, Pp.c1);
+        PP.c1 = norm(add(m, m));
+    }
+    if (mulout_is_zero(PP.c0) && F::is_zero(Pp)) {  // same x (exact test only when the cheap one fires): doubling or cancellation
+        if (F::is_zero(R)) acc = xyzz_dbl_affine<F>(q);
+        else acc = xyzz_identity<F>();
+        return;
+    }
+    const Fp2x28 PPP = F::mul(Pp, PP), Q = F::mul(acc.X, PP);
+    Fp2x28 RR;
+    RR.c0 = mul(add(R.c0, R.c1), sub<12>(R.c0, R.c1));
+    {
+        const Fp28 m = mul(R.c0, R.c1);
+        RR.c1 = norm(add(m, m));
+    }
+    Fp2x28 X3;
+    X3.c0 = reduce(sub<12>(sub<12>(sub<12>(RR.c0, PPP.c0), Q.c0), Q.c0));
+    X3.c1 = reduce(sub<12>(sub<12>(sub<12>(RR.c1, PPP.c1), Q.c1), Q.c1));
+    const Fp2x28 T = {norm(sub<3>(Q.c0, X3.c0)), norm(sub<3>(Q.c1, X3.c1))};
+    acc.ZZ = F::mul(acc.ZZ, PP);
+    acc.ZZZ = F::mul(acc.ZZZ, PPP);
+    const Fp28 nR1 = sub<12>(zero(), R.c1), nY0 = sub<3>(zero(), acc.Y.c0), nY1 = sub<3>(zero(), acc.Y.c1);
+    Fp2x28 Y3;
+    Y3.c0 = mul4_body(R.c0, T.c0, nR1, T.c1, nY0, PPP.c0, acc.Y.c1, PPP.c1);
+    Y3.c1 = mul4_body(R.c0, T.c1, R.c1, T.c0, nY0, PPP.c1, nY1, PPP.c0);
+    acc.X = X3;
+    acc.Y = Y3;
+}
 BZK_HD Fp2x28 fp2_to28(const Fp2& a) { return {fp28::to28(a.c0), fp28::to28(a.c1)}; }
 BZK_HD Fp2 fp2_from28(const Fp2x28& a) { return {fp28::from28(a.c0), fp28::from28(a.c1)}; }
 BZK_HD G2A28 affine_to28(const G2Affine& a) { return {fp2_to28(a.x), fp2_to28(a.y)}; }

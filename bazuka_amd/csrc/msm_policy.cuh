@@ -97,9 +97,13 @@ struct G2Fast {
     static constexpr int ACC_OCC = BZK_G2_ACC_OCC;
     __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2x28Ops>(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p_in, bool neg) {
+#if BZK_G2_FAST_MIXED
+        g2x28::add_mixed(acc, p_in, neg);
+#else
         DevAff p = p_in;
         if (neg) p.y = Fp2x28Ops::neg(p.y);
         xyzz_add_mixed<Fp2x28Ops>(acc, p);
+#endif
     }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2x28Ops>(acc, q); }
     // second operand left in memory (LDS / global): see xyzz_add_mem

@@ -126,6 +126,36 @@ int hc_g2x28_sum_mixed(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* o
     st_g2(out193, g2x28::to_std(acc));
     return 0;
 }
+// the accumulation's own G2 mixed addition (g2x28::add_mixed: static bounds, Y under one reduction per component): a chain of
+// (+/-) points, then - mode 1 - the chain's sum is handed to the GENERIC general addition (the tail kernels' consumer discipline)
+int hc_g2x28_sum_mixed_fast(const uint8_t* pts, const uint8_t* neg, int n, int mode, uint8_t* out193) {
+    G2X28 acc = xyzz_identity<Fp2x28Ops>();
+    for (int i = 0; i < n; ++i) {
+        G2A28 a = g2x28::affine_to28(ld_g2(pts + 192 * i));
+        if (mode == 2) {  // bases as the table build / the de-duplication hand them over: outputs of Fp2 products (c0 < 5p, c1 < 8p)
+            const Fp2x28 one = Fp2x28Ops::one();
+            a.x = Fp2x28Ops::mul(a.x, one);
+            a.y = Fp2x28Ops::mul(a.y, one);
+        }
+        g2x28::add_mixed(acc, a, neg[i] != 0);
+    }
+    // invariants the next addition relies on: X, Y < 3p (top limb below 3 * 0x1a012), every limb normalised
+    if (!(fp28::limbs_all_zero(acc.ZZ.c0) && fp28::limbs_all_zero(acc.ZZ.c1))) {
+        const Fp28* xy[4] = {&acc.X.c0, &acc.X.c1, &acc.Y.c0, &acc.Y.c1};
+        for (int e = 0; e < 4; ++e) {
+            if (xy[e]->l[13] >= 3 * 0x1a012u) return -1;
+            for (int i = 0; i < 13; ++i)
+                if (xy[e]->l[i] >> 28) return -2;
+        }
+    }
+    if (mode == 1) {
+        G2X28 twice = acc;
+        xyzz_add<Fp2x28Ops>(twice, acc);  // generic consumer: 2 * sum
+        acc = twice;
+    }
+    st_g2(out193, g2x28::to_std(acc));
+    return 0;
+}
 // sum_i (+/-) k_i * P_i with EVERY general addition done by xyzz_add_mem (second operand read from memory - what the G2
 // tail kernels use on the device), including the double-and-add of the scalar multiplication; mode 1 adds each term twice
 // through a parked copy (P + P = doubling inside add_mem), mode 2 adds a term and its negation (cancellation -> identity)

@@ -187,6 +187,28 @@ def test_reduced_radix_curves_on_host_match_oracle(hc, co, pr):
     assert hc.hc_g2x28_lincomb_mem(b2, (C.c_uint32 * n)(*ks), neg, n, 1, out2) == 0
     sc3 = b"".join((3 * int.from_bytes(sc[32 * i:32 * i + 32], "little") % pr.R_MOD).to_bytes(32, "little") for i in range(n))
     assert out2.raw == co.msm_g2(b2, sc3, mont=False, naive=True)
+    # g2x28::add_mixed (what msm_accumulate<G2> runs): long signed chains, doubling and cancellation through the mixed add, and its
+    # result handed to the generic general addition; bound assertions on, invariants (X, Y < 3p, normalised) checked by the harness
+    m2 = 120
+    b4 = co.g2_bases(11, 0, m2)
+    negs2 = bytes(rnd.randrange(2) for _ in range(m2))
+    sc4 = b"".join(((pr.R_MOD - 1) if negs2[i] else 1).to_bytes(32, "little") for i in range(m2))
+    assert hc.hc_g2x28_sum_mixed_fast(b4, negs2, m2, 0, out2) == 0
+    assert out2.raw == co.msm_g2(b4, sc4, mont=False, naive=True)
+    assert hc.hc_g2x28_sum_mixed_fast(b4, negs2, m2, 2, out2) == 0  # bases that are Fp2 product outputs (table entries, group sums)
+    assert out2.raw == co.msm_g2(b4, sc4, mont=False, naive=True)
+    assert hc.hc_g2x28_sum_mixed_fast(b4, negs2, m2, 1, out2) == 0
+    sc4x2 = b"".join((2 * int.from_bytes(sc4[32 * i:32 * i + 32], "little") % pr.R_MOD).to_bytes(32, "little") for i in range(m2))
+    assert out2.raw == co.msm_g2(b4, sc4x2, mont=False, naive=True)
+    Q2 = b4[:192]
+    assert hc.hc_g2x28_sum_mixed_fast(Q2 + Q2, bytes([0, 0]), 2, 0, out2) == 0
+    assert out2.raw == co.msm_g2(Q2, (2).to_bytes(32, "little"), mont=False, naive=True)  # doubling through the mixed add
+    assert hc.hc_g2x28_sum_mixed_fast(Q2 + Q2, bytes([1, 1]), 2, 0, out2) == 0
+    assert out2.raw == co.msm_g2(Q2, (pr.R_MOD - 2).to_bytes(32, "little"), mont=False, naive=True)
+    assert hc.hc_g2x28_sum_mixed_fast(Q2 + Q2, bytes([0, 1]), 2, 0, out2) == 0
+    assert out2.raw[192] == 1  # cancellation -> identity
+    assert hc.hc_g2x28_sum_mixed_fast(Q2 + Q2 + Q2, bytes([0, 1, 0]), 3, 0, out2) == 0
+    assert out2.raw == co.msm_g2(Q2, (1).to_bytes(32, "little"), mont=False, naive=True)  # identity accumulator takes a point again
     m = 150  # long chains of mixed adds: the weak-reduction bounds must hold indefinitely
     b3 = co.g1_bases(9, 0, m)
     negs = bytes(rnd.randrange(2) for _ in range(m))
