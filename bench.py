@@ -34,8 +34,9 @@ MULS_PER_MIXED_ADD = 9.5
 # chip (profiles/r01_ubench_int.txt)
 MADS_PER_MIXED_ADD = 6 * 394 + 2 * 301 + (3 * 196 + 2)
 MAD_PEAK_T = 31.4
-# G2: 8 Fp2 products (3 Fp products each) + 2 Fp2 squares (2 Fp products each)
-FP_MULS_PER_G2_MIXED_ADD = 8 * 3 + 2 * 2
+# G2: 6 Fp2 products (3 Fp products each) + 2 Fp2 squares (2 Fp products each) + the fused Y (8 multiplications under 2 reductions
+# = 5 products' worth of multiply-adds); 28 before round 2's g2x28::add_mixed
+FP_MULS_PER_G2_MIXED_ADD = 6 * 3 + 2 * 2 + 5
 PROOF_ALG_BYTES = 1.24e9  # MSM 481 MB (G1) + 203 MB (G2) + 7 NTTs x 67 MB + vectors 87 MB per 2^20-class proof
 SEED = 0x42415A554B41
 HBM_PEAK_GBS = 8000.0
