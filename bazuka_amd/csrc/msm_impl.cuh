@@ -205,11 +205,13 @@ static __global__ void __launch_bounds__(256) msm_offsets_wiv_kernel(const uint3
 
 // count[g] = end[g] - start[g] (in place over `endx`), iota[g] = g
 static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* __restrict__ start, uint32_t* __restrict__ endx_count,
-                                                        uint32_t* __restrict__ iota, uint32_t nb) {
+                                                        uint32_t* __restrict__ iota, uint32_t* __restrict__ ckey, uint32_t nb) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nb) return;
-    endx_count[g] = endx_count[g] - start[g];
+    const uint32_t c = endx_count[g] - start[g];
+    endx_count[g] = c;
     iota[g] = g;
+    ckey[g] = c < 65535u ? c : 65535u;  // 16-bit sort key of the population order (true counts are gathered through the order)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,14 +220,6 @@ static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* _
 // atomics to random addresses run at ~27 G/s on MI355X, they are resolved beyond the per-XCD L2); 2^24: 20.1 ms against 6.5 ms
 // (profiles/r02_run2_csort_ab.txt).
 // ------------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256) msm_iota_clamp_kernel(const uint32_t* __restrict__ count, uint32_t* __restrict__ iota,
-                                                                    uint32_t* __restrict__ ckey, uint32_t nb) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nb) return;
-    const uint32_t c = count[g];
-    iota[g] = g;
-    ckey[g] = c < 65535u ? c : 65535u;
-}
 
 // ------------------------------------------------------------------------------------------------
 // 3c. (round 2, removed again) two-pass LDS partition of the pairs instead of the radix sort: coarse bins of 256 buckets per
@@ -775,8 +769,13 @@ template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
                                  uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
                                  bool group_sums = false, uint32_t wiv_half = 0) {
-    BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
-    BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
+    // start[] and count[] are taken from the workspace back to back: one fill covers both
+    if ((const char*)A.count > (const char*)A.start && (size_t)((const char*)A.count - (const char*)A.start) <= (size_t)nb * 4 + 256) {
+        BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)((const char*)A.count - (const char*)A.start) + (size_t)nb * 4, ctx->stream));
+    } else {
+        BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)nb * 4, ctx->stream));
+        BZK_HIP(ctx, hipMemsetAsync(A.count, 0, (size_t)nb * 4, ctx->stream));
+    }
     const uint32_t vmask = wiv_half ? 0x07ffffffu : 0x7fffffffu;
     if (wiv_half) {
         BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_wiv_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, vals_s, len, wiv_half,
@@ -784,9 +783,9 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     } else {
         BZK_LAUNCH(ctx, "msm_offsets", msm_offsets_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, keys_s, len, nb, A.start, A.count);
     }
-    BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, nb);
-    // clamped population keys: A.ntask holds them until msm_ntask overwrites it, A.tbase receives the (unused) sorted keys
-    BZK_LAUNCH(ctx, "msm_iota_clamp", msm_iota_clamp_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.iota, A.ntask, nb);
+    // counts, identity permutation and the clamped population keys in one pass: A.ntask holds the keys until msm_ntask overwrites it,
+    // A.tbase receives the (unused) sorted keys
+    BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, A.ntask, nb);
     {
         ProfScope ps(ctx, "msm_sort_buckets");
         size_t t = tmp;

@@ -194,18 +194,44 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
         }
     }
     __syncthreads();
-    for (int s = 0; s < b; ++s) {
-        const uint32_t m = 1u << s;
+    // Butterfly stages, two per LDS round trip (radix 4 in registers: half the barriers and half the LDS traffic of one stage per
+    // round).  Stage 0 has the single twiddle w^0 = one and its operands are fresh products (the load phase's conversion or the
+    // previous pass's inter-pass twiddle: k 2, the bound sub3 needs), so it multiplies nothing.  An odd stage count starts with that
+    // lone multiplication-free stage.
+    int s0 = 0;
+    if (b & 1) {
         for (uint32_t q = threadIdx.x; q < tile_n / 2; q += blockDim.x) {
             const uint32_t c = q & (CC - 1), bq = q >> lc;
-            const uint32_t j = bq & (m - 1);
-            const uint32_t k = ((bq >> s) << (s + 1)) + j;
-            const uint32_t i0 = (k << lc) + c, i1 = ((k + m) << lc) + c;
-            const Fr29 u = ld29(tile[i0]);
-            Fr29 t = ld29(tile[i1]);
-            t = fr29::mul(t, ld29(a.tw_r[j << (b - 1 - s)]));  // k 2 (j = 0: the table holds 2^261 = one)
+            const uint32_t i0 = ((bq << 1) << lc) + c, i1 = (((bq << 1) + 1) << lc) + c;
+            const Fr29 u = ld29(tile[i0]), t = ld29(tile[i1]);
             tile[i0] = st29(fr29::norm(fr29::add(u, t)));
             tile[i1] = st29(fr29::sub3(u, t));
+        }
+        __syncthreads();
+        s0 = 1;
+    }
+    for (int s = s0; s < b; s += 2) {
+        const uint32_t m = 1u << s;
+        for (uint32_t q = threadIdx.x; q < tile_n / 4; q += blockDim.x) {
+            const uint32_t c = q & (CC - 1), bq = q >> lc;
+            const uint32_t j = bq & (m - 1);
+            const uint32_t k0 = ((bq >> s) << (s + 2)) + j;
+            const uint32_t i0 = (k0 << lc) + c, i1 = ((k0 + m) << lc) + c, i2 = ((k0 + 2 * m) << lc) + c, i3 = ((k0 + 3 * m) << lc) + c;
+            Fr29 x0 = ld29(tile[i0]), x1 = ld29(tile[i1]), x2 = ld29(tile[i2]), x3 = ld29(tile[i3]);
+            if (s) {  // stage s: both butterflies of the group use w^(j 2^(b-1-s))
+                const Fr29 wa = ld29(a.tw_r[j << (b - 1 - s)]);
+                x1 = fr29::mul(x1, wa);
+                x3 = fr29::mul(x3, wa);
+            }
+            const Fr29 y0 = fr29::norm(fr29::add(x0, x1)), y1 = fr29::sub3(x0, x1);
+            const Fr29 y2 = fr29::norm(fr29::add(x2, x3)), y3 = fr29::sub3(x2, x3);
+            // stage s + 1: (y0, y2) at position j, (y1, y3) at position j + m of their 4m-blocks
+            const Fr29 u2 = fr29::mul(y2, ld29(a.tw_r[j << (b - 2 - s)]));
+            const Fr29 u3 = fr29::mul(y3, ld29(a.tw_r[(j + m) << (b - 2 - s)]));
+            tile[i0] = st29(fr29::norm(fr29::add(y0, u2)));
+            tile[i2] = st29(fr29::sub3(y0, u2));
+            tile[i1] = st29(fr29::norm(fr29::add(y1, u3)));
+            tile[i3] = st29(fr29::sub3(y1, u3));
         }
         __syncthreads();
     }
