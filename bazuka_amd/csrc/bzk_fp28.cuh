@@ -52,6 +52,8 @@ static constexpr Consts D6 = {{0x1ffe0002u, 0x1f9ffffeu, 0x17fffe5au, 0x1fff827e
                                0x1b51e706u, 0x1acbc51cu, 0x1c60d0c4u, 0x15ee4592u, 0x1679dc29u, 0x1b7d58feu, 0x009c065u}};
 static constexpr Consts D12 = {{0x1ffc0004u, 0x1f3ffffeu, 0x1ffffcb6u, 0x1fff04fdu, 0x19b1700eu, 0x18b904b7u, 0x18d649deu,
                                 0x16a3ce0eu, 0x15978a3au, 0x18c1a18au, 0x1bdc8b26u, 0x1cf3b853u, 0x16fab1fdu, 0x01380ccu}};
+static constexpr Consts D24 = {{0x1ff80008u, 0x1e7ffffeu, 0x1ffff96eu, 0x1ffe09fcu, 0x1362e01eu, 0x11720970u, 0x11ac93beu,
+                                0x1d479c1eu, 0x1b2f1475u, 0x11834315u, 0x17b9164eu, 0x19e770a8u, 0x1df563fcu, 0x00270199u}};
 // 2^400 mod p and 2^384 mod p as plain integers (conversion multipliers), 2^392 mod p (Montgomery one)
 static constexpr Consts C_IN = {{0x80e6299u, 0x3500034u, 0xeb12856u, 0xdeb2699u, 0xc988670u, 0x4ef6697u, 0x70983e8u,
                                  0xa4e6fe9u, 0x3e8a053u, 0xecf271eu, 0xc20d323u, 0x6eb6385u, 0x47f1286u, 0x00156dau}};
@@ -329,11 +331,11 @@ BZK_HD Fp28 add(const Fp28& a, const Fp28& b) {
 // a + K*p - b ; b normalised, value(b) < K*p
 template <int K>
 BZK_HD Fp28 sub(const Fp28& a, const Fp28& b) {
-    static_assert(K == 3 || K == 6 || K == 12, "no table for this multiple of p");
+    static_assert(K == 3 || K == 6 || K == 12 || K == 24, "no table for this multiple of p");
     Fp28 r;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t d = K == 3 ? D3.v[i] : K == 6 ? D6.v[i] : D12.v[i];
+        const uint32_t d = K == 3 ? D3.v[i] : K == 6 ? D6.v[i] : K == 12 ? D12.v[i] : D24.v[i];
 #if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
         assert(d >= b.l[i]);                                 // no limb underflow
         assert((uint64_t)a.l[i] + d - b.l[i] < (1ull << 32));  // no u32 overflow
@@ -923,6 +925,100 @@ BZK_HD void add_mixed(XyzzT<Fp2x28Ops>& acc, const AffineT<Fp2x28Ops>& q_in, boo
     Y3.c1 = mul4_body(R.c0, T.c1, R.c1, T.c0, nY0, PPP.c1, nY1, PPP.c0);
     acc.X = X3;
     acc.Y = Y3;
+}
+// ---- general addition and doubling of the tail kernels with the same static bounds (folds, bucket reduction, window sums: 4
+// quotient-estimate reductions per operation instead of 20 / 16 in the generic code).  Inputs follow the generic discipline (every
+// component normalised and < 8p; identity <=> ZZ limbs all zero), outputs do too (X, Y < 3p; ZZ, ZZZ product outputs), so generic and
+// static code mix freely.  The Y coordinate keeps its two Fp2 products (the fused form is inlined code, and these functions are
+// expanded several times per kernel).  sq(): (c0 + c1)(c0 - c1), 2 c0 c1 for normalised components below kp, K > k the next table.
+#ifndef BZK_G2_FAST_TAILS
+#define BZK_G2_FAST_TAILS 1  // 0: generic xyzz_add_mem / xyzz_add / xyzz_dbl in the tail kernels (A/B builds)
+#endif
+template <int K>
+BZK_HD Fp2x28 sq(const Fp2x28& a) {
+    using namespace fp28;
+    Fp2x28 r;
+    r.c0 = mul(add(a.c0, a.c1), sub<K>(a.c0, a.c1));
+    const Fp28 m = mul(a.c0, a.c1);
+    r.c1 = norm(add(m, m));
+    return r;
+}
+BZK_HD bool is_identity(const XyzzT<Fp2x28Ops>& p) { return fp28::limbs_all_zero(p.ZZ.c0) && fp28::limbs_all_zero(p.ZZ.c1); }
+
+BZK_HD XyzzT<Fp2x28Ops> dbl(const XyzzT<Fp2x28Ops>& p) {  // dbl-2008-s-1
+    using namespace fp28;
+    typedef Fp2x28Ops F;
+    if (is_identity(p)) return p;
+    const Fp2x28 U = {norm(add(p.Y.c0, p.Y.c0)), norm(add(p.Y.c1, p.Y.c1))};  // k 16
+    const Fp2x28 V = sq<24>(U);                                                 // (32)(16 + 24) = 1280
+    const Fp2x28 Wv = F::mul(U, V), S = F::mul(p.X, V);                          // (32)(6), (16)(6)
+    const Fp2x28 xx = sq<12>(p.X);                                               // (16)(8 + 12)
+    const Fp2x28 M = {norm(add(add(xx.c0, xx.c0), xx.c0)), norm(add(add(xx.c1, xx.c1), xx.c1))};  // (6, 12)
+    const Fp2x28 MM = sq<24>(M);                                                 // (18)(6 + 24)
+    XyzzT<Fp2x28Ops> r;
+    r.X = {reduce(sub<12>(sub<12>(MM.c0, S.c0), S.c0)), reduce(sub<12>(sub<12>(MM.c1, S.c1), S.c1))};
+    const Fp2x28 T = {norm(sub<3>(S.c0, r.X.c0)), norm(sub<3>(S.c1, r.X.c1))};  // k 11
+    const Fp2x28 m1 = F::mul(M, T), m2 = F::mul(Wv, p.Y);                        // (18)(22), (13)(16)
+    r.Y = {reduce(sub<12>(m1.c0, m2.c0)), reduce(sub<12>(m1.c1, m2.c1))};
+    r.ZZ = F::mul(V, p.ZZ);
+    r.ZZZ = F::mul(Wv, p.ZZZ);
+    return r;
+}
+
+// acc += *q, q left in memory (each coordinate read where the formula uses it, see xyzz_add_mem)
+BZK_HD void add_mem(XyzzT<Fp2x28Ops>& acc, const XyzzT<Fp2x28Ops>* q) {
+    using namespace fp28;
+    typedef Fp2x28Ops F;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BZK_G2_FENCE() __asm__ volatile("" ::: "memory")
+#else
+#define BZK_G2_FENCE() ((void)0)
+#endif
+    {
+        const Fp2x28 qzz = q->ZZ;
+        if (limbs_all_zero(qzz.c0) && limbs_all_zero(qzz.c1)) return;  // q is the identity
+        if (is_identity(acc)) {
+            acc = *q;
+            return;
+        }
+    }
+    BZK_G2_FENCE();
+    const Fp2x28 U1 = F::mul(acc.X, q->ZZ);  // (16)(16) = 256
+    BZK_G2_FENCE();
+    const Fp2x28 U2 = F::mul(q->X, acc.ZZ);
+    const Fp2x28 Pp = {norm(sub<12>(U2.c0, U1.c0)), norm(sub<12>(U2.c1, U1.c1))};  // k 20
+    BZK_G2_FENCE();
+    const Fp2x28 S1 = F::mul(acc.Y, q->ZZZ);
+    BZK_G2_FENCE();
+    const Fp2x28 S2 = F::mul(q->Y, acc.ZZZ);
+    const Fp2x28 R = {norm(sub<12>(S2.c0, S1.c0)), norm(sub<12>(S2.c1, S1.c1))};   // k 20
+    const Fp2x28 PP = sq<24>(Pp);                                                    // (40)(20 + 24) = 1760
+    if (mulout_is_zero(PP.c0) && F::is_zero(Pp)) {  // same x (exact test only when the cheap one fires)
+        if (F::is_zero(R)) acc = dbl(acc);
+        else acc = xyzz_identity<F>();
+        return;
+    }
+    const Fp2x28 PPP = F::mul(Pp, PP), Q = F::mul(U1, PP);  // (40)(6), (13)(6)
+    const Fp2x28 RR = sq<24>(R);
+    const Fp2x28 X3 = {reduce(sub<12>(sub<12>(sub<12>(RR.c0, PPP.c0), Q.c0), Q.c0)),
+                       reduce(sub<12>(sub<12>(sub<12>(RR.c1, PPP.c1), Q.c1), Q.c1))};
+    const Fp2x28 T = {norm(sub<3>(Q.c0, X3.c0)), norm(sub<3>(Q.c1, X3.c1))};        // k 11
+    const Fp2x28 m1 = F::mul(R, T), m2 = F::mul(S1, PPP);                            // (40)(22) = 880, (13)(13)
+    acc.X = X3;
+    acc.Y = {reduce(sub<12>(m1.c0, m2.c0)), reduce(sub<12>(m1.c1, m2.c1))};
+    BZK_G2_FENCE();
+    acc.ZZ = F::mul(F::mul(acc.ZZ, q->ZZ), PP);
+    BZK_G2_FENCE();
+    acc.ZZZ = F::mul(F::mul(acc.ZZZ, q->ZZZ), PPP);
+#undef BZK_G2_FENCE
+}
+BZK_HD XyzzT<Fp2x28Ops> mul_u32(const XyzzT<Fp2x28Ops>& p, uint32_t k) {
+    XyzzT<Fp2x28Ops> r = xyzz_identity<Fp2x28Ops>();
+    for (int i = 31; i >= 0; --i) {
+        r = dbl(r);
+        if ((k >> i) & 1) add_mem(r, &p);
+    }
+    return r;
 }
 BZK_HD Fp2x28 fp2_to28(const Fp2& a) { return {fp28::to28(a.c0), fp28::to28(a.c1)}; }
 BZK_HD Fp2 fp2_from28(const Fp2x28& a) { return {fp28::from28(a.c0), fp28::from28(a.c1)}; }

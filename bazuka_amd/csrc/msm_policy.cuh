@@ -105,12 +105,18 @@ struct G2Fast {
         xyzz_add_mixed<Fp2x28Ops>(acc, p);
 #endif
     }
-    __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2x28Ops>(acc, q); }
     // second operand left in memory (LDS / global): see xyzz_add_mem
     static constexpr bool PARK_REDUCE = true;
+    __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { xyzz_add<Fp2x28Ops>(acc, q); }  // by-value form: unused by the G2 kernels
+#if BZK_G2_FAST_TAILS
+    __device__ static __forceinline__ void add_mem(Pt& acc, const Pt* q) { g2x28::add_mem(acc, q); }
+    __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return g2x28::mul_u32(p, k); }
+    __device__ static __forceinline__ Pt dbl(const Pt& p) { return g2x28::dbl(p); }
+#else
     __device__ static __forceinline__ void add_mem(Pt& acc, const Pt* q) { xyzz_add_mem<Fp2x28Ops>(acc, q); }
     __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return xyzz_mul_u32<Fp2x28Ops>(p, k); }
     __device__ static __forceinline__ Pt dbl(const Pt& p) { return xyzz_dbl<Fp2x28Ops>(p); }
+#endif
     __device__ static __forceinline__ DevAff to_dev_affine(const Pt& p) {
         DevAff a;
         xyzz_to_affine<Fp2x28Ops>(p, a);

@@ -159,6 +159,47 @@ int hc_g2x28_sum_mixed_fast(const uint8_t* pts, const uint8_t* neg, int n, int m
 // sum_i (+/-) k_i * P_i with EVERY general addition done by xyzz_add_mem (second operand read from memory - what the G2
 // tail kernels use on the device), including the double-and-add of the scalar multiplication; mode 1 adds each term twice
 // through a parked copy (P + P = doubling inside add_mem), mode 2 adds a term and its negation (cancellation -> identity)
+// the same with the static-bound general addition / doubling of the tail kernels (g2x28::add_mem, g2x28::dbl); the terms enter through
+// the accumulation's mixed addition, and the sum is finally handed to the GENERIC addition once (both disciplines must mix)
+int hc_g2x28_lincomb_mem_fast(const uint8_t* pts, const uint32_t* k, const uint8_t* neg, int n, int mode, uint8_t* out193) {
+    typedef Fp2x28Ops F;
+    G2X28 acc = xyzz_identity<F>();
+    for (int i = 0; i < n; ++i) {
+        G2X28 t = xyzz_identity<F>();
+        g2x28::add_mixed(t, g2x28::affine_to28(ld_g2(pts + 192 * i)), neg[i] != 0);
+        G2X28 m = xyzz_identity<F>();
+        for (int b = 31; b >= 0; --b) {
+            m = g2x28::dbl(m);
+            if ((k[i] >> b) & 1) g2x28::add_mem(m, &t);
+        }
+        const G2X28 parked = m;
+        g2x28::add_mem(acc, &parked);
+        if (mode == 1) {
+            G2X28 d = parked;
+            g2x28::add_mem(d, &parked);  // doubling branch
+            g2x28::add_mem(acc, &d);
+        } else if (mode == 2) {
+            G2X28 c = parked;
+            const G2X28 minus = xyzz_neg<F>(parked);
+            g2x28::add_mem(c, &minus);   // cancellation branch
+            if (!g2x28::is_identity(c)) return 1;
+            g2x28::add_mem(acc, &c);
+        }
+        // invariants: X, Y < 3p and normalised
+        if (!g2x28::is_identity(acc)) {
+            const Fp28* xy[4] = {&acc.X.c0, &acc.X.c1, &acc.Y.c0, &acc.Y.c1};
+            for (int e = 0; e < 4; ++e) {
+                if (xy[e]->l[13] >= 3 * 0x1a012u) return -1;
+                for (int j = 0; j < 13; ++j)
+                    if (xy[e]->l[j] >> 28) return -2;
+            }
+        }
+    }
+    G2X28 z = xyzz_identity<F>();
+    xyzz_add<F>(z, acc);  // generic consumer
+    st_g2(out193, g2x28::to_std(z));
+    return 0;
+}
 int hc_g2x28_lincomb_mem(const uint8_t* pts, const uint32_t* k, const uint8_t* neg, int n, int mode, uint8_t* out193) {
     typedef Fp2x28Ops F;
     G2X28 acc = xyzz_identity<F>();

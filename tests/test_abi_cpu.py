@@ -187,6 +187,13 @@ def test_reduced_radix_curves_on_host_match_oracle(hc, co, pr):
     assert hc.hc_g2x28_lincomb_mem(b2, (C.c_uint32 * n)(*ks), neg, n, 1, out2) == 0
     sc3 = b"".join((3 * int.from_bytes(sc[32 * i:32 * i + 32], "little") % pr.R_MOD).to_bytes(32, "little") for i in range(n))
     assert out2.raw == co.msm_g2(b2, sc3, mont=False, naive=True)
+    # the static-bound general addition / doubling of the G2 tail kernels (g2x28::add_mem, g2x28::dbl): same three modes
+    assert hc.hc_g2x28_lincomb_mem_fast(b2, (C.c_uint32 * n)(*ks), neg, n, 0, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    assert hc.hc_g2x28_lincomb_mem_fast(b2, (C.c_uint32 * n)(*ks), neg, n, 2, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    assert hc.hc_g2x28_lincomb_mem_fast(b2, (C.c_uint32 * n)(*ks), neg, n, 1, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc3, mont=False, naive=True)
     # g2x28::add_mixed (what msm_accumulate<G2> runs): long signed chains, doubling and cancellation through the mixed add, and its
     # result handed to the generic general addition; bound assertions on, invariants (X, Y < 3p, normalised) checked by the harness
     m2 = 120
