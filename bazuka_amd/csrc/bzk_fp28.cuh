@@ -740,11 +740,19 @@ BZK_HD G1X28 dbl(const G1X28& p) {  // dbl-2008-s-1
     return r;
 }
 
-// acc += q  (q affine, never the identity); neg_q: add -q instead
-BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q) {
+// acc += q  (q affine, never the identity); neg_q: add -q instead.
+// `pre` is called exactly once, after the last CALL of the formula and before its inlined tail (the fused Y): the accumulation issues
+// the NEXT base's loads there.  A call is a wait-for-all-loads point for the compiler, so loads issued any earlier would be waited for
+// at the next product; issued here they fly during the ~3 us of the inlined body and are complete when the next addition starts.
+struct NoPre {
+    BZK_HD void operator()() const {}
+};
+template <class Pre = NoPre>
+BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q, Pre&& pre = Pre()) {
     G1A28 q = q_in;
     if (neg_q) q.y = norm(sub<3>(zero(), q.y));  // 3p - y, k 3
     if (is_identity(acc)) {
+        pre();
         acc = {q.x, q.y, one(), one()};
         return;
     }
@@ -756,12 +764,14 @@ BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q) {
         Fp28 RR = sqr(R);
         if (mulout_is_zero(RR)) acc = dbl_affine(q);
         else acc = identity();
+        pre();
         return;
     }
     Fp28 PPP = mul(Pp, PP), Q = mul(acc.X, PP), RR = sqr(R);
     Fp28 X3 = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));             // k 11
     acc.ZZ = mul(acc.ZZ, PP);
     acc.ZZZ = mul(acc.ZZZ, PPP);
+    pre();
 #if BZK_G1_FUSED_Y
     acc.Y = mul_sub2_body(R, sub<12>(Q, X3), PPP, acc.Y);              // R (Q - X3) - Y PPP, one reduction; k 2
 #else
@@ -881,7 +891,8 @@ namespace g2x28 {
 //   T = Q - X3: sub<3> + norm, k <= 11
 //   Y3.re = R0 T0 + (12p - R1) T1 + (3p - Y0) PPP0 + Y1 PPP1      (121 + 132 + 15 + 24 = 292 <= 2048; columns 14 * 7 * 2^56 < 2^64)
 //   Y3.im = R0 T1 + R1 T0 + (3p - Y0) PPP1 + (3p - Y1) PPP0       (121 + 121 + 24 + 15)                       -> product outputs, k 2
-BZK_HD void add_mixed(XyzzT<Fp2x28Ops>& acc, const AffineT<Fp2x28Ops>& q_in, bool neg_q) {
+template <class Pre = g1x28::NoPre>
+BZK_HD void add_mixed(XyzzT<Fp2x28Ops>& acc, const AffineT<Fp2x28Ops>& q_in, bool neg_q, Pre&& pre = Pre()) {  // pre: see g1x28::add_mixed
     using namespace fp28;
     typedef Fp2x28Ops F;
     // q: components normalised and < 8p - converted bases are product outputs (< 2p), table entries and the group sums of the
@@ -889,6 +900,7 @@ BZK_HD void add_mixed(XyzzT<Fp2x28Ops>& acc, const AffineT<Fp2x28Ops>& q_in, boo
     AffineT<Fp2x28Ops> q = q_in;
     if (neg_q) q.y = {norm(sub<12>(zero(), q.y.c0)), norm(sub<12>(zero(), q.y.c1))};  // 12p - y, k 12
     if (limbs_all_zero(acc.ZZ.c0) && limbs_all_zero(acc.ZZ.c1)) {
+        pre();
         acc = {{reduce(q.x.c0), reduce(q.x.c1)}, {reduce(q.y.c0), reduce(q.y.c1)}, F::one(), F::one()};  // X, Y < 3p (once per run)
         return;
     }
@@ -904,6 +916,7 @@ BZK_HD void add_mixed(XyzzT<Fp2x28Ops>& acc, const AffineT<Fp2x28Ops>& q_in, boo
     if (mulout_is_zero(PP.c0) && F::is_zero(Pp)) {  // same x (exact test only when the cheap one fires): doubling or cancellation
         if (F::is_zero(R)) acc = xyzz_dbl_affine<F>(q);
         else acc = xyzz_identity<F>();
+        pre();
         return;
     }
     const Fp2x28 PPP = F::mul(Pp, PP), Q = F::mul(acc.X, PP);
@@ -919,6 +932,7 @@ BZK_HD void add_mixed(XyzzT<Fp2x28Ops>& acc, const AffineT<Fp2x28Ops>& q_in, boo
     const Fp2x28 T = {norm(sub<3>(Q.c0, X3.c0)), norm(sub<3>(Q.c1, X3.c1))};
     acc.ZZ = F::mul(acc.ZZ, PP);
     acc.ZZZ = F::mul(acc.ZZZ, PPP);
+    pre();
     const Fp28 nR1 = sub<12>(zero(), R.c1), nY0 = sub<3>(zero(), acc.Y.c0), nY1 = sub<3>(zero(), acc.Y.c1);
     Fp2x28 Y3;
     Y3.c0 = mul4_body(R.c0, T.c0, nR1, T.c1, nY0, PPP.c0, acc.Y.c1, PPP.c1);

@@ -6,15 +6,17 @@
 // Pipeline (on the ctx stream unless noted, data stays in HBM):
 //   0. msm_convert     raw 96-byte bases -> internal 112-byte form, on the call's SIDE stream (joined before step 5)
 //   1. msm_digits      one lane per scalar: Montgomery -> canonical, signed c-bit window recoding,
-//                      emits (bucket key, point index | sign) pairs, window-major => coalesced stores
-//   2. radix sort      rocPRIM pair sort by bucket key (HBM-bound streaming passes)
-//   3. msm_offsets     bucket boundaries from the sorted keys
+//                      emits (bucket within its window, point index | window | sign) pairs, window-major => coalesced stores
+//   2. radix sort      rocPRIM pair sort by the bucket-within-window key (c - 1 bits + sentinel: two 8-bit passes at c = 16; the
+//                      sort is stable and the pairs were emitted window-major, so (bucket, window) runs stay contiguous)
+//   3. msm_offsets     run boundaries from the sorted keys and the window bits of the values
 //   4. size sort       buckets ordered by population (descending, on 16-bit clamped counts) so the 64 lanes of a
 //                      wavefront run equally long accumulation loops; task table (runs of <= seg entries)
 //   5. msm_accumulate  one lane per TASK: gathers its affine points (7 x 16 B loads each) and folds them with XYZZ
 //                      mixed adds                                           <-- dominant kernel
 //      msm_fold*       partial sums of multi-task buckets (regime picked on the device, see msm_fold_threshold)
-//   6. msm_reduce      per chunk of CH buckets: running-sum  sum (b+1) B_b  (+ chunk offset)
+//   6. msm_reduce      per chunk of CH buckets: running-sum  sum (b+1) B_b  (+ chunk offset); BZK_F_THROUGHPUT: two levels
+//                      (chunk sums and totals, then the offsets as a second reduction over the totals)
 //   7. msm_window_sum  per window: LDS trees over the chunk results
 //   8. host            Horner over <= 32 window sums, to affine, pack
 // With BZK_F_DEDUP (section 8) equal scalars are merged first: 32-bit hash sort, group sums through steps 4 - 5, batched
@@ -290,6 +292,9 @@ static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* _
     ntask[i] = c <= seg ? 1u : (c + seg - 1) / seg;  // empty buckets keep one task (writes the identity)
 }
 
+#ifndef BZK_MSM_PREFETCH
+#define BZK_MSM_PREFETCH 1  // 0: gather each base at the top of its own addition (A/B builds)
+#endif
 template <class C, int OCC>
 __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                              const uint32_t* __restrict__ start,
@@ -319,11 +324,30 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
     const uint32_t s = start[g] + k * q;
     const uint32_t len = k * q >= cnt ? 0u : (cnt - k * q < q ? cnt - k * q : q);  // empty bucket: writes the identity
     typename C::Pt acc = C::identity();
+#if BZK_MSM_PREFETCH
+    if (len) {
+        // software pipelining of the gathers: the next base is requested inside the current addition, after its last product CALL
+        // (see g1x28::add_mixed), and arrives under the inlined tail of the formula
+        uint32_t v = vals[s];
+        typename C::DevAff p = C::load(bases, v & vmask);
+        for (uint32_t j = 0; j < len; ++j) {
+            // unconditional (the last iteration re-reads its own entry): a branch around the loads would force their results to be
+            // merged with a default - i.e. waited for - on the spot.  The index word is requested at the top of the iteration, the
+            // seven 16-byte loads of the base it names inside the addition
+            const uint32_t vn = vals[s + (j + 1 < len ? j + 1 : j)];
+            typename C::DevAff pn;
+            C::add_mixed_pre(acc, p, (v >> 31) != 0, [&]() { pn = C::load(bases, vn & vmask); });
+            p = pn;
+            v = vn;
+        }
+    }
+#else
     for (uint32_t j = 0; j < len; ++j) {
         const uint32_t v = vals[s + j];
         typename C::DevAff p = C::load(bases, v & vmask);
         C::add_mixed(acc, p, (v >> 31) != 0);
     }
+#endif
     if (cnt <= seg) buckets[g] = acc;
     else partial[t] = acc;
 }

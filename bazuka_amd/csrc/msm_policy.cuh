@@ -35,6 +35,8 @@ struct G1Fast {
     __device__ static __forceinline__ void add_mem(Pt& acc, const Pt* q) { g1x28::add_mem(acc, q); }
     __device__ static __forceinline__ Pt identity() { return g1x28::identity(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p, bool neg) { g1x28::add_mixed(acc, p, neg); }
+    template <class Pre>
+    __device__ static __forceinline__ void add_mixed_pre(Pt& acc, const DevAff& p, bool neg, Pre&& pre) { g1x28::add_mixed(acc, p, neg, pre); }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { g1x28::add_full(acc, q); }
     __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return g1x28::mul_u32(p, k); }
     __device__ static __forceinline__ Pt dbl(const Pt& p) { return g1x28::dbl(p); }
@@ -96,6 +98,15 @@ struct G2Fast {
     // 35 spilled (profiles/r01_run15: 12.7 ms vs 13.0 ms at 2^20)
     static constexpr int ACC_OCC = BZK_G2_ACC_OCC;
     __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2x28Ops>(); }
+    template <class Pre>
+    __device__ static __forceinline__ void add_mixed_pre(Pt& acc, const DevAff& p_in, bool neg, Pre&& pre) {
+#if BZK_G2_FAST_MIXED
+        g2x28::add_mixed(acc, p_in, neg, pre);
+#else
+        pre();
+        add_mixed(acc, p_in, neg);
+#endif
+    }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p_in, bool neg) {
 #if BZK_G2_FAST_MIXED
         g2x28::add_mixed(acc, p_in, neg);
