@@ -22,7 +22,10 @@ struct G1Fast {
     static constexpr int RAW = 96, PACKED = 97;
     static constexpr bool CONVERT_BASES = true;
     static constexpr int WSUM_THREADS = 256;  // 256 x 224 B = 56 KiB LDS
-    static constexpr int ACC_OCC = 2;
+#ifndef BZK_G1_ACC_OCC
+#define BZK_G1_ACC_OCC 2  // waves per SIMD the accumulate kernel is compiled for (A/B builds)
+#endif
+    static constexpr int ACC_OCC = BZK_G1_ACC_OCC;
 #ifndef BZK_G1_PARK_REDUCE
 #define BZK_G1_PARK_REDUCE 0
 #endif
