@@ -508,8 +508,12 @@ def main():
     if not args.no_proofs:
         try:
             # N ranks share the host: split its cores between the ranks' witness producers
-            pt = 16 if world == 1 else max(2, min(16, (os.cpu_count() or 64) // world // 6))
-            proofs = full_prove_section(ctx, n_prod=6, prod_threads=pt, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+            # 8 producers x 8 worker threads measured best of the producer / thread sweeps (profiles/r02_run34_35_producer_sweep.txt:
+            # 49.4 - 50.4 proofs/s against 45.8 - 45.9 for 6 x 16 on the same boxes; the GPU-side ceiling there was 54.7 - 55.0)
+            n_prod = int(os.environ.get("BZK_BENCH_PRODUCERS", "8"))
+            pt = 8 if world == 1 else max(2, min(8, (os.cpu_count() or 64) // world // n_prod))
+            pt = int(os.environ.get("BZK_BENCH_PROD_THREADS", str(pt)))
+            proofs = full_prove_section(ctx, n_prod=n_prod, prod_threads=pt, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # the headline MSM line must still be printed
             proofs = {"error": repr(e)}
         if world > 1:
