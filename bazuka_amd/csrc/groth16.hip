@@ -254,11 +254,17 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
     // one host thread per lane) so that one MSM's tail overlaps another's accumulation; l, a, b only need z, so
     // they start while az/bz/cz are still being copied and the h polynomial is computed on the main stream.
     // h-query table: 2^16 .. 2^21 domains (13 levels x 112 B x m: 1.5 GB at 2^20, 3 GB at 2^21 - the production 2^24 domain would
-    // need 24 GB per prover slot and keeps the per-call pipeline); env BZK_PROVE_H_TABLE=0 switches it off (A/B runs)
+    // need 24 GB per prover slot and keeps the per-call pipeline unless env BZK_PROVE_H_TABLE_MAX_LOG raises the limit - a deployment
+    // with one or two slots per GPU can afford it); env BZK_PROVE_H_TABLE=0 switches the table off (A/B runs)
     if (!p->h_table_tried) {
         p->h_table_tried = true;
         static const bool want = [] { const char* e = getenv("BZK_PROVE_H_TABLE"); return !e || atoi(e) != 0; }();
-        if (want && p->log_m >= 16 && p->log_m <= 21) {
+        static const uint32_t max_log = [] {
+            const char* e = getenv("BZK_PROVE_H_TABLE_MAX_LOG");
+            const int v = e ? atoi(e) : 21;
+            return (uint32_t)(v < 16 ? 16 : (v > 26 ? 26 : v));
+        }();
+        if (want && p->log_m >= 16 && p->log_m <= max_log) {
             const uint32_t c = p->log_m > 20 ? 20u : p->log_m;
             if (bzk_msm_g1_table_build_c(ctx, p->h, m - 1, c, &p->h_table) != BZK_OK) {
                 p->h_table = nullptr;  // not enough memory: the per-call pipeline works without it

@@ -23,6 +23,19 @@ def test_libbzk_exports_every_header_symbol():
     L.load_library()
 
 
+def test_flag_and_status_constants_match_the_header():
+    """the ctypes driver's flag / status constants are the header's #defines (a flag added on one side only would be silently ignored)"""
+    from bazuka_amd import lib as L
+    hdr = open(os.path.join(ROOT, "include", "bzk.h")).read()
+    defs = {k: int(v.rstrip("u")) for k, v in re.findall(r"#define\s+(BZK_[A-Z_]+)\s+\(?(-?\d+u?)\)?", hdr)}
+    for name in ("BZK_F_CANONICAL", "BZK_F_DEDUP", "BZK_F_THROUGHPUT"):
+        assert getattr(L, name) == defs[name], name
+    flags = [defs[k] for k in defs if k.startswith("BZK_F_")]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)  # distinct single bits
+    assert L._flags(True, True, True) == defs["BZK_F_CANONICAL"] | defs["BZK_F_DEDUP"] | defs["BZK_F_THROUGHPUT"]
+    assert defs["BZK_OK"] == 0 and defs["BZK_E_DEVICE"] == -3
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     from bazuka_amd import Bzk, BzkError
