@@ -1,5 +1,7 @@
 """Where is the pipelined proof rate bound?  N prover slots on one GPU proving the SAME pre-built witness in a loop (no host producers, no
-queue): the GPU-side ceiling of bench.py's pipelined figure.  usage: python tools/pipe_probe.py [slots=4] [proofs_per_slot=16]"""
+queue): the GPU-side ceiling of bench.py's pipelined figure.  With bg_producers > 0 that many witness producers (bg_threads worker threads
+each) synthesize batches in the background and THROW THEM AWAY: what the producers' mere presence on the host costs the prover.
+usage: python tools/pipe_probe.py [slots=4] [proofs_per_slot=16] [bg_producers=0] [bg_threads=8]"""
 import json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +15,7 @@ def fr(x):
     return (x * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little")
 
 
-def main(n_slots=4, per=16):
+def main(n_slots=4, per=16, bg_producers=0, bg_threads=8):
     torch.cuda.init()
     ZIESHA = fr(1)
     w = L.MpnWorld(15, 3)
@@ -37,6 +39,28 @@ def main(n_slots=4, per=16):
 
     for i in range(n_slots):
         run(i, 2)
+    stop = threading.Event()
+    made = [0]
+
+    def background(seed):
+        pw = L.MpnWorld(15, 3)
+        pw.set_threads(bg_threads)
+        for i in range(32):
+            pw.add_account(i, b"bg%dacct%d" % (seed, i), ZIESHA, 10 ** 12)
+        k = 0
+        while not stop.is_set():
+            k += 1
+            for i in range(16):
+                pw.push_tx(i, 16 + i, ZIESHA, 100 + i + k, ZIESHA, i % 7)
+            rr = pw.update_synthesize(2, fr(99), ZIESHA)
+            assert rr.satisfied
+            made[0] += 1
+
+    bg = [threading.Thread(target=background, args=(s,), daemon=True) for s in range(bg_producers)]
+    for t in bg:
+        t.start()
+    if bg:
+        time.sleep(1.0)  # let them reach their steady state
     t0 = time.perf_counter()
     th = [threading.Thread(target=run, args=(i, per)) for i in range(n_slots)]
     for t in th:
@@ -44,7 +68,14 @@ def main(n_slots=4, per=16):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    print(json.dumps({"slots": n_slots, "proofs": n_slots * per, "proofs_per_s_same_witness_no_producers": round(n_slots * per / dt, 2)}))
+    stop.set()
+    out = {"slots": n_slots, "proofs": n_slots * per, "proofs_per_s_same_witness_no_producers": round(n_slots * per / dt, 2)}
+    if bg_producers:
+        out = {"slots": n_slots, "proofs": n_slots * per, "background_producers": bg_producers, "threads_each": bg_threads,
+               "proofs_per_s_same_witness_with_idle_producers": round(n_slots * per / dt, 2), "witnesses_discarded": made[0]}
+    print(json.dumps(out))
+    for t in bg:
+        t.join()
 
 
 if __name__ == "__main__":
