@@ -349,6 +349,10 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): 2^log-n points PER GPU; strong: 2^log-n-total points for the whole job (SURVEY 8d C4 reading (i))")
     ap.add_argument("--log-n-total", type=int, default=24, help="log2 points of the whole job in --scaling strong (24 or 26)")
+    ap.add_argument("--partition", choices=("windows", "points"), default="windows",
+                    help="N > 1: windows = the north star's scalar-window ranges over all points (default); points = every rank runs "
+                         "all windows over its own slice of the points (no rank converts or recodes another rank's points); same "
+                         "single all-gather + fold, same result")
     args = ap.parse_args()
 
     import torch
@@ -390,13 +394,20 @@ def main():
     torch.cuda.synchronize()
 
     from bazuka_amd.dist import allgather_fold, window_range
-    W = ctx.msm_window_count(n)
-    w0, w1 = window_range(W, rank, world)
+    by_points = world > 1 and args.partition == "points"
+    p_lo, p_hi = (n * rank // world, n * (rank + 1) // world) if by_points else (0, n)
+    n_rank = p_hi - p_lo                      # points this rank's launches touch
+    W = ctx.msm_window_count(n_rank if by_points else n)
+    w0, w1 = (0, W) if by_points else window_range(W, rank, world)
+    bases_rank, scalars_rank = bases[96 * p_lo:96 * p_hi], scalars[p_lo:p_hi]
 
     def step():
         if world == 1:
             return ctx.msm_g1_dev(bases, scalars, n)
-        part = ctx.msm_g1_windows_dev(bases, scalars, n, w0, w1)
+        if by_points:   # the MSM is linear in its points: any partition of them folds to the same element
+            part = ctx.msm_g1_dev(bases_rank, scalars_rank, n_rank)
+        else:
+            part = ctx.msm_g1_windows_dev(bases, scalars, n, w0, w1)
         return allgather_fold(part, device=None if dry else dev)  # RCCL all-gather of 97-byte partials + local fold
 
     def fence():
@@ -492,10 +503,11 @@ def main():
         "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[1]: 2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU "
                                 f"(bases k_i*G, uniform scalars, resident in HBM)") if args.scaling == "weak" else
-                               (f"BASELINE configs[3] reading (i): ONE 2^{args.log_n_total}-point G1 MSM for the whole job, window-sharded "
-                                f"over the ranks (bases k_i*G, uniform scalars, replicated in HBM)"),
-                   "points_total": n, "windows": W, "window_range_this_rank": [w0, w1],
-                   "parallelism": "single-gpu" if world == 1 else f"window-sharded x{world} + RCCL all-gather of partial sums"},
+                               (f"BASELINE configs[3] reading (i): ONE 2^{args.log_n_total}-point G1 MSM for the whole job, "
+                                f"{'point' if by_points else 'window'}-sharded over the ranks (bases k_i*G, uniform scalars, replicated in HBM)"),
+                   "points_total": n, "windows": W, "window_range_this_rank": [w0, w1], "point_range_this_rank": [p_lo, p_hi],
+                   "parallelism": "single-gpu" if world == 1 else
+                                  f"{'point' if by_points else 'window'}-sharded x{world} + RCCL all-gather of partial sums"},
         "proofs_per_sec": None,
     }
     if world > 1:  # what the collective layer actually saw
@@ -525,7 +537,7 @@ def main():
     if rank == 0:
         if acc_n:
             per_launch_ms = acc_ms / acc_n
-            alg_bytes = 128.0 * n  # 96 B affine base + 32 B scalar per (point, scalar) pair
+            alg_bytes = 128.0 * n_rank  # 96 B affine base + 32 B scalar per (point, scalar) pair of this rank's launch
             achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
@@ -533,7 +545,7 @@ def main():
                                "avg_launch_ms": round(per_launch_ms, 4),
                                "note": "integer-ALU bound (381-bit Montgomery carry chains); HBM fraction is "
                                        "structurally ~1e-3, see DESIGN.md"}
-            pairs = n * (w1 - w0)  # one mixed add per (point, window) pair (zero digits skipped: ~2^-16 of them)
+            pairs = n_rank * (w1 - w0)  # one mixed add per (point, window) pair (zero digits skipped: ~2^-16 of them)
             gmul = pairs * MULS_PER_MIXED_ADD / (per_launch_ms * 1e-3) / 1e9
             out["roofline"]["alu"] = {"achieved": round(gmul, 2), "peak": FP_MUL_PEAK_G, "unit": "G Fp-mul/s",
                                       "frac": round(gmul / FP_MUL_PEAK_G, 4),
