@@ -109,6 +109,12 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
         return BZK_E_DEVICE;
     }
     if (hipSetDevice(device_id) != hipSuccess) return BZK_E_DEVICE;
+    // env BZK_SYNC_BLOCKING=1: host threads that wait for the GPU sleep on an interrupt instead of spinning.  A prover keeps ~4 host
+    // threads per slot waiting most of the time; inside a CPU-quota'd container (cgroup cpu.max) their spinning is charged against the
+    // same budget as the witness producers' work (profiles/r02_run37_45_host_interference.txt)
+    if (const char* e = getenv("BZK_SYNC_BLOCKING")) {
+        if (atoi(e) != 0 && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+    }
     bzk_ctx* ctx = new (std::nothrow) bzk_ctx();
     if (!ctx) return BZK_E_ALLOC;
     ctx->device = device_id;

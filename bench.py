@@ -53,6 +53,23 @@ def _fr(x: int) -> bytes:
 MSM_KERNEL_SOURCES = ("msm_impl.cuh", "msm_policy.cuh", "msm_g1.hip", "bzk_fp28.cuh", "bzk_curve.cuh", "bzk_field.cuh")
 
 
+def cpu_quota():
+    """CPUs the container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), None when unlimited.  The GPU box shows 256
+    logical CPUs but runs this job inside a 16-CPU quota (profiles/r02_run37_46_host_interference.txt): `cores` of a cpu_baseline is the
+    number of THREADS the oracle used, `cpu_quota` what the kernel lets them consume."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def msm_source_stamp():
     """sha256 over the sources the MSM kernels are built from: a PMC measurement is only quoted for the build it was taken on
     (the GPU box has no .git, so the stamp is a content hash, not a commit id)"""
@@ -147,7 +164,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
         want = co.groth16_prove(d, cur.view("z"), cur.view("az"), cur.view("bz"), cur.view("cz"), rk, sk, nthreads=co.ncpu())
         dt = time.perf_counter() - t0
         assert want == gpu_proof, "GPU proof bytes differ from the CPU oracle's"
-        out["cpu_baseline"] = {"value": round(1 / dt, 4), "unit": "proofs/s", "cores": co.ncpu(), "kind": "port",
+        out["cpu_baseline"] = {"value": round(1 / dt, 4), "unit": "proofs/s", "cores": co.ncpu(), "cpu_quota": cpu_quota(), "kind": "port",
                                "sample": f"1 proof of the same 16-tx circuit (same CRS, witness, r, s), {dt:.2f} s",
                                "parity": "bit-exact (387 proof bytes)"}
         del d
@@ -568,7 +585,7 @@ def main():
             want = co.msm_g1(hb, hs, nthreads=cores)
             dt = time.perf_counter() - t0
             assert want == result, "GPU MSM result differs from the CPU oracle"
-            out["cpu_baseline"] = {"value": round(n / dt / 1e6, 4), "unit": "Mpt/s", "cores": cores, "kind": "port",
+            out["cpu_baseline"] = {"value": round(n / dt / 1e6, 4), "unit": "Mpt/s", "cores": cores, "cpu_quota": cpu_quota(), "kind": "port",
                                    "sample": f"the full 2^{args.log_n}-point MSM of this run, 1 run, "
                                              f"window-per-thread Pippenger (bellman-equivalent), {dt:.2f} s",
                                    "parity": "bit-exact (97-byte affine result)"}
