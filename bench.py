@@ -12,7 +12,14 @@ roofline  = msm_accumulate (dominant kernel): algorithmic 128 B per (point, scal
             event time, against the 8 TB/s HBM peak.  The kernel is integer-ALU bound, so this
             fraction is tiny by construction; int_ops/s is reported beside it.
 cpu_baseline = the C++ oracle Pippenger (bellman-equivalent algorithm, "port") on the host cores,
-            rank 0, N=1 only; its result doubles as the parity check of the timed GPU result.
+            rank 0, N=1 only; its result doubles as the parity check of the timed GPU result.  `cores` = threads
+            used, `cpu_quota` = CPUs the container may actually consume (cgroup; 16 of the 256 shown on the GPU box).
+Other sections of the same JSON line (N = 1): `proofs` (full Groth16 proofs of the 2^20-class Update circuit:
+            single, serial and pipelined - 8 host witness producers x 8 threads -> 4 prover slots on the GPU - with
+            their own cpu_baseline and `proof_roofline`), `other_configs` (2^24-leaf tree, MPN-shaped state, NTT
+            2^20 / 2^24, h stage, G2 MSM 2^20, static-table G1 MSM), `two_msms_in_flight`, `kernel_ms_per_step`.
+Options:    --scaling strong --log-n-total 24|26 (fixed job), --partition points (rank r owns points, not windows),
+            --no-proofs / --no-others / --no-overlap / --no-cpu-baseline (shorter runs for profiling).
 """
 import argparse
 import json
