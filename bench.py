@@ -357,6 +357,23 @@ def other_configs_section(ctx, dev):
                                        "ms": round(ms, 3), "Mpt_per_s": round(n / ms / 1e3, 2), "same_bytes_as_per_call_pipeline": same,
                                        "kernel_ms": kernels(lambda: ctx.msm_table_run_dev(tab, sc, n))}
     ctx.msm_table_free(tab)
+    del gb, sc
+    # the same per-call pipeline at 2^24 points (bases 1.9 GB in internal form: beyond the Infinity Cache; 32 entries per bucket -> 512):
+    # where the fixed cost of the bucket reduction and the window sums is 3 % of the call instead of 23 %
+    n = 1 << 24
+    gb = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+    ctx.g1_synth_bases_dev(SEED, 0, n, gb)
+    sc = rand_fr(n, 17)
+    ms = timeit(lambda: ctx.msm_g1_dev(gb, sc, n), reps=2)
+    k = kernels(lambda: ctx.msm_g1_dev(gb, sc, n))
+    acc = k.get("msm_accumulate", 0.0)
+    sec = {"ms": round(ms, 3), "Mpt_per_s": round(n / ms / 1e3, 2), "kernel_ms": k}
+    if acc:
+        sec["roofline"] = {"bound": "hbm", "achieved": round(128.0 * n / (acc * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(128.0 * n / (acc * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "kernel": "msm_accumulate", "avg_launch_ms": round(acc, 4)}
+        tmad = n * 16 * MADS_PER_MIXED_ADD / (acc * 1e-3) / 1e12
+        sec["alu_mad"] = {"achieved": round(tmad, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s", "frac": round(tmad / MAD_PEAK_T, 4)}
+    out["msm_g1_2p24"] = sec
     return out
 
 
