@@ -72,4 +72,40 @@ uint32_t bzk_msm_table_window_count(const bzk_msm_table* table) {
 }
 uint32_t bzk_msm_table_levels(const bzk_msm_table* table) { return table ? (uint32_t)((const MsmTable*)table)->levels : 0; }
 
+// resident base sets (see msm_impl.cuh MsmBases): a static point set converted once to the internal form
+int32_t bzk_msm_g1_bases_load_dev(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_bases** out) {
+    MsmBases* b = nullptr;
+    int32_t st = msm_bases_load<G1Fast>(ctx, bases_dev, n, &b);
+    if (out) *out = (bzk_msm_bases*)b;
+    return st;
+}
+int32_t bzk_msm_g1_bases_run_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                 uint8_t out[97]) {
+    return msm_bases_entry<G1Fast>(ctx, (const MsmBases*)bases, scalars_dev, n, flags, 0, -1, out);
+}
+int32_t bzk_msm_g1_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                     uint32_t w_begin, uint32_t w_end, uint8_t out[97]) {
+    return msm_bases_entry<G1Fast>(ctx, (const MsmBases*)bases, scalars_dev, n, flags, (int)w_begin, (int)w_end, out);
+}
+void bzk_msm_bases_free(bzk_ctx* ctx, bzk_msm_bases* bases) { msm_bases_free(ctx, (MsmBases*)bases); }
+uint64_t bzk_msm_bases_size(const bzk_msm_bases* bases) { return bases ? ((const MsmBases*)bases)->n : 0; }
+
 }  // extern "C"
+
+// hooks for mg.hip / groth16.hip (not part of the C ABI)
+namespace bzk {
+int32_t msm_g1_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
+                           int w_begin, int w_end, void* d_win, int32_t info[4]) {
+    return msm_windows_dev<G1Fast>(ctx, (const MsmBases*)bases, bases_raw, scalars, n, flags, w_begin, w_end, d_win, info);
+}
+int msm_window_bits(uint64_t n) {  // the window size behind bzk_msm_window_count(n): what a call that names a window range runs with
+    int c = msm_pick_c(n ? n : 1);
+    if (const char* e = getenv("BZK_MSM_C")) {
+        int v = atoi(e);
+        if (v >= 2 && v <= 20) c = v;
+    }
+    return c;
+}
+int32_t g1_horner_packed(const void* S, int count, int c, int w0, uint8_t* out) { return horner_packed<FpOps>(S, count, c, w0, out); }
+}  // namespace bzk
+

@@ -50,4 +50,30 @@ int32_t bzk_msm_g2_table_windows_dev(bzk_ctx* ctx, const bzk_msm_table* table, c
     return msm_table_entry<G2Fast>(ctx, (const MsmTable*)table, scalars_dev, n, flags, (int)w_begin, (int)w_end, out);
 }
 
+// resident base sets (see msm_impl.cuh MsmBases): a static point set converted once to the internal form
+int32_t bzk_msm_g2_bases_load_dev(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_bases** out) {
+    MsmBases* b = nullptr;
+    int32_t st = msm_bases_load<G2Fast>(ctx, bases_dev, n, &b);
+    if (out) *out = (bzk_msm_bases*)b;
+    return st;
+}
+int32_t bzk_msm_g2_bases_run_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                 uint8_t out[193]) {
+    return msm_bases_entry<G2Fast>(ctx, (const MsmBases*)bases, scalars_dev, n, flags, 0, -1, out);
+}
+int32_t bzk_msm_g2_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                     uint32_t w_begin, uint32_t w_end, uint8_t out[193]) {
+    return msm_bases_entry<G2Fast>(ctx, (const MsmBases*)bases, scalars_dev, n, flags, (int)w_begin, (int)w_end, out);
+}
+
 }  // extern "C"
+
+// hooks for mg.hip / groth16.hip (not part of the C ABI)
+namespace bzk {
+int32_t msm_g2_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
+                           int w_begin, int w_end, void* d_win, int32_t info[4]) {
+    return msm_windows_dev<G2Fast>(ctx, (const MsmBases*)bases, bases_raw, scalars, n, flags, w_begin, w_end, d_win, info);
+}
+int32_t g2_horner_packed(const void* S, int count, int c, int w0, uint8_t* out) { return horner_packed<Fp2Ops>(S, count, c, w0, out); }
+}  // namespace bzk
+

@@ -302,9 +302,13 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
                                                              const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t t_max,
                                                              uint32_t seg, typename C::Pt* __restrict__ buckets,
-                                                             typename C::Pt* __restrict__ partial, uint32_t vmask) {
+                                                             typename C::Pt* __restrict__ partial, uint32_t vmask,
+                                                             const void* __restrict__ bases2, uint32_t n_split) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= t_max) return;
+    // base indices >= n_split name entries of a SECOND array (the de-duplication's group sums, which live in the call's workspace
+    // while the bases proper may be a resident, shared, read-only set - MsmBases): one compare + select per gather
+    auto ld = [&](uint32_t idx) { return idx >= n_split ? C::load(bases2, idx - n_split) : C::load(bases, idx); };
     // last sorted position i with tbase[i] <= t
     uint32_t lo = 0, hi = nb;
     while (lo + 1 < hi) {
@@ -329,14 +333,14 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
         // software pipelining of the gathers: the next base is requested inside the current addition, after its last product CALL
         // (see g1x28::add_mixed), and arrives under the inlined tail of the formula
         uint32_t v = vals[s];
-        typename C::DevAff p = C::load(bases, v & vmask);
+        typename C::DevAff p = ld(v & vmask);
         for (uint32_t j = 0; j < len; ++j) {
             // unconditional (the last iteration re-reads its own entry): a branch around the loads would force their results to be
             // merged with a default - i.e. waited for - on the spot.  The index word is requested at the top of the iteration, the
             // seven 16-byte loads of the base it names inside the addition
             const uint32_t vn = vals[s + (j + 1 < len ? j + 1 : j)];
             typename C::DevAff pn;
-            C::add_mixed_pre(acc, p, (v >> 31) != 0, [&]() { pn = C::load(bases, vn & vmask); });
+            C::add_mixed_pre(acc, p, (v >> 31) != 0, [&]() { pn = ld(vn & vmask); });
             p = pn;
             v = vn;
         }
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
 #else
     for (uint32_t j = 0; j < len; ++j) {
         const uint32_t v = vals[s + j];
-        typename C::DevAff p = C::load(bases, v & vmask);
+        typename C::DevAff p = ld(v & vmask);
         C::add_mixed(acc, p, (v >> 31) != 0);
     }
 #endif
@@ -792,7 +796,7 @@ struct BucketArrays {
 template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
                                  uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
-                                 bool group_sums = false, uint32_t wiv_half = 0) {
+                                 bool group_sums = false, uint32_t wiv_half = 0, const void* bases2 = nullptr, uint32_t n_split = 0xffffffffu) {
     // start[] and count[] are taken from the workspace back to back: one fill covers both
     if ((const char*)A.count > (const char*)A.start && (size_t)((const char*)A.count - (const char*)A.start) <= (size_t)nb * 4 + 256) {
         BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)((const char*)A.count - (const char*)A.start) + (size_t)nb * 4, ctx->stream));
@@ -833,15 +837,21 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     auto k_fold_small = msm_fold_small_kernel<C>;
     if (group_sums) {
         BZK_LAUNCH(ctx, "dedup_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
-                   nb, t_max, seg, buckets, A.partial, vmask);
+                   nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split);
     } else {
         BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
-                   nb, t_max, seg, buckets, A.partial, vmask);
+                   nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split);
     }
     // only sorted positions < len / seg can hold a multi-task bucket; of those only the first
     // len / (seg * MSM_FOLD_SMALL) can need the workgroup-wide fold
     const uint32_t n_pos = (uint32_t)std::min<uint64_t>(nb, len / seg + 1);
-    const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * MSM_FOLD_SMALL) + 1);
+    // upper bound of the partial sums beyond one per bucket is len / seg: below MSM_FOLD_BULK_FROM the device is certainly in the
+    // latency regime (thr = 2); at or above it may be in either, and the workgroup fold must still cover positions with > 2 tasks
+    // unless even the LOWER bound of `extra` says bulk.  extra >= tasks of full runs only = sum floor(cnt / seg) - (buckets with
+    // cnt > seg) which the host does not know; so: bulk is assumed only for the launch SIZE when len / seg >= 4 x the threshold (the
+    // 2^24-point regime: 524 288 launches that exit at once otherwise) and the kernel re-checks per bucket either way
+    const bool surely_bulk = len / seg >= 4ull * MSM_FOLD_BULK_FROM && len / seg >= 2ull * nb;
+    const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * (surely_bulk ? MSM_FOLD_SMALL_BULK : MSM_FOLD_SMALL)) + 1);
     BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, seg, A.partial, buckets);
     BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_pos, seg,
                A.partial, buckets);
@@ -896,15 +906,47 @@ struct MsmTable {
     int levels = 0, wpl = 1; // table levels; windows per level (1 = full table)
 };
 
+// A resident base set in the policy's internal form (G1: 112 B, G2: 224 B per point): converted ONCE when a static point set - a
+// Groth16 CRS query - is loaded, shared read-only by every later call (and by every rank of a window-sharded MSM: no rank converts
+// anything per call).  bzk_msm_g*_bases_*.
+struct MsmBases {
+    void* data = nullptr;  // DevAff[n]
+    uint64_t n = 0;
+    int device = 0;
+};
+// Where a call that must not finish on this host thread leaves its window sums: `d_win` receives, in DEVICE memory and in stream
+// order, the (w_end - w_begin) window sums S_w as standard-limb XYZZ points; no read-back, no Horner, no synchronisation.  The
+// caller combines them - possibly with the windows of other devices - through msm_horner_host.  (bzk_mg: multi-GPU entry points.)
+struct MsmWinOut {
+    void* d_win = nullptr;
+    int c = 0, w_total = 0, w_begin = 0, w_end = 0;  // filled in by msm_run
+    bool single = false;                             // full static table: d_win[0] is the result itself
+};
+
+// Horner over window sums (host, 64-bit limbs behind xyzz_*<F>): result = sum_k 2^(c (w0 + k)) S[k]
+template <class F>
+static XyzzT<F> msm_horner_host(const XyzzT<F>* S, int count, int c, int w0) {
+    XyzzT<F> acc = xyzz_identity<F>();
+    for (int k = count - 1; k >= 0; --k) {
+        for (int d = 0; d < c; ++d) acc = xyzz_dbl<F>(acc);
+        xyzz_add<F>(acc, S[k]);
+    }
+    for (int d = 0; d < c * w0; ++d) acc = xyzz_dbl<F>(acc);
+    return acc;
+}
+
 template <class C>
 static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
-                       int w_end, XyzzT<typename C::HostF>& result, const MsmTable* table = nullptr) {
+                       int w_end, XyzzT<typename C::HostF>& result, const MsmTable* table = nullptr, const MsmBases* prep = nullptr,
+                       MsmWinOut* wout = nullptr) {
     typedef typename C::HostF F;
     typedef typename C::Pt Pt;
     typedef XyzzT<F> StdPt;
     result = xyzz_identity<F>();
+    if (wout) { wout->c = 0; wout->w_total = 0; wout->w_begin = wout->w_end = 0; wout->single = false; }
     if (n == 0 || (w_end >= 0 && w_begin >= w_end)) return BZK_OK;  // w_end < 0: every window (resolved once c is known)
     if (n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
+    if (prep && (table || n > prep->n || !prep->data)) return BZK_E_ARG;
     int c = table ? table->c : (ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n));
     // the work-model pick applies to unsharded calls only: a caller that names a window range counts windows with
     // bzk_msm_window_count(n), i.e. with the plain pick
@@ -928,6 +970,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && (flags & BZK_F_THROUGHPUT)));
     const uint32_t per_win_out = two_level ? per_win + per_win / ch2 : per_win;  // chunk results per window handed to the window sums
     const bool dedup = (flags & BZK_F_DEDUP) && C::CONVERT_BASES && !table && n >= 4096 && n < ((uint64_t)1 << 30);
+    if (wout) { wout->c = c; wout->w_total = w_total; wout->w_begin = w_begin; wout->w_end = w_end; wout->single = table && !folded; }
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
     int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w_end - w_begin), ((uint64_t)1 << 30) / n));
@@ -986,7 +1029,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (two_level) total += ws_pad((size_t)group * per_win * sizeof(Pt));
     total += ws_pad(((size_t)group * (per_win_out / C::WSUM_THREADS + 1)) * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(StdPt));
-    if (C::CONVERT_BASES && !table) total += ws_pad((size_t)(n + m_max) * sizeof(typename C::DevAff));
+    if (C::CONVERT_BASES && !table) total += ws_pad((size_t)((prep ? 0 : n) + m_max) * sizeof(typename C::DevAff));
     if (dedup) {
         total += 11 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
     }
@@ -1014,9 +1057,14 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     StdPt* win_out = cur.take<StdPt>(w_total);
     const void* bases = table ? table->data : bases_raw;
     typename C::DevAff* conv = nullptr;
+    typename C::DevAff* sums_aff = nullptr;  // de-duplication group sums in affine form: base indices n .. n + m_max
     AuxJoin aux(ctx);
-    if (C::CONVERT_BASES && !table) {
+    if (prep) {
+        bases = prep->data;  // resident internal form: nothing to convert
+        if (m_max) sums_aff = cur.take<typename C::DevAff>(m_max);
+    } else if (C::CONVERT_BASES && !table) {
         conv = cur.take<typename C::DevAff>(n + m_max);
+        sums_aff = conv + n;
         // the conversion is not needed before the first accumulation: it runs on the side stream beside digits / sort
         if (msm_aux_ready(ctx) && hipEventRecord(ctx->ev_fork, ctx->stream) == hipSuccess &&
             hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0) == hipSuccess) {
@@ -1034,6 +1082,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         }
         bases = conv;
     }
+    const uint32_t n_split = dedup ? (uint32_t)n : 0xffffffffu;
     uint32_t *hkey = nullptr, *hkey_s = nullptr;
     uint32_t *didx = nullptr, *didx_s = nullptr, *head = nullptr, *mhead = nullptr, *gid_ex = nullptr, *mid_ex = nullptr, *key2 = nullptr,
              *rep = nullptr, *gof = nullptr;
@@ -1088,14 +1137,24 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t G = hp[0] + hp[1], M = hp[2] + hp[3];
         if (ctx->timing) fprintf(stderr, "[bzk] dedup: n %llu -> %u distinct non-zero scalars, %u groups of >= 2\n", (unsigned long long)n, G, M);
-        if (G == 0) return BZK_OK;  // every scalar is zero
+        if (G == 0) {  // every scalar is zero
+            // every other exit of this function ends in a host-side wait for the stream; here the side stream's conversion may still be
+            // reading the caller's bases and writing the workspace: wait for it before the caller may touch either
+            aux.join();
+            BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (wout) {  // the window sums of an all-zero scalar vector: identities
+                std::vector<StdPt> ids((size_t)(wout->single ? 1 : w_end - w_begin), xyzz_identity<F>());
+                BZK_HIP(ctx, hipMemcpy(wout->d_win, ids.data(), ids.size() * sizeof(StdPt), hipMemcpyHostToDevice));
+            }
+            return BZK_OK;
+        }
         if (M > m_max) { ctx->last_error = "dedup: group count out of range"; return BZK_E_INTERNAL; }
         BZK_LAUNCH(ctx, "dedup_assign", dedup_assign_kernel, dim3(gb), dim3(256), 0, (const U128*)scalars, (const uint32_t*)hkey_s,
                    (const uint32_t*)didx_s, (const uint32_t*)head, (const uint32_t*)mhead, (const uint32_t*)gid_ex, (const uint32_t*)mid_ex,
                    n, 0xffffffffu, key2, scal2, rep, gof);
         if (M) {
             aux.join();
-            BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true));
+            BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true, 0u, sums_aff, n_split));
             static const uint32_t K = [] {  // sums per lane of the batched inversion (env BZK_DEDUP_K for A/B runs)
                 const char* e = getenv("BZK_DEDUP_K");
                 const int v = e ? atoi(e) : 8;
@@ -1103,7 +1162,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             }();
             auto k_aff = dedup_affine_kernel<C>;
             BZK_LAUNCH(ctx, "dedup_affine", k_aff, dim3((unsigned)(((M + K - 1) / K + 63) / 64)), dim3(64), 0, (const Pt*)buckets, M, K, pref,
-                       conv + n, (const uint32_t*)gof, scal2);
+                       sums_aff, (const uint32_t*)gof, scal2);
         }
         n_eff = G;
         scal_eff = scal2;
@@ -1131,7 +1190,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         aux.join();
-        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, wiv ? half : 0u));
+        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, wiv ? half : 0u, sums_aff, n_split));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         if (two_level) {
@@ -1151,7 +1210,12 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         auto k_wp = msm_window_partial_kernel<C, WT>;
         auto k_ws = msm_window_sum_kernel<C, WT>;
         BZK_LAUNCH(ctx, "msm_window_partial", k_wp, dim3((unsigned)n_red_win * groups), dim3(WT), 0, chunk_out, per_win_out, groups, wpart);
-        BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_out);
+        StdPt* const win_dst = wout ? (StdPt*)wout->d_win + ((table && !folded) ? 0 : wb - w_begin) : win_out;
+        BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_dst);
+        if (wout) {
+            if (table && !folded) return BZK_OK;
+            continue;  // window sums stay on the device, in stream order; the caller reads them back and combines
+        }
         BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, win_out, (size_t)n_red_win * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (table && !folded) {  // the table already carries the 2^(c w) factors: the single bucket-set sum IS the result
@@ -1160,14 +1224,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         }
         memcpy(&wsum[wb - w_begin], ctx->pinned, (size_t)wc * sizeof(StdPt));
     }
+    if (wout) return BZK_OK;
     // Horner over the window sums (host): result = 2^(c*w_begin) * sum_k 2^(c k) S_{w_begin+k}
-    StdPt acc = xyzz_identity<F>();
-    for (int k = (int)wsum.size() - 1; k >= 0; --k) {
-        for (int d = 0; d < c; ++d) acc = xyzz_dbl<F>(acc);
-        xyzz_add<F>(acc, wsum[k]);
-    }
-    for (int d = 0; d < c * w_begin; ++d) acc = xyzz_dbl<F>(acc);
-    result = acc;
+    result = msm_horner_host<F>(wsum.data(), (int)wsum.size(), c, w_begin);
     return BZK_OK;
 }
 
@@ -1254,6 +1313,78 @@ static int32_t msm_table_entry(bzk_ctx* ctx, const MsmTable* t, const void* scal
     (void)hipSetDevice(ctx->device);
     XyzzT<F> r;
     BZK_TRY(msm_run<C>(ctx, nullptr, scalars, n, flags, w_begin, w_end, r, t));
+    PointIO<F>::pack(r, out);
+    return BZK_OK;
+}
+
+// ---- resident base sets (MsmBases) -------------------------------------------------------------------------------------------
+template <class C>
+static int32_t msm_bases_load(bzk_ctx* ctx, const void* bases_raw, uint64_t n, MsmBases** out) {
+    if (!ctx || !out || !bases_raw || n == 0 || n >= ((uint64_t)1 << 31)) return BZK_E_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    MsmBases* b = new (std::nothrow) MsmBases();
+    if (!b) return BZK_E_ALLOC;
+    b->n = n;
+    b->device = ctx->device;
+    hipError_t e = hipMalloc(&b->data, (size_t)n * sizeof(typename C::DevAff));
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("bases alloc: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        delete b;
+        return BZK_E_ALLOC;
+    }
+    int32_t st = msm_convert_launch<C>(ctx, bases_raw, n, (typename C::DevAff*)b->data);
+    if (st == BZK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = BZK_E_DEVICE;
+    if (st != BZK_OK) {
+        (void)hipFree(b->data);
+        delete b;
+        return st;
+    }
+    *out = b;
+    return BZK_OK;
+}
+static void msm_bases_free(bzk_ctx* ctx, MsmBases* b) {
+    if (!b) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (b->data) (void)hipFree(b->data);
+    delete b;
+}
+template <class C>
+static int32_t msm_bases_entry(bzk_ctx* ctx, const MsmBases* b, const void* scalars, uint64_t n, uint32_t flags, int w_begin, int w_end,
+                               uint8_t* out) {
+    typedef typename C::HostF F;
+    if (!ctx || !b || !out || (n && !scalars)) return BZK_E_ARG;
+    if (b->device != ctx->device) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    XyzzT<F> r;
+    BZK_TRY(msm_run<C>(ctx, nullptr, scalars, n, flags, w_begin, w_end, r, nullptr, b));
+    PointIO<F>::pack(r, out);
+    return BZK_OK;
+}
+// multi-GPU hook (mg.hip): windows [w_begin, w_end) of the MSM over a resident base set (or raw bases), window sums left in
+// DEVICE memory at d_win (standard-limb XYZZ, sizeof = 4 field elements), nothing read back.  w_end < 0: every window.
+template <class C>
+static int32_t msm_windows_dev(bzk_ctx* ctx, const MsmBases* b, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
+                               int w_begin, int w_end, void* d_win, int32_t info[4]) {
+    typedef typename C::HostF F;
+    if (!ctx || (!b && !bases_raw) || !d_win || (n && !scalars)) return BZK_E_ARG;
+    if (b && b->device != ctx->device) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    XyzzT<F> r;
+    MsmWinOut wo;
+    wo.d_win = d_win;
+    BZK_TRY(msm_run<C>(ctx, bases_raw, scalars, n, flags, w_begin, w_end, r, nullptr, b, &wo));
+    if (info) { info[0] = wo.c; info[1] = wo.w_total; info[2] = wo.w_begin; info[3] = wo.w_end; }
+    return BZK_OK;
+}
+template <class F>
+static int32_t horner_packed(const void* S, int count, int c, int w0, uint8_t* out) {
+    if (!out || count < 0 || (count && !S)) return BZK_E_ARG;
+    XyzzT<F> r = msm_horner_host<F>((const XyzzT<F>*)S, count, c, w0);
     PointIO<F>::pack(r, out);
     return BZK_OK;
 }

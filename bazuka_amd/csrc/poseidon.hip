@@ -835,6 +835,9 @@ struct bzk_mpn_tree {
     Fr* tok = nullptr;           // cap x 4^T x 2
     Fr* tl[9] = {};              // token forest: tl[k] = cap x 4^k hashes (k = 0: the accounts' tokens_root)
     std::unordered_map<uint64_t, uint64_t> slot_of;
+    // a device error in the middle of set_accounts leaves contents, leaf hashes and inner nodes out of step: the handle refuses
+    // every later call instead of answering from a half-updated state
+    bool poisoned = false;
 };
 namespace {
 // re-hash, level by level, exactly the parents with a changed child.  lvl[d] = array of depth d (d = 0 .. depth_leaf);
@@ -947,6 +950,7 @@ void bzk_mpn_tree_free(bzk_ctx* ctx, bzk_mpn_tree* t) {
 
 int32_t bzk_mpn_tree_root(bzk_ctx* ctx, const bzk_mpn_tree* t, uint8_t root[32]) {
     if (!ctx || !t) return BZK_E_ARG;
+    if (t->poisoned) return BZK_E_INTERNAL;
     return bzk_tree4_root(ctx, t->acct, root);
 }
 
@@ -954,12 +958,21 @@ uint64_t bzk_mpn_tree_accounts(const bzk_mpn_tree* t) { return t ? t->used - 1 :
 
 // Batched `set_mpn_account` (src/zk/state/mod.rs:158-208): account a := (cells[a], its token slots tok_index[tok_off[a] ..
 // tok_off[a+1]) := tok_vals).  As in the reference, token slots that are not named keep their contents.
+static int32_t mpn_tree_set_accounts_body(bzk_ctx* ctx, bzk_mpn_tree* t, const uint64_t* idx, const uint8_t* cells, const uint8_t* tok_vals,
+                                          uint64_t n, uint64_t m, const std::vector<uint64_t>& slots, const std::vector<uint64_t>& cell_pos,
+                                          const std::vector<uint64_t>& tok_pos, const std::vector<uint64_t>& g, DevBuf& d_pos, DevBuf& d_val,
+                                          DevBuf& d_h);
+
 int32_t bzk_mpn_tree_set_accounts(bzk_ctx* ctx, bzk_mpn_tree* t, const uint64_t* idx, const uint8_t* cells, const uint64_t* tok_off,
                                   const uint64_t* tok_index, const uint8_t* tok_vals, uint64_t n) {
     if (!ctx || !t || (n && (!idx || !cells || !tok_off))) return BZK_E_ARG;
+    if (t->poisoned) return BZK_E_INTERNAL;
     if (n == 0) return BZK_OK;
     (void)hipSetDevice(ctx->device);
     const uint64_t n_acct = (uint64_t)1 << (2 * t->L), ts = (uint64_t)1 << (2 * t->T);
+    // tok_off is a CSR row pointer: it starts at 0 (entries before tok_off[0] would belong to no account and were once scattered into
+    // pool slot 0, the shared default account - ADVICE r2)
+    if (tok_off[0] != 0) return BZK_E_ARG;
     const uint64_t m = tok_off[n];
     if (m && (!tok_index || !tok_vals)) return BZK_E_ARG;
     // validation before anything is changed
@@ -980,10 +993,22 @@ int32_t bzk_mpn_tree_set_accounts(bzk_ctx* ctx, bzk_mpn_tree* t, const uint64_t*
         ctx->last_error = "mpn_tree: account pool exhausted";
         return BZK_E_ALLOC;
     }
+    // staging (positions, values, intermediate hashes) is allocated BEFORE the slot map changes: an allocation failure leaves the
+    // handle exactly as it was
+    DevBuf d_pos, d_val, d_h;
+    const size_t pos_cnt = std::max<size_t>(n * 4, m * 2);
+    BZK_TRY(d_pos.alloc(ctx, pos_cnt * 8));
+    BZK_TRY(d_val.alloc(ctx, std::max<size_t>(n * 5, m * 2) * sizeof(Fr)));
+    BZK_TRY(d_h.alloc(ctx, std::max<size_t>(n, m) * sizeof(Fr)));
+    // new slots are handed out from a local cursor and committed to the handle only together with the first device write
     std::vector<uint64_t> slots(n), cell_pos(n * 4), tok_pos(m * 2), g(m);
+    std::vector<std::pair<uint64_t, uint64_t>> fresh_slots;
+    uint64_t next = t->used;
     for (uint64_t a = 0; a < n; ++a) {
         auto it = t->slot_of.find(idx[a]);
-        const uint64_t s = it != t->slot_of.end() ? it->second : (t->slot_of[idx[a]] = t->used++);
+        uint64_t s;
+        if (it != t->slot_of.end()) s = it->second;
+        else { s = next++; fresh_slots.push_back({idx[a], s}); }
         slots[a] = s;
         for (int j = 0; j < 4; ++j) cell_pos[a * 4 + j] = s * 4 + j;
         for (uint64_t q = tok_off[a]; q < tok_off[a + 1]; ++q) {
@@ -992,12 +1017,17 @@ int32_t bzk_mpn_tree_set_accounts(bzk_ctx* ctx, bzk_mpn_tree* t, const uint64_t*
             tok_pos[2 * q + 1] = 2 * g[q] + 1;
         }
     }
-    // staging: positions, values, intermediate hashes
-    DevBuf d_pos, d_val, d_h;
-    const size_t pos_cnt = std::max<size_t>(n * 4, m * 2);
-    BZK_TRY(d_pos.alloc(ctx, pos_cnt * 8));
-    BZK_TRY(d_val.alloc(ctx, std::max<size_t>(n * 5, m * 2) * sizeof(Fr)));
-    BZK_TRY(d_h.alloc(ctx, std::max<size_t>(n, m) * sizeof(Fr)));
+    for (auto& fs : fresh_slots) t->slot_of[fs.first] = fs.second;
+    t->used = next;
+    const int32_t st = mpn_tree_set_accounts_body(ctx, t, idx, cells, tok_vals, n, m, slots, cell_pos, tok_pos, g, d_pos, d_val, d_h);
+    if (st != BZK_OK) t->poisoned = true;  // contents / leaf hashes / inner nodes may disagree from here on
+    return st;
+}
+
+static int32_t mpn_tree_set_accounts_body(bzk_ctx* ctx, bzk_mpn_tree* t, const uint64_t* idx, const uint8_t* cells, const uint8_t* tok_vals,
+                                          uint64_t n, uint64_t m, const std::vector<uint64_t>& slots, const std::vector<uint64_t>& cell_pos,
+                                          const std::vector<uint64_t>& tok_pos, const std::vector<uint64_t>& g, DevBuf& d_pos, DevBuf& d_val,
+                                          DevBuf& d_h) {
     // 1. cells
     BZK_HIP(ctx, hipMemcpyAsync(d_pos.p, cell_pos.data(), n * 4 * 8, hipMemcpyHostToDevice, ctx->stream));
     BZK_HIP(ctx, hipMemcpyAsync(d_val.p, cells, n * 4 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
@@ -1046,6 +1076,7 @@ int32_t bzk_mpn_tree_set_accounts(bzk_ctx* ctx, bzk_mpn_tree* t, const uint64_t*
 // every token slot.  Accounts that were never set read as the default account (all zero, default tokens_root).
 int32_t bzk_mpn_tree_get_accounts(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint64_t* idx, uint64_t n, uint8_t* out) {
     if (!ctx || !t || (n && (!idx || !out))) return BZK_E_ARG;
+    if (t->poisoned) return BZK_E_INTERNAL;
     if (n == 0) return BZK_OK;
     (void)hipSetDevice(ctx->device);
     const uint64_t n_acct = (uint64_t)1 << (2 * t->L), ts = (uint64_t)1 << (2 * t->T);
@@ -1070,6 +1101,7 @@ int32_t bzk_mpn_tree_get_accounts(bzk_ctx* ctx, const bzk_mpn_tree* t, const uin
 // `prove(tree_loc = [], index)`: L sibling triples per account (the src_proof / dst_proof / proof of the transitions)
 int32_t bzk_mpn_tree_prove(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint64_t* idx, uint64_t n, uint8_t* out) {
     if (!ctx || !t) return BZK_E_ARG;
+    if (t->poisoned) return BZK_E_INTERNAL;
     return bzk_tree4_prove(ctx, t->acct, idx, n, out);
 }
 
@@ -1077,6 +1109,7 @@ int32_t bzk_mpn_tree_prove(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint64_t* 
 int32_t bzk_mpn_tree_prove_token(bzk_ctx* ctx, const bzk_mpn_tree* t, const uint64_t* account_idx, const uint64_t* token_idx, uint64_t n,
                                  uint8_t* out) {
     if (!ctx || !t || (n && (!account_idx || !token_idx || !out))) return BZK_E_ARG;
+    if (t->poisoned) return BZK_E_INTERNAL;
     if (n == 0) return BZK_OK;
     (void)hipSetDevice(ctx->device);
     const uint64_t n_acct = (uint64_t)1 << (2 * t->L), ts = (uint64_t)1 << (2 * t->T);

@@ -126,6 +126,33 @@ SIGNATURES = {
     "bzk_host_scalar_new": (_i32, [_vp, _u32, _vp]),
     "bzk_zkproof_encode": (_i32, [_vp, _vp]),
     "bzk_zkproof_decode": (_i32, [_vp, _u64, _vp]),
+    "bzk_msm_g1_bases_load_dev": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_msm_g2_bases_load_dev": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_msm_bases_free": (None, [_vp, _vp]),
+    "bzk_msm_bases_size": (_u64, [_vp]),
+    "bzk_msm_g1_bases_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "bzk_msm_g2_bases_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "bzk_msm_g1_bases_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    "bzk_msm_g2_bases_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    "bzk_mg_unique_id": (_i32, [_vp]),
+    "bzk_mg_create": (_i32, [C.POINTER(_i32), _i32, _u32, C.POINTER(_vp)]),
+    "bzk_mg_create_rank": (_i32, [_i32, _i32, _i32, _vp, _u32, C.POINTER(_vp)]),
+    "bzk_mg_destroy": (None, [_vp]),
+    "bzk_mg_world": (_i32, [_vp]),
+    "bzk_mg_local": (_i32, [_vp]),
+    "bzk_mg_rank": (_i32, [_vp]),
+    "bzk_mg_exchange": (_u32, [_vp]),
+    "bzk_mg_ctx": (_vp, [_vp, _i32]),
+    "bzk_mg_last_error": (C.c_char_p, [_vp]),
+    "bzk_mg_bases_g1_load": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_mg_bases_g2_load": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_mg_bases_g1_load_dev": (_i32, [_vp, C.POINTER(_vp), _u64, C.POINTER(_vp)]),
+    "bzk_mg_bases_g2_load_dev": (_i32, [_vp, C.POINTER(_vp), _u64, C.POINTER(_vp)]),
+    "bzk_mg_bases_free": (None, [_vp, _vp]),
+    "bzk_mg_msm_g1": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "bzk_mg_msm_g2": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "bzk_mg_msm_g1_dev": (_i32, [_vp, _vp, C.POINTER(_vp), _u64, _u32, _vp]),
+    "bzk_mg_msm_g2_dev": (_i32, [_vp, _vp, C.POINTER(_vp), _u64, _u32, _vp]),
     "bzk_g1_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
     "bzk_g2_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
 }
@@ -190,8 +217,13 @@ def _ptr(x):
 class Bzk:
     """One context = one GPU + one HIP stream (pass torch's stream handle to share it)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, handle=None):
         self.lib = load_library()
+        self.borrowed = handle is not None
+        if handle is not None:  # a context owned by someone else (bzk_mg_ctx): never destroyed from here
+            self.h = C.c_void_p(handle) if isinstance(handle, int) else handle
+            self.device = device
+            return
         h = C.c_void_p()
         st = self.lib.bzk_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
         if st != 0:
@@ -201,7 +233,8 @@ class Bzk:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.bzk_ctx_destroy(self.h)
+            if not self.borrowed:
+                self.lib.bzk_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -337,6 +370,29 @@ class Bzk:
         out = C.create_string_buffer(193)
         flags = _flags(canonical, dedup, throughput)
         self._ck(self.lib.bzk_msm_g2_windows_dev(self.h, _ptr(bases), _ptr(scalars), n, flags, w0, w1, out), "msm_g2_windows_dev")
+        return out.raw
+
+    # ---- resident base sets
+    def msm_bases_load_dev(self, bases, n: int, g2=False):
+        """a static point set converted once into the internal form and kept in HBM (include/bzk.h: resident base sets)"""
+        h = C.c_void_p()
+        fn = self.lib.bzk_msm_g2_bases_load_dev if g2 else self.lib.bzk_msm_g1_bases_load_dev
+        self._ck(fn(self.h, _ptr(bases), n, C.byref(h)), "msm_bases_load_dev")
+        return h
+
+    def msm_bases_free(self, handle):
+        self.lib.bzk_msm_bases_free(self.h, handle)
+
+    def msm_bases_run_dev(self, handle, scalars, n: int, g2=False, canonical=False, dedup=False, throughput=False) -> bytes:
+        out = C.create_string_buffer(193 if g2 else 97)
+        fn = self.lib.bzk_msm_g2_bases_run_dev if g2 else self.lib.bzk_msm_g1_bases_run_dev
+        self._ck(fn(self.h, handle, _ptr(scalars), n, _flags(canonical, dedup, throughput), out), "msm_bases_run_dev")
+        return out.raw
+
+    def msm_bases_windows_dev(self, handle, scalars, n: int, w0: int, w1: int, g2=False, canonical=False, dedup=False) -> bytes:
+        out = C.create_string_buffer(193 if g2 else 97)
+        fn = self.lib.bzk_msm_g2_bases_windows_dev if g2 else self.lib.bzk_msm_g1_bases_windows_dev
+        self._ck(fn(self.h, handle, _ptr(scalars), n, _flags(canonical, dedup), w0, w1, out), "msm_bases_windows_dev")
         return out.raw
 
     def msm_table_build_c(self, bases, n: int, c: int):
@@ -522,6 +578,89 @@ class Bzk:
 # --------------------------------------------------------------------------------------------------
 # host-side (CPU, C++) MPN witness / R1CS generator - no GPU needed
 # --------------------------------------------------------------------------------------------------
+MG_X_AUTO, MG_X_HOST, MG_X_PEER, MG_X_RCCL = 0, 1, 2, 3
+MG_X_NAMES = {MG_X_HOST: "host", MG_X_PEER: "peer", MG_X_RCCL: "rccl"}
+
+
+def mg_unique_id() -> bytes:
+    """group id of a process-per-GPU deployment: rank 0 draws it, the host hands it to the other ranks (bzk_mg_unique_id)"""
+    lib = load_library()
+    out = C.create_string_buffer(128)
+    st = lib.bzk_mg_unique_id(out)
+    if st != 0:
+        raise BzkError(f"bzk_mg_unique_id: {lib.bzk_strerror(st).decode()}")
+    return out.raw
+
+
+class Mg:
+    """A device group behind the C ABI (include/bzk.h row (e)): window-sharded MSMs and a proof pool over 1..8 GPUs.
+    Mg(devices=[0, 1, ...])                 one process drives the devices
+    Mg(device=d, rank=r, world=N, uid=...)  one process per GPU (uid from mg_unique_id() on rank 0)"""
+
+    def __init__(self, devices=None, device=None, rank=None, world=None, uid=None, exchange=MG_X_AUTO):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if devices is not None:
+            arr = (_i32 * len(devices))(*devices)
+            st = self.lib.bzk_mg_create(arr, len(devices), exchange, C.byref(h))
+        else:
+            st = self.lib.bzk_mg_create_rank(device, rank, world, _ptr(uid), exchange, C.byref(h))
+        if st != 0:
+            raise BzkError(f"bzk_mg_create: {self.lib.bzk_strerror(st).decode()}")
+        self.h = h
+        self.world, self.local, self.rank = self.lib.bzk_mg_world(h), self.lib.bzk_mg_local(h), self.lib.bzk_mg_rank(h)
+        self.exchange = MG_X_NAMES.get(self.lib.bzk_mg_exchange(h), "?")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bzk_mg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, what):
+        if st != 0:
+            raise BzkError(f"{what}: {self.lib.bzk_strerror(st).decode()} [{self.lib.bzk_mg_last_error(self.h).decode()}]")
+
+    def _ptrs(self, xs):
+        assert len(xs) == self.local, "one device pointer per local device"
+        return (_vp * self.local)(*[_ptr(x) for x in xs])
+
+    def ctx_handle(self, i: int):
+        return self.lib.bzk_mg_ctx(self.h, i)
+
+    def bases_load(self, bases_host: bytes, n: int, g2=False):
+        h = C.c_void_p()
+        fn = self.lib.bzk_mg_bases_g2_load if g2 else self.lib.bzk_mg_bases_g1_load
+        self._ck(fn(self.h, _ptr(bases_host), n, C.byref(h)), "mg_bases_load")
+        return h
+
+    def bases_load_dev(self, bases_dev, n: int, g2=False):
+        h = C.c_void_p()
+        fn = self.lib.bzk_mg_bases_g2_load_dev if g2 else self.lib.bzk_mg_bases_g1_load_dev
+        self._ck(fn(self.h, self._ptrs(bases_dev), n, C.byref(h)), "mg_bases_load_dev")
+        return h
+
+    def bases_free(self, handle):
+        self.lib.bzk_mg_bases_free(self.h, handle)
+
+    def msm(self, bases, scalars_host: bytes, n: int, g2=False, canonical=False, dedup=False, throughput=False) -> bytes:
+        out = C.create_string_buffer(193 if g2 else 97)
+        fn = self.lib.bzk_mg_msm_g2 if g2 else self.lib.bzk_mg_msm_g1
+        self._ck(fn(self.h, bases, _ptr(scalars_host), n, _flags(canonical, dedup, throughput), out), "mg_msm")
+        return out.raw
+
+    def msm_dev(self, bases, scalars_dev, n: int, g2=False, canonical=False, dedup=False, throughput=False) -> bytes:
+        out = C.create_string_buffer(193 if g2 else 97)
+        fn = self.lib.bzk_mg_msm_g2_dev if g2 else self.lib.bzk_mg_msm_g1_dev
+        self._ck(fn(self.h, bases, self._ptrs(scalars_dev), n, _flags(canonical, dedup, throughput), out), "mg_msm_dev")
+        return out.raw
+
+
 def _st(st, what):
     if st != 0:
         raise BzkError(f"{what}: {load_library().bzk_strerror(st).decode()}")

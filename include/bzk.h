@@ -383,6 +383,73 @@ int32_t bzk_msm_g2_table_windows_dev(bzk_ctx* ctx, const bzk_msm_table* table, c
 uint32_t bzk_msm_table_window_count(const bzk_msm_table* table);
 void bzk_msm_table_free(bzk_ctx* ctx, bzk_msm_table* table);
 
+/* ---- resident base sets --------------------------------------------------------------------------------------------
+ * A Groth16 CRS query is a STATIC point set (bellman `Parameters`: h, l, a, b_g1, b_g2): load converts it once into the
+ * library's internal limb form (G1 112 B, G2 224 B per point) and keeps it in HBM; every later MSM over it - and every
+ * rank of a window-sharded MSM - gathers from the resident set and converts nothing per call.  Same result bytes as
+ * bzk_msm_*_dev on the raw bases.  n scalars (n <= set size) use bases [0, n).  A set is read-only after load and may be
+ * shared by any number of contexts of the same device. */
+typedef struct bzk_msm_bases bzk_msm_bases;
+int32_t bzk_msm_g1_bases_load_dev(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_bases** out);
+int32_t bzk_msm_g2_bases_load_dev(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_bases** out);
+void bzk_msm_bases_free(bzk_ctx* ctx, bzk_msm_bases* bases);
+uint64_t bzk_msm_bases_size(const bzk_msm_bases* bases);
+int32_t bzk_msm_g1_bases_run_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[97]);
+int32_t bzk_msm_g2_bases_run_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[193]);
+int32_t bzk_msm_g1_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                     uint32_t w_begin, uint32_t w_end, uint8_t out[97]);
+int32_t bzk_msm_g2_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags,
+                                     uint32_t w_begin, uint32_t w_end, uint8_t out[193]);
+
+/* ---- row (e): multi-GPU ------------------------------------------------------------------------------------------------
+ * A device GROUP behind the boundary: a Rust prover drives 1..8 MI355X of a node through these entry points alone (no
+ * torch.distributed, no Python).  SURVEY.md 8b proposed `bzk_ctx_create(device_ids, n)`; the group is its own handle so that
+ * the single-device ctx keeps its one-stream, one-thread contract.
+ *   MSM    : sharded by SCALAR-WINDOW RANGE over the group (north star): rank r computes windows [W r / world, W (r + 1) / world)
+ *            over all points from a resident base set replicated at load time; ONE all-gather of the W window sums (3 - 6 KB
+ *            for the whole group; RCCL cannot add curve points, so gather + combine), then the Horner combine over the W windows
+ *            on the host, as in the single-GPU call.  Same 97 / 193 result bytes as bzk_msm_g*_dev.
+ *   proofs : replicas (the reference's own split of a block's proofs over provers, src/mpn/mod.rs:79-107): a pool of prover slots
+ *            on every device takes proofs from one queue (submit / wait), CRS shared per device.
+ * Deployments: bzk_mg_create - ONE process drives n devices (one persistent host thread each; device ids may repeat, e.g. for a
+ * rehearsal on a one-GPU box); bzk_mg_create_rank - one process PER GPU (torchrun style): rank 0 draws bzk_mg_unique_id() and
+ * the host hands the 128 bytes to the other ranks by its own means, every rank then calls bzk_mg_create_rank and later the same
+ * bzk_mg_msm_* call with its own device pointers; every rank receives the result.
+ * Exchange: BZK_MG_X_RCCL = ncclAllGather(uint8) over xGMI (librccl is loaded at run time); BZK_MG_X_HOST = pinned host memory
+ * (one process) or a POSIX shared-memory segment (process per GPU, single node) - the only transport for ranks that SHARE a
+ * device; BZK_MG_X_PEER = hipMemcpyPeerAsync into device 0 (one process).  BZK_MG_X_AUTO = RCCL when the group spans distinct
+ * devices and librccl loads, else HOST.  One collective call at a time per group; bzk_mg_ctx(i) exposes the i-th local context
+ * (allocation, uploads, profiling) and must not be used concurrently with a group call. */
+#define BZK_MG_UID_BYTES 128
+#define BZK_MG_X_AUTO 0u
+#define BZK_MG_X_HOST 1u
+#define BZK_MG_X_PEER 2u
+#define BZK_MG_X_RCCL 3u
+typedef struct bzk_mg bzk_mg;
+typedef struct bzk_mg_bases bzk_mg_bases;
+int32_t bzk_mg_unique_id(uint8_t uid[BZK_MG_UID_BYTES]);
+int32_t bzk_mg_create(const int32_t* device_ids, int32_t n_devices, uint32_t exchange, bzk_mg** out);
+int32_t bzk_mg_create_rank(int32_t device_id, int32_t rank, int32_t world, const uint8_t uid[BZK_MG_UID_BYTES], uint32_t exchange, bzk_mg** out);
+void bzk_mg_destroy(bzk_mg* mg);
+int32_t bzk_mg_world(const bzk_mg* mg);      /* ranks of the group */
+int32_t bzk_mg_local(const bzk_mg* mg);      /* devices this process drives */
+int32_t bzk_mg_rank(const bzk_mg* mg);       /* rank of local device 0 */
+uint32_t bzk_mg_exchange(const bzk_mg* mg);  /* the transport in use (BZK_MG_X_*) */
+bzk_ctx* bzk_mg_ctx(bzk_mg* mg, int32_t local_index);
+const char* bzk_mg_last_error(bzk_mg* mg);
+/* replicate a static base set on every local device (host pointer: uploaded + converted per device; _dev: one device pointer
+ * per local device, raw affine) */
+int32_t bzk_mg_bases_g1_load(bzk_mg* mg, const uint8_t* bases_host, uint64_t n, bzk_mg_bases** out);
+int32_t bzk_mg_bases_g2_load(bzk_mg* mg, const uint8_t* bases_host, uint64_t n, bzk_mg_bases** out);
+int32_t bzk_mg_bases_g1_load_dev(bzk_mg* mg, const void* const* bases_dev, uint64_t n, bzk_mg_bases** out);
+int32_t bzk_mg_bases_g2_load_dev(bzk_mg* mg, const void* const* bases_dev, uint64_t n, bzk_mg_bases** out);
+void bzk_mg_bases_free(bzk_mg* mg, bzk_mg_bases* bases);
+/* scalars: one host vector (broadcast to the local devices), or one DEVICE pointer per local device holding the same n scalars */
+int32_t bzk_mg_msm_g1(bzk_mg* mg, const bzk_mg_bases* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[97]);
+int32_t bzk_mg_msm_g2(bzk_mg* mg, const bzk_mg_bases* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[193]);
+int32_t bzk_mg_msm_g1_dev(bzk_mg* mg, const bzk_mg_bases* bases, const void* const* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[97]);
+int32_t bzk_mg_msm_g2_dev(bzk_mg* mg, const bzk_mg_bases* bases, const void* const* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[193]);
+
 /* synthetic-input helpers (device side, for benches and tests): base_i = k_i * G with
  * k_i = SplitMix64(seed + 0x632BE59BD9B4E019 * (start+i)).next() | 1 ; raw affine out */
 int32_t bzk_g1_synth_bases_dev(bzk_ctx* ctx, uint64_t seed, uint64_t start, uint64_t n, void* out_dev);
