@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <string.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,7 @@ struct bzk_ctx {
     // lanes: child contexts (own stream, workspace, pinned staging) for independent sub-jobs of one call that
     // should overlap on the device - the five MSMs of a Groth16 proof.  Created on first use, owned by the parent.
     std::vector<bzk_ctx*> lanes;
+    std::vector<struct bzk_lane_thread*> lane_threads;  // one persistent host thread per lane (ctx.hip: lane_post / lane_wait)
     bool no_coop = false;  // env BZK_NO_COOP=1: never use the cooperative (8 lanes per node) Poseidon kernel (A/B runs)
     bool timing = false;  // env BZK_TIMING=1: host-side phase timings of bzk_groth16_prove on stderr
     hipEvent_t ev_z = nullptr;  // "assignment staged" event of bzk_groth16_prove: created on first use, destroyed with the ctx
@@ -75,6 +77,10 @@ namespace bzk {
 int32_t ws_reserve(bzk_ctx* ctx, size_t bytes);           // ensures ctx->ws has >= bytes
 bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i);                // i-th child context (nullptr on failure)
 int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes);
+// runs `job` on the persistent host thread of lane i (created on first use, bound to the ctx's device); lane_wait blocks until that
+// job has returned.  One job per lane at a time.
+void lane_post(bzk_ctx* ctx, size_t i, std::function<void()> job);
+void lane_wait(bzk_ctx* ctx, size_t i);
 
 // bump allocator over ctx->ws
 struct WsCursor {

@@ -3,7 +3,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 
 #include "bzk_internal.h"
 
@@ -77,6 +80,56 @@ bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
 
 }  // namespace bzk
 
+struct bzk_lane_thread {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, busy = false, quit = false;
+};
+
+namespace bzk {
+
+static void lane_thread_main(bzk_lane_thread* t, int device) {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(t->m);
+    for (;;) {
+        t->cv.wait(lk, [&] { return t->has_job || t->quit; });
+        if (t->quit) return;
+        auto job = std::move(t->job);
+        t->has_job = false;
+        lk.unlock();
+        job();
+        lk.lock();
+        t->busy = false;
+        t->cv.notify_all();
+    }
+}
+
+void lane_post(bzk_ctx* ctx, size_t i, std::function<void()> job) {
+    while (ctx->lane_threads.size() <= i) {
+        bzk_lane_thread* t = new bzk_lane_thread();
+        t->th = std::thread(lane_thread_main, t, ctx->device);
+        ctx->lane_threads.push_back(t);
+    }
+    bzk_lane_thread* t = ctx->lane_threads[i];
+    std::unique_lock<std::mutex> lk(t->m);
+    t->cv.wait(lk, [&] { return !t->busy; });
+    t->job = std::move(job);
+    t->has_job = true;
+    t->busy = true;
+    t->cv.notify_all();
+}
+
+void lane_wait(bzk_ctx* ctx, size_t i) {
+    if (i >= ctx->lane_threads.size()) return;
+    bzk_lane_thread* t = ctx->lane_threads[i];
+    std::unique_lock<std::mutex> lk(t->m);
+    t->cv.wait(lk, [&] { return !t->busy; });
+}
+
+}  // namespace bzk
+
 extern "C" {
 
 uint32_t bzk_abi_version(void) { return 1; }
@@ -141,6 +194,16 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (bzk_lane_thread* t : ctx->lane_threads) {
+        {
+            std::unique_lock<std::mutex> lk(t->m);
+            t->cv.wait(lk, [&] { return !t->busy; });
+            t->quit = true;
+            t->cv.notify_all();
+        }
+        if (t->th.joinable()) t->th.join();
+        delete t;
+    }
     for (bzk_ctx* c : ctx->lanes) bzk_ctx_destroy(c);
     for (auto& r : ctx->recs) {
         (void)hipEventDestroy(r.a);

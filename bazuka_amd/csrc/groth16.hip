@@ -13,24 +13,36 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "bzk_curve.cuh"
 #include "bzk_internal.h"
 
-struct bzk_params {
-    uint32_t n_in, n_aux, log_m, n_a, n_b;
+// The CRS of one circuit on one device, shared (reference-counted, read-only once prepared) by every prover SLOT of that device:
+// a slot = bzk_params = the shared CRS + its own per-proof scratch.  Four slots per GPU (bench.py) used to hold four CRS copies and
+// four 1.5 GB h tables; now one of each.
+struct CrsShared {
+    std::atomic<int> refs{1};
+    std::mutex m;  // guards the lazy preparation below
+    int device = 0;
+    uint32_t n_in = 0, n_aux = 0, log_m = 0, n_a = 0, n_b = 0;
     uint8_t vk[870];
-    void *h, *l, *a, *b_g1, *b_g2;      // device CRS
-    uint32_t *a_idx, *b_idx;            // device: variable index of each dense entry
-    void *d_z, *d_a, *d_b, *d_c, *d_sa, *d_sb;  // device scratch sized for this circuit
-    // static-base table of the h query (built on the first proof): the h bases never change and their scalars are never
-    // de-duplicated, so all windows can share one bucket set at a window size of ~log2 m (fewer windows = fewer additions)
-    bzk_msm_table* h_table;
-    bool h_table_tried;
+    void *h = nullptr, *l = nullptr, *a = nullptr, *b_g1 = nullptr, *b_g2 = nullptr;  // raw affine, as loaded (bzk_params_read)
+    uint32_t *a_idx = nullptr, *b_idx = nullptr;                                       // variable index of each dense entry
+    // resident internal forms of the queries (bzk_msm_bases: converted once, no per-proof conversion), built on first use
+    bzk_msm_bases *rl = nullptr, *ra = nullptr, *rb1 = nullptr, *rb2 = nullptr, *rh = nullptr;
+    // static-base table of the h query: the h bases never change and their scalars are never de-duplicated, so all windows can share one
+    // bucket set at a window size of ~log2 m (fewer windows = fewer additions)
+    bzk_msm_table* h_table = nullptr;
+    bool prepared = false;
+};
+struct bzk_params {
+    CrsShared* crs;
+    void *d_z, *d_a, *d_b, *d_c, *d_sa, *d_sb;  // device scratch sized for this circuit, one set per slot
 };
 
 namespace bzk {
@@ -128,17 +140,51 @@ using namespace bzk;
 
 extern "C" {
 
+static void crs_release(bzk_ctx* ctx, CrsShared* c) {
+    if (!c || c->refs.fetch_sub(1) != 1) return;
+    if (c->h_table) bzk_msm_table_free(ctx, c->h_table);
+    for (bzk_msm_bases* b : {c->rl, c->ra, c->rb1, c->rb2, c->rh})
+        if (b) bzk_msm_bases_free(ctx, b);
+    void* bufs[] = {c->h, c->l, c->a, c->b_g1, c->b_g2, c->a_idx, c->b_idx};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete c;
+}
+
 void bzk_params_free(bzk_ctx* ctx, bzk_params* p) {
     if (!p) return;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        for (bzk_ctx* c : ctx->lanes) (void)hipStreamSynchronize(c->stream);
     }
-    if (p->h_table) bzk_msm_table_free(ctx, p->h_table);
-    void* bufs[] = {p->h, p->l, p->a, p->b_g1, p->b_g2, p->a_idx, p->b_idx, p->d_z, p->d_a, p->d_b, p->d_c, p->d_sa, p->d_sb};
+    void* bufs[] = {p->d_z, p->d_a, p->d_b, p->d_c, p->d_sa, p->d_sb};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    crs_release(ctx, p->crs);
     delete p;
+}
+
+static int32_t slot_alloc(bzk_ctx* ctx, CrsShared* c, bzk_params** out) {
+    bzk_params* p = new (std::nothrow) bzk_params();
+    if (!p) return BZK_E_ALLOC;
+    memset(p, 0, sizeof(*p));
+    p->crs = c;
+    const uint64_t m = (uint64_t)1 << c->log_m, nv = (uint64_t)c->n_in + c->n_aux;
+    struct Al { void** dst; size_t bytes; };
+    Al als[] = {{&p->d_z, (size_t)nv * 32}, {&p->d_a, (size_t)m * 32}, {&p->d_b, (size_t)m * 32}, {&p->d_c, (size_t)m * 32},
+                {&p->d_sa, (size_t)c->n_a * 32}, {&p->d_sb, (size_t)c->n_b * 32}};
+    for (auto& a : als) {
+        if (hipMalloc(a.dst, a.bytes ? a.bytes : 32) != hipSuccess) {
+            ctx->last_error = "params: scratch allocation";
+            (void)hipGetLastError();
+            p->crs = nullptr;  // the caller still owns its reference
+            bzk_params_free(ctx, p);
+            return BZK_E_ALLOC;
+        }
+    }
+    *out = p;
+    return BZK_OK;
 }
 
 static int32_t params_build(bzk_ctx* ctx, const bzk_params_desc* d, bool upload_crs, bzk_params** out) {
@@ -155,19 +201,17 @@ static int32_t params_build(bzk_ctx* ctx, const bzk_params_desc* d, bool upload_
     if (ia.size() != d->n_a || ib.size() != d->n_b) return BZK_E_ARG;
     if (upload_crs && ((m > 1 && !d->h) || (d->n_aux && !d->l) || (d->n_a && !d->a) || (d->n_b && (!d->b_g1 || !d->b_g2))))
         return BZK_E_ARG;
-    bzk_params* p = new (std::nothrow) bzk_params();
-    if (!p) return BZK_E_ALLOC;
-    memset(p, 0, sizeof(*p));
-    p->n_in = d->n_in; p->n_aux = d->n_aux; p->log_m = d->log_m; p->n_a = d->n_a; p->n_b = d->n_b;
-    memcpy(p->vk, d->vk, 870);
+    CrsShared* c = new (std::nothrow) CrsShared();
+    if (!c) return BZK_E_ALLOC;
+    c->device = ctx->device;
+    c->n_in = d->n_in; c->n_aux = d->n_aux; c->log_m = d->log_m; c->n_a = d->n_a; c->n_b = d->n_b;
+    memcpy(c->vk, d->vk, 870);
     struct Up { void** dst; const void* src; size_t bytes; };
     Up ups[] = {
-        {&p->h, upload_crs ? d->h : nullptr, (size_t)(m - 1) * 96}, {&p->l, upload_crs ? d->l : nullptr, (size_t)d->n_aux * 96},
-        {&p->a, upload_crs ? d->a : nullptr, (size_t)d->n_a * 96}, {&p->b_g1, upload_crs ? d->b_g1 : nullptr, (size_t)d->n_b * 96},
-        {&p->b_g2, upload_crs ? d->b_g2 : nullptr, (size_t)d->n_b * 192},
-        {(void**)&p->a_idx, ia.data(), ia.size() * 4}, {(void**)&p->b_idx, ib.data(), ib.size() * 4},
-        {&p->d_z, nullptr, (size_t)nv * 32}, {&p->d_a, nullptr, (size_t)m * 32}, {&p->d_b, nullptr, (size_t)m * 32},
-        {&p->d_c, nullptr, (size_t)m * 32}, {&p->d_sa, nullptr, (size_t)d->n_a * 32}, {&p->d_sb, nullptr, (size_t)d->n_b * 32},
+        {&c->h, upload_crs ? d->h : nullptr, (size_t)(m - 1) * 96}, {&c->l, upload_crs ? d->l : nullptr, (size_t)d->n_aux * 96},
+        {&c->a, upload_crs ? d->a : nullptr, (size_t)d->n_a * 96}, {&c->b_g1, upload_crs ? d->b_g1 : nullptr, (size_t)d->n_b * 96},
+        {&c->b_g2, upload_crs ? d->b_g2 : nullptr, (size_t)d->n_b * 192},
+        {(void**)&c->a_idx, ia.data(), ia.size() * 4}, {(void**)&c->b_idx, ib.data(), ib.size() * 4},
     };
     for (auto& u : ups) {
         hipError_t e = hipMalloc(u.dst, u.bytes ? u.bytes : 32);
@@ -175,23 +219,85 @@ static int32_t params_build(bzk_ctx* ctx, const bzk_params_desc* d, bool upload_
         if (e != hipSuccess) {
             ctx->last_error = std::string("params_load: ") + hipGetErrorString(e);
             (void)hipGetLastError();
-            bzk_params_free(ctx, p);
+            (void)hipStreamSynchronize(ctx->stream);
+            crs_release(ctx, c);
             return BZK_E_ALLOC;
         }
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        bzk_params_free(ctx, p);
+        crs_release(ctx, c);
         return BZK_E_DEVICE;
     }
-    *out = p;
-    return BZK_OK;
+    const int32_t st = slot_alloc(ctx, c, out);
+    if (st != BZK_OK) crs_release(ctx, c);
+    return st;
+}
+
+// another prover slot over the SAME device-resident CRS (tables and resident base sets included): own scratch, shared queries
+int32_t bzk_params_slot(bzk_ctx* ctx, const bzk_params* src, bzk_params** out) {
+    if (!ctx || !src || !out) return BZK_E_ARG;
+    *out = nullptr;
+    if (src->crs->device != ctx->device) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    src->crs->refs.fetch_add(1);
+    const int32_t st = slot_alloc(ctx, src->crs, out);
+    if (st != BZK_OK) src->crs->refs.fetch_sub(1);
+    return st;
+}
+
+// Resident forms of the CRS, built once per device under the CRS mutex by whichever slot proves first:
+//   l, a, b_g1, b_g2 (and h where no table is built) -> bzk_msm_bases (internal limb form: no conversion inside a proof)
+//   h                                                -> full static table with a 20-bit window for 2^16 .. 2^21 domains (13 levels x 112 B x m:
+//                                                        1.5 GB at 2^20, 3 GB at 2^21; env BZK_PROVE_H_TABLE_MAX_LOG raises the limit, e.g. 24 =
+//                                                        24 GB for the production domain; BZK_PROVE_H_TABLE=0 switches the table off)
+// Memory policy: a resident form is only built when hipMemGetInfo shows its size plus a reserve for the provers' grow-only
+// workspaces free; anything that does not fit is simply not built (the per-call pipeline on the raw bases works without it), and
+// bzk_groth16_prove drops the table and retries once if a workspace allocation fails later while it is the CRS's only user.
+static bool crs_fits(size_t need, size_t reserve) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return fr >= need + reserve;
+}
+static void crs_prepare(bzk_ctx* ctx, CrsShared* c) {
+    std::lock_guard<std::mutex> lk(c->m);
+    if (c->prepared) return;
+    c->prepared = true;
+    const uint64_t m = (uint64_t)1 << c->log_m;
+    static const bool want_tab = [] { const char* e = getenv("BZK_PROVE_H_TABLE"); return !e || atoi(e) != 0; }();
+    static const bool want_res = [] { const char* e = getenv("BZK_PROVE_RESIDENT_BASES"); return !e || atoi(e) != 0; }();
+    static const uint32_t max_log = [] {
+        const char* e = getenv("BZK_PROVE_H_TABLE_MAX_LOG");
+        const int v = e ? atoi(e) : 21;
+        return (uint32_t)(v < 16 ? 16 : (v > 26 ? 26 : v));
+    }();
+    // reserve: what the slots of this device may still allocate - MSM workspaces of the five lanes (~40 B x 16 windows per point) x 4 slots
+    const size_t reserve = ((size_t)8 << 30) + (size_t)m * 16 * 40 * 4;
+    if (want_tab && c->log_m >= 16 && c->log_m <= max_log && m > 1) {
+        const uint32_t cw = c->log_m > 20 ? 20u : c->log_m;
+        const size_t need = (size_t)((256 + cw - 1) / cw) * 112 * (m - 1);
+        if (!crs_fits(need, reserve) || bzk_msm_g1_table_build_c(ctx, c->h, m - 1, cw, &c->h_table) != BZK_OK) {
+            c->h_table = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    if (!want_res) return;
+    struct Q { const void* raw; uint64_t n; bzk_msm_bases** dst; bool g2; };
+    Q qs[] = {{c->b_g2, c->n_b, &c->rb2, true}, {c->l, c->n_aux, &c->rl, false}, {c->a, c->n_a, &c->ra, false}, {c->b_g1, c->n_b, &c->rb1, false},
+              {c->h_table ? nullptr : c->h, m - 1, &c->rh, false}};
+    for (auto& q : qs) {
+        if (!q.raw || !q.n) continue;
+        if (!crs_fits((size_t)q.n * (q.g2 ? 224 : 112), reserve)) continue;
+        const int32_t st = q.g2 ? bzk_msm_g2_bases_load_dev(ctx, q.raw, q.n, q.dst) : bzk_msm_g1_bases_load_dev(ctx, q.raw, q.n, q.dst);
+        if (st != BZK_OK) { *q.dst = nullptr; (void)hipGetLastError(); }
+    }
 }
 
 int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out) { return params_build(ctx, d, true, out); }
 
 // which: 0 vk (870 B), 1 h, 2 l, 3 a, 4 b_g1, 5 b_g2 ; copies min(cap, size) bytes, *size_out = full size
-int32_t bzk_params_read(bzk_ctx* ctx, const bzk_params* p, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out) {
-    if (!ctx || !p || (cap && !out)) return BZK_E_ARG;
+int32_t bzk_params_read(bzk_ctx* ctx, const bzk_params* slot, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out) {
+    if (!ctx || !slot || (cap && !out)) return BZK_E_ARG;
+    const CrsShared* p = slot->crs;
     (void)hipSetDevice(ctx->device);
     const uint64_t m = (uint64_t)1 << p->log_m;
     const void* src = nullptr;
@@ -229,20 +335,67 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
 int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
                           uint8_t proof[387]) {
     if (!ctx || !p || !asg || !r32 || !s32 || !proof || !asg->z || !asg->az || !asg->bz || !asg->cz) return BZK_E_ARG;
+    if (p->crs->device != ctx->device) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
-    const int32_t st = groth16_prove_impl(ctx, p, asg, r32, s32, proof);
-    if (st != BZK_OK) {
+    crs_prepare(ctx, p->crs);
+    int32_t st = groth16_prove_impl(ctx, p, asg, r32, s32, proof);
+    auto quiesce = [&] {
         // the caller frees (re-uses) the assignment arrays as soon as this returns: no copy out of them may still be in
         // flight, on the main stream or on a lane
         (void)hipStreamSynchronize(ctx->stream);
         for (bzk_ctx* c : ctx->lanes) (void)hipStreamSynchronize(c->stream);
         (void)hipGetLastError();
+    };
+    if (st == BZK_E_ALLOC) {
+        // a grow-only workspace did not fit beside the resident h table: if this slot is the CRS's only user, give the table's memory
+        // back and prove once more through the per-call pipeline; a shared table cannot be pulled from under other slots
+        quiesce();
+        CrsShared* c = p->crs;
+        bool dropped = false;
+        {
+            std::lock_guard<std::mutex> lk(c->m);
+            if (c->h_table && c->refs.load() == 1) {
+                bzk_msm_table_free(ctx, c->h_table);
+                c->h_table = nullptr;
+                dropped = true;
+            }
+        }
+        if (dropped) st = groth16_prove_impl(ctx, p, asg, r32, s32, proof);
     }
+    if (st != BZK_OK) quiesce();
     return st;
 }
 
-static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
+// explicit control of the h table (1: build it now if it fits, 0: drop it - only while this slot is the CRS's sole user)
+int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* p, int32_t on) {
+    if (!ctx || !p) return BZK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    CrsShared* c = p->crs;
+    if (on) {
+        crs_prepare(ctx, c);
+        std::lock_guard<std::mutex> lk(c->m);
+        if (c->h_table) return BZK_OK;
+        const uint64_t m = (uint64_t)1 << c->log_m;
+        if (c->log_m < 16 || m <= 1) return BZK_E_ARG;
+        const uint32_t cw = c->log_m > 20 ? 20u : c->log_m;
+        const int32_t st = bzk_msm_g1_table_build_c(ctx, c->h, m - 1, cw, &c->h_table);
+        if (st != BZK_OK) c->h_table = nullptr;
+        return st;
+    }
+    std::lock_guard<std::mutex> lk(c->m);
+    c->prepared = true;  // an explicit "off" also keeps the first proof from building it
+    if (!c->h_table) return BZK_OK;
+    if (c->refs.load() != 1) return BZK_E_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (bzk_ctx* l : ctx->lanes) (void)hipStreamSynchronize(l->stream);
+    bzk_msm_table_free(ctx, c->h_table);
+    c->h_table = nullptr;
+    return BZK_OK;
+}
+
+static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
                                   uint8_t proof[387]) {
+    const CrsShared* p = slot->crs;
     const uint64_t m = (uint64_t)1 << p->log_m, nv = (uint64_t)p->n_in + p->n_aux;
     if (asg->n_rows > m) return BZK_E_ARG;
     if (asg->n_vars != nv) {  // an R1CS of another circuit shape than the CRS: refuse instead of reading past `z`
@@ -250,39 +403,21 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
         return BZK_E_ARG;
     }
     // Schedule: the five MSMs are independent, and each ends in a latency-bound tail (bucket reduction, window
-    // sums, 97-byte read-back) that leaves most CUs idle.  They run on separate lanes (stream + workspace each,
-    // one host thread per lane) so that one MSM's tail overlaps another's accumulation; l, a, b only need z, so
-    // they start while az/bz/cz are still being copied and the h polynomial is computed on the main stream.
-    // h-query table: 2^16 .. 2^21 domains (13 levels x 112 B x m: 1.5 GB at 2^20, 3 GB at 2^21 - the production 2^24 domain would
-    // need 24 GB per prover slot and keeps the per-call pipeline unless env BZK_PROVE_H_TABLE_MAX_LOG raises the limit - a deployment
-    // with one or two slots per GPU can afford it); env BZK_PROVE_H_TABLE=0 switches the table off (A/B runs)
-    if (!p->h_table_tried) {
-        p->h_table_tried = true;
-        static const bool want = [] { const char* e = getenv("BZK_PROVE_H_TABLE"); return !e || atoi(e) != 0; }();
-        static const uint32_t max_log = [] {
-            const char* e = getenv("BZK_PROVE_H_TABLE_MAX_LOG");
-            const int v = e ? atoi(e) : 21;
-            return (uint32_t)(v < 16 ? 16 : (v > 26 ? 26 : v));
-        }();
-        if (want && p->log_m >= 16 && p->log_m <= max_log) {
-            const uint32_t c = p->log_m > 20 ? 20u : p->log_m;
-            if (bzk_msm_g1_table_build_c(ctx, p->h, m - 1, c, &p->h_table) != BZK_OK) {
-                p->h_table = nullptr;  // not enough memory: the per-call pipeline works without it
-                (void)hipGetLastError();
-            }
-        }
-    }
+    // sums, read-back) that leaves most CUs idle.  They run on separate lanes (stream + workspace each, one PERSISTENT host
+    // thread per lane - bzk::lane_post - since round 3; three std::thread creations per proof before) so that one MSM's tail
+    // overlaps another's accumulation; l, a, b only need z, so they start while az/bz/cz are still being copied and the h
+    // polynomial is computed on the main stream.
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     bzk_ctx* lane[3];
     for (int i = 0; i < 3; ++i)
         if (!(lane[i] = bzk::ctx_lane(ctx, (size_t)i))) return BZK_E_DEVICE;
-    BZK_HIP(ctx, hipMemcpyAsync(p->d_z, asg->z, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(slot->d_z, asg->z, nv * 32, hipMemcpyHostToDevice, ctx->stream));
     // density-filtered scalar vectors
     if (p->n_a)
-        BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_a + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->a_idx, p->n_a, (Fr*)p->d_sa);
+        BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_a + 255) / 256), dim3(256), 0, (const Fr*)slot->d_z, p->a_idx, p->n_a, (Fr*)slot->d_sa);
     if (p->n_b)
-        BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_b + 255) / 256), dim3(256), 0, (const Fr*)p->d_z, p->b_idx, p->n_b, (Fr*)p->d_sb);
+        BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_b + 255) / 256), dim3(256), 0, (const Fr*)slot->d_z, p->b_idx, p->n_b, (Fr*)slot->d_sb);
     if (!ctx->ev_z) BZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
     const hipEvent_t z_ready = ctx->ev_z;
     BZK_HIP(ctx, hipEventRecord(z_ready, ctx->stream));
@@ -300,19 +435,26 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
     static const uint32_t tflag = (getenv("BZK_PROVE_LATENCY") && atoi(getenv("BZK_PROVE_LATENCY")) != 0) ? 0u : BZK_F_THROUGHPUT;
     static const uint32_t wflags = ((getenv("BZK_PROVE_NODEDUP") && atoi(getenv("BZK_PROVE_NODEDUP")) != 0) ? 0u : BZK_F_DEDUP) | tflag;
     static const bool serial = getenv("BZK_PROVE_SERIAL") && atoi(getenv("BZK_PROVE_SERIAL")) != 0;
-    std::thread th[3];
+    const void* z_aux = (const char*)slot->d_z + (size_t)p->n_in * 32;
+    // every query through its resident set where one was built (crs_prepare), through the raw bases otherwise
+    auto g1 = [&](bzk_ctx* c, const bzk_msm_bases* res, const void* raw, const void* sc, uint64_t n, uint32_t fl, uint8_t* out) {
+        return res ? bzk_msm_g1_bases_run_dev(c, res, sc, n, fl, out) : bzk_msm_g1_dev(c, raw, sc, n, fl, out);
+    };
     auto job0 = [&] {
         (void)hipSetDevice(dev);
-        st[0] = bzk_msm_g2_dev(lane[0], p->b_g2, p->d_sb, p->n_b, wflags, pB2);
+        st[0] = p->rb2 ? bzk_msm_g2_bases_run_dev(lane[0], p->rb2, slot->d_sb, p->n_b, wflags, pB2)
+                       : bzk_msm_g2_dev(lane[0], p->b_g2, slot->d_sb, p->n_b, wflags, pB2);
     };
+    auto job1a = [&] { st[1] = g1(lane[1], p->rl, p->l, z_aux, p->n_aux, wflags, pL); };
+    auto job1b = [&] { if (st[1] == BZK_OK) st[1] = g1(lane[1], p->rb1, p->b_g1, slot->d_sb, p->n_b, wflags, pB1); };
     auto job1 = [&] {
         (void)hipSetDevice(dev);
-        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, wflags, pL);
-        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, wflags, pB1);
+        job1a();
+        job1b();
     };
     auto job2 = [&] {
         (void)hipSetDevice(dev);
-        st[2] = bzk_msm_g1_dev(lane[2], p->a, p->d_sa, p->n_a, wflags, pA);
+        st[2] = g1(lane[2], p->ra, p->a, slot->d_sa, p->n_a, wflags, pA);
     };
     if (serial) {
         auto dump = [&](int i, const char* what) {
@@ -327,35 +469,33 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
         };
         job0(); dump(0, "b_g2");
         (void)hipSetDevice(dev);
-        st[1] = bzk_msm_g1_dev(lane[1], p->l, (const char*)p->d_z + (size_t)p->n_in * 32, p->n_aux, wflags, pL);
-        dump(1, "l");
-        if (st[1] == BZK_OK) st[1] = bzk_msm_g1_dev(lane[1], p->b_g1, p->d_sb, p->n_b, wflags, pB1);
-        dump(1, "b_g1");
+        job1a(); dump(1, "l");
+        job1b(); dump(1, "b_g1");
         job2(); dump(2, "a");
     } else {
-        th[0] = std::thread(job0);
-        th[1] = std::thread(job1);
-        th[2] = std::thread(job2);
+        bzk::lane_post(ctx, 0, job0);
+        bzk::lane_post(ctx, 1, job1);
+        bzk::lane_post(ctx, 2, job2);
     }
     // main stream: stage the evaluations, h polynomial, h MSM
     int32_t st_main = BZK_OK;
     auto main_part = [&]() -> int32_t {
-        void* ev[3] = {p->d_a, p->d_b, p->d_c};
+        void* ev[3] = {slot->d_a, slot->d_b, slot->d_c};
         const uint8_t* hv[3] = {asg->az, asg->bz, asg->cz};
         for (int k = 0; k < 3; ++k) {
             BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
             if (m > asg->n_rows)
                 BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
         }
-        BZK_TRY(groth16_h(ctx, p->d_a, p->d_b, p->d_c, p->log_m));
-        if (p->h_table) return bzk_msm_g1_table_run_dev(ctx, p->h_table, p->d_a, m - 1, tflag, pH);
-        return bzk_msm_g1_dev(ctx, p->h, p->d_a, m - 1, tflag, pH);
+        BZK_TRY(groth16_h(ctx, slot->d_a, slot->d_b, slot->d_c, p->log_m));
+        if (p->h_table) return bzk_msm_g1_table_run_dev(ctx, p->h_table, slot->d_a, m - 1, tflag, pH);
+        return g1(ctx, p->rh, p->h, slot->d_a, m - 1, tflag, pH);
     };
     const auto t2 = clk::now();
     st_main = main_part();
     const auto t3 = clk::now();
     if (!serial)
-        for (auto& t : th) t.join();
+        for (size_t i = 0; i < 3; ++i) bzk::lane_wait(ctx, i);  // always: the jobs reference this frame
     const auto t4 = clk::now();
     if (st_main != BZK_OK) return st_main;
     for (int i = 0; i < 3; ++i)
@@ -403,6 +543,6 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignm
 // internal hooks for setup.hip (CRS generated in place on the device)
 int32_t bzk_params_alloc_internal(bzk_ctx* ctx, const bzk_params_desc* d, bzk_params** out) { return params_build(ctx, d, false, out); }
 void bzk_params_buffers_internal(bzk_params* p, void** h, void** l, void** a, void** b_g1, void** b_g2) {
-    *h = p->h; *l = p->l; *a = p->a; *b_g1 = p->b_g1; *b_g2 = p->b_g2;
+    *h = p->crs->h; *l = p->crs->l; *a = p->crs->a; *b_g1 = p->crs->b_g1; *b_g2 = p->crs->b_g2;
 }
-void bzk_params_set_vk_internal(bzk_params* p, const uint8_t vk[870]) { memcpy(p->vk, vk, 870); }
+void bzk_params_set_vk_internal(bzk_params* p, const uint8_t vk[870]) { memcpy(p->crs->vk, vk, 870); }

@@ -39,6 +39,8 @@
 
 #include "bzk_internal.h"
 
+struct bzk_mg_params;
+
 namespace {
 
 constexpr int MG_MAX_W = 64;          // windows of a call (c >= 4 -> W <= 64)
@@ -111,6 +113,26 @@ struct bzk_mg {
     size_t shm_bytes = 0;
     uint64_t seq = 0;
     std::string shm_name;
+};
+// proof pool: `slots` prover slots (context + lanes + scratch) per local device over one shared CRS per device; one host thread per
+// slot takes proofs from a common queue - whichever slot is free next, on whichever device (replicas: proofs do not shard)
+struct MgProofJob {
+    const bzk_assignment* asg;
+    uint8_t r[32], s[32];
+    uint8_t* out;
+    uint64_t ticket;
+};
+struct bzk_mg_params {
+    bzk_mg* mg = nullptr;
+    struct Slot { int dev_index; bzk_ctx* ctx; bzk_params* params; std::thread th; uint64_t proofs = 0; };
+    std::vector<Slot*> slots;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<MgProofJob> queue;
+    std::vector<std::pair<uint64_t, int32_t>> finished;  // (ticket, status)
+    std::vector<std::pair<uint64_t, std::string>> errors;
+    uint64_t next_ticket = 1;
+    bool quit = false;
 };
 struct bzk_mg_bases {
     std::vector<bzk_msm_bases*> per_dev;
@@ -553,6 +575,137 @@ int32_t bzk_mg_msm_g1(bzk_mg* mg, const bzk_mg_bases* bases, const uint8_t* scal
 }
 int32_t bzk_mg_msm_g2(bzk_mg* mg, const bzk_mg_bases* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[193]) {
     return mg_msm(mg, bases, 1, nullptr, scalars, n, flags, out);
+}
+
+// ---- proof pool (replicas) -------------------------------------------------------------------------------------------------
+static void mg_slot_main(bzk_mg_params* P, bzk_mg_params::Slot* sl) {
+    (void)hipSetDevice(P->mg->devices[sl->dev_index]);
+    for (;;) {
+        MgProofJob job;
+        {
+            std::unique_lock<std::mutex> lk(P->m);
+            P->cv_work.wait(lk, [&] { return P->quit || !P->queue.empty(); });
+            if (P->queue.empty()) return;  // quit and drained
+            job = P->queue.front();
+            P->queue.pop_front();
+        }
+        const int32_t st = bzk_groth16_prove(sl->ctx, sl->params, job.asg, job.r, job.s, job.out);
+        {
+            std::lock_guard<std::mutex> lk(P->m);
+            ++sl->proofs;
+            P->finished.push_back({job.ticket, st});
+            if (st != BZK_OK) P->errors.push_back({job.ticket, "device " + std::to_string(P->mg->devices[sl->dev_index]) + ": " + sl->ctx->last_error});
+            P->cv_done.notify_all();
+        }
+    }
+}
+
+int32_t bzk_mg_params_load(bzk_mg* mg, const bzk_params_desc* desc, uint32_t slots_per_device, bzk_mg_params** out) {
+    if (!mg || !desc || !out || slots_per_device < 1 || slots_per_device > 16) return BZK_E_ARG;
+    *out = nullptr;
+    bzk_mg_params* P = new (std::nothrow) bzk_mg_params();
+    if (!P) return BZK_E_ALLOC;
+    P->mg = mg;
+    int32_t st = BZK_OK;
+    std::vector<bzk_params*> first(mg->n_local, nullptr);
+    for (int i = 0; i < mg->n_local && st == BZK_OK; ++i) {
+        (void)hipSetDevice(mg->devices[i]);
+        // local entries that share a device share its CRS too
+        for (int j = 0; j < i; ++j)
+            if (mg->devices[j] == mg->devices[i]) first[i] = first[j];
+        for (uint32_t k = 0; k < slots_per_device && st == BZK_OK; ++k) {
+            bzk_mg_params::Slot* sl = new bzk_mg_params::Slot();
+            sl->dev_index = i;
+            sl->ctx = nullptr;
+            sl->params = nullptr;
+            P->slots.push_back(sl);
+            st = bzk_ctx_create(mg->devices[i], nullptr, &sl->ctx);
+            if (st != BZK_OK) break;
+            st = first[i] ? bzk_params_slot(sl->ctx, first[i], &sl->params) : bzk_params_load(sl->ctx, desc, &sl->params);
+            if (st == BZK_OK && !first[i]) first[i] = sl->params;
+            if (st != BZK_OK) mg->last_error = "bzk_mg_params_load, device " + std::to_string(mg->devices[i]) + ": " + sl->ctx->last_error;
+        }
+    }
+    if (st != BZK_OK) {
+        bzk_mg_params_free(mg, P);
+        return st;
+    }
+    for (auto* sl : P->slots) sl->th = std::thread(mg_slot_main, P, sl);
+    *out = P;
+    return BZK_OK;
+}
+
+void bzk_mg_params_free(bzk_mg* mg, bzk_mg_params* P) {
+    (void)mg;
+    if (!P) return;
+    {
+        std::lock_guard<std::mutex> lk(P->m);
+        P->quit = true;
+        P->cv_work.notify_all();
+    }
+    for (auto* sl : P->slots)
+        if (sl->th.joinable()) sl->th.join();
+    for (auto* sl : P->slots) {
+        if (sl->ctx) {
+            (void)hipSetDevice(P->mg->devices[sl->dev_index]);
+            if (sl->params) bzk_params_free(sl->ctx, sl->params);
+            bzk_ctx_destroy(sl->ctx);
+        }
+        delete sl;
+    }
+    delete P;
+}
+
+uint32_t bzk_mg_params_slots(const bzk_mg_params* P) { return P ? (uint32_t)P->slots.size() : 0; }
+
+int32_t bzk_mg_prove_submit(bzk_mg* mg, bzk_mg_params* P, const bzk_assignment* asg, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[387],
+                            uint64_t* ticket) {
+    if (!mg || !P || !asg || !r || !s || !proof_out || !ticket || P->mg != mg) return BZK_E_ARG;
+    std::lock_guard<std::mutex> lk(P->m);
+    MgProofJob j;
+    j.asg = asg;
+    memcpy(j.r, r, 32);
+    memcpy(j.s, s, 32);
+    j.out = proof_out;
+    j.ticket = *ticket = P->next_ticket++;
+    P->queue.push_back(j);
+    P->cv_work.notify_one();
+    return BZK_OK;
+}
+
+int32_t bzk_mg_prove_wait(bzk_mg* mg, bzk_mg_params* P, uint64_t ticket) {
+    if (!mg || !P || P->mg != mg) return BZK_E_ARG;
+    std::unique_lock<std::mutex> lk(P->m);
+    if (ticket == 0 || ticket >= P->next_ticket) return BZK_E_ARG;
+    for (;;) {
+        for (size_t i = 0; i < P->finished.size(); ++i) {
+            if (P->finished[i].first != ticket) continue;
+            const int32_t st = P->finished[i].second;
+            P->finished.erase(P->finished.begin() + (long)i);
+            for (size_t e = 0; e < P->errors.size(); ++e)
+                if (P->errors[e].first == ticket) {
+                    mg->last_error = P->errors[e].second;
+                    P->errors.erase(P->errors.begin() + (long)e);
+                    break;
+                }
+            return st;
+        }
+        P->cv_done.wait(lk);
+    }
+}
+
+int32_t bzk_mg_prove(bzk_mg* mg, bzk_mg_params* P, const bzk_assignment* asg, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[387]) {
+    uint64_t t = 0;
+    BZK_TRY(bzk_mg_prove_submit(mg, P, asg, r, s, proof_out, &t));
+    return bzk_mg_prove_wait(mg, P, t);
+}
+
+// proofs each slot has finished so far (load-balance evidence for tests / the bench): out[i] for slot i, i < bzk_mg_params_slots()
+int32_t bzk_mg_params_stats(bzk_mg_params* P, uint64_t* out, uint32_t cap) {
+    if (!P || !out) return BZK_E_ARG;
+    std::lock_guard<std::mutex> lk(P->m);
+    for (uint32_t i = 0; i < cap && i < P->slots.size(); ++i) out[i] = P->slots[i]->proofs;
+    return BZK_OK;
 }
 
 }  // extern "C"

@@ -53,6 +53,8 @@ SIGNATURES = {
     "bzk_g2_sum": (_i32, [_vp, _u32, _vp]),
     "bzk_params_load": (_i32, [_vp, _vp, C.POINTER(_vp)]),
     "bzk_params_free": (None, [_vp, _vp]),
+    "bzk_params_slot": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "bzk_params_h_table": (_i32, [_vp, _vp, _i32]),
     "bzk_groth16_prove": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "bzk_bellman_params_info": (_i32, [_vp, _u64, C.POINTER(_u64)]),
     "bzk_bellman_params_decode": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
@@ -153,6 +155,13 @@ SIGNATURES = {
     "bzk_mg_msm_g2": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "bzk_mg_msm_g1_dev": (_i32, [_vp, _vp, C.POINTER(_vp), _u64, _u32, _vp]),
     "bzk_mg_msm_g2_dev": (_i32, [_vp, _vp, C.POINTER(_vp), _u64, _u32, _vp]),
+    "bzk_mg_params_load": (_i32, [_vp, _vp, _u32, C.POINTER(_vp)]),
+    "bzk_mg_params_free": (None, [_vp, _vp]),
+    "bzk_mg_params_slots": (_u32, [_vp]),
+    "bzk_mg_params_stats": (_i32, [_vp, C.POINTER(_u64), _u32]),
+    "bzk_mg_prove_submit": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "bzk_mg_prove_wait": (_i32, [_vp, _vp, _u64]),
+    "bzk_mg_prove": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "bzk_g1_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
     "bzk_g2_synth_bases_dev": (_i32, [_vp, _u64, _u64, _u64, _vp]),
 }
@@ -529,6 +538,15 @@ class Bzk:
     def params_free(self, ph):
         self.lib.bzk_params_free(self.h, ph)
 
+    def params_slot(self, ph):
+        """another prover slot over the same device-resident CRS (own scratch): one ctx + one slot per concurrent prover thread"""
+        h = C.c_void_p()
+        self._ck(self.lib.bzk_params_slot(self.h, ph, C.byref(h)), "params_slot")
+        return h
+
+    def params_h_table(self, ph, on: bool):
+        self._ck(self.lib.bzk_params_h_table(self.h, ph, int(on)), "params_h_table")
+
     def groth16_prove(self, ph, z, az, bz, cz, r: bytes, s: bytes) -> bytes:
         """z / az / bz / cz: bytes or zero-copy ctypes views (R1cs.raw) - passed by address, never copied here."""
         keep = [x if not isinstance(x, bytearray) else bytes(x) for x in (z, az, bz, cz)]
@@ -659,6 +677,37 @@ class Mg:
         fn = self.lib.bzk_mg_msm_g2_dev if g2 else self.lib.bzk_mg_msm_g1_dev
         self._ck(fn(self.h, bases, self._ptrs(scalars_dev), n, _flags(canonical, dedup, throughput), out), "mg_msm_dev")
         return out.raw
+
+    # ---- proof pool
+    def params_load(self, params: dict, slots_per_device: int = 2):
+        keep = {k: C.create_string_buffer(bytes(params[k]), max(1, len(params[k])))
+                for k in ("vk", "h", "l", "a", "b_g1", "b_g2", "a_density", "b_density")}
+        d = ParamsDesc(params["n_in"], params["n_aux"], params["log_m"], params["n_a"], params["n_b"],
+                       *[C.cast(keep[k], C.c_void_p) for k in ("vk", "h", "l", "a", "b_g1", "b_g2", "a_density", "b_density")])
+        h = C.c_void_p()
+        self._ck(self.lib.bzk_mg_params_load(self.h, C.byref(d), slots_per_device, C.byref(h)), "mg_params_load")
+        return h
+
+    def params_free(self, ph):
+        self.lib.bzk_mg_params_free(self.h, ph)
+
+    def params_stats(self, ph):
+        n = self.lib.bzk_mg_params_slots(ph)
+        arr = (_u64 * max(1, n))()
+        self._ck(self.lib.bzk_mg_params_stats(ph, arr, n), "mg_params_stats")
+        return list(arr)[:n]
+
+    def prove_submit(self, ph, z, az, bz, cz, r: bytes, s: bytes):
+        """returns a pending-proof record; keep it (it owns the buffers) until prove_wait"""
+        asg = Assignment(*[_ptr(x) for x in (z, az, bz, cz)], len(az) // 32, len(z) // 32)
+        out = C.create_string_buffer(387)
+        t = _u64()
+        self._ck(self.lib.bzk_mg_prove_submit(self.h, ph, C.byref(asg), _ptr(r), _ptr(s), out, C.byref(t)), "mg_prove_submit")
+        return {"ticket": t.value, "out": out, "keep": (asg, z, az, bz, cz, r, s), "ph": ph}
+
+    def prove_wait(self, pending) -> bytes:
+        self._ck(self.lib.bzk_mg_prove_wait(self.h, pending["ph"], pending["ticket"]), "mg_prove_wait")
+        return pending["out"].raw
 
 
 def _st(st, what):

@@ -215,15 +215,15 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     threads = [threading.Thread(target=producer, args=(s,), daemon=True) for s in range(n_prod)]
     for th in threads:
         th.start()
-    # Two prover slots on the same GPU (each its own context, streams and CRS copy - 288 GB is there to be used):
-    # the latency-bound tails of one proof (bucket reduction, window sums, batched inversions) overlap the
-    # throughput-bound bucket accumulation of the other.
+    # Several prover slots on the same GPU (each its own context, lanes and scratch; since round 3 they SHARE the device-resident
+    # CRS, its resident base sets and the h table - bzk_params_slot): the latency-bound tails of one proof (bucket reduction, window
+    # sums, batched inversions) overlap the throughput-bound bucket accumulation of the others.
     from bazuka_amd import Bzk
     n_slots = max(1, int(os.environ.get("BZK_BENCH_SLOTS", "4")))
     slots = [(ctx, ph)]
     for _ in range(n_slots - 1):
         cx = Bzk(ctx.device)
-        slots.append((cx, cx.groth16_setup(csr, r.n_in, r.n_aux, tox)[0]))
+        slots.append((cx, cx.params_slot(ph)))
     # the slots keep proving n_drain more proofs after the timed ones, so that the last timed proofs do not run on a draining GPU
     # (the timed window is steady state on both sides: n_warm completions before it, every slot still busy at its end)
     n_drain = len(slots)

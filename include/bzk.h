@@ -204,6 +204,17 @@ typedef struct {
 /* uploads the CRS to HBM once (host pointers in the descriptor are not retained) */
 int32_t bzk_params_load(bzk_ctx* ctx, const bzk_params_desc* desc, bzk_params** out);
 void bzk_params_free(bzk_ctx* ctx, bzk_params* params);
+/* A further prover SLOT over the same device-resident CRS: `bzk_groth16_prove` is not re-entrant per params handle, which owns its
+ * per-proof device scratch,, so a prover that keeps several proofs in flight on one GPU (their latency-bound phases hide under
+ * each other's accumulation) uses one ctx + one slot per thread.  Slots SHARE the uploaded CRS, its resident internal forms and the
+ * h table (reference-counted; the last bzk_params_free releases them): n slots cost n x scratch, not n x CRS. */
+int32_t bzk_params_slot(bzk_ctx* ctx, const bzk_params* params, bzk_params** out);
+/* The first proof over a CRS builds, ONCE per device and only where hipMemGetInfo shows room for them beside a workspace reserve,
+ * the resident internal forms of l / a / b_g1 / b_g2 (no base conversion inside a proof) and, for 2^16 .. 2^21 domains, a static
+ * table of the h query (13 levels: 1.5 GB at 2^20).  bzk_params_h_table(.., 1) builds that table now, for any domain size that
+ * fits; (.., 0) drops it / keeps the first proof from building it (only while this handle is the CRS's sole slot).  Environment:
+ * BZK_PROVE_H_TABLE=0, BZK_PROVE_H_TABLE_MAX_LOG, BZK_PROVE_RESIDENT_BASES=0. */
+int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* params, int32_t on);
 /* r, s: Montgomery scalars (the prover's blinding factors; bellman draws them from the rng) */
 int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* params, const bzk_assignment* asg, const uint8_t r[32],
                           const uint8_t s[32], uint8_t proof_out[387]);
@@ -449,6 +460,20 @@ int32_t bzk_mg_msm_g1(bzk_mg* mg, const bzk_mg_bases* bases, const uint8_t* scal
 int32_t bzk_mg_msm_g2(bzk_mg* mg, const bzk_mg_bases* bases, const uint8_t* scalars, uint64_t n, uint32_t flags, uint8_t out[193]);
 int32_t bzk_mg_msm_g1_dev(bzk_mg* mg, const bzk_mg_bases* bases, const void* const* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[97]);
 int32_t bzk_mg_msm_g2_dev(bzk_mg* mg, const bzk_mg_bases* bases, const void* const* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[193]);
+
+/* proof pool over the group's local devices: `slots_per_device` prover slots (context + lanes + scratch each) per device over ONE
+ * CRS upload per device; one host thread per slot takes proofs from a common queue (whichever slot is free next).  The assignment
+ * arrays and proof_out must stay valid until the ticket has been waited for; wait returns that proof's status. */
+typedef struct bzk_mg_params bzk_mg_params;
+int32_t bzk_mg_params_load(bzk_mg* mg, const bzk_params_desc* desc, uint32_t slots_per_device, bzk_mg_params** out);
+void bzk_mg_params_free(bzk_mg* mg, bzk_mg_params* params);
+uint32_t bzk_mg_params_slots(const bzk_mg_params* params);
+int32_t bzk_mg_params_stats(bzk_mg_params* params, uint64_t* proofs_per_slot, uint32_t cap);
+int32_t bzk_mg_prove_submit(bzk_mg* mg, bzk_mg_params* params, const bzk_assignment* asg, const uint8_t r[32], const uint8_t s[32],
+                            uint8_t proof_out[387], uint64_t* ticket);
+int32_t bzk_mg_prove_wait(bzk_mg* mg, bzk_mg_params* params, uint64_t ticket);
+int32_t bzk_mg_prove(bzk_mg* mg, bzk_mg_params* params, const bzk_assignment* asg, const uint8_t r[32], const uint8_t s[32],
+                     uint8_t proof_out[387]);
 
 /* synthetic-input helpers (device side, for benches and tests): base_i = k_i * G with
  * k_i = SplitMix64(seed + 0x632BE59BD9B4E019 * (start+i)).next() | 1 ; raw affine out */

@@ -135,3 +135,44 @@ def test_bellman_parameters_file_round_trip_through_the_prover(bzk, co, pr):
         bzk.params_load_bellman(blob[:-7], r1["n_in"], r1["n_aux"], a_d, b_d)
     bzk.params_free(ph)
     bzk.params_free(ph2)
+
+
+def test_groth16_slots_share_one_crs_and_prove_concurrently(bzk, co, pr):
+    """bzk_params_slot: several prover slots (own ctx + scratch) over ONE device-resident CRS prove different witnesses at the same
+    time from different host threads; every proof equals the oracle's; the h table can be dropped / rebuilt by a sole owner"""
+    import threading
+    from bazuka_amd import Bzk
+    r1, params, zb, az, bz, cz = _setup(co, pr, 40000, 4242)   # 2^16 domain: the h query runs through its static table
+    rs = [(fr_bytes(fr_list(2, 50 + k))[:32], fr_bytes(fr_list(2, 50 + k))[32:]) for k in range(4)]
+    want = [co.groth16_prove(params, zb, az, bz, cz, r, s, nthreads=co.ncpu()) for r, s in rs]
+    ph = bzk.params_load(params)
+    assert bzk.groth16_prove(ph, zb, az, bz, cz, *rs[0]) == want[0]
+    ctxs = [Bzk(0) for _ in range(3)]
+    slots = [c.params_slot(ph) for c in ctxs]
+    got = [None] * 4
+
+    def run(k):
+        c, p = ([bzk] + ctxs)[k], ([ph] + slots)[k]
+        for _ in range(3):
+            got[k] = c.groth16_prove(p, zb, az, bz, cz, *rs[k])
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == want
+    # the CRS outlives its first handle: slots keep it alive (reference count)
+    bzk.params_free(ph)
+    assert ctxs[0].groth16_prove(slots[0], zb, az, bz, cz, *rs[1]) == want[1]
+    with pytest.raises(Exception):
+        ctxs[0].params_h_table(slots[0], False)      # shared: refused
+    ctxs[1].params_free(slots[1])
+    ctxs[2].params_free(slots[2])
+    ctxs[0].params_h_table(slots[0], False)          # sole owner now: dropped ...
+    assert ctxs[0].groth16_prove(slots[0], zb, az, bz, cz, *rs[2]) == want[2]
+    ctxs[0].params_h_table(slots[0], True)           # ... and rebuilt
+    assert ctxs[0].groth16_prove(slots[0], zb, az, bz, cz, *rs[3]) == want[3]
+    ctxs[0].params_free(slots[0])
+    for c in ctxs:
+        c.close()

@@ -168,3 +168,23 @@ def test_mg_process_per_gpu_shared_memory_exchange(bzk, co, world, g2):
     want = (co.msm_g2 if g2 else co.msm_g1)(dev_bytes(d), scb, nthreads=co.ncpu())
     for r, o in enumerate(outs):
         assert o[1] == str(r) and o[2] == "host" and bytes.fromhex(o[3]) == want
+
+
+def test_mg_proof_pool_replicas(bzk, co, pr):
+    """bzk_mg_params_load / bzk_mg_prove_submit / _wait: a pool of prover slots over the group's devices (one CRS upload per device)
+    proves a queue of different (r, s) pairs; every proof equals the oracle's and more than one slot did work"""
+    from bazuka_amd import Mg
+    from test_gpu_groth16 import _setup
+    r1, params, zb, az, bz, cz = _setup(co, pr, 2500, 777)
+    rs = [(fr_bytes(fr_list(2, 90 + k))[:32], fr_bytes(fr_list(2, 90 + k))[32:]) for k in range(6)]
+    want = [co.groth16_prove(params, zb, az, bz, cz, r, s, nthreads=co.ncpu()) for r, s in rs]
+    mg = Mg(devices=[0, 0], exchange=1)
+    ph = mg.params_load(params, slots_per_device=2)
+    for _ in range(2):
+        pend = [mg.prove_submit(ph, zb, az, bz, cz, r, s) for r, s in rs]
+        got = [mg.prove_wait(p) for p in reversed(pend)][::-1]   # waited out of order
+        assert got == want
+    st = mg.params_stats(ph)
+    assert len(st) == 4 and sum(st) == 12 and sum(1 for x in st if x) >= 2
+    mg.params_free(ph)
+    mg.close()
