@@ -40,6 +40,9 @@ SIGNATURES = {
     "bzk_poseidon_batch_dev": (_i32, [_vp, _vp, _u32, _u64, _vp]),
     "bzk_merkle4_root": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "bzk_merkle4_root_dev": (_i32, [_vp, _vp, _u32, _vp, _vp]),
+    "bzk_state_compress": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp, C.POINTER(_u64)]),
+    "bzk_state_compress_bincode": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp]),
+    "bzk_state_model_default": (_i32, [_vp, _u64, _vp]),
     "bzk_ntt": (_i32, [_vp, _vp, _u32, _i32, _i32]),
     "bzk_ntt_dev": (_i32, [_vp, _vp, _u32, _i32, _i32]),
     "bzk_msm_g1": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
@@ -450,6 +453,28 @@ class Bzk:
     def g2_sum(self, packed: bytes) -> bytes:
         out = C.create_string_buffer(193)
         self._ck(self.lib.bzk_g2_sum(_ptr(packed), len(packed) // 193, out), "g2_sum")
+        return out.raw
+
+    # ---- general `ZkStateModel::compress`
+    def state_compress(self, model_bincode: bytes, pairs):
+        """pairs: iterable of (locator tuple of ints, 32-byte Montgomery scalar) -> (state_hash 32 B, state_size)"""
+        pairs = list(pairs)
+        off, loc = [0], []
+        for l, _ in pairs:
+            loc.extend(l)
+            off.append(len(loc))
+        o = (_u64 * len(off))(*off)
+        lo = (_u64 * max(1, len(loc)))(*loc)
+        vals = b"".join(v for _, v in pairs)
+        out, size = C.create_string_buffer(32), _u64()
+        self._ck(self.lib.bzk_state_compress(self.h, _ptr(model_bincode), len(model_bincode), o, lo, _ptr(vals), len(pairs), out, C.byref(size)),
+                 "state_compress")
+        return out.raw, size.value
+
+    def state_compress_bincode(self, model_bincode: bytes, pairs_bincode: bytes) -> bytes:
+        out = C.create_string_buffer(40)
+        self._ck(self.lib.bzk_state_compress_bincode(self.h, _ptr(model_bincode), len(model_bincode), _ptr(pairs_bincode), len(pairs_bincode), out),
+                 "state_compress_bincode")
         return out.raw
 
     # ---- device-resident MPN account state (SURVEY 8f-3)
@@ -966,6 +991,13 @@ def mpn_circuit_empty(kind, L, T, B, commitment, height, state, aux, next_state,
     _st(load_library().bzk_mpn_circuit_empty(kind, L, T, B, _ptr(commitment), height, _ptr(state), _ptr(aux), _ptr(next_state),
                                              int(record_matrices), C.byref(h)), "circuit_empty")
     return R1cs(h)
+
+
+def state_model_default(model_bincode: bytes) -> bytes:
+    """`ZkStateModel::compress_default` (host)"""
+    out = C.create_string_buffer(32)
+    _st(load_library().bzk_state_model_default(_ptr(model_bincode), len(model_bincode), out), "state_model_default")
+    return out.raw
 
 
 def host_poseidon(inp: bytes) -> bytes:

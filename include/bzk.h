@@ -137,6 +137,24 @@ int32_t bzk_mpn_tree_prove(bzk_ctx* ctx, const bzk_mpn_tree* tree, const uint64_
 int32_t bzk_mpn_tree_prove_token(bzk_ctx* ctx, const bzk_mpn_tree* tree, const uint64_t* account_indices, const uint64_t* token_indices,
                                  uint64_t n, uint8_t* out);
 
+/* General seam `ZkStateModel::compress::<H>(&data)` (src/zk/mod.rs:392-399; `ZkStateBuilder::{batch_set, compress}`
+ * src/zk/state/mod.rs:66-90 over `set_data` 310-420): ANY nesting of Scalar / Struct{field_types} / List{log4_size, item_type}
+ * (src/zk/mod.rs:332-345) over SPARSE (ZkDataLocator, ZkScalar) pairs, untouched sub-trees at `compress_default` (401-423).  The
+ * touched part of the state is laid out on the host, grouped by (height, arity), and every group is one batched Poseidon launch.
+ *   model          bincode(ZkStateModel) (u32 tags 0 Scalar / 1 Struct + Vec / 2 List + u8 + Box)
+ *   loc_off, loc   CSR of the n locators: pair i's indices are loc[loc_off[i] .. loc_off[i + 1])
+ *   values         n x 32-byte Montgomery scalars
+ *   state_hash, state_size = the two fields of `ZkCompressedState` (size = non-zero scalars, as set_data counts them)
+ * BZK_E_ARG where the reference returns LocatorError / NonScalarLocatorError (or panics): a locator that does not end at a
+ * scalar, an index >= 4^log4_size or >= the number of fields, a repeated locator, a struct with 0 or > 16 fields (`is_valid`).
+ * _bincode: pairs = bincode(ZkDataPairs), out = bincode(ZkCompressedState) (40 B) - what a Rust host holds already.
+ * bzk_state_model_default = `compress_default` (host). */
+int32_t bzk_state_compress(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint64_t* loc_off, const uint64_t* loc,
+                           const uint8_t* values, uint64_t n, uint8_t state_hash[32], uint64_t* state_size);
+int32_t bzk_state_compress_bincode(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint8_t* pairs, uint64_t pairs_len,
+                                   uint8_t compressed_out[40]);
+int32_t bzk_state_model_default(const uint8_t* model, uint64_t model_len, uint8_t out[32]);
+
 /* ---- K3: radix-2 NTT over Fr -----------------------------------------------------------------
  * bellman 0.14 `EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}` (third-party crate; reached
  * from `create_random_proof`, src/mpn/circuits/test.rs:135,175,215).  In place, natural order in and

@@ -71,3 +71,97 @@ class PyMpnState:
 
     def prove_token(self, index, slot):
         return self._prove(self._token_levels(index), self.T, self.tok_def, slot)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# General restatement of `ZkStateModel::compress` (test infrastructure for bzk_state_compress): ANY nesting of
+#   ("scalar",) | ("struct", [field models]) | ("list", log4_size, item model)
+# written from /root/reference/src/zk/mod.rs:392-423 (`compress`, `compress_default`) and src/zk/state/mod.rs:310-420 (`set_data`:
+# struct = H(fields), list = 4-ary tree whose missing nodes take the default of their level, log4_size = 0 -> the item itself).
+# Values are plain integers mod r.  `compress` returns (state_hash, state_size).
+# ---------------------------------------------------------------------------------------------------------------------------
+def model_default(model):
+    if model[0] == "scalar":
+        return 0
+    if model[0] == "struct":
+        return pr.poseidon([model_default(f) for f in model[1]])
+    d = model_default(model[2])
+    for _ in range(model[1]):
+        d = pr.poseidon([d, d, d, d])
+    return d
+
+
+def model_locate(model, locator):
+    """`ZkStateModel::locate`: the sub-model a locator names (ValueError where the reference errors or panics)"""
+    cur = model
+    for l in locator:
+        if cur[0] == "struct":
+            if l >= len(cur[1]):
+                raise ValueError("field index out of range")
+            cur = cur[1][l]
+        elif cur[0] == "list":
+            if l >= 1 << (2 * cur[1]):
+                raise ValueError("InvalidLocator")
+            cur = cur[2]
+        else:
+            raise ValueError("InvalidLocator")
+    return cur
+
+
+def _value(model, pairs, depth):
+    """pairs: non-empty list of (locator, value) sharing their first `depth` indices"""
+    if model[0] == "scalar":
+        assert len(pairs) == 1 and len(pairs[0][0]) == depth
+        return pairs[0][1]
+    if model[0] == "struct":
+        vals = []
+        for f, fm in enumerate(model[1]):
+            sub = [p for p in pairs if p[0][depth] == f]
+            vals.append(_value(fm, sub, depth + 1) if sub else model_default(fm))
+        return pr.poseidon(vals)
+    log4, item = model[1], model[2]
+    level = {}
+    for idx in {p[0][depth] for p in pairs}:
+        level[idx] = _value(item, [p for p in pairs if p[0][depth] == idx], depth + 1)
+    d = model_default(item)
+    for _ in range(log4):
+        up = {}
+        for parent in {i >> 2 for i in level}:
+            up[parent] = pr.poseidon([level.get(4 * parent + j, d) for j in range(4)])
+        level, d = up, pr.poseidon([d, d, d, d])
+    return level[0]
+
+
+def compress(model, pairs):
+    """pairs: dict {locator tuple: int}.  -> (state_hash, state_size)"""
+    for loc in pairs:
+        if model_locate(model, loc)[0] != "scalar":
+            raise ValueError("NonScalarLocatorError")
+    items = [(tuple(k), v % pr.R_MOD) for k, v in pairs.items()]
+    size = sum(1 for _, v in items if v)
+    if not items:
+        return model_default(model), 0
+    return _value(model, items, 0), size
+
+
+def model_bincode(model) -> bytes:
+    """bincode 1.3 of `ZkStateModel` (src/zk/mod.rs:332-345): u32 tag, Struct: u64 count + fields, List: u8 log4_size + boxed item"""
+    if model[0] == "scalar":
+        return (0).to_bytes(4, "little")
+    if model[0] == "struct":
+        return (1).to_bytes(4, "little") + len(model[1]).to_bytes(8, "little") + b"".join(model_bincode(f) for f in model[1])
+    return (2).to_bytes(4, "little") + bytes([model[1]]) + model_bincode(model[2])
+
+
+def pairs_bincode(pairs) -> bytes:
+    """bincode of `ZkDataPairs(HashMap<ZkDataLocator, ZkScalar>)`: u64 count; per entry Vec<u64> + the 4 Montgomery limbs"""
+    out = len(pairs).to_bytes(8, "little")
+    for loc, v in pairs.items():
+        out += len(loc).to_bytes(8, "little") + b"".join(int(x).to_bytes(8, "little") for x in loc) + pr.fr_to_mont_bytes(v % pr.R_MOD)
+    return out
+
+
+def mpn_model(L, T):
+    """`MpnConfig::state_model` (src/mpn/mod.rs:218-241)"""
+    S = ("scalar",)
+    return ("list", L, ("struct", [S, S, S, S, ("list", T, ("struct", [S, S]))]))
