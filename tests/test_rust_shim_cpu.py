@@ -1,0 +1,102 @@
+"""CPU suite: the Rust shim (rust/, shipped as source - no rustc here) is checked mechanically against include/bzk.h:
+the generated raw layer is up to date, agrees with an independent parse of the header on names / arity / pointer mutability /
+struct field order, and the hand-written safe layer only calls symbols that exist, with the right number of arguments."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SYS_RS = os.path.join(ROOT, "rust", "bzk-sys", "src", "lib.rs")
+GPU_RS = os.path.join(ROOT, "rust", "bazuka-gpu", "src", "lib.rs")
+
+
+def _rust_externs():
+    src = open(SYS_RS).read()
+    block = src[src.index('extern "C" {'):]
+    out = {}
+    for m in re.finditer(r"pub fn (bzk_\w+)\((.*?)\)( -> ([^;]+))?;", block):
+        params = [p.strip() for p in m.group(2).split(", ")] if m.group(2).strip() else []
+        out[m.group(1)] = ([p.split(": ", 1)[1] for p in params], (m.group(4) or "").strip())
+    return out
+
+
+def test_generated_raw_layer_is_up_to_date():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_raw_layer_matches_the_header_and_the_ctypes_binding():
+    """independent of the generator's own parser: names from the header by regex, arity and pointer-ness from the ctypes table the
+    GPU tests run through (bazuka_amd/lib.py SIGNATURES - the VERIFIED binding)"""
+    import ctypes as C
+    from bazuka_amd import lib as L
+    hdr = open(os.path.join(ROOT, "include", "bzk.h")).read()
+    declared = set(re.findall(r"\b(bzk_[a-z0-9_]+)\s*\(", hdr)) - {"bzk_ctx"}
+    ext = _rust_externs()
+    assert set(ext) == declared == set(L.SIGNATURES)
+    for name, (res, args) in L.SIGNATURES.items():
+        rargs, rret = ext[name]
+        assert len(rargs) == len(args), name
+        for ra, ca in zip(rargs, args):
+            is_ptr_c = ca in (C.c_void_p, C.c_char_p) or (isinstance(ca, type) and issubclass(ca, C._Pointer))
+            assert ra.startswith("*") == is_ptr_c, (name, ra, ca)
+            if not is_ptr_c:
+                assert ra == {C.c_int32: "i32", C.c_uint32: "u32", C.c_uint64: "u64"}[ca], (name, ra, ca)
+        want_ret = {None: "", C.c_int32: "i32", C.c_uint32: "u32", C.c_uint64: "u64"}.get(res)
+        if want_ret is not None:
+            assert rret == want_ret, (name, rret, res)
+        else:
+            assert rret.startswith("*"), (name, rret)
+    # const-ness straight from the header text for a few load-bearing prototypes
+    assert ext["bzk_groth16_prove"][0] == ["*mut bzk_ctx", "*mut bzk_params", "*const bzk_assignment", "*const u8", "*const u8", "*mut u8"]
+    assert ext["bzk_mg_msm_g1_dev"][0][2] == "*const *const c_void"
+    assert ext["bzk_mg_create"][0][0] == "*const i32"
+
+
+def test_repr_c_structs_keep_the_header_field_order():
+    from bazuka_amd import lib as L
+    src = open(SYS_RS).read()
+    for rust_name, ct in (("bzk_params_desc", L.ParamsDesc), ("bzk_assignment", L.Assignment), ("bzk_csr", L.CsrDesc),
+                          ("bzk_mpn_work_config", L.WorkConfig)):
+        m = re.search(r"#\[repr\(C\)\]\n#\[derive\(Clone, Copy\)\]\npub struct %s \{(.*?)\n\}" % rust_name, src, flags=re.S)
+        assert m, rust_name
+        fields = re.findall(r"pub (\w+): ([^,]+),", m.group(1))
+        assert [f for f, _ in fields] == [f for f, _ in ct._fields_], rust_name
+        import ctypes as C
+        for (fname, rty), (_, cty) in zip(fields, ct._fields_):
+            size = {"u8": 1, "u32": 4, "u64": 8}.get(rty, 8 if rty.startswith("*") else None)
+            assert size == C.sizeof(cty), (rust_name, fname, rty)
+
+
+def test_safe_layer_calls_only_existing_symbols_with_the_right_arity():
+    ext = _rust_externs()
+    src = open(GPU_RS).read()
+    assert "UNVERIFIED BY COMPILATION" in src.split("\n", 4)[2] + src[:600]
+    used = 0
+    for m in re.finditer(r"sys::(bzk_\w+)\(", src):
+        name = m.group(1)
+        assert name in ext, f"{name} is not in bzk-sys"
+        # count top-level commas of the call's argument list
+        i, depth, commas, any_arg = m.end(), 1, 0, False
+        while depth:
+            ch = src[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                commas += 1
+            elif not ch.isspace() and depth >= 1:
+                any_arg = True
+            i += 1
+        n_args = commas + 1 if any_arg else 0
+        assert n_args == len(ext[name][0]), f"{name}: called with {n_args} arguments, declared with {len(ext[name][0])}"
+        used += 1
+    assert used >= 20
+    for const in set(re.findall(r"sys::(BZK_[A-Z_]+)", src)):
+        assert re.search(r"pub const %s:" % const, open(SYS_RS).read()), const
+    # the reference signatures this layer claims to mirror
+    assert "impl ZkHasher for GpuPoseidonHasher" in src and "const MAX_ARITY: usize = 16;" in src
+    assert re.search(r"pub fn compress\(model: &ZkStateModel, data: &ZkDataPairs\) -> Result<ZkCompressedState, StateManagerError>", src)
+    assert re.search(r"pub fn groth16_prove\(params: &ProvingParams, witness: &Witness, r: ZkScalar, s: ZkScalar\) -> Result<Groth16Proof", src)
