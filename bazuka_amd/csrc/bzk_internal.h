@@ -96,6 +96,7 @@ struct WsCursor {
     }
 };
 int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int coset);  // ntt.hip
+int32_t ntt_h_chain(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m);              // ntt.hip: the h polynomial's 7 transforms, fused
 // msm_g1.hip / msm_g2.hip: windows [w_begin, w_end) (w_end < 0: all) of an MSM over a resident base set (or raw bases when `bases` is
 // null); the window sums stay in DEVICE memory at d_win as standard-limb XYZZ points (G1 192 B, G2 384 B each), in stream order,
 // nothing is read back.  info = {c, w_total, w_begin, w_end}.  *_horner_packed: host Horner sum_k 2^(c (w0 + k)) S[k] -> packed point

@@ -74,6 +74,10 @@ static Fr host_fr_pow(Fr b, uint64_t e) {
 
 int32_t groth16_h(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m) {
     if (log_m > 28) return BZK_E_ARG;
+    // env BZK_H_UNFUSED=1: the round-1/2 form - seven stand-alone transforms and a pointwise kernel (A/B runs, and the parity
+    // reference of the fused chain inside the GPU tests)
+    static const bool unfused = getenv("BZK_H_UNFUSED") && atoi(getenv("BZK_H_UNFUSED")) != 0;
+    if (!unfused && log_m >= 1) return ntt_h_chain(ctx, a, b, c, log_m);
     const uint64_t m = (uint64_t)1 << log_m;
     void* v[3] = {a, b, c};
     for (int k = 0; k < 3; ++k) {

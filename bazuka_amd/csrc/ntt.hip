@@ -148,19 +148,63 @@ struct NttPass {
     const void* src;   // first pass: Fr (8 x 32-bit Montgomery-256); later passes: Fr29P
     void* dst;         // final pass: Fr; earlier passes: Fr29P
     int b, log_cc, final_pass, first_pass;
+    // what the FIRST pass does with the raw 32-byte limbs it loads (x_raw = x * 2^256 mod r, < 2^256):
+    //   FIRST_MUL   v = x_raw * (pre[i] or 2^266) * 2^-261          - the value is carried as x * 2^261 ("Montgomery-261")
+    //   FIRST_RAW   v = x_raw, no multiplication (round 3)           - carried as x * 2^256; the twiddles stay Montgomery-261, so every
+    //               product keeps that scale and the final store's constant is 2^261 instead of 2^256.  Stage 0 multiplies nothing
+    //               and takes any operand below 2^256 (sub3 needs its subtrahend < 3 r and the top limb < 2^24.4)
+    //   FIRST_PW    the h-polynomial's pointwise step fused into the load (round 3): with a_raw = A 2^256, b_raw = B 2^256 and
+    //               c_raw = C 2^251 (the producing transform scales C by 2^-5 in ITS final store, for free)
+    //               v = ((a_raw * b_raw) 2^-261 - c_raw + 3 r) * kmul 2^-261 = (A B - C) zinv * 2^261 for kmul = zinv * 2^271
+    int first_mode;
+    const void* src_b;    // FIRST_PW
+    const void* src_c;
+    const Fr29P* kmul;
     uint64_t S;           // COL: column stride = size of the inner dimension
     uint32_t R1, R2;      // FINAL: sizes of the digits already transformed
     const Fr29P* tw_r;    // w_R^j * 2^261, j < R/2
     const Fr29P* tlo;     // COL: w_N'^j * 2^261, j < 1024
     const Fr29P* thi;     // COL: w_N'^(1024 j) * 2^261
-    const Fr29P* pre;     // first pass: g^i * 2^266 by input index (forward coset transform) or null (constant 2^266)
-    const Fr29P* post;    // final pass: (g^-k / n) * 2^256 by output index (inverse coset transform) or null
-    const Fr29P* post_c;  // final pass: one element: 2^256 (forward) or 2^256 / n (inverse)
+    const Fr29P* pre;     // FIRST_MUL: g^i * 2^266 by input index (forward coset transform) or null (constant 2^266)
+    const Fr29P* post;    // final pass: a multiplier per OUTPUT index ((g^-k / n) 2^256, or (g^k / n) 2^261 for the fused inverse -> coset hand-over) or null
+    const Fr29P* post_c;  // final pass: one element (see NttTables::post_one)
 };
+enum { FIRST_MUL = 0, FIRST_RAW = 1, FIRST_PW = 2 };
 
-__global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    Fr29P* tile = (Fr29P*)smem;
+// LDS tile: 9 dwords (36 B) per element since round 3 (was 48 B, padded for 16-byte accesses): a 1024-element tile is 36 KiB, so FOUR
+// workgroups share a CU's 160 KiB instead of three (4 waves per SIMD; the 2048 tiles of a 2^20-point pass are exactly two rounds of
+// the 1024 resident workgroups instead of 2.67), and the odd dword stride spreads neighbouring elements over all 32 banks.
+static constexpr uint32_t LDSW = 9;
+__device__ __forceinline__ Fr29 lds_ld(const uint32_t* tile, uint32_t idx) {
+    Fr29 r;
+    const uint32_t* p = tile + idx * LDSW;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ void lds_st(uint32_t* tile, uint32_t idx, const Fr29& v) {
+    uint32_t* p = tile + idx * LDSW;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = v.l[i];
+}
+
+__device__ __forceinline__ Fr29 ntt_first_load(const NttPass& a, uint64_t addr, const Fr29& c_in) {
+    const Fr29 x = fr29::repack_from32(((const Fr*)a.src)[addr]);
+    if (a.first_mode == FIRST_RAW) return x;
+    if (a.first_mode == FIRST_PW) {
+        const Fr29 y = fr29::repack_from32(((const Fr*)a.src_b)[addr]);
+        const Fr29 z = fr29::repack_from32(((const Fr*)a.src_c)[addr]);
+        return fr29::mul(fr29::sub3(fr29::mul(x, y), z), ld29(*a.kmul));
+    }
+    return fr29::mul(x, a.pre ? ld29(a.pre[addr]) : c_in);
+}
+
+// OCC: waves per SIMD the kernel is compiled for (4 = one workgroup per 36 KiB tile slot of the CU, needs <= 128 registers);
+// PF: 2 = all three twiddles of a round requested before the LDS reads, 1 = the first-stage twiddle early and the second-stage pair
+// after the first two products, 0 = every twiddle loaded where it is used.  A/B builds: env BZK_NTT_VARIANT (ntt_run_ex).
+template <int OCC, int PF>
+__global__ void __launch_bounds__(256, OCC) ntt_pass_kernel(NttPass a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     const int b = a.b, lc = a.log_cc;
     const uint32_t R = 1u << b, CC = 1u << lc, tile_n = R << lc;
     uint64_t base = 0, inner0 = 0;
@@ -175,10 +219,8 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
         for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
             const uint32_t c = t & (CC - 1), r = t >> lc;
             const uint64_t addr = base + (uint64_t)r * a.S + c;
-            Fr29 v;
-            if (a.first_pass) v = fr29::mul(fr29::repack_from32(((const Fr*)a.src)[addr]), a.pre ? ld29(a.pre[addr]) : c_in);
-            else v = ld29(((const Fr29P*)a.src)[addr]);
-            tile[(bitrev(r, b) << lc) + c] = st29(v);
+            const Fr29 v = a.first_pass ? ntt_first_load(a, addr, c_in) : ld29(((const Fr29P*)a.src)[addr]);
+            lds_st(tile, (bitrev(r, b) << lc) + c, v);
         }
     } else {
         const uint32_t groups = a.R1 >> lc;
@@ -187,25 +229,22 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
         for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
             const uint32_t r = t & (R - 1), c = t >> b;
             const uint64_t addr = ((uint64_t)(k1 + c) * a.R2 + k2) * R + r;
-            Fr29 v;
-            if (a.first_pass) v = fr29::mul(fr29::repack_from32(((const Fr*)a.src)[addr]), a.pre ? ld29(a.pre[addr]) : c_in);
-            else v = ld29(((const Fr29P*)a.src)[addr]);
-            tile[(bitrev(r, b) << lc) + c] = st29(v);
+            const Fr29 v = a.first_pass ? ntt_first_load(a, addr, c_in) : ld29(((const Fr29P*)a.src)[addr]);
+            lds_st(tile, (bitrev(r, b) << lc) + c, v);
         }
     }
     __syncthreads();
     // Butterfly stages, two per LDS round trip (radix 4 in registers: half the barriers and half the LDS traffic of one stage per
-    // round).  Stage 0 has the single twiddle w^0 = one and its operands are fresh products (the load phase's conversion or the
-    // previous pass's inter-pass twiddle: k 2, the bound sub3 needs), so it multiplies nothing.  An odd stage count starts with that
-    // lone multiplication-free stage.
+    // round).  Stage 0 has the single twiddle w^0 = one and its operands are fresh products or raw inputs below 2^256 (what sub3
+    // needs), so it multiplies nothing.  An odd stage count starts with that lone multiplication-free stage.
     int s0 = 0;
     if (b & 1) {
         for (uint32_t q = threadIdx.x; q < tile_n / 2; q += blockDim.x) {
             const uint32_t c = q & (CC - 1), bq = q >> lc;
             const uint32_t i0 = ((bq << 1) << lc) + c, i1 = (((bq << 1) + 1) << lc) + c;
-            const Fr29 u = ld29(tile[i0]), t = ld29(tile[i1]);
-            tile[i0] = st29(fr29::norm(fr29::add(u, t)));
-            tile[i1] = st29(fr29::sub3(u, t));
+            const Fr29 u = lds_ld(tile, i0), t = lds_ld(tile, i1);
+            lds_st(tile, i0, fr29::norm(fr29::add(u, t)));
+            lds_st(tile, i1, fr29::sub3(u, t));
         }
         __syncthreads();
         s0 = 1;
@@ -217,27 +256,36 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPass a) {
             const uint32_t j = bq & (m - 1);
             const uint32_t k0 = ((bq >> s) << (s + 2)) + j;
             const uint32_t i0 = (k0 << lc) + c, i1 = ((k0 + m) << lc) + c, i2 = ((k0 + 2 * m) << lc) + c, i3 = ((k0 + 3 * m) << lc) + c;
-            Fr29 x0 = ld29(tile[i0]), x1 = ld29(tile[i1]), x2 = ld29(tile[i2]), x3 = ld29(tile[i3]);
+            // the round's three twiddles depend on the position only: their (L2-resident) loads are issued before the LDS reads they
+            // would otherwise queue behind, and complete under them
+            const Fr29P* pa = a.tw_r + ((size_t)j << (b - 1 - s));
+            const Fr29P* pb = a.tw_r + ((size_t)j << (b - 2 - s));
+            const Fr29P* pc = a.tw_r + ((size_t)(j + m) << (b - 2 - s));
+            Fr29 wa, wb, wc;
+            if (PF >= 1 && s) wa = ld29(*pa);
+            if (PF >= 2) { wb = ld29(*pb); wc = ld29(*pc); }
+            Fr29 x0 = lds_ld(tile, i0), x1 = lds_ld(tile, i1), x2 = lds_ld(tile, i2), x3 = lds_ld(tile, i3);
             if (s) {  // stage s: both butterflies of the group use w^(j 2^(b-1-s))
-                const Fr29 wa = ld29(a.tw_r[j << (b - 1 - s)]);
+                if (PF == 0) wa = ld29(*pa);
                 x1 = fr29::mul(x1, wa);
                 x3 = fr29::mul(x3, wa);
             }
+            if (PF < 2) { wb = ld29(*pb); wc = ld29(*pc); }
             const Fr29 y0 = fr29::norm(fr29::add(x0, x1)), y1 = fr29::sub3(x0, x1);
             const Fr29 y2 = fr29::norm(fr29::add(x2, x3)), y3 = fr29::sub3(x2, x3);
             // stage s + 1: (y0, y2) at position j, (y1, y3) at position j + m of their 4m-blocks
-            const Fr29 u2 = fr29::mul(y2, ld29(a.tw_r[j << (b - 2 - s)]));
-            const Fr29 u3 = fr29::mul(y3, ld29(a.tw_r[(j + m) << (b - 2 - s)]));
-            tile[i0] = st29(fr29::norm(fr29::add(y0, u2)));
-            tile[i2] = st29(fr29::sub3(y0, u2));
-            tile[i1] = st29(fr29::norm(fr29::add(y1, u3)));
-            tile[i3] = st29(fr29::sub3(y1, u3));
+            const Fr29 u2 = fr29::mul(y2, wb);
+            const Fr29 u3 = fr29::mul(y3, wc);
+            lds_st(tile, i0, fr29::norm(fr29::add(y0, u2)));
+            lds_st(tile, i2, fr29::sub3(y0, u2));
+            lds_st(tile, i1, fr29::norm(fr29::add(y1, u3)));
+            lds_st(tile, i3, fr29::sub3(y1, u3));
         }
         __syncthreads();
     }
     for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
         const uint32_t c = t & (CC - 1), ka = t >> lc;  // natural order after the DIT stages
-        Fr29 v = ld29(tile[t]);
+        Fr29 v = lds_ld(tile, t);
         if (!a.final_pass) {
             const uint64_t e = (inner0 + c) * ka;
             Fr29 w = ld29(a.tlo[e & 1023]);
@@ -265,9 +313,15 @@ struct NttTables {
     Fr29P* tw_r[2][3] = {};   // [inverse][pass]: w_R^j
     Fr29P* tlo[2][2] = {};    // [inverse][col pass]
     Fr29P* thi[2][2] = {};
-    Fr29P* pre_g = nullptr;        // g^j * 2^266, j < n
-    Fr29P* post_ginv = nullptr;    // (g^-j / n) * 2^256
-    Fr29P* post_one = nullptr;     // [0] = 2^256, [1] = 2^256 / n
+    // per-index multiplier tables (n x 48 B each), built on first use:
+    Fr29P* pre_g = nullptr;        // g^j * 2^266          first load of a stand-alone forward coset transform
+    Fr29P* post_ginv = nullptr;    // (g^-j / n) * 2^256   final store of an inverse coset transform (input carried as x 2^261)
+    Fr29P* post_g = nullptr;       // (g^j / n) * 2^261    final store of an inverse transform (input carried raw) whose output goes
+                                   //                      straight into a forward COSET transform: that one then loads raw, no multiplication
+    Fr29P* post_one = nullptr;     // [0] = 2^256, [1] = 2^256 / n (input carried as x 2^261) ; [2] = 2^261, [3] = 2^261 / n (carried raw)
+    Fr29P* kmul = nullptr;         // [0] = 2^271 / (g^n - 1): the h polynomial's pointwise step fused into a first load (FIRST_PW)
+    uint64_t n = 0;
+    std::mutex lazy;
 };
 
 static int ntt_bmax() {
@@ -336,33 +390,79 @@ static int32_t ntt_tables(bzk_ctx* ctx, int log_n, NttTables** out) {
             BZK_TRY(build_table29(ctx, host_pow_u64(base, 1024), (np + 1023) / 1024, c5, &T->thi[d][k]));
         }
     }
-    BZK_TRY(build_table29(ctx, g, n, c10, &T->pre_g));
     {
-        // (g^-j / n) * 2^256: the powers table scaled by 1/n, kept as raw Montgomery-256 values
-        const Fr gi = fe_inv<FrParams>(g), ninv = fe_inv<FrParams>(host_from_u64(n));
-        BZK_TRY(build_table29(ctx, gi, n, ninv, &T->post_ginv));
-        Fr two[2] = {Fr::one(), ninv};
+        const Fr ninv = fe_inv<FrParams>(host_from_u64(n));
+        // Z(g) = g^n - 1 on the coset; kmul = 2^271 / Z as a raw value (c = Montgomery(2^15) on top of the Montgomery-256 limbs)
+        const Fr zinv = fe_inv<FrParams>(fe_sub<FrParams>(host_pow(g, n), Fr::one()));
+        Fr five[5] = {Fr::one(), ninv, c5, fe_mul<FrParams>(ninv, c5), fe_mul<FrParams>(zinv, host_from_u64(32768))};
         void* raw = nullptr;
         void* p = nullptr;
-        BZK_HIP(ctx, hipMalloc(&raw, sizeof two));
-        BZK_HIP(ctx, hipMalloc(&p, 2 * sizeof(Fr29P)));
-        BZK_HIP(ctx, hipMemcpyAsync(raw, two, sizeof two, hipMemcpyHostToDevice, ctx->stream));
-        BZK_LAUNCH(ctx, "ntt_table29", ntt_table29_kernel, dim3(1), dim3(256), 0, (const Fr*)raw, (uint64_t)2, c0, (Fr29P*)p);
+        BZK_HIP(ctx, hipMalloc(&raw, sizeof five));
+        BZK_HIP(ctx, hipMalloc(&p, 5 * sizeof(Fr29P)));
+        BZK_HIP(ctx, hipMemcpyAsync(raw, five, sizeof five, hipMemcpyHostToDevice, ctx->stream));
+        BZK_LAUNCH(ctx, "ntt_table29", ntt_table29_kernel, dim3(1), dim3(256), 0, (const Fr*)raw, (uint64_t)5, c0, (Fr29P*)p);
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         BZK_HIP(ctx, hipFree(raw));
         T->post_one = (Fr29P*)p;
+        T->kmul = (Fr29P*)p + 4;
+        (void)c10;
     }
+    T->n = n;
     ctx->ntt_tw[log_n][1] = T;
     *out = T;
     return BZK_OK;
 }
 
-int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int coset) {
+// the three per-index tables are only built when a transform asks for them (a prover needs post_g and post_ginv, a stand-alone
+// forward coset transform pre_g): 48 B x n each
+static int32_t ntt_lazy_table(bzk_ctx* ctx, NttTables* T, int which, Fr29P** out) {
+    std::lock_guard<std::mutex> lk(T->lazy);
+    Fr29P** slot = which == 0 ? &T->pre_g : (which == 1 ? &T->post_ginv : &T->post_g);
+    if (!*slot) {
+        const Fr g = host_from_u64(7), ninv = fe_inv<FrParams>(host_from_u64(T->n));
+        if (which == 0) BZK_TRY(build_table29(ctx, g, T->n, host_from_u64(1024), slot));                            // g^j 2^266
+        else if (which == 1) BZK_TRY(build_table29(ctx, fe_inv<FrParams>(g), T->n, ninv, slot));                    // g^-j / n 2^256
+        else BZK_TRY(build_table29(ctx, g, T->n, fe_mul<FrParams>(ninv, host_from_u64(32)), slot));                 // g^j / n 2^261
+    }
+    *out = *slot;
+    return BZK_OK;
+}
+
+// fuse: 0 = the transform bzk_ntt describes.  The h-polynomial chain (groth16_h) uses
+//   NTT_INV_TO_COSET  inverse plain transform whose final store also applies the coset scaling g^k of the FOLLOWING forward coset
+//                     transform (table post_g) - that one is then run as NTT_FWD_RAW
+//   NTT_FWD_RAW       forward transform of already coset-scaled input: nothing to multiply on load
+//   NTT_FWD_RAW_S5    the same with the output scaled by 2^-5 (the C vector of the pointwise step, see FIRST_PW)
+//   NTT_INV_COSET_PW  inverse coset transform of (A B - C) / Z, the pointwise step fused into its first load (src_b, src_c)
+enum { NTT_PLAIN = 0, NTT_INV_TO_COSET = 1, NTT_FWD_RAW = 2, NTT_FWD_RAW_S5 = 3, NTT_INV_COSET_PW = 4 };
+
+static int32_t ntt_run_ex(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int coset, int fuse, const void* src_b,
+                          const void* src_c) {
     if (log_n > 28) return BZK_E_ARG;
     const uint64_t n = (uint64_t)1 << log_n;
     if (log_n == 0) return BZK_OK;
     NttTables* T;
     BZK_TRY(ntt_tables(ctx, (int)log_n, &T));
+    // first-load / final-store plan
+    int first_mode = FIRST_RAW;
+    const Fr29P *pre = nullptr, *post = nullptr, *post_c = nullptr;
+    switch (fuse) {
+        case NTT_INV_TO_COSET: inverse = 1; BZK_TRY(ntt_lazy_table(ctx, T, 2, (Fr29P**)&post)); break;
+        case NTT_FWD_RAW: inverse = 0; post_c = T->post_one + 2; break;
+        case NTT_FWD_RAW_S5: inverse = 0; post_c = T->post_one + 0; break;
+        case NTT_INV_COSET_PW: inverse = 1; first_mode = FIRST_PW; BZK_TRY(ntt_lazy_table(ctx, T, 1, (Fr29P**)&post)); break;
+        default:
+            if (coset && !inverse) {  // g^i on load: the value is carried as x 2^261
+                first_mode = FIRST_MUL;
+                BZK_TRY(ntt_lazy_table(ctx, T, 0, (Fr29P**)&pre));
+                post_c = T->post_one + 0;
+            } else if (coset) {       // g^-k / n on store (table in the x 2^261 convention)
+                first_mode = FIRST_MUL;
+                BZK_TRY(ntt_lazy_table(ctx, T, 1, (Fr29P**)&post));
+            } else {
+                post_c = T->post_one + (inverse ? 3 : 2);  // carried raw: no multiplication on load
+            }
+    }
     Fr29P* tmp = nullptr;
     if (T->nb > 1) {
         BZK_TRY(ws_reserve(ctx, ws_pad(n * sizeof(Fr29P)) + 512));
@@ -372,9 +472,17 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
     const uint32_t tile_max = ntt_tile_elems();
     // tiles above 64 KiB of dynamic LDS need the opt-in; the attribute is per DEVICE, so remember it per device id (a process
     // may hold contexts on several GPUs, and prover slots call this from concurrent threads)
+    typedef void (*pass_fn)(NttPass);
+    static const pass_fn variants[4] = {ntt_pass_kernel<3, 2>, ntt_pass_kernel<4, 2>, ntt_pass_kernel<4, 1>, ntt_pass_kernel<4, 0>};
+    static const int variant = [] {
+        const char* e = getenv("BZK_NTT_VARIANT");
+        const int v = e ? atoi(e) : 2;
+        return v < 0 || v > 3 ? 2 : v;
+    }();
+    const pass_fn kern = variants[variant];
     static std::once_flag lds_attr_once[64];
     std::call_once(lds_attr_once[ctx->device & 63], [] {
-        (void)hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (pass_fn f : variants) (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     });
     uint64_t S = n;
@@ -387,10 +495,14 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
         a.b = b;
         a.first_pass = k == 0;
         a.final_pass = k == T->nb - 1;
+        a.first_mode = first_mode;
+        a.src_b = src_b;
+        a.src_c = src_c;
+        a.kmul = T->kmul;
         a.src = k == 0 ? data_dev : (const void*)tmp;
         a.dst = a.final_pass ? data_dev : (void*)tmp;
         a.tw_r = T->tw_r[d][k];
-        a.pre = (k == 0 && coset && !inverse) ? T->pre_g : nullptr;
+        a.pre = pre;
         uint64_t lanes;  // how many adjacent columns exist
         if (!a.final_pass) {
             a.S = S;
@@ -400,8 +512,8 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
         } else {
             a.R1 = T->nb >= 2 ? 1u << T->b[0] : 1u;
             a.R2 = T->nb == 3 ? 1u << T->b[1] : 1u;
-            a.post = (inverse && coset) ? T->post_ginv : nullptr;
-            a.post_c = T->post_one + (inverse ? 1 : 0);
+            a.post = post;
+            a.post_c = post_c;
             lanes = a.R1;
         }
         int lc = 0;
@@ -409,13 +521,31 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
         a.log_cc = lc;
         const uint64_t tiles = n >> (b + lc);
         if (tiles > 0x7fffffffull) return BZK_E_ARG;
+        const size_t lds = (size_t)(LDSW * 4) << (b + lc);
         if (a.final_pass) {
-            BZK_LAUNCH(ctx, "ntt_final", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr29P) << (b + lc), a);
+            BZK_LAUNCH(ctx, "ntt_final", kern, dim3((unsigned)tiles), dim3(256), lds, a);
         } else {
-            BZK_LAUNCH(ctx, "ntt_col", ntt_pass_kernel, dim3((unsigned)tiles), dim3(256), (size_t)sizeof(Fr29P) << (b + lc), a);
+            BZK_LAUNCH(ctx, "ntt_col", kern, dim3((unsigned)tiles), dim3(256), lds, a);
         }
     }
     return BZK_OK;
+}
+
+int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int coset) {
+    return ntt_run_ex(ctx, data_dev, log_n, inverse, coset, NTT_PLAIN, nullptr, nullptr);
+}
+
+// h(x) = (A(x) B(x) - C(x)) / Z(x) from the evaluations a, b, c (zero-padded to m): on return a holds the coefficients of h.
+// bellman `create_proof`'s seven transforms + two pointwise passes (a4); round 3: 3 x (inverse -> coset forward) with the coset
+// scaling riding on the inverse transform's final store, and the pointwise (a b - c) / Z riding on the last transform's first load:
+// no stand-alone pointwise kernel, 7 of the 14 load / store conversions multiply nothing.
+int32_t ntt_h_chain(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m) {
+    void* v[3] = {a, b, c};
+    for (int k = 0; k < 3; ++k) {
+        BZK_TRY(ntt_run_ex(ctx, v[k], log_m, 1, 0, NTT_INV_TO_COSET, nullptr, nullptr));
+        BZK_TRY(ntt_run_ex(ctx, v[k], log_m, 0, 1, k == 2 ? NTT_FWD_RAW_S5 : NTT_FWD_RAW, nullptr, nullptr));
+    }
+    return ntt_run_ex(ctx, a, log_m, 1, 1, NTT_INV_COSET_PW, b, c);
 }
 
 void ntt_free_tables(bzk_ctx* ctx) {
@@ -430,8 +560,9 @@ void ntt_free_tables(bzk_ctx* ctx) {
                 if (T->thi[d][k]) (void)hipFree(T->thi[d][k]);
             }
         }
-        (void)hipFree(T->pre_g);
-        (void)hipFree(T->post_ginv);
+        if (T->pre_g) (void)hipFree(T->pre_g);
+        if (T->post_ginv) (void)hipFree(T->post_ginv);
+        if (T->post_g) (void)hipFree(T->post_g);
         (void)hipFree(T->post_one);
         delete T;
         ctx->ntt_tw[i][1] = nullptr;

@@ -50,6 +50,21 @@ def test_groth16_h_stage_vs_oracle_2p16(bzk, co):
     assert dev_bytes(da)[: 32 * (m - 1)] == co.groth16_h(az, bz, cz, log_m, nthreads=co.ncpu())
 
 
+@pytest.mark.parametrize("log_m", [1, 2, 5, 10, 11, 14, 21])
+def test_groth16_h_chain_sizes_vs_oracle(bzk, co, log_m):
+    """the fused h chain (coset scaling on the inverse transforms' final stores, pointwise step on the last transform's first
+    load) over 1-, 2- and 3-pass plans == the oracle's seven transforms + pointwise, coefficient for coefficient"""
+    m = 1 << log_m
+    n_rows = max(1, m - (m // 3))
+    az, bz, cz = (rand_scalars_bytes(n_rows, 10 * log_m + k) for k in (1, 2, 3))
+    pad = b"\0" * (32 * (m - n_rows))
+    da, db, dc = to_dev(az + pad), to_dev(bz + pad), to_dev(cz + pad)
+    torch.cuda.synchronize()
+    bzk.groth16_h_dev(da, db, dc, log_m)
+    torch.cuda.synchronize()
+    assert dev_bytes(da)[: 32 * (m - 1)] == co.groth16_h(az, bz, cz, log_m, nthreads=co.ncpu())
+
+
 def _csr_bytes(co, r1):
     import array
     out = []

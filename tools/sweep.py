@@ -53,12 +53,15 @@ def child(mode, log_n):
         print(json.dumps({"mode": mode, "arity": ar, "n": n, "ms": round(ms, 3), "Mhash/s": round(n / ms / 1e3, 2)}))
     elif mode == "ntt":
         d = rand_fr(n)
-        ms = timeit(lambda: ctx.ntt_dev(d, log_n, False, True))
-        print(json.dumps({"mode": mode, "log_n": log_n, "tile": os.environ.get("BZK_NTT_TILE"), "bmax": os.environ.get("BZK_NTT_BMAX"), "ms": round(ms, 4), "alg_GB/s": round(64 * n / ms / 1e6, 1)}))
+        ms = timeit(lambda: ctx.ntt_dev(d, log_n, False, bool(int(os.environ.get("NTT_COSET", "0")))))
+        print(json.dumps({"mode": mode, "log_n": log_n, "coset": os.environ.get("NTT_COSET", "0"), "variant": os.environ.get("BZK_NTT_VARIANT"),
+                          "tile": os.environ.get("BZK_NTT_TILE"), "bmax": os.environ.get("BZK_NTT_BMAX"), "ms": round(ms, 4),
+                          "alg_GB/s": round(64 * n / ms / 1e6, 1), "G_fr_products/s": round(log_n * n / 2 / ms / 1e6, 1)}))
     elif mode == "h":
         a, b, c = rand_fr(n), rand_fr(n), rand_fr(n)
         ms = timeit(lambda: ctx.groth16_h_dev(a, b, c, log_n), reps=3)
-        print(json.dumps({"mode": mode, "log_m": log_n, "ms_7_ntts_plus_pointwise": round(ms, 3)}))
+        print(json.dumps({"mode": mode, "log_m": log_n, "variant": os.environ.get("BZK_NTT_VARIANT"), "unfused": os.environ.get("BZK_H_UNFUSED"),
+                          "ms_7_ntts_plus_pointwise": round(ms, 3)}))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -118,6 +121,16 @@ if __name__ == "__main__":
         for lg in (18, 20, 22, 24):
             run("g1", lg)
         run("g2", 20); run("g2", 18)
+    if what in ("r3ntt",):  # round 3: 36-byte LDS tiles (4 workgroups per CU), raw first loads, fused h chain; kernel variants (occupancy, twiddle prefetch)
+        for v in ("0", "1", "2", "3"):
+            for lg in (20, 24):
+                run("ntt", lg, {"BZK_NTT_VARIANT": v})
+            run("h", 20, {"BZK_NTT_VARIANT": v})
+        run("ntt", 20, {"NTT_COSET": "1"}); run("ntt", 24, {"NTT_COSET": "1"})
+        run("h", 20, {"BZK_H_UNFUSED": "1"}); run("h", 24); run("h", 24, {"BZK_H_UNFUSED": "1"})
+        for lg in (16, 18, 22):
+            run("ntt", lg)
+        run("ntt", 20, {"BZK_NTT_TILE": "2048"}); run("ntt", 24, {"BZK_NTT_TILE": "2048"})
     if what in ("r26",):
         for lg in (16, 18, 20, 22, 24):
             run("ntt", lg)
