@@ -108,8 +108,12 @@ G2A g2_add(const G2A& t, const G2A& q, const E2& lam) {
     return {x3, F2::sub(F2::mul(lam, F2::sub(t.x, x3)), t.y), false};
 }
 
-// product of the Miller functions of n pairs (pairs with an identity member contribute 1)
-E12 multi_miller(const G1A* p, const G2A* q, int n) {
+// product of the Miller functions of n pairs (pairs with an identity member contribute 1).  *degenerate is set when a line's slope has
+// a zero denominator (T of order 2, or T = +-Q): impossible for points of the prime-order subgroup, reachable only with low-order G2
+// points, which the callers only check to be on the curve (as the reference does - it transmutes unchecked points into bellman's
+// projective Miller loop).  Such a proof cannot satisfy the pairing equation; the verdict is then "does not verify" instead of a value
+// computed from 1 / 0.
+E12 multi_miller(const G1A* p, const G2A* q, int n, bool* degenerate) {
     const uint64_t X = 0xd201000000010000ull;
     G2A t[4];
     bool live[4];
@@ -120,14 +124,18 @@ E12 multi_miller(const G1A* p, const G2A* q, int n) {
         for (int k = 0; k < n; ++k) {
             if (!live[k]) continue;
             const E2 xx = F2::sqr(t[k].x);
-            const E2 lam = F2::mul(F2::add(F2::add(xx, xx), xx), F2::inv(F2::add(t[k].y, t[k].y)));
+            const E2 den = F2::add(t[k].y, t[k].y);
+            if (F2::is_zero(den)) { *degenerate = true; return e12_one(); }
+            const E2 lam = F2::mul(F2::add(F2::add(xx, xx), xx), F2::inv(den));
             f = e12_mul(f, line(lam, t[k], p[k]));
             t[k] = g2_dbl(t[k], lam);
         }
         if ((X >> i) & 1) {
             for (int k = 0; k < n; ++k) {
                 if (!live[k]) continue;
-                const E2 lam = F2::mul(F2::sub(q[k].y, t[k].y), F2::inv(F2::sub(q[k].x, t[k].x)));
+                const E2 den = F2::sub(q[k].x, t[k].x);
+                if (F2::is_zero(den)) { *degenerate = true; return e12_one(); }
+                const E2 lam = F2::mul(F2::sub(q[k].y, t[k].y), F2::inv(den));
                 f = e12_mul(f, line(lam, t[k], p[k]));
                 t[k] = g2_add(t[k], q[k], lam);
             }
@@ -136,11 +144,19 @@ E12 multi_miller(const G1A* p, const G2A* q, int n) {
     return e12_conj(f);  // the curve parameter is -|x|
 }
 
-bool g1_unpack(const uint8_t* in, G1A& o) {  // packed 97 bytes; on-curve check
+// Montgomery limbs of an Fp element are below p: anything else is not a value `Fp([u64; 6])` can legitimately hold, and arithmetic on
+// it would leave the verdict to the reduction details of whichever library runs it
+bool fp_in_range(const Fp& a) {
+    Fp t = a;
+    fe_reduce_once<FpParams>(t);
+    return t.equals(a);
+}
+bool g1_unpack(const uint8_t* in, G1A& o) {  // packed 97 bytes; range + on-curve check
     o.inf = in[96] != 0;
     memcpy(o.x.l, in, 48);
     memcpy(o.y.l, in + 48, 48);
     if (o.inf) return true;
+    if (!fp_in_range(o.x) || !fp_in_range(o.y)) return false;
     Fp four = Fp::zero();
     four.l[0] = 4;
     four = fe_to_mont<FpParams>(four);
@@ -150,6 +166,7 @@ bool g2_unpack(const uint8_t* in, G2A& o) {
     o.inf = in[192] != 0;
     memcpy(o.x.c0.l, in, 48); memcpy(o.x.c1.l, in + 48, 48); memcpy(o.y.c0.l, in + 96, 48); memcpy(o.y.c1.l, in + 144, 48);
     if (o.inf) return true;
+    if (!fp_in_range(o.x.c0) || !fp_in_range(o.x.c1) || !fp_in_range(o.y.c0) || !fp_in_range(o.y.c1)) return false;
     Fp four = Fp::zero();
     four.l[0] = 4;
     four = fe_to_mont<FpParams>(four);
@@ -203,7 +220,10 @@ int32_t bzk_groth16_verify(const uint8_t* vk, uint64_t vk_len, const uint8_t* in
     qs[1].y = F2::neg(gamma.y);
     qs[2].y = F2::neg(delta.y);
     ps[3].y = fe_neg<FpParams>(alpha.y);
-    return e12_is_one(final_exp(multi_miller(ps, qs, 4))) ? 1 : 0;
+    bool degenerate = false;
+    const E12 f = multi_miller(ps, qs, 4, &degenerate);
+    if (degenerate) return 0;
+    return e12_is_one(final_exp(f)) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -416,8 +416,8 @@ __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict
     const uint32_t nt = (cnt + seg - 1) / seg;
     if (nt <= msm_fold_threshold(tbase, ntask, nb)) return;
     const Pt* src = partial + tbase[i];
-    Pt acc = C::identity();
-    for (uint32_t j = threadIdx.x; j < nt; j += 64) add_from<C>(acc, &src[j]);
+    Pt acc = threadIdx.x < nt ? src[threadIdx.x] : C::identity();
+    for (uint32_t j = threadIdx.x + 64; j < nt; j += 64) add_from<C>(acc, &src[j]);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 32; s > 0; s >>= 1) {
@@ -526,12 +526,14 @@ __global__ void __launch_bounds__(64) msm_reduce_kernel(const typename C::Pt* __
 //    stage A: THREADS consecutive chunk results -> 1 partial        (grid = windows x groups)
 //    stage B: the <= THREADS partials of a window -> the window sum, converted to standard limbs
 // ------------------------------------------------------------------------------------------------
+// `active`: a power of two <= THREADS; lanes >= active hold the identity, so the tree starts at active / 2 (every level is one
+// general addition of latency - ~16 us in G1, ~43 us in G2 - whether or not its operands are identities)
 template <class C, int THREADS>
-__device__ __forceinline__ typename C::Pt block_tree_sum(typename C::Pt acc, typename C::Pt* sh) {
+__device__ __forceinline__ typename C::Pt block_tree_sum(typename C::Pt acc, typename C::Pt* sh, int active = THREADS) {
     typedef typename C::Pt Pt;
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = THREADS / 2; s > 0; s >>= 1) {
+    for (int s = active / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             Pt a = sh[threadIdx.x];
             add_from<C>(a, &sh[threadIdx.x + s]);
@@ -561,9 +563,12 @@ __global__ void __launch_bounds__(THREADS) msm_window_sum_kernel(const typename 
     __shared__ Pt sh[THREADS];
     const uint32_t w = blockIdx.x;
     const Pt* src = partials + (size_t)w * groups;
-    Pt acc = C::identity();
-    for (uint32_t i = threadIdx.x; i < groups; i += THREADS) add_from<C>(acc, &src[i]);
-    Pt r = block_tree_sum<C, THREADS>(acc, sh);
+    // the first term is loaded, not added to an identity (one general addition of latency less)
+    Pt acc = threadIdx.x < groups ? src[threadIdx.x] : C::identity();
+    for (uint32_t i = threadIdx.x + THREADS; i < groups; i += THREADS) add_from<C>(acc, &src[i]);
+    int active = 1;
+    while (active < THREADS && (uint32_t)active < groups) active <<= 1;  // 16 partials per window at c = 16: 4 levels, not 8
+    Pt r = block_tree_sum<C, THREADS>(acc, sh, active);
     if (threadIdx.x == 0) win_out[w] = C::to_std(r);  // standard 12 x 32-bit XYZZ for the host
 }
 

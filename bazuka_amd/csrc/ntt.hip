@@ -157,6 +157,7 @@ struct NttPass {
     //               c_raw = C 2^251 (the producing transform scales C by 2^-5 in ITS final store, for free)
     //               v = ((a_raw * b_raw) 2^-261 - c_raw + 3 r) * kmul 2^-261 = (A B - C) zinv * 2^261 for kmul = zinv * 2^271
     int first_mode;
+    uint32_t xcd_group;   // COL passes: see the block -> tile mapping in the kernel (0 / 1: identity)
     const void* src_b;    // FIRST_PW
     const void* src_c;
     const Fr29P* kmul;
@@ -175,15 +176,27 @@ enum { FIRST_MUL = 0, FIRST_RAW = 1, FIRST_PW = 2 };
 // workgroups share a CU's 160 KiB instead of three (4 waves per SIMD; the 2048 tiles of a 2^20-point pass are exactly two rounds of
 // the 1024 resident workgroups instead of 2.67), and the odd dword stride spreads neighbouring elements over all 32 banks.
 static constexpr uint32_t LDSW = 9;
+// Bank swizzle.  With 9-dword elements the bank of limb k of element p is (9 p + k) mod 32 - a bijection of p mod 32 - so the 32 lanes
+// of a ds_*_b32 lane group conflict exactly when their element indices agree mod 32.  The kernel's access patterns vary these index
+// bits across a lane group: the bit-reversed scatter of the load phase {5..9} (ALL lanes on one bank: 32-way), round 0 {2..6} (4-way),
+// round 2 {0,1,4,5,6} (4-way), round 4 {0..3,6} (2-way), later rounds and the store phase {0..4} - PMC: SQ_LDS_BANK_CONFLICT 13.3 M
+// cycles per 85 us launch at 2^20, SQ_WAIT_INST_LDS 18 % of the wave cycles (profiles/r03_run5_ntt_pmc.txt).  The element index is
+// therefore permuted inside its block of 32 by a GF(2)-linear map of the block number h = idx >> 5:
+//     low5 ^= h ^ ((h & 3) << 2) ^ ((h & 2) << 3)
+// which is a bijection on every one of those bit sets (checked for every (b, log_cc) the planner produces: tools/ntt_bank_sim.py).
+__device__ __forceinline__ uint32_t lds_sw(uint32_t idx) {
+    const uint32_t h = idx >> 5;
+    return idx ^ ((h ^ ((h & 3u) << 2) ^ ((h & 2u) << 3)) & 31u);
+}
 __device__ __forceinline__ Fr29 lds_ld(const uint32_t* tile, uint32_t idx) {
     Fr29 r;
-    const uint32_t* p = tile + idx * LDSW;
+    const uint32_t* p = tile + lds_sw(idx) * LDSW;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = p[i];
     return r;
 }
 __device__ __forceinline__ void lds_st(uint32_t* tile, uint32_t idx, const Fr29& v) {
-    uint32_t* p = tile + idx * LDSW;
+    uint32_t* p = tile + lds_sw(idx) * LDSW;
 #pragma unroll
     for (int i = 0; i < 9; ++i) p[i] = v.l[i];
 }
@@ -202,7 +215,14 @@ __device__ __forceinline__ Fr29 ntt_first_load(const NttPass& a, uint64_t addr, 
 // OCC: waves per SIMD the kernel is compiled for (4 = one workgroup per 36 KiB tile slot of the CU, needs <= 128 registers);
 // PF: 2 = all three twiddles of a round requested before the LDS reads, 1 = the first-stage twiddle early and the second-stage pair
 // after the first two products, 0 = every twiddle loaded where it is used.  A/B builds: env BZK_NTT_VARIANT (ntt_run_ex).
-template <int OCC, int PF>
+// INL: 1 = the butterflies' products are inlined (fr29::mul_body; ~1.5 KB of code each, eight sites: still inside the 64 KiB instruction
+// cache, and two independent products of a butterfly can interleave), 0 = calls to the one resident copy (fr29::mul)
+template <int INL>
+__device__ __forceinline__ Fr29 nmul(const Fr29& x, const Fr29& y) {
+    if constexpr (INL) return fr29::mul_body(x, y);
+    else return fr29::mul(x, y);
+}
+template <int OCC, int PF, int INL>
 __global__ void __launch_bounds__(256, OCC) ntt_pass_kernel(NttPass a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     const int b = a.b, lc = a.log_cc;
@@ -213,7 +233,15 @@ __global__ void __launch_bounds__(256, OCC) ntt_pass_kernel(NttPass a) {
     // load: global row r goes to LDS row bitrev(r) (decimation in time)
     if (!a.final_pass) {
         const uint64_t gpo = a.S >> lc;  // column groups per outer block
-        const uint64_t o = blockIdx.x / gpo, cg = blockIdx.x % gpo;
+        // Tiles narrower than a 128-byte line (CC x 32 B on the first pass): the G = 4 / CC tiles that share each line are given to
+        // blocks x, x + 8, x + 16, .. - workgroups are dealt to the 8 XCDs round-robin, so these land on ONE XCD back to back and three
+        // of the four reads of a line (and the partial-line stores) meet in that XCD's L2 instead of fetching the line four times
+        uint64_t bid = blockIdx.x;
+        if (a.xcd_group > 1) {
+            const uint64_t G = a.xcd_group, x = bid & 7, y = bid >> 3;
+            bid = ((y / G) * 8 + x) * G + (y % G);
+        }
+        const uint64_t o = bid / gpo, cg = bid % gpo;
         inner0 = cg << lc;
         base = o * R * a.S + inner0;
         for (uint32_t t = threadIdx.x; t < tile_n; t += blockDim.x) {
@@ -267,15 +295,15 @@ __global__ void __launch_bounds__(256, OCC) ntt_pass_kernel(NttPass a) {
             Fr29 x0 = lds_ld(tile, i0), x1 = lds_ld(tile, i1), x2 = lds_ld(tile, i2), x3 = lds_ld(tile, i3);
             if (s) {  // stage s: both butterflies of the group use w^(j 2^(b-1-s))
                 if (PF == 0) wa = ld29(*pa);
-                x1 = fr29::mul(x1, wa);
-                x3 = fr29::mul(x3, wa);
+                x1 = nmul<INL>(x1, wa);
+                x3 = nmul<INL>(x3, wa);
             }
             if (PF < 2) { wb = ld29(*pb); wc = ld29(*pc); }
             const Fr29 y0 = fr29::norm(fr29::add(x0, x1)), y1 = fr29::sub3(x0, x1);
             const Fr29 y2 = fr29::norm(fr29::add(x2, x3)), y3 = fr29::sub3(x2, x3);
             // stage s + 1: (y0, y2) at position j, (y1, y3) at position j + m of their 4m-blocks
-            const Fr29 u2 = fr29::mul(y2, wb);
-            const Fr29 u3 = fr29::mul(y3, wc);
+            const Fr29 u2 = nmul<INL>(y2, wb);
+            const Fr29 u3 = nmul<INL>(y3, wc);
             lds_st(tile, i0, fr29::norm(fr29::add(y0, u2)));
             lds_st(tile, i2, fr29::sub3(y0, u2));
             lds_st(tile, i1, fr29::norm(fr29::add(y1, u3)));
@@ -473,12 +501,14 @@ static int32_t ntt_run_ex(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inve
     // tiles above 64 KiB of dynamic LDS need the opt-in; the attribute is per DEVICE, so remember it per device id (a process
     // may hold contexts on several GPUs, and prover slots call this from concurrent threads)
     typedef void (*pass_fn)(NttPass);
-    static const pass_fn variants[4] = {ntt_pass_kernel<3, 2>, ntt_pass_kernel<4, 2>, ntt_pass_kernel<4, 1>, ntt_pass_kernel<4, 0>};
+    static const pass_fn variants[6] = {ntt_pass_kernel<3, 2, 0>, ntt_pass_kernel<4, 2, 0>, ntt_pass_kernel<4, 1, 0>, ntt_pass_kernel<4, 0, 0>,
+                                        ntt_pass_kernel<4, 1, 1>, ntt_pass_kernel<3, 2, 1>};
     static const int variant = [] {
         const char* e = getenv("BZK_NTT_VARIANT");
-        const int v = e ? atoi(e) : 2;
-        return v < 0 || v > 3 ? 2 : v;
+        const int v = e ? atoi(e) : 4;  // 4 waves per SIMD, first-stage twiddle requested early, products inlined (profiles/r03_run5...)
+        return v < 0 || v > 5 ? 4 : v;
     }();
+    static const bool xcd_swz = [] { const char* e = getenv("BZK_NTT_NO_XCD"); return !(e && atoi(e) != 0); }();
     const pass_fn kern = variants[variant];
     static std::once_flag lds_attr_once[64];
     std::call_once(lds_attr_once[ctx->device & 63], [] {
@@ -520,6 +550,7 @@ static int32_t ntt_run_ex(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inve
         while (((uint64_t)2 << lc) <= lanes && (R << (lc + 1)) <= tile_max) ++lc;
         a.log_cc = lc;
         const uint64_t tiles = n >> (b + lc);
+        if (!a.final_pass && xcd_swz && lc < 2 && tiles % (8u << (2 - lc)) == 0) a.xcd_group = 4u >> lc;
         if (tiles > 0x7fffffffull) return BZK_E_ARG;
         const size_t lds = (size_t)(LDSW * 4) << (b + lc);
         if (a.final_pass) {

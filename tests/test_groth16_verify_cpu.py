@@ -40,6 +40,8 @@ def test_same_verdict_as_the_oracle_verifier(co, n_mul, n_in):
         "tampered c.x": (vkb, inputs, proof[:290] + bytes([proof[290] ^ 1]) + proof[291:]),      # off the curve
         "identity a": (vkb, inputs, pr.g1_to_bytes(None) + proof[97:]),
         "fewer inputs": (vkb, inputs[:-32], proof),
+        # the same point with x's Montgomery limbs raised by p: not a value Fp([u64; 6]) may hold - refused, never computed with
+        "limbs >= p": (vkb, inputs, (int.from_bytes(proof[:48], "little") + pr.P_MOD).to_bytes(48, "little") + proof[48:]),
     }
     for name, (v, i, p) in cases.items():
         assert L.groth16_verify(v, i, p) is False, name

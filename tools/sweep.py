@@ -121,6 +121,15 @@ if __name__ == "__main__":
         for lg in (18, 20, 22, 24):
             run("g1", lg)
         run("g2", 20); run("g2", 18)
+    if what in ("r3ntt2",):  # round 3, second step: inlined products, XCD-aware column tiles
+        for v in ("2", "4", "5"):
+            for lg in (20, 22, 24):
+                run("ntt", lg, {"BZK_NTT_VARIANT": v})
+            run("h", 20, {"BZK_NTT_VARIANT": v})
+        for v in ("2", "4"):
+            for lg in (20, 24):
+                run("ntt", lg, {"BZK_NTT_VARIANT": v, "BZK_NTT_NO_XCD": "1"})
+            run("h", 20, {"BZK_NTT_VARIANT": v, "BZK_NTT_NO_XCD": "1"})
     if what in ("r3ntt",):  # round 3: 36-byte LDS tiles (4 workgroups per CU), raw first loads, fused h chain; kernel variants (occupancy, twiddle prefetch)
         for v in ("0", "1", "2", "3"):
             for lg in (20, 24):
