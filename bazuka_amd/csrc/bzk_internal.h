@@ -109,6 +109,17 @@ int32_t g1_horner_packed(const void* S, int count, int c, int w0, uint8_t* out);
 int32_t g2_horner_packed(const void* S, int count, int c, int w0, uint8_t* out);
 static inline size_t ws_pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
+// A schedule of Poseidon hashes over one value array (state.hip): values [0, n_up) are uploaded 32-byte scalars, group g's outputs
+// follow in group order.  Groups run one batched launch each, in order, so a group may consume anything uploaded or produced by an
+// earlier group.  Used by the general state compress and by the device path of the MPN witness builders (mpn.hip).
+struct HashGroup {
+    uint32_t arity = 0;
+    std::vector<uint32_t> in;  // count * arity value ids (already resolved: < n_up + outputs of earlier groups)
+    uint32_t count() const { return arity ? (uint32_t)(in.size() / arity) : 0; }
+};
+// uploaded: n_up x 32 B Montgomery scalars; hashed_out receives sum(count) x 32 B in group order
+int32_t hash_plan_run(bzk_ctx* ctx, const uint8_t* uploaded, uint64_t n_up, const std::vector<HashGroup>& groups, std::vector<uint8_t>& hashed_out);
+
 struct ProfScope {
     bzk_ctx* ctx;
     hipEvent_t a = nullptr, b = nullptr;

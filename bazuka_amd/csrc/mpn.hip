@@ -92,6 +92,8 @@ struct bzk_mpn {
     uint64_t height = 0;
     ZkScalar contract_id = ZkScalar::from_u64(0x4D504E);  // ContractId::Custom of the MPN contract (payments of synthetic txs)
     int threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    bzk_ctx* dev = nullptr;  // bzk_mpn_set_device: the witness builders hash their Merkle updates in batches on this context
+    std::string dev_error;
 
     bzk_mpn(int l, int t) : L(l), T(t) {
         token_default = token_leaf(Money());
@@ -286,6 +288,300 @@ static void build_transitions(bzk_mpn& w, int log4_batch, const ZkScalar& fee_to
         out.push_back(std::move(t));
     }
     w.mempool.swap(rest);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device path of the witness builders ("replacing the per-tx KV walk in prepare_works", src/mpn/mod.rs:353-414).
+//
+// The host builders above walk the account tree once per transaction: prove -> set -> prove -> set, ~50 sequential Poseidon hashes per
+// update transaction (1.06 ms on a host core at L = 15, T = 3: 0.27 s of a 256-tx batch).  Inside a batch every proof is taken against
+// the state the previous transition left, so the transactions cannot simply be hashed side by side - but the hashes can be grouped BY
+// LEVEL: every transaction's ACCEPTANCE depends on account data only (balances, nonces, keys), so a first pass decides the batch and
+// lists, in time order, the leaf writes it causes ("events": token slot writes in the accounts' token trees, then account-leaf writes).
+// For one tree level, event e re-hashes exactly one node from its four children, each of which is either the value event e itself
+// just produced one level below, or the LATEST earlier event's value for that child, or the value the tree held before the batch.
+// That is known on the host without hashing anything, so each level of each tree is ONE batched Poseidon launch over all events
+// (hash_plan_run: T + 1 launches for the token forest, 1 for the account leaves, L for the account tree), and the three sibling
+// inputs of event e's hash at each level ARE its Merkle proof.  No conflict-free waves are needed: transactions may share accounts.
+// Result: the same transitions, byte for byte (tests/test_gpu_mpn_prove.py), and the host-side sparse tree is brought up to date
+// from the returned node values.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t VH = 0x80000000u;  // value-id tag: output `pos` of hash group `g`: VH | g << 20 | pos
+struct VPlan {
+    std::vector<uint8_t> up;           // uploaded scalars
+    std::vector<HashGroup> groups;     // inputs hold SYMBOLIC ids until resolve()
+    uint32_t upload(const ZkScalar& v) {
+        const uint32_t id = (uint32_t)(up.size() / 32);
+        up.resize(up.size() + 32);
+        v.to_bytes(up.data() + 32 * (size_t)id);
+        return id;
+    }
+    uint32_t new_group(uint32_t arity) {
+        groups.emplace_back();
+        groups.back().arity = arity;
+        return (uint32_t)groups.size() - 1;
+    }
+    uint32_t add(uint32_t g, const uint32_t* in) {
+        HashGroup& G = groups[g];
+        const uint32_t pos = G.count();
+        G.in.insert(G.in.end(), in, in + G.arity);
+        return VH | (g << 20) | pos;
+    }
+    std::vector<uint32_t> base;        // first output id of each group (after resolve)
+    std::vector<uint8_t> hashed;
+    bool sizes_ok() const {
+        if (groups.size() >= 2048) return false;
+        for (auto& g : groups)
+            if (g.count() >= (1u << 20)) return false;
+        return up.size() / 32 < (1u << 30);
+    }
+    uint32_t final_id(uint32_t id) const { return (id & VH) ? base[(id >> 20) & 2047] + (id & 0xfffffu) : id; }
+    int32_t run(bzk_ctx* ctx) {
+        if (!sizes_ok()) return BZK_E_ARG;
+        base.assign(groups.size(), 0);
+        uint32_t next = (uint32_t)(up.size() / 32);
+        for (size_t g = 0; g < groups.size(); ++g) { base[g] = next; next += groups[g].count(); }
+        for (auto& g : groups)
+            for (uint32_t& id : g.in) id = final_id(id);
+        return hash_plan_run(ctx, up.data(), up.size() / 32, groups, hashed);
+    }
+    ZkScalar value(uint32_t id) const {
+        const uint32_t f = final_id(id), n_up = (uint32_t)(up.size() / 32);
+        return ZkScalar::from_bytes(f < n_up ? up.data() + 32 * (size_t)f : hashed.data() + 32 * (size_t)(f - n_up));
+    }
+};
+
+// one write of a leaf in one tree of a forest of equal-depth 4-ary trees
+struct VEvent {
+    uint64_t tree = 0, leaf = 0;
+    uint32_t leaf_val = 0;                       // value id of the new leaf
+    std::vector<std::array<uint32_t, 3>> sib;    // per level, leaf level first: the value ids of the three siblings BEFORE this write
+    std::vector<uint32_t> node_val;              // per level 1..depth: value id of the re-hashed ancestor
+    uint32_t root_before = 0, root_after = 0;
+};
+// plans the re-hash of every event's path, level by level (one hash group per level); initial(lv, tree, idx) = value id of a node
+// no event of this batch has written yet (lv 0 = leaves)
+template <class Initial>
+void vforest_plan(int depth, std::vector<VEvent>& evs, VPlan& P, Initial&& initial) {
+    const size_t E = evs.size();
+    std::vector<uint32_t> val(E);
+    std::vector<uint64_t> idx(E);
+    for (size_t e = 0; e < E; ++e) {
+        val[e] = evs[e].leaf_val;
+        idx[e] = evs[e].leaf;
+        evs[e].sib.assign(depth, {0, 0, 0});
+        evs[e].node_val.assign(depth, 0);
+    }
+    auto key = [](uint64_t tree, uint64_t i) { return (tree << 34) ^ i; };  // i < 4^15 = 2^30, tree < 2^30
+    for (int lv = 0; lv < depth; ++lv) {
+        const uint32_t g = P.new_group(4);
+        std::unordered_map<uint64_t, uint32_t> latest;
+        latest.reserve(E * 2);
+        for (size_t e = 0; e < E; ++e) {
+            const uint64_t own = idx[e], b = own & ~(uint64_t)3;
+            uint32_t in[4];
+            int k = 0;
+            for (uint64_t j = 0; j < 4; ++j) {
+                if (b + j == own) { in[j] = val[e]; continue; }
+                auto it = latest.find(key(evs[e].tree, b + j));
+                in[j] = it != latest.end() ? it->second : initial(lv, evs[e].tree, b + j);
+                evs[e].sib[lv][k++] = in[j];
+            }
+            latest[key(evs[e].tree, own)] = val[e];
+            val[e] = P.add(g, in);
+            evs[e].node_val[lv] = val[e];
+            idx[e] = own >> 2;
+        }
+    }
+    std::unordered_map<uint64_t, uint32_t> root;
+    for (size_t e = 0; e < E; ++e) {
+        auto it = root.find(evs[e].tree);
+        evs[e].root_before = it != root.end() ? it->second : initial(depth, evs[e].tree, 0);
+        evs[e].root_after = depth ? val[e] : evs[e].leaf_val;
+        root[evs[e].tree] = evs[e].root_after;
+    }
+}
+
+// the token forest + account tree of one batch
+struct DevBatch {
+    bzk_mpn& w;
+    VPlan P;
+    std::vector<VEvent> tok, acc;           // events in time order
+    uint32_t g_h2, g_h5;
+    std::vector<uint32_t> tok_default;      // value ids of the empty token tree's levels
+    std::map<uint64_t, bool> seen;          // accounts whose token tree has been populated in this batch
+    explicit DevBatch(bzk_mpn& world) : w(world) {
+        g_h2 = P.new_group(2);
+        for (int lv = 0; lv <= w.T; ++lv) tok_default.push_back(P.upload(w.empty_tokens->defaults[lv]));
+    }
+    uint32_t token_leaf_id(const Money& m) {
+        const uint32_t in[2] = {P.upload(m.token_id), P.upload(ZkScalar::from_u64(m.amount))};
+        return P.add(g_h2, in);
+    }
+    // first touch of an account in this batch: its token tree as it stands is built by the same machinery (writes of the populated
+    // slots, before any real event of the account)
+    void touch(uint64_t index, const MpnAccount& as_it_stands) {
+        if (seen.count(index)) return;
+        seen[index] = true;
+        for (auto& kv : as_it_stands.tokens) {
+            VEvent e;
+            e.tree = index;
+            e.leaf = kv.first;
+            e.leaf_val = token_leaf_id(kv.second);
+            tok.push_back(e);
+        }
+    }
+    size_t token_write(uint64_t index, uint64_t slot, const Money& m) {
+        VEvent e;
+        e.tree = index;
+        e.leaf = slot;
+        e.leaf_val = token_leaf_id(m);
+        tok.push_back(e);
+        return tok.size() - 1;
+    }
+    // account leaf H5(nonce, withdraw nonce, x, y, tokens root after token event `tok_ev`)
+    struct PendingLeaf { uint64_t index; MpnAccount a; size_t tok_ev; };
+    std::vector<PendingLeaf> leaves;
+    size_t account_write(uint64_t index, const MpnAccount& a, size_t tok_ev) {
+        leaves.push_back({index, a, tok_ev});
+        return leaves.size() - 1;
+    }
+    int32_t run() {
+        vforest_plan(w.T, tok, P, [&](int lv, uint64_t, uint64_t) { return tok_default[lv]; });
+        g_h5 = P.new_group(5);
+        for (auto& pl : leaves) {
+            const uint32_t in[5] = {P.upload(ZkScalar::from_u64(pl.a.tx_nonce)), P.upload(ZkScalar::from_u64(pl.a.withdraw_nonce)),
+                                    P.upload(pl.a.address.x), P.upload(pl.a.address.y), tok[pl.tok_ev].root_after};
+            VEvent e;
+            e.tree = 0;
+            e.leaf = pl.index;
+            e.leaf_val = P.add(g_h5, in);
+            acc.push_back(e);
+        }
+        std::unordered_map<uint64_t, uint32_t> init_cache;
+        vforest_plan(w.L, acc, P, [&](int lv, uint64_t, uint64_t i) {
+            const uint64_t k = ((uint64_t)lv << 40) | i;
+            auto it = init_cache.find(k);
+            if (it != init_cache.end()) return it->second;
+            return init_cache[k] = P.upload(w.accounts->get(lv, i));
+        });
+        const int32_t st = P.run(w.dev);
+        if (st != BZK_OK) {
+            w.dev_error = bzk_last_error(w.dev);
+            return st;
+        }
+        // bring the host-side sparse account tree up to date: every event's leaf and ancestors, in time order (the last write wins)
+        for (auto& e : acc) {
+            uint64_t i = e.leaf;
+            w.accounts->level[0][i] = P.value(e.leaf_val);
+            for (int lv = 0; lv < w.L; ++lv) {
+                i >>= 2;
+                w.accounts->level[lv + 1][i] = P.value(e.node_val[lv]);
+            }
+        }
+        return BZK_OK;
+    }
+    Proof4 proof(const VEvent& e) const {
+        Proof4 p(e.sib.size());
+        for (size_t lv = 0; lv < e.sib.size(); ++lv)
+            for (int k = 0; k < 3; ++k) p[lv][k] = P.value(e.sib[lv][k]);
+        return p;
+    }
+};
+}  // namespace
+
+// update::update (src/mpn/update.rs:8-299) with the Merkle work batched on the device; same acceptance rules, same transitions
+static int32_t build_transitions_dev(bzk_mpn& w, int log4_batch, const ZkScalar& fee_token, std::vector<UpdateTransition>& out,
+                                     uint64_t& fee_sum, uint64_t& rejected) {
+    const size_t cap = (size_t)1 << (2 * log4_batch);
+    fee_sum = 0;
+    rejected = 0;
+    DevBatch B(w);
+    struct Rec { size_t ev_sti, ev_sfi, ev_dti, leaf_src, leaf_dst; };
+    std::vector<Rec> recs;
+    std::vector<MpnTx> rest;
+    for (const MpnTx& tx : w.mempool) {
+        if (out.size() == cap) {
+            rest.push_back(tx);
+            continue;
+        }
+        if (tx.fee.token_id != fee_token || !tx.src_pub.is_on_curve() || !tx.dst_pub.is_on_curve()) { ++rejected; continue; }
+        long src_index = -1, dst_index = -1;
+        for (auto& kv : w.acct) {
+            if (kv.second.address == tx.src_pub && src_index < 0) src_index = (long)kv.first;
+            if (kv.second.address == tx.dst_pub && dst_index < 0) dst_index = (long)kv.first;
+        }
+        if (src_index < 0) { ++rejected; continue; }
+        if (dst_index < 0) dst_index = w.acct.empty() ? 0 : (long)(w.acct.rbegin()->first + 1);
+        MpnAccount src_before = w.get(src_index), dst_before0 = w.get(dst_index);
+        long sti = src_before.find_token_index(w.L, tx.amount.token_id, false);
+        long dti = dst_before0.find_token_index(w.L, tx.amount.token_id, true);
+        long sfi = src_before.find_token_index(w.L, tx.fee.token_id, false);
+        if (sti < 0 || dti < 0 || sfi < 0) { ++rejected; continue; }
+        Money src_token = src_before.tokens[sti];
+        const bool dst_has = dst_before0.tokens.count(dti) != 0;
+        if (tx.nonce != src_before.tx_nonce + 1 || !(src_before.address == tx.src_pub) ||
+            (dst_before0.address.is_on_curve() && !(dst_before0.address == tx.dst_pub)) ||
+            (dst_has && src_token.token_id != dst_before0.tokens[dti].token_id) || src_token.token_id != tx.amount.token_id ||
+            src_token.amount < tx.amount.amount) {
+            ++rejected;
+            continue;
+        }
+        MpnAccount src_after = src_before;
+        src_after.tx_nonce += 1;
+        src_after.tokens[sti].amount -= tx.amount.amount;
+        if (!src_after.tokens.count(sfi)) { ++rejected; continue; }
+        const Money src_fee_token = src_after.tokens[sfi];
+        if (src_fee_token.token_id != tx.fee.token_id || src_fee_token.amount < tx.fee.amount) { ++rejected; continue; }
+
+        UpdateTransition t;
+        t.enabled = true;
+        t.tx = tx;
+        t.src_index = src_index; t.dst_index = dst_index;
+        t.src_token_index = sti; t.dst_token_index = dti; t.src_fee_token_index = sfi;
+        t.src_before = src_before;
+        t.src_before_balance = src_token;
+        t.src_before_fee_balance = src_fee_token;
+        Rec r;
+        B.touch(src_index, src_before);
+        r.ev_sti = B.token_write(src_index, sti, src_after.tokens[sti]);
+        src_after.tokens[sfi].amount -= tx.fee.amount;
+        r.ev_sfi = B.token_write(src_index, sfi, src_after.tokens[sfi]);
+        w.acct[src_index] = src_after;
+        r.leaf_src = B.account_write(src_index, src_after, r.ev_sfi);
+        MpnAccount dst_before = w.get(dst_index);  // read AFTER the sender update (matters when src == dst)
+        t.dst_before = dst_before;
+        t.dst_before_balance = dst_before.tokens.count(dti) ? dst_before.tokens[dti] : Money();
+        MpnAccount dst_after = dst_before;
+        dst_after.address = tx.dst_pub;
+        if (!dst_after.tokens.count(dti)) dst_after.tokens[dti] = Money{tx.amount.token_id, 0};
+        dst_after.tokens[dti].amount += tx.amount.amount;
+        B.touch(dst_index, dst_before);
+        r.ev_dti = B.token_write(dst_index, dti, dst_after.tokens[dti]);
+        w.acct[dst_index] = dst_after;
+        r.leaf_dst = B.account_write(dst_index, dst_after, r.ev_dti);
+        fee_sum += tx.fee.amount;
+        out.push_back(std::move(t));
+        recs.push_back(r);
+    }
+    w.mempool.swap(rest);
+    if (recs.empty()) return BZK_OK;
+    BZK_TRY(B.run());
+    const size_t first = out.size() - recs.size();
+    for (size_t k = 0; k < recs.size(); ++k) {
+        UpdateTransition& t = out[first + k];
+        const Rec& r = recs[k];
+        t.src_before_balances_hash = B.P.value(B.tok[r.ev_sti].root_before);
+        t.src_balance_proof = B.proof(B.tok[r.ev_sti]);
+        t.src_fee_balance_proof = B.proof(B.tok[r.ev_sfi]);
+        t.dst_before_balances_hash = B.P.value(B.tok[r.ev_dti].root_before);
+        t.dst_balance_proof = B.proof(B.tok[r.ev_dti]);
+        t.src_proof = B.proof(B.acc[r.leaf_src]);
+        t.dst_proof = B.proof(B.acc[r.leaf_dst]);
+        t.state_after = B.P.value(B.acc[r.leaf_dst].root_after);
+    }
+    return BZK_OK;
 }
 
 struct LcModeGuard {
@@ -658,6 +954,61 @@ static void build_deposits(bzk_mpn& w, int log4_batch, std::vector<DepositTransi
     w.deposit_queue.swap(rest);
 }
 
+// deposit::deposit (src/mpn/deposit.rs:11-233) with the Merkle work batched on the device (see DevBatch)
+static int32_t build_deposits_dev(bzk_mpn& w, int log4_batch, std::vector<DepositTransition>& out, uint64_t& rejected) {
+    const size_t cap = (size_t)1 << (2 * log4_batch);
+    rejected = 0;
+    DevBatch B(w);
+    struct Rec { size_t ev_tok, leaf; bool had_tokens; };
+    std::vector<Rec> recs;
+    std::vector<DepositTx> rest;
+    for (const DepositTx& tx : w.deposit_queue) {
+        if (out.size() == cap) { rest.push_back(tx); continue; }
+        long index = -1;
+        for (auto& kv : w.acct)
+            if (kv.second.address == tx.mpn_address) { index = (long)kv.first; break; }
+        if (index < 0) index = w.acct.empty() ? 0 : (long)(w.acct.rbegin()->first + 1);
+        MpnAccount acc = w.get(index);
+        long ti = acc.find_token_index(w.L, tx.amount.token_id, true);
+        if (ti < 0) { ++rejected; continue; }
+        const bool has = acc.tokens.count(ti) != 0;
+        if ((!(acc.address == PointAffine()) && !(tx.mpn_address == acc.address)) || (has && acc.tokens[ti].token_id != tx.amount.token_id)) {
+            ++rejected;
+            continue;
+        }
+        DepositTransition t;
+        t.enabled = true;
+        t.tx = tx;
+        t.account_index = index;
+        t.token_index = ti;
+        t.before = acc;
+        t.before_balance = has ? acc.tokens[ti] : Money();
+        MpnAccount upd = acc;
+        upd.address = tx.mpn_address;
+        if (!has) upd.tokens[ti] = Money{tx.amount.token_id, 0};
+        upd.tokens[ti].amount += tx.amount.amount;
+        Rec r;
+        B.touch(index, acc);
+        r.ev_tok = B.token_write(index, ti, upd.tokens[ti]);
+        w.acct[index] = upd;
+        r.leaf = B.account_write(index, upd, r.ev_tok);
+        out.push_back(std::move(t));
+        recs.push_back(r);
+    }
+    w.deposit_queue.swap(rest);
+    if (recs.empty()) return BZK_OK;
+    BZK_TRY(B.run());
+    const size_t first = out.size() - recs.size();
+    for (size_t k = 0; k < recs.size(); ++k) {
+        DepositTransition& t = out[first + k];
+        t.before_balances_hash = B.P.value(B.tok[recs[k].ev_tok].root_before);
+        t.balance_proof = B.proof(B.tok[recs[k].ev_tok]);
+        t.proof = B.proof(B.acc[recs[k].leaf]);
+        t.state_after = B.P.value(B.acc[recs[k].leaf].root_after);
+    }
+    return BZK_OK;
+}
+
 static ZkScalar deposit_aux(const std::vector<DepositTransition>& trs, int log4_batch) {
     std::vector<std::vector<ZkScalar>> items;
     for (auto& t : trs) {
@@ -790,6 +1141,69 @@ static void build_withdraws(bzk_mpn& w, int log4_batch, std::vector<WithdrawTran
         out.push_back(std::move(t));
     }
     w.withdraw_queue.swap(rest);
+}
+
+// withdraw::withdraw (src/mpn/withdraw.rs:10-259) with the Merkle work batched on the device (see DevBatch)
+static int32_t build_withdraws_dev(bzk_mpn& w, int log4_batch, std::vector<WithdrawTransition>& out, uint64_t& rejected) {
+    const size_t cap = (size_t)1 << (2 * log4_batch);
+    rejected = 0;
+    DevBatch B(w);
+    struct Rec { size_t ev_ti, ev_fi, leaf; };
+    std::vector<Rec> recs;
+    std::vector<WithdrawTx> rest;
+    for (const WithdrawTx& tx : w.withdraw_queue) {
+        if (out.size() == cap) { rest.push_back(tx); continue; }
+        long index = -1;
+        for (auto& kv : w.acct)
+            if (kv.second.address == tx.mpn_address) { index = (long)kv.first; break; }
+        if (index < 0) { ++rejected; continue; }
+        MpnAccount acc = w.get(index);
+        long ti = acc.find_token_index(w.L, tx.amount.token_id, false), fi = acc.find_token_index(w.L, tx.fee.token_id, false);
+        if (ti < 0 || fi < 0 || !acc.tokens.count(ti)) { ++rejected; continue; }
+        const Money acc_token = acc.tokens[ti];
+        if ((!(acc.address == PointAffine()) && !(tx.mpn_address == acc.address)) ||
+            !jubjub_verify(tx.mpn_address, tx.sign_message(), tx.sig) || tx.nonce != acc.withdraw_nonce + 1 ||
+            tx.amount.token_id != acc_token.token_id || tx.amount.amount > acc_token.amount) {
+            ++rejected;
+            continue;
+        }
+        MpnAccount upd = acc;
+        upd.address = tx.mpn_address;
+        upd.withdraw_nonce += 1;
+        upd.tokens[ti].amount -= tx.amount.amount;
+        if (!upd.tokens.count(fi)) { ++rejected; continue; }
+        const Money acc_fee = upd.tokens[fi];
+        if (tx.fee.token_id != acc_fee.token_id || tx.fee.amount > acc_fee.amount) { ++rejected; continue; }
+        WithdrawTransition t;
+        t.enabled = true;
+        t.tx = tx;
+        t.account_index = index; t.token_index = ti; t.fee_token_index = fi;
+        t.before = acc;
+        t.before_token_balance = acc_token;
+        t.before_fee_balance = acc_fee;
+        Rec r;
+        B.touch(index, acc);
+        r.ev_ti = B.token_write(index, ti, upd.tokens[ti]);
+        upd.tokens[fi].amount -= tx.fee.amount;
+        r.ev_fi = B.token_write(index, fi, upd.tokens[fi]);
+        w.acct[index] = upd;
+        r.leaf = B.account_write(index, upd, r.ev_fi);
+        out.push_back(std::move(t));
+        recs.push_back(r);
+    }
+    w.withdraw_queue.swap(rest);
+    if (recs.empty()) return BZK_OK;
+    BZK_TRY(B.run());
+    const size_t first = out.size() - recs.size();
+    for (size_t k = 0; k < recs.size(); ++k) {
+        WithdrawTransition& t = out[first + k];
+        t.before_token_hash = B.P.value(B.tok[recs[k].ev_ti].root_before);
+        t.token_balance_proof = B.proof(B.tok[recs[k].ev_ti]);
+        t.fee_balance_proof = B.proof(B.tok[recs[k].ev_fi]);
+        t.proof = B.proof(B.acc[recs[k].leaf]);
+        t.state_after = B.P.value(B.acc[recs[k].leaf].root_after);
+    }
+    return BZK_OK;
 }
 
 static ZkScalar withdraw_aux(const std::vector<WithdrawTransition>& trs, int log4_batch) {
@@ -951,6 +1365,15 @@ int32_t bzk_mpn_set_height(bzk_mpn* w, uint64_t height) {
     return BZK_OK;
 }
 
+// ctx non-NULL: the witness builders of this world (bzk_mpn_{update,deposit,withdraw}_synthesize, bzk_mpn_make_work) batch their
+// Merkle re-hashing on that context (DevBatch above) instead of hashing transaction by transaction on the host; NULL: host path.
+// The caller keeps the context alive and does not use it concurrently.  Same transitions and works, byte for byte.
+int32_t bzk_mpn_set_device(bzk_mpn* w, bzk_ctx* ctx) {
+    if (!w) return BZK_E_ARG;
+    w->dev = ctx;
+    return BZK_OK;
+}
+
 int32_t bzk_mpn_set_threads(bzk_mpn* w, int32_t n) {
     if (!w || n < 1) return BZK_E_ARG;
     w->threads = n;
@@ -1020,7 +1443,8 @@ int32_t bzk_mpn_update_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t
         const ZkScalar state = w->accounts->root();
         std::vector<UpdateTransition> trs;
         uint64_t fee_sum = 0, rejected = 0;
-        build_transitions(*w, (int)log4_batch, ft, trs, fee_sum, rejected);
+        if (w->dev) { const int32_t ds = build_transitions_dev(*w, (int)log4_batch, ft, trs, fee_sum, rejected); if (ds != BZK_OK) return ds; }
+        else build_transitions(*w, (int)log4_batch, ft, trs, fee_sum, rejected);
         double t1 = now();
         const uint64_t accepted = trs.size();
         while (trs.size() < ((size_t)1 << (2 * log4_batch))) trs.push_back(UpdateTransition::null(w->L, w->T));
@@ -1122,7 +1546,8 @@ int32_t bzk_mpn_deposit_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_
         const ZkScalar state = w->accounts->root();
         std::vector<DepositTransition> trs;
         uint64_t rejected = 0;
-        build_deposits(*w, (int)log4_batch, trs, rejected);
+        if (w->dev) { const int32_t ds = build_deposits_dev(*w, (int)log4_batch, trs, rejected); if (ds != BZK_OK) return ds; }
+        else build_deposits(*w, (int)log4_batch, trs, rejected);
         const uint64_t accepted = trs.size();
         const ZkScalar aux = deposit_aux(trs, (int)log4_batch);
         while (trs.size() < ((size_t)1 << (2 * log4_batch))) trs.push_back(DepositTransition::null(w->L, w->T));
@@ -1151,7 +1576,8 @@ int32_t bzk_mpn_withdraw_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8
         const ZkScalar state = w->accounts->root();
         std::vector<WithdrawTransition> trs;
         uint64_t rejected = 0;
-        build_withdraws(*w, (int)log4_batch, trs, rejected);
+        if (w->dev) { const int32_t ds = build_withdraws_dev(*w, (int)log4_batch, trs, rejected); if (ds != BZK_OK) return ds; }
+        else build_withdraws(*w, (int)log4_batch, trs, rejected);
         const uint64_t accepted = trs.size();
         const ZkScalar aux = withdraw_aux(trs, (int)log4_batch);
         while (trs.size() < ((size_t)1 << (2 * log4_batch))) trs.push_back(WithdrawTransition::null(w->L, w->T));
@@ -1539,15 +1965,18 @@ int32_t bzk_mpn_make_work(bzk_mpn* w, int32_t kind, const bzk_mpn_work_config* c
         uint64_t rejected = 0;
         if (kind == 2) {
             uint64_t fee_sum = 0;
-            build_transitions(*w, c.log4_update_batch, ZkScalar::one(), o.updates, fee_sum, rejected);
+            if (w->dev) { const int32_t ds = build_transitions_dev(*w, c.log4_update_batch, ZkScalar::one(), o.updates, fee_sum, rejected); if (ds != BZK_OK) return ds; }
+            else build_transitions(*w, c.log4_update_batch, ZkScalar::one(), o.updates, fee_sum, rejected);
             o.aux_data = h2(ZkScalar::one(), ZkScalar::from_u64(fee_sum));
         } else if (kind == 0) {
-            build_deposits(*w, c.log4_deposit_batch, o.deposits, rejected);
+            if (w->dev) { const int32_t ds = build_deposits_dev(*w, c.log4_deposit_batch, o.deposits, rejected); if (ds != BZK_OK) return ds; }
+            else build_deposits(*w, c.log4_deposit_batch, o.deposits, rejected);
             o.aux_data = deposit_aux(o.deposits, c.log4_deposit_batch);
         } else {
             for (auto& tx : w->withdraw_queue)
                 if (tx.payment.empty()) return BZK_E_ARG;  // queued with an opaque fingerprint: no wire form
-            build_withdraws(*w, c.log4_withdraw_batch, o.withdraws, rejected);
+            if (w->dev) { const int32_t ds = build_withdraws_dev(*w, c.log4_withdraw_batch, o.withdraws, rejected); if (ds != BZK_OK) return ds; }
+            else build_withdraws(*w, c.log4_withdraw_batch, o.withdraws, rejected);
             o.aux_data = withdraw_aux(o.withdraws, c.log4_withdraw_batch);
         }
         o.next_state = w->accounts->root();

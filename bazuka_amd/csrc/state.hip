@@ -321,6 +321,47 @@ int32_t compress_core(bzk_ctx* ctx, const Model& M, const uint64_t* loc_off, con
 
 }  // namespace
 
+namespace bzk {
+int32_t hash_plan_run(bzk_ctx* ctx, const uint8_t* uploaded, uint64_t n_up, const std::vector<HashGroup>& groups, std::vector<uint8_t>& hashed_out) {
+    if (!ctx || (n_up && !uploaded)) return BZK_E_ARG;
+    uint64_t n_hash = 0, n_idx = 0, widest = 0;
+    for (auto& g : groups) {
+        if (g.arity < 1 || g.arity > 16 || g.in.size() % g.arity) return BZK_E_ARG;
+        for (uint32_t id : g.in)
+            if (id >= n_up + n_hash) return BZK_E_INTERNAL;  // a group may only consume earlier values
+        n_hash += g.count();
+        n_idx += g.in.size();
+        widest = std::max<uint64_t>(widest, g.in.size());
+    }
+    hashed_out.assign((size_t)n_hash * 32, 0);
+    if (!n_hash) return BZK_OK;
+    (void)hipSetDevice(ctx->device);
+    BZK_TRY(ws_reserve(ctx, ws_pad((n_up + n_hash) * 32) + ws_pad(n_idx * 4) + ws_pad(widest * 32) + 4096));
+    WsCursor cur(ctx->ws);
+    Fr* d_vals = cur.take<Fr>(n_up + n_hash);
+    uint32_t* d_idx = cur.take<uint32_t>(n_idx);
+    Fr* d_in = cur.take<Fr>(widest);
+    std::vector<uint32_t> all;
+    all.reserve(n_idx);
+    for (auto& g : groups) all.insert(all.end(), g.in.begin(), g.in.end());
+    if (n_up) BZK_HIP(ctx, hipMemcpyAsync(d_vals, uploaded, (size_t)n_up * 32, hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(d_idx, all.data(), all.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t off = 0, out = n_up;
+    for (auto& g : groups) {
+        const uint64_t cnt = g.in.size();
+        if (!cnt) continue;
+        BZK_LAUNCH(ctx, "state_gather", state_gather_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (const Fr*)d_vals,
+                   (const uint32_t*)(d_idx + off), cnt, d_in);
+        BZK_TRY(poseidon_launch(ctx, d_in, g.arity, g.count(), d_vals + out));
+        off += cnt;
+        out += g.count();
+    }
+    BZK_HIP(ctx, hipMemcpyAsync(hashed_out.data(), d_vals + n_up, (size_t)n_hash * 32, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BZK_OK;
+}
+}  // namespace bzk
+
 extern "C" {
 
 int32_t bzk_state_model_default(const uint8_t* model, uint64_t model_len, uint8_t out[32]) {

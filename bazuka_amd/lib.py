@@ -71,6 +71,7 @@ SIGNATURES = {
     "bzk_mpn_destroy": (None, [_vp]),
     "bzk_mpn_set_height": (_i32, [_vp, _u64]),
     "bzk_mpn_set_threads": (_i32, [_vp, _i32]),
+    "bzk_mpn_set_device": (_i32, [_vp, _vp]),
     "bzk_mpn_add_account": (_i32, [_vp, _u64, _vp, _u32, _vp, _u64, _vp]),
     "bzk_mpn_add_key": (_i32, [_vp, _u64, _vp, _u32]),
     "bzk_mpn_root": (_i32, [_vp, _vp]),
@@ -804,6 +805,11 @@ class MpnWorld:
 
     def set_threads(self, n: int):
         _st(self.lib.bzk_mpn_set_threads(self.h, n), "set_threads")
+
+    def set_device(self, ctx):
+        """ctx: a Bzk context (kept alive by this object) whose GPU batches the builders' Merkle hashing; None: host path"""
+        self._dev = ctx
+        _st(self.lib.bzk_mpn_set_device(self.h, ctx.h if ctx is not None else None), "set_device")
 
     def add_account(self, index: int, seed: bytes, token_id: bytes, balance: int) -> bytes:
         out = C.create_string_buffer(64)

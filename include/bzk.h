@@ -296,6 +296,12 @@ int32_t bzk_mpn_create(uint32_t log4_tree, uint32_t log4_token_tree, bzk_mpn** o
 void bzk_mpn_destroy(bzk_mpn* w);
 int32_t bzk_mpn_set_height(bzk_mpn* w, uint64_t height);
 int32_t bzk_mpn_set_threads(bzk_mpn* w, int32_t n); /* worker threads of the witness generator (default: all cores) */
+/* SURVEY 8f-3 ("replacing the per-tx KV walk in prepare_works", src/mpn/mod.rs:353-414): with a context set, the builders below and
+ * bzk_mpn_make_work decide a batch from account DATA first and then re-hash its Merkle paths LEVEL BY LEVEL on the device - one
+ * batched Poseidon launch per tree level over all transactions of the batch (~L + T + 2 launches instead of ~50 sequential host
+ * hashes per transaction); the sibling inputs of those hashes are the transitions' Merkle proofs.  Transactions may share accounts.
+ * Same transitions / MpnWork bytes as the host path.  ctx NULL: back to the host path.  The ctx must outlive its use here. */
+int32_t bzk_mpn_set_device(bzk_mpn* w, bzk_ctx* ctx);
 /* account `index` := keys from `JubJub::generate_keys(seed)` (src/crypto/jubjub/mod.rs:112-124), token
  * slot 0 = (token_id, balance); pub_xy_out (optional) receives address x|y */
 int32_t bzk_mpn_add_account(bzk_mpn* w, uint64_t index, const uint8_t* seed, uint32_t seed_len, const uint8_t token_id[32],

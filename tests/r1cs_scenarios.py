@@ -25,9 +25,12 @@ SCENARIOS = {
 }
 
 
-def make_work(name):
+def make_work(name, dev=None):
+    """dev: a Bzk context - the validator-side builder then batches its Merkle hashing on the GPU (bzk_mpn_set_device)"""
     kind, L4, T4, B4 = SCENARIOS[name]
     w = L.MpnWorld(L4, T4)
+    if dev is not None:
+        w.set_device(dev)
     n_acct = 4 if B4 == 1 else 12
     for i in range(n_acct):
         w.add_account(i * 37 % (4 ** L4) if L4 > 3 else i, b"acct%d" % i, ZIESHA, 10 ** 9)
