@@ -326,19 +326,80 @@ def other_configs_section(ctx, dev):
                                      "ms": round(ms, 3), "Mhash_per_s": round(hashes / ms / 1e3, 2), "hashes": hashes,
                                      "roofline": hbm(32.0 * n_acct * (4 + 2 * ts) + 32.0 * hashes, ms)}
     del cells, toks
-    # NTT (a4): 64 B per element per transform in one HBM round trip, coset forward = the h stage's variant
+    # NTT (a4): 64 B per element per transform in one HBM round trip.  Timed: the plain forward transform (bellman `fft`) -
+    # since round 3 the form every transform of the h chain takes (the coset scalings ride on the neighbouring transforms' stores);
+    # the stand-alone coset transform (one more product per element on load) beside it
     for lg in (20, 24):
         d = rand_fr(1 << lg, lg)
-        ms = timeit(lambda: ctx.ntt_dev(d, lg, False, True))
-        out[f"ntt_2p{lg}"] = {"ms": round(ms, 4), "roofline": hbm(64.0 * (1 << lg), ms),
+        ms = timeit(lambda: ctx.ntt_dev(d, lg, False, False))
+        ms_coset = timeit(lambda: ctx.ntt_dev(d, lg, False, True))
+        out[f"ntt_2p{lg}"] = {"ms": round(ms, 4), "coset_ms": round(ms_coset, 4), "roofline": hbm(64.0 * (1 << lg), ms),
                               "alu": {"fr_products": (lg * (1 << lg)) // 2, "G_per_s": round(lg * (1 << lg) / 2 / ms / 1e6, 2), "peak": 162.9,
                                       "peak_source": "Fr29 product as dependent calls, profiles/r01_ubench_int.txt"}}
         del d
     a, b, c = rand_fr(1 << 20, 1), rand_fr(1 << 20, 2), rand_fr(1 << 20, 3)
     ms = timeit(lambda: ctx.groth16_h_dev(a, b, c, 20))
-    out["h_stage_2p20"] = {"what": "3 iNTT + 3 coset NTT + pointwise (a b - c) / Z + 1 inverse coset NTT", "ms": round(ms, 3),
+    out["h_stage_2p20"] = {"what": "3 iNTT + 3 coset NTT + pointwise (a b - c) / Z + 1 inverse coset NTT (fused chain: 7 launches pairs, no pointwise kernel)",
+                           "ms": round(ms, 3),
                            "roofline": hbm(7 * 64.0 * (1 << 20) + 128.0 * (1 << 20), ms)}
     del a, b, c
+    # general `ZkStateModel::compress` seam (row b): the MPN model at production depth over 4096 sparse accounts (one token each)
+    try:
+        import random as _r
+        rnd = _r.Random(5)
+
+        def mb(m):
+            if m[0] == "scalar":
+                return (0).to_bytes(4, "little")
+            if m[0] == "struct":
+                return (1).to_bytes(4, "little") + len(m[1]).to_bytes(8, "little") + b"".join(mb(f) for f in m[1])
+            return (2).to_bytes(4, "little") + bytes([m[1]]) + mb(m[2])
+        S_ = ("scalar",)
+        model = mb(("list", 15, ("struct", [S_, S_, S_, S_, ("list", 3, ("struct", [S_, S_]))])))
+        pairs = []
+        for a in rnd.sample(range(4 ** 15), 4096):
+            for j in range(4):
+                pairs.append(((a, j), _fr(rnd.randrange(1, 1 << 60))))
+            pairs.append(((a, 4, 0, 0), _fr(1)))
+            pairs.append(((a, 4, 0, 1), _fr(rnd.randrange(1, 1 << 40))))
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            h_, n_ = ctx.state_compress(model, pairs)
+            best = min(best, time.perf_counter() - t)
+        out["state_compress_sparse_mpn"] = {"what": "bzk_state_compress: MpnConfig::state_model (L = 15, T = 3), 4096 populated accounts = 24 576 (locator, scalar) pairs, "
+                                                    "~86 k hashes in 21 batched launches; includes the ctypes marshalling of the pairs",
+                                            "ms": round(best * 1e3, 2), "state_size": n_}
+    except Exception as e:
+        out["state_compress_sparse_mpn"] = {"error": repr(e)}
+    # validator-side work preparation (f-3): 256 update transactions at the production shape, host walk vs device batches
+    try:
+        from bazuka_amd import lib as L_
+        import json as _json
+        vks = [bytes.fromhex(h) for h in _json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))["verifying_keys_bincode_hex"]]
+        Z_ = _fr(1)
+        res = {}
+        for key, dev_on in (("host_s", False), ("device_s", True)):
+            w_ = L_.MpnWorld(15, 3)
+            if dev_on:
+                w_.set_device(ctx)
+            for i in range(512):
+                w_.add_account((i * 7919 + 1) % 4 ** 15, b"a%d" % i, Z_, 10 ** 12)
+            ts = []
+            for k in range(2):
+                for i in range(256):
+                    w_.push_tx((i * 7919 + 1) % 4 ** 15, ((256 + i) * 7919 + 1) % 4 ** 15, Z_, 100 + i + k, Z_, i % 7)
+                t = time.perf_counter()
+                wk = w_.make_work(2, vks, 1, log4_batches=(1, 1, 4))
+                ts.append(time.perf_counter() - t)
+                if k == 0:
+                    res[key + "_bytes"] = wk.encode()
+            res[key] = round(min(ts), 4)
+        out["mpn_make_work_256tx"] = {"what": "one update work of `prepare_works` (256 transactions, L = 15, T = 3): transitions with their Merkle proofs; "
+                                              "host = per-transaction walk of the sparse tree, device = bzk_mpn_set_device (one batched Poseidon launch per level)",
+                                      "host_s": res["host_s"], "device_s": res["device_s"], "same_work_bytes": res["host_s_bytes"] == res["device_s_bytes"]}
+    except Exception as e:
+        out["mpn_make_work_256tx"] = {"error": repr(e)}
     # G2 MSM (a6): 224 algorithmic bytes per (point, scalar) pair
     n = 1 << 20
     bases = torch.empty(n * 192, dtype=torch.uint8, device=dev)
