@@ -339,7 +339,7 @@ def other_configs_section(ctx, dev):
         del d
     a, b, c = rand_fr(1 << 20, 1), rand_fr(1 << 20, 2), rand_fr(1 << 20, 3)
     ms = timeit(lambda: ctx.groth16_h_dev(a, b, c, 20))
-    out["h_stage_2p20"] = {"what": "3 iNTT + 3 coset NTT + pointwise (a b - c) / Z + 1 inverse coset NTT (fused chain: 7 launches pairs, no pointwise kernel)",
+    out["h_stage_2p20"] = {"what": "3 iNTT + 3 coset NTT + pointwise (a b - c) / Z + 1 inverse coset NTT (fused chain since round 3: coset scaling on the inverse transforms' stores, pointwise step on the last transform's load)",
                            "ms": round(ms, 3),
                            "roofline": hbm(7 * 64.0 * (1 << 20) + 128.0 * (1 << 20), ms)}
     del a, b, c
@@ -489,6 +489,20 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("BZK_BENCH_SPAWN_ONLY"):
+        # CPU-side check of the launch path (tests/test_bench_spawn_cpu.py): the ranks rendezvous over gloo, pass a 128-byte group id
+        # from rank 0 to everybody exactly as the GPU run does, report it and leave - no device is touched
+        assert world == args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks"
+        if world > 1:
+            dist.init_process_group("gloo")
+            box = [bytes(range(128)) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            dist.barrier()
+            print(json.dumps({"spawn_only": True, "rank": rank, "world": world, "uid_ok": box[0] == bytes(range(128))}), flush=True)
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({"spawn_only": True, "rank": 0, "world": 1, "uid_ok": True}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU: libbzk has no CPU path"
     # BZK_BENCH_DRYRUN_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks
     # share devices, the 97-byte exchange goes through gloo on the host).  Never set by the driver; the line
@@ -666,7 +680,8 @@ def main():
                                            f"{W} window sums (192 B each) per MSM, Horner combine on the host") if mg else
                                           "torch.distributed all-gather of 97-byte partial sums + bzk_g1_sum (--partition points)"}
     if dry:
-        out["dryrun"] = f"ranks share GPUs, exchange over {dry}: NOT a measurement"
+        out["dryrun"] = (f"ranks share GPUs (rendezvous over {dry}; window sums exchanged through libbzk's shared-memory transport, RCCL refuses "
+                         "two ranks on one device): a rehearsal of the code path, NOT a measurement")
     # Second half of the metric: full Groth16 proofs/s.  Every rank proves its own batches (replicas).
     proofs, rates = None, []
     if not args.no_proofs:

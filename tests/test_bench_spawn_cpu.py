@@ -1,0 +1,45 @@
+"""CPU suite: `python bench.py --gpus N` with no launcher (how the driver may call it - VERDICT r2 item 1) becomes its own
+launcher: it re-executes under torch.distributed.run with N ranks on 127.0.0.1, the ranks rendezvous and rank 0's 128-byte group
+id reaches every rank (what bzk_mg_create_rank needs).  BZK_BENCH_SPAWN_ONLY stops the ranks before they touch a device."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None):
+    env = dict(os.environ, BZK_BENCH_SPAWN_ONLY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and "spawn_only" in ln]
+    return r, lines
+
+
+def test_bench_spawns_its_own_ranks():
+    r, lines = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(ln["rank"] for ln in lines) == [0, 1]
+    assert all(ln["world"] == 2 and ln["uid_ok"] for ln in lines)
+
+
+def test_bench_single_gpu_needs_no_launcher():
+    r, lines = _run(["--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert lines == [{"spawn_only": True, "rank": 0, "world": 1, "uid_ok": True}]
+
+
+def test_bench_under_an_external_launcher_is_not_respawned():
+    """the documented driver form: python -m torch.distributed.run ... bench.py --gpus 2"""
+    env = dict(os.environ, BZK_BENCH_SPAWN_ONLY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29713", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and "spawn_only" in ln]
+    assert sorted(ln["rank"] for ln in lines) == [0, 1] and all(ln["uid_ok"] for ln in lines)

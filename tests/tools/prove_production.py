@@ -2,7 +2,8 @@
 14 443 117 constraints, NTT domain 2^24 (src/config/blockchain.rs:22-26) - or any other B given on the command line.
 Product code end to end (host generator, CRS on the GPU, proof on the GPU); the proof is then checked with the
 oracle's pairing verifier against the batch's public inputs, and (optionally) byte-compared with the oracle prover.
-usage: python tests/tools/prove_production.py [log4_batch=4] [n_proofs=2] [compare_oracle=0]"""
+usage: python tests/tools/prove_production.py [log4_batch=4] [n_proofs=2] [compare_oracle=0] [device_builder=0]
+device_builder=1: the witness builder batches its Merkle hashing on the GPU (bzk_mpn_set_device)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -15,12 +16,14 @@ def fr(x):
     return (x * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little")
 
 
-def main(b=4, n_proofs=2, compare=0):
+def main(b=4, n_proofs=2, compare=0, device_builder=0):
     ZIESHA = fr(1)
     lg, t = 15, 3
     ctx = Bzk(0)
     n_tx = 1 << (2 * b)
     w = L.MpnWorld(lg, t)
+    if device_builder:
+        w.set_device(Bzk(0))
     for i in range(2 * n_tx):
         w.add_account(i, b"acct%d" % i, ZIESHA, 10 ** 12)
 
@@ -28,7 +31,7 @@ def main(b=4, n_proofs=2, compare=0):
         for i in range(n_tx):
             w.push_tx(i, n_tx + i, ZIESHA, 100 + i + k, ZIESHA, i % 7)
 
-    out = {"circuit": f"UpdateCircuit(L={lg},T={t},B={b}): {n_tx} tx"}
+    out = {"circuit": f"UpdateCircuit(L={lg},T={t},B={b}): {n_tx} tx", "witness_builder": "device (bzk_mpn_set_device)" if device_builder else "host"}
     t0 = time.perf_counter(); batch(0); out["sign_s"] = round(time.perf_counter() - t0, 3)
     t0 = time.perf_counter(); r = w.update_synthesize(b, fr(99), ZIESHA, record_matrices=True)
     out["synthesize_with_matrices_s"] = round(time.perf_counter() - t0, 2)
