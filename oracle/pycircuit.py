@@ -1142,3 +1142,146 @@ def all_views(cs):
     for which in "ABC":
         out["val" + which], out["col" + which], out["rp" + which] = csr_bytes(cs, which)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RECALLED bellman 0.14 behaviour, as a list a maintainer with Rust can tick off.
+# Everything above that is tagged [recalled] rests on these statements about the published crate (bellman = "0.14.0",
+# /root/reference/Cargo.toml:29 - un-vendored, so nothing in the reference tree confirms them).  Each entry names the bellman item
+# it restates, says what is assumed, and carries a check that pins THIS restatement to the statement (run by
+# tests/test_pycircuit_cpu.py::test_recalled_bellman_behaviours) - so that a divergence shows up as "the list is wrong", not as
+# an unexplained CRS mismatch.  The product's generator (bazuka_amd/csrc/host_r1cs.h) is compared with this module byte for byte.
+# ---------------------------------------------------------------------------------------------------------------------
+def _fresh():
+    return ConstraintSystem()
+
+
+def _chk_lc_appends():
+    lc = lc_add_term(lc_add_term([], 2, 5), 3, 5)
+    assert lc == [(5, 2), (5, 3)], "LinearCombination + (coeff, var) pushes a term; equal variables are NOT merged"
+    assert lc_sub_lc([(1, 1)], [(1, 1)]) == [(1, 1), (1, R_MOD - 1)], "lc - &other appends the negated terms"
+
+
+def _chk_one_is_input_zero():
+    cs = _fresh()
+    assert cs.inputs == [1] and cs.flat(ONE) == 0, "CS::one() = Variable(Index::Input(0)) with value 1; flat index 0"
+
+
+def _chk_alloc_num():
+    cs = _fresh()
+    a = AllocatedNum.alloc(cs, 7)
+    assert (cs.n_aux, len(cs.A)) == (1, 0) and a.var == 0, "AllocatedNum::alloc: one aux variable, no constraint"
+
+
+def _chk_inputize():
+    cs = _fresh()
+    a = AllocatedNum.alloc(cs, 7)
+    a.inputize(cs)
+    assert cs.inputs == [1, 7] and (cs.A[-1], cs.B[-1], cs.C[-1]) == ([(-2, 1)], [(ONE, 1)], [(a.var, 1)]), \
+        "AllocatedNum::inputize: alloc_input(value), then enforce input * ONE = var (lc!() + input, lc!() + CS::one(), lc!() + self.variable)"
+
+
+def _chk_num_mul():
+    cs = _fresh()
+    a, b = AllocatedNum.alloc(cs, 3), AllocatedNum.alloc(cs, 5)
+    c = a.mul(cs, b)
+    assert c.value == 15 and c.var == 2 and (cs.A[-1], cs.B[-1], cs.C[-1]) == ([(0, 1)], [(1, 1)], [(2, 1)]), \
+        "AllocatedNum::mul: product allocated AFTER both operands, one constraint a * b = out"
+
+
+def _chk_bit_alloc():
+    cs = _fresh()
+    b = AllocatedBit.alloc(cs, 1)
+    assert (cs.A[-1], cs.B[-1], cs.C[-1]) == ([(ONE, 1), (b.var, R_MOD - 1)], [(b.var, 1)], []), \
+        "AllocatedBit::alloc: (1 - a) * a = 0 with A = lc!() + CS::one() - var, B = lc!() + var, C = lc!()"
+
+
+def _chk_bit_alloc_conditionally():
+    cs = _fresh()
+    m = AllocatedBit.alloc(cs, 0)
+    b = AllocatedBit.alloc_conditionally(cs, 1, m)
+    assert cs.A[-1] == [(ONE, 1), (m.var, R_MOD - 1), (b.var, R_MOD - 1)] and cs.B[-1] == [(b.var, 1)] and cs.C[-1] == [], \
+        "AllocatedBit::alloc_conditionally: (1 - must_be_false - a) * a = 0, terms in that order"
+
+
+def _chk_bit_ops():
+    cs = _fresh()
+    a, b = AllocatedBit.alloc(cs, 1), AllocatedBit.alloc(cs, 0)
+    n = len(cs.A)
+    x = AllocatedBit.and_(cs, a, b)
+    y = AllocatedBit.and_not(cs, a, b)
+    z = AllocatedBit.nor(cs, a, b)
+    assert (x.value, y.value, z.value) == (0, 1, 0)
+    assert (cs.A[n], cs.B[n], cs.C[n]) == ([(a.var, 1)], [(b.var, 1)], [(x.var, 1)]), "AllocatedBit::and: a * b = out"
+    assert (cs.A[n + 1], cs.B[n + 1], cs.C[n + 1]) == ([(a.var, 1)], [(ONE, 1), (b.var, R_MOD - 1)], [(y.var, 1)]), "and_not: a * (1 - b) = out"
+    assert (cs.A[n + 2], cs.B[n + 2], cs.C[n + 2]) == ([(ONE, 1), (a.var, R_MOD - 1)], [(ONE, 1), (b.var, R_MOD - 1)], [(z.var, 1)]), \
+        "nor: (1 - a) * (1 - b) = out"
+    assert len(cs.A) == n + 3 and cs.n_aux == 5, "each of and / and_not / nor: ONE new aux variable, ONE constraint, no booleanity constraint on the result"
+
+
+def _chk_boolean_and_dispatch():
+    cs = _fresh()
+    a, b = Boolean.is_(AllocatedBit.alloc(cs, 1)), Boolean.is_(AllocatedBit.alloc(cs, 1))
+    n = cs.n_aux
+    assert Boolean.and_(cs, Boolean("const", const=True), b) is b and cs.n_aux == n, "Boolean::and with a constant allocates nothing"
+    Boolean.and_(cs, a, b.not_())
+    assert cs.B[-1] == [(ONE, 1), (b.bit.var, R_MOD - 1)], "Boolean::and(Is, Not) = AllocatedBit::and_not(is, not)"
+    Boolean.and_(cs, a.not_(), b.not_())
+    assert cs.A[-1] == [(ONE, 1), (a.bit.var, R_MOD - 1)], "Boolean::and(Not, Not) = AllocatedBit::nor"
+
+
+def _chk_to_bits_le_strict():
+    cs = _fresh()
+    a = AllocatedNum.alloc(cs, 5)
+    bits = a.to_bits_le_strict(cs)
+    assert len(bits) == 255 and [b.bit.value for b in bits[:4]] == [1, 0, 1, 0], "to_bits_le_strict: 255 Booleans, little-endian"
+    # r - 1 has 255 significant bits: one bit variable per bit (AllocatedBit::alloc on a one of r - 1, alloc_conditionally on a zero), and
+    # at every zero of r - 1 that closes a run of ones a kary_and over the run (+ the previous chain's result): len - 1 `and` gates
+    r1 = R_MOD - 1
+    gates, run, have_last = 0, 0, False
+    for i in range(254, -1, -1):
+        if (r1 >> i) & 1:
+            run += 1
+        elif run:
+            gates += run + (1 if have_last else 0) - 1
+            run, have_last = 0, True
+    assert run == 0, "r - 1 is even: its lowest bit is a zero, so no run of ones is left open"
+    assert cs.n_aux == 1 + 255 + gates and len(cs.A) == 255 + gates + 1, "one booleanity constraint per bit, one constraint per and gate, one packing constraint"
+    last = (cs.A[-1], cs.B[-1], cs.C[-1])
+    assert last[0] == [] and last[1] == [] and last[2][-1] == (a.var, R_MOD - 1) and len(last[2]) == 256, \
+        "packing constraint LAST: 0 * 0 = sum 2^i bit_i - self, bits from the least significant up, self appended at the end"
+    assert last[2][0][1] == 1 and last[2][1][1] == 2, "coefficients double from the FIRST term (the least significant bit)"
+
+
+def _chk_input_rows():
+    cs = _fresh()
+    AllocatedNum.alloc(cs, 9).inputize(cs)
+    A, B, C = cs.rows("A"), cs.rows("B"), cs.rows("C")
+    assert A[-2:] == [[(0, 1)], [(1, 1)]] and B[-2:] == [[], []] and C[-2:] == [[], []], \
+        "generator and prover append one `input_i * 0 = 0` row per input (A = the input, B = C = empty) AFTER the circuit's rows"
+
+
+def _chk_density_rule():
+    cs = _fresh()
+    a = AllocatedNum.alloc(cs, 4)
+    cs.enforce([(a.var, 0)], [(a.var, 1)], [])
+    z = cs.z()
+    assert cs.eval_lc(cs.A[0]) == 0 and z[cs.flat(a.var)] == 4
+    # prover.rs `eval`: a term with a ZERO coefficient is skipped before the density tracker is touched (`if coeff.is_zero() { continue }`),
+    # so the variable counts as dense for B (coefficient 1) and not for A; tests/test_pycircuit_cpu.py derives the density maps this way
+
+
+RECALLED_BELLMAN = [
+    ("LinearCombination: `+ (coeff, var)`, `+ &lc`, `- &lc` append terms, never merge equal variables", "bellman::LinearCombination (lc.rs)", _chk_lc_appends),
+    ("ConstraintSystem::one() is Input(0) with value 1", "bellman::ConstraintSystem::one", _chk_one_is_input_zero),
+    ("AllocatedNum::alloc: one aux, no constraint", "bellman::gadgets::num::AllocatedNum::alloc", _chk_alloc_num),
+    ("AllocatedNum::inputize: alloc_input + `input * 1 = var`", "bellman::gadgets::num::AllocatedNum::inputize", _chk_inputize),
+    ("AllocatedNum::mul: out allocated after the operands, `a * b = out`", "bellman::gadgets::num::AllocatedNum::mul", _chk_num_mul),
+    ("AllocatedBit::alloc: `(1 - a) * a = 0`", "bellman::gadgets::boolean::AllocatedBit::alloc", _chk_bit_alloc),
+    ("AllocatedBit::alloc_conditionally: `(1 - must_be_false - a) * a = 0`", "bellman::gadgets::boolean::AllocatedBit::alloc_conditionally", _chk_bit_alloc_conditionally),
+    ("AllocatedBit::{and, and_not, nor}: one aux + one constraint each, forms a*b, a*(1-b), (1-a)*(1-b)", "bellman::gadgets::boolean::AllocatedBit", _chk_bit_ops),
+    ("Boolean::and dispatch: constants fold, (Is, Not) -> and_not, (Not, Not) -> nor", "bellman::gadgets::boolean::Boolean::and", _chk_boolean_and_dispatch),
+    ("AllocatedNum::to_bits_le_strict: walk r - 1 from the top, kary_and per run, packing constraint last", "bellman::gadgets::num::AllocatedNum::to_bits_le_strict", _chk_to_bits_le_strict),
+    ("n_in trailing `input_i * 0 = 0` rows appended by generator and prover", "bellman::groth16::{generator, prover}", _chk_input_rows),
+    ("density: a variable is dense in A / B iff it occurs there with a non-zero coefficient", "bellman::groth16::prover::eval + DensityTracker", _chk_density_rule),
+]

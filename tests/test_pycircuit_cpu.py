@@ -217,3 +217,14 @@ def test_decompress_restatement():
         assert pc.pt_decompress(pub[0], pub[1] & 1) == pub
     assert pc.pt_decompress(0, False) == (0, pr.R_MOD - 1) and pc.pt_is_on_curve((0, pr.R_MOD - 1))
     assert pc.base_cofactor() == pr.jj_mul(pr.JJ_BASE, 8)
+
+
+def test_recalled_bellman_behaviours():
+    """every behaviour of bellman 0.14 that the R1CS parity rests on and the reference tree cannot confirm (un-vendored crate) is a
+    named entry of oracle/pycircuit.py::RECALLED_BELLMAN with the bellman item it restates and an executable statement of the
+    assumption: a maintainer with Rust checks the list; here each check pins the restatement to its statement"""
+    from oracle import pycircuit as pc
+    assert len(pc.RECALLED_BELLMAN) >= 12
+    for what, item, check in pc.RECALLED_BELLMAN:
+        assert item.startswith("bellman::") and what
+        check()
