@@ -251,9 +251,9 @@ int32_t bzk_params_slot(bzk_ctx* ctx, const bzk_params* src, bzk_params** out) {
 
 // Resident forms of the CRS, built once per device under the CRS mutex by whichever slot proves first:
 //   l, a, b_g1, b_g2 (and h where no table is built) -> bzk_msm_bases (internal limb form: no conversion inside a proof)
-//   h                                                -> full static table with a 20-bit window for 2^16 .. 2^21 domains (13 levels x 112 B x m:
-//                                                        1.5 GB at 2^20, 3 GB at 2^21; env BZK_PROVE_H_TABLE_MAX_LOG raises the limit, e.g. 24 =
-//                                                        24 GB for the production domain; BZK_PROVE_H_TABLE=0 switches the table off)
+//   h                                                -> full static table with a 20-bit window for 2^16 .. 2^24 domains (13 levels x 112 B x m:
+//                                                        1.5 GB at 2^20, 24 GB at the production 2^24; env BZK_PROVE_H_TABLE_MAX_LOG moves the
+//                                                        limit; BZK_PROVE_H_TABLE=0 switches the table off)
 // Memory policy: a resident form is only built when hipMemGetInfo shows its size plus a reserve for the provers' grow-only
 // workspaces free; anything that does not fit is simply not built (the per-call pipeline on the raw bases works without it), and
 // bzk_groth16_prove drops the table and retries once if a workspace allocation fails later while it is the CRS's only user.
@@ -271,7 +271,7 @@ static void crs_prepare(bzk_ctx* ctx, CrsShared* c) {
     static const bool want_res = [] { const char* e = getenv("BZK_PROVE_RESIDENT_BASES"); return !e || atoi(e) != 0; }();
     static const uint32_t max_log = [] {
         const char* e = getenv("BZK_PROVE_H_TABLE_MAX_LOG");
-        const int v = e ? atoi(e) : 21;
+        const int v = e ? atoi(e) : 24;  // round 3: one table per DEVICE (shared by the slots), so the production 2^24 domain's 24 GB is affordable by default
         return (uint32_t)(v < 16 ? 16 : (v > 26 ? 26 : v));
     }();
     // reserve: what the slots of this device may still allocate - MSM workspaces of the five lanes (~40 B x 16 windows per point) x 4 slots

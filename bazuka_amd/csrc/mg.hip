@@ -421,8 +421,10 @@ extern "C" {
 
 int32_t bzk_mg_unique_id(uint8_t uid[BZK_MG_UID_BYTES]) {
     if (!uid) return BZK_E_ARG;
-    RcclApi* R = rccl_api();
-    if (R->ok()) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
+    RcclApi* R = n_dev > 0 ? rccl_api() : nullptr;  // without a device RCCL has nothing to offer (and says so loudly)
+    if (R && R->ok()) {
         ncclUniqueId id;
         if (R->GetUniqueId(&id) == ncclSuccess) {
             memcpy(uid, id.internal, BZK_MG_UID_BYTES);

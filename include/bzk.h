@@ -228,8 +228,8 @@ void bzk_params_free(bzk_ctx* ctx, bzk_params* params);
  * h table (reference-counted; the last bzk_params_free releases them): n slots cost n x scratch, not n x CRS. */
 int32_t bzk_params_slot(bzk_ctx* ctx, const bzk_params* params, bzk_params** out);
 /* The first proof over a CRS builds, ONCE per device and only where hipMemGetInfo shows room for them beside a workspace reserve,
- * the resident internal forms of l / a / b_g1 / b_g2 (no base conversion inside a proof) and, for 2^16 .. 2^21 domains, a static
- * table of the h query (13 levels: 1.5 GB at 2^20).  bzk_params_h_table(.., 1) builds that table now, for any domain size that
+ * the resident internal forms of l / a / b_g1 / b_g2 (no base conversion inside a proof) and, for 2^16 .. 2^24 domains, a static
+ * table of the h query (13 levels: 1.5 GB at 2^20, 24 GB at the production 2^24 - one per DEVICE, shared by the slots).  bzk_params_h_table(.., 1) builds that table now, for any domain size that
  * fits; (.., 0) drops it / keeps the first proof from building it (only while this handle is the CRS's sole slot).  Environment:
  * BZK_PROVE_H_TABLE=0, BZK_PROVE_H_TABLE_MAX_LOG, BZK_PROVE_RESIDENT_BASES=0. */
 int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* params, int32_t on);
