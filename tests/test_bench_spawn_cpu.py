@@ -3,10 +3,16 @@ launcher: it re-executes under torch.distributed.run with N ranks on 127.0.0.1, 
 id reaches every rank (what bzk_mg_create_rank needs).  BZK_BENCH_SPAWN_ONLY stops the ranks before they touch a device."""
 import json
 import os
+import re
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _reports(stdout):
+    """the ranks share one stdout: their one-line reports may land on the same line"""
+    return [json.loads(m) for m in re.findall(r'\{"spawn_only".*?\}', stdout)]
 
 
 def _run(args, extra_env=None):
@@ -15,8 +21,7 @@ def _run(args, extra_env=None):
         env.pop(k, None)
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and "spawn_only" in ln]
-    return r, lines
+    return r, _reports(r.stdout)
 
 
 def test_bench_spawns_its_own_ranks():
@@ -37,9 +42,13 @@ def test_bench_under_an_external_launcher_is_not_respawned():
     env = dict(os.environ, BZK_BENCH_SPAWN_ONLY="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29713", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and "spawn_only" in ln]
+    lines = _reports(r.stdout)
     assert sorted(ln["rank"] for ln in lines) == [0, 1] and all(ln["uid_ok"] for ln in lines)
