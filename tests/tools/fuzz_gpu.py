@@ -41,8 +41,71 @@ def main(seconds=60, seed=1):
     counts = {}
     t_end = time.time() + seconds
     while time.time() < t_end:
-        kind = rnd.choice(("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows", "table", "window_size"))
+        kind = rnd.choice(("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows", "table", "window_size",
+                           "bases", "mg", "h_chain", "state"))
         counts[kind] = counts.get(kind, 0) + 1
+        if kind in ("bases", "mg"):  # round 3: resident base sets, device groups (several contexts on this one GPU)
+            import torch
+            from bazuka_amd import Mg
+            g2 = rnd.random() < 0.25
+            n = rnd.choice((1, 3, 300, 5000, 20000)) if not g2 else rnd.choice((1, 300, 5000))
+            bases = (co.g2_bases if g2 else co.g1_bases)(rnd.randrange(1 << 30), 0, n, nthreads=nt)
+            sc = scalars(rnd, n)
+            want = (co.msm_g2 if g2 else co.msm_g1)(bases, sc, nthreads=nt)
+            dd = rnd.random() < 0.5
+            if kind == "bases":
+                db = torch.frombuffer(bytearray(bases), dtype=torch.uint8).cuda(); ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+                torch.cuda.synchronize()
+                hb = ctx.msm_bases_load_dev(db, n, g2=g2)
+                assert ctx.msm_bases_run_dev(hb, ds, n, g2=g2, dedup=dd) == want, (kind, n, g2, dd)
+                W = ctx.msm_window_count(n)
+                cut = sorted({0, W, rnd.randrange(W + 1)})
+                parts = b"".join(ctx.msm_bases_windows_dev(hb, ds, n, a, b, g2=g2) for a, b in zip(cut, cut[1:]))
+                assert (ctx.g2_sum if g2 else ctx.g1_sum)(parts) == want, (kind, n, cut)
+                ctx.msm_bases_free(hb)
+            else:
+                mg = Mg(devices=[0] * rnd.randrange(1, 5), exchange=rnd.choice((1, 2)))
+                hb = mg.bases_load(bases, n, g2=g2)
+                assert mg.msm(hb, sc, n, g2=g2, dedup=dd) == want, (kind, n, g2, dd, mg.world, mg.exchange)
+                mg.bases_free(hb)
+                mg.close()
+            continue
+        if kind == "h_chain":  # the fused h chain against the oracle's seven transforms + pointwise
+            import torch
+            lg = rnd.randrange(1, 15)
+            m = 1 << lg
+            rows = rnd.randrange(1, m + 1)
+            az, bz, cz = (rand_scalars_bytes(rows, rnd.randrange(1 << 30)) for _ in range(3))
+            pad = bytes(32 * (m - rows))
+            d = [torch.frombuffer(bytearray(x + pad), dtype=torch.uint8).cuda() for x in (az, bz, cz)]
+            torch.cuda.synchronize()
+            ctx.groth16_h_dev(d[0], d[1], d[2], lg)
+            torch.cuda.synchronize()
+            assert bytes(d[0].cpu().numpy().tobytes())[: 32 * (m - 1)] == co.groth16_h(az, bz, cz, lg, nthreads=nt), (kind, lg, rows)
+            continue
+        if kind == "state":  # general ZkStateModel::compress against the general Python restatement (small cases: pure-Python Poseidon)
+            import pystate as ps
+            def rmodel(depth):
+                k = rnd.random()
+                if depth == 0 or k < 0.3:
+                    return ("scalar",)
+                if k < 0.65:
+                    return ("struct", [rmodel(depth - 1) for _ in range(rnd.randint(1, 4))])
+                return ("list", rnd.randint(0, 3), rmodel(depth - 1))
+            def rloc(model):
+                loc = []
+                while model[0] != "scalar":
+                    if model[0] == "struct":
+                        f = rnd.randrange(len(model[1])); loc.append(f); model = model[1][f]
+                    else:
+                        loc.append(rnd.randrange(4 ** model[1])); model = model[2]
+                return tuple(loc)
+            model = rmodel(3)
+            pairs = {rloc(model): rnd.choice((0, 1, rnd.randrange(pr.R_MOD))) for _ in range(rnd.choice((0, 1, 4, 30)))}
+            got = ctx.state_compress(ps.model_bincode(model), [(k, pr.fr_to_mont_bytes(v)) for k, v in pairs.items()])
+            wh, wn = ps.compress(model, pairs)
+            assert got == (pr.fr_to_mont_bytes(wh), wn), (kind, model, pairs)
+            continue
         if kind in ("table", "window_size"):
             import torch
             n = rnd.choice((1, 5, 300, 2000, 6000))

@@ -58,12 +58,9 @@ def main(n_proofs=600, n_slots=1):
     for x in th:
         x.start()
     slots = [(ctx, ph)]
-    csr2 = None
-    for _ in range(n_slots - 1):
-        if csr2 is None:
-            csr2 = [(r.n_constraints, r.view("rp" + x), r.view("col" + x), r.view("val" + x)) for x in "ABC"]
+    for _ in range(n_slots - 1):  # further slots share the device-resident CRS of the first (bzk_params_slot, round 3)
         cx = Bzk(0)
-        slots.append((cx, cx.groth16_setup(csr2, r.n_in, r.n_aux, b"".join(fr(x) for x in (11, 22, 33, 44, 55)))[0]))
+        slots.append((cx, cx.params_slot(ph)))
     marks = []
     lock = threading.Lock()
     state = {"taken": 0, "done": 0, "bad": 0, "checked": 0}
