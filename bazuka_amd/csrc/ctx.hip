@@ -53,7 +53,9 @@ bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
         // lane 0 carries the job with the longest latency-bound tail (the G2 MSM of a proof): its stream gets the
         // highest priority so that this tail is reached early and hides under the other lanes' accumulation
         hipStream_t s = nullptr;
-        if (ctx->lanes.empty()) {
+        // env BZK_PRIO (A/B runs): "g2" (default) = lane 0 high; "main" = the ctx's own stream high (bzk_ctx_create), lanes normal; "none"
+        static const bool lane0_high = [] { const char* e = getenv("BZK_PRIO"); return !e || !strcmp(e, "g2"); }();
+        if (ctx->lanes.empty() && lane0_high) {
             int lo = 0, hi = 0;
             if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
                 (void)hipGetLastError();
@@ -174,7 +176,15 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        static const bool main_high = [] { const char* e = getenv("BZK_PRIO"); return e && !strcmp(e, "main"); }();
+        int lo = 0, hi = 0;
+        hipError_t e = hipErrorUnknown;
+        if (main_high && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        }
+        if (e != hipSuccess) {
             delete ctx;
             return BZK_E_DEVICE;
         }

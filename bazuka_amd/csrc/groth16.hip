@@ -413,8 +413,10 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     // polynomial is computed on the main stream.
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
-    bzk_ctx* lane[3];
-    for (int i = 0; i < 3; ++i)
+    // env BZK_PROVE_LANES=4: b_g1 on a lane of its own instead of behind l (A/B: the end of a proof is then four tails side by side)
+    static const int n_lanes = [] { const char* e = getenv("BZK_PROVE_LANES"); return e && atoi(e) == 4 ? 4 : 3; }();
+    bzk_ctx* lane[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < n_lanes; ++i)
         if (!(lane[i] = bzk::ctx_lane(ctx, (size_t)i))) return BZK_E_DEVICE;
     BZK_HIP(ctx, hipMemcpyAsync(slot->d_z, asg->z, nv * 32, hipMemcpyHostToDevice, ctx->stream));
     // density-filtered scalar vectors
@@ -425,10 +427,10 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     if (!ctx->ev_z) BZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
     const hipEvent_t z_ready = ctx->ev_z;
     BZK_HIP(ctx, hipEventRecord(z_ready, ctx->stream));
-    for (int i = 0; i < 3; ++i) BZK_HIP(ctx, hipStreamWaitEvent(lane[i]->stream, z_ready, 0));
+    for (int i = 0; i < n_lanes; ++i) BZK_HIP(ctx, hipStreamWaitEvent(lane[i]->stream, z_ready, 0));
     const auto t1 = clk::now();
     uint8_t pH[97], pL[97], pA[97], pB1[97], pB2[193];
-    int32_t st[3] = {BZK_OK, BZK_OK, BZK_OK};
+    int32_t st[4] = {BZK_OK, BZK_OK, BZK_OK, BZK_OK};
     const int dev = ctx->device;
     // env BZK_PROVE_SERIAL=1: the same five MSMs one after the other on the lanes' streams (clean per-kernel event
     // timings for profiling; the lanes otherwise overlap and stretch each other's intervals)
@@ -444,21 +446,31 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     auto g1 = [&](bzk_ctx* c, const bzk_msm_bases* res, const void* raw, const void* sc, uint64_t n, uint32_t fl, uint8_t* out) {
         return res ? bzk_msm_g1_bases_run_dev(c, res, sc, n, fl, out) : bzk_msm_g1_dev(c, raw, sc, n, fl, out);
     };
+    double lane_done_ms[4] = {0, 0, 0, 0};  // BZK_TIMING: when each lane's host thread returned, relative to t0
+    auto stamp = [&](int i) { lane_done_ms[i] = std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     auto job0 = [&] {
         (void)hipSetDevice(dev);
         st[0] = p->rb2 ? bzk_msm_g2_bases_run_dev(lane[0], p->rb2, slot->d_sb, p->n_b, wflags, pB2)
                        : bzk_msm_g2_dev(lane[0], p->b_g2, slot->d_sb, p->n_b, wflags, pB2);
+        stamp(0);
     };
     auto job1a = [&] { st[1] = g1(lane[1], p->rl, p->l, z_aux, p->n_aux, wflags, pL); };
     auto job1b = [&] { if (st[1] == BZK_OK) st[1] = g1(lane[1], p->rb1, p->b_g1, slot->d_sb, p->n_b, wflags, pB1); };
     auto job1 = [&] {
         (void)hipSetDevice(dev);
         job1a();
-        job1b();
+        if (n_lanes == 3) job1b();
+        stamp(1);
+    };
+    auto job3 = [&] {  // four-lane form: b_g1 beside l
+        (void)hipSetDevice(dev);
+        st[3] = g1(lane[3], p->rb1, p->b_g1, slot->d_sb, p->n_b, wflags, pB1);
+        stamp(3);
     };
     auto job2 = [&] {
         (void)hipSetDevice(dev);
         st[2] = g1(lane[2], p->ra, p->a, slot->d_sa, p->n_a, wflags, pA);
+        stamp(2);
     };
     if (serial) {
         auto dump = [&](int i, const char* what) {
@@ -480,6 +492,7 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
         bzk::lane_post(ctx, 0, job0);
         bzk::lane_post(ctx, 1, job1);
         bzk::lane_post(ctx, 2, job2);
+        if (n_lanes == 4) bzk::lane_post(ctx, 3, job3);
     }
     // main stream: stage the evaluations, h polynomial, h MSM
     int32_t st_main = BZK_OK;
@@ -499,10 +512,10 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     st_main = main_part();
     const auto t3 = clk::now();
     if (!serial)
-        for (size_t i = 0; i < 3; ++i) bzk::lane_wait(ctx, i);  // always: the jobs reference this frame
+        for (size_t i = 0; i < (size_t)n_lanes; ++i) bzk::lane_wait(ctx, i);  // always: the jobs reference this frame
     const auto t4 = clk::now();
     if (st_main != BZK_OK) return st_main;
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < n_lanes; ++i)
         if (st[i] != BZK_OK) {
             ctx->last_error = "lane " + std::to_string(i) + ": " + lane[i]->last_error;
             return st[i];
@@ -536,8 +549,10 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     pack_g1(gc, proof + 290);
     if (ctx->timing) {
         auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[bzk] groth16_prove: z staged %.2f ms, lanes started %.2f, h chain %.2f, lanes joined +%.2f, assembly %.2f\n",
-                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, clk::now()));
+        fprintf(stderr, "[bzk] groth16_prove: z staged %.2f ms, lanes started %.2f, h chain %.2f, lanes joined +%.2f, assembly %.2f; lanes done at "
+                        "b_g2 %.2f, l%s %.2f, a %.2f, b_g1 %.2f, main %.2f ms\n",
+                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, clk::now()), lane_done_ms[0], n_lanes == 3 ? "+b_g1" : "", lane_done_ms[1],
+                lane_done_ms[2], lane_done_ms[3], ms(t0, t3));
     }
     return BZK_OK;
 }

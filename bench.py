@@ -552,7 +552,23 @@ def main():
     elif not by_points:
         box = [mg_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        mg = Mg(device=local_rank, rank=rank, world=world, uid=box[0], exchange=1 if dry else 0)  # ranks sharing a GPU: shared memory
+        # ranks sharing a GPU (rehearsal) use the shared-memory transport outright; otherwise AUTO (RCCL over xGMI), and if ANY rank
+        # fails to build its RCCL communicator every rank falls back to the shared-memory transport together - the run then still
+        # measures the sharded MSM, and the line says which transport carried it
+        want_x = 1 if dry else int(os.environ.get("BZK_BENCH_MG_EXCHANGE", "0"))
+        try:
+            mg = Mg(device=local_rank, rank=rank, world=world, uid=box[0], exchange=want_x)
+        except Exception as e:  # noqa: BLE001 - any failure counts
+            print(f"[bench] rank {rank}: device group with exchange {want_x} failed: {e!r}", file=sys.stderr, flush=True)
+            mg = None
+        ok = torch.tensor([1 if mg is not None else 0], dtype=torch.int32, device="cpu" if dry else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if mg is not None:
+                mg.close()
+            box = [mg_unique_id() if rank == 0 else None]   # a fresh id: the first one may have been consumed by a half-built group
+            dist.broadcast_object_list(box, src=0)
+            mg = Mg(device=local_rank, rank=rank, world=world, uid=box[0], exchange=1)
         mg_bases = mg.bases_load_dev([bases], n)
         pctx = Bzk(local_rank, handle=mg.ctx_handle(0))
 
