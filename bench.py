@@ -191,9 +191,13 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     q = queue.Queue(maxsize=4)
     stop = threading.Event()
 
+    prod_dev = os.environ.get("BZK_BENCH_PRODUCER_DEV", "0") != "0"
+
     def producer(seed):
         pw = L.MpnWorld(lg, t)
         pw.set_threads(prod_threads)
+        if prod_dev:  # A/B: the producers' Merkle hashing in batched launches on the GPU (bzk_mpn_set_device) instead of on their host threads
+            pw.set_device(Bzk(ctx.device))
         for i in range(2 * n_tx):
             pw.add_account(i, b"p%dacct%d" % (seed, i), ZIESHA, 10 ** 12)
         k = 0
@@ -253,7 +257,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     finished.sort()  # completion times: rate over the n_pipe completions after the first n_warm
     out["proofs_per_s_pipelined"] = round(n_pipe / (finished[n_warm + n_pipe - 1] - finished[n_warm - 1]), 3)
     out["producer_synth_s_mean_under_load"] = round(sum(synth_s) / len(synth_s), 4)
-    out["pipeline"] = (f"{n_prod} host producers ({prod_threads} worker threads each) -> {len(slots)} prover slots on 1 GPU, "
+    out["pipeline"] = (f"{n_prod} host producers ({prod_threads} worker threads each{', tree hashing on the device' if prod_dev else ''}) -> {len(slots)} prover slots on 1 GPU, "
                        f"{n_pipe} proofs timed (after {n_warm}, before the last {n_drain})")
     stop.set()
     for th in threads:
