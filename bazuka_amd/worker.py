@@ -80,6 +80,8 @@ class DevSetup:
         """cache_dir: keep each generated CRS on disk (one file per circuit shape and toxic waste) so that a restarted
         worker uploads it with bzk_params_load instead of regenerating it (minutes for the production circuits)"""
         self.bzk, self.toxic, self.cache, self.cache_dir = bzk, toxic_by_kind, {}, cache_dir
+        import threading
+        self._lock = threading.Lock()  # several prover slots may ask for the same shape at once: generate / load it once
 
     def shape_circuit(self, kind: int, L4: int, T4: int, B4: int) -> L.R1cs:
         z = bytes(32)
@@ -90,6 +92,10 @@ class DevSetup:
     def keys(self, kind: int, L4: int, T4: int, B4: int):
         """(params handle, bincode Groth16VerifyingKey) for a circuit shape"""
         key = (kind, L4, T4, B4)
+        with self._lock:
+            return self._keys_locked(key, kind, L4, T4, B4)
+
+    def _keys_locked(self, key, kind, L4, T4, B4):
         if key not in self.cache:
             path = None
             if self.cache_dir:
@@ -175,9 +181,15 @@ class BellmanKeys:
 
     def __init__(self, bzk: L.Bzk, path_by_kind: dict[int, str]):
         self.bzk, self.paths, self.cache = bzk, path_by_kind, {}
+        import threading
+        self._lock = threading.Lock()
 
     def keys(self, kind: int, L4: int, T4: int, B4: int):
         key = (kind, L4, T4, B4)
+        with self._lock:
+            return self._keys_locked(key, kind, L4, T4, B4)
+
+    def _keys_locked(self, key, kind, L4, T4, B4):
         if key not in self.cache:
             r = DevSetup.shape_circuit(None, kind, L4, T4, B4)
             with open(self.paths[kind], "rb") as f:
@@ -198,15 +210,43 @@ class BellmanKeys:
         self.cache = {}
 
 
+class SlotKeys:
+    """Key source of a FURTHER prover slot on a device whose first slot already holds the keys: the slot shares the device-resident
+    CRS (its resident base sets and h table included) through bzk_params_slot and owns only its per-proof scratch."""
+
+    def __init__(self, bzk: L.Bzk, first_keys):
+        self.bzk, self.first, self.cache = bzk, first_keys, {}
+
+    def __call__(self, work: L.MpnWork):  # called from this slot's thread only
+        ph0 = self.first(work)
+        key = ph0.value
+        if key not in self.cache:
+            self.cache[key] = self.bzk.params_slot(ph0)
+        return self.cache[key]
+
+    def close(self):
+        for ph in self.cache.values():
+            self.bzk.params_free(ph)
+        self.cache = {}
+
+
 # ---- the loop ----------------------------------------------------------------------------------------------------------
 class Worker:
     def __init__(self, bzk: L.Bzk, address: bytes, node: tuple[str, int], params_for, flags: int = 0, threads: int = 0,
-                 rng=os.urandom, timeout_s: float = 30.0, self_check: bool = False):
+                 rng=os.urandom, timeout_s: float = 30.0, self_check: bool = False, extra_slots=()):
         """self_check: verify every proof on the host with the work's own verifying key before posting it (bzk_groth16_verify =
-        the check the node will run, src/mpn/mod.rs:281-295; ~20 ms of one core per proof) - a proof that fails is not posted"""
+        the check the node will run, src/mpn/mod.rs:281-295; ~20 ms of one core per proof) - a proof that fails is not posted.
+        extra_slots: further (Bzk, params_for) prover slots - more slots on the same GPU (params_for = SlotKeys: shared CRS) and / or
+        slots on other GPUs of the node (their own key source).  The works of a round are then proved side by side, one host thread
+        per slot taking works from a common queue: replicas, as the node's own pool hands a block's proofs to several provers
+        (src/mpn/mod.rs:79-107)."""
         self.bzk, self.address, self.node, self.params_for = bzk, address, node, params_for
+        self.slots = [(bzk, params_for)] + list(extra_slots)
         self.flags, self.threads, self.rng, self.timeout_s, self.self_check = flags, threads, rng, timeout_s, self_check
-        self.stats = {"fetched": 0, "proved": 0, "accepted": 0, "unsat": 0, "self_check_failed": 0, "synth_s": 0.0, "prove_s": 0.0}
+        self.stats = {"fetched": 0, "proved": 0, "accepted": 0, "unsat": 0, "self_check_failed": 0, "synth_s": 0.0, "prove_s": 0.0,
+                      "proved_by_slot": [0] * len(self.slots)}
+        import threading
+        self._lock = threading.Lock()
 
     def _http(self, method: str, path: str, body: bytes) -> bytes:
         conn = http.client.HTTPConnection(self.node[0], self.node[1], timeout=self.timeout_s)
@@ -229,26 +269,30 @@ class Worker:
         self.stats["fetched"] += len(works)
         return works
 
-    def prove(self, work: L.MpnWork) -> bytes | None:
+    def prove(self, work: L.MpnWork, slot: int = 0) -> bytes | None:
         """387 proof bytes for the work, or None when the work's witness does not satisfy its circuit (a proof of it
-        could only be rejected by the node)."""
+        could only be rejected by the node).  slot: which prover slot runs it."""
+        bzk, params_for = self.slots[slot]
         t0 = time.perf_counter()
         r1cs = work.synthesize(self.address, threads=self.threads)
         t1 = time.perf_counter()
-        self.stats["synth_s"] += t1 - t0
         if not r1cs.satisfied:
-            self.stats["unsat"] += 1
+            with self._lock:
+                self.stats["synth_s"] += t1 - t0
+                self.stats["unsat"] += 1
             return None
-        ph = self.params_for(work)
+        ph = params_for(work)
         r, s = L.host_scalar_new(self.rng(64)), L.host_scalar_new(self.rng(64))  # bellman: `E::Fr::random(rng)` twice
-        proof = self.bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
-        self.stats["prove_s"] += time.perf_counter() - t1
-        self.stats["proved"] += 1
-        if self.self_check:
-            if not work.verify(self.address, proof):   # MpnWork::verify: the node's own acceptance test
+        proof = bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
+        ok = (not self.self_check) or work.verify(self.address, proof)   # MpnWork::verify: the node's own acceptance test
+        with self._lock:
+            self.stats["synth_s"] += t1 - t0
+            self.stats["prove_s"] += time.perf_counter() - t1
+            self.stats["proved"] += 1
+            self.stats["proved_by_slot"][slot] += 1
+            if not ok:
                 self.stats["self_check_failed"] += 1
-                return None
-        return proof
+        return proof if ok else None
 
     def submit(self, proofs: dict[int, bytes]) -> int:
         acc = parse_solution_response(self._http("POST", "/bincode/mpn/solution", solution_request(self.address, proofs)))
@@ -256,12 +300,55 @@ class Worker:
         return acc
 
     def run_once(self) -> int:
-        """one round: fetch the works assigned to this address, prove them, post the solutions; returns `accepted`"""
+        """one round: fetch the works assigned to this address, prove them (side by side when there are several slots), post the
+        solutions; returns `accepted`"""
+        works = self.fetch()
         proofs = {}
-        for wid, work in self.fetch().items():
-            p = self.prove(work)
-            if p is not None:
-                proofs[wid] = p
+        if len(self.slots) == 1 or len(works) <= 1:
+            for wid, work in works.items():
+                p = self.prove(work)
+                if p is not None:
+                    proofs[wid] = p
+        else:
+            import queue
+            import threading
+            # key sources generate / load a shape's CRS on THEIR context the first time it is asked for: do that here, before the slot
+            # threads start, so that no context is used from two threads (further slots of a device only add a scratch set: SlotKeys)
+            warmed = set()
+            for work in works.values():
+                shape = (work.kind, work.log4_tree, work.log4_token_tree, work.log4_batch)
+                if shape not in warmed:
+                    warmed.add(shape)
+                    for _, params_for in self.slots:
+                        if not isinstance(params_for, SlotKeys):
+                            params_for(work)
+            todo = queue.Queue()
+            for item in works.items():
+                todo.put(item)
+            errors = []
+
+            def run(slot):
+                while True:
+                    try:
+                        wid, work = todo.get_nowait()
+                    except queue.Empty:
+                        return
+                    try:
+                        p = self.prove(work, slot)
+                    except L.BzkError as e:  # reported after the round; the other slots keep going
+                        errors.append(e)
+                        continue
+                    if p is not None:
+                        with self._lock:
+                            proofs[wid] = p
+
+            th = [threading.Thread(target=run, args=(k,)) for k in range(min(len(self.slots), len(works)))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errors and not proofs:
+                raise errors[0]
         return self.submit(proofs) if proofs else 0
 
     def run_forever(self, poll_s: float = 1.0, rounds: int | None = None):
@@ -289,6 +376,8 @@ def main(argv=None):
     ap.add_argument("--params", nargs=3, metavar=("DEPOSIT", "WITHDRAW", "UPDATE"),
                     help="bellman `Parameters` files of the network's three circuits (instead of --dev-toxic)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--devices", default=None, help="comma-separated GPU ordinals of this node to prove on (replicas); overrides --device")
+    ap.add_argument("--slots-per-device", type=int, default=1, help="prover slots per GPU (they share the device-resident CRS)")
     ap.add_argument("--poll", type=float, default=1.0)
     ap.add_argument("--rounds", type=int, default=None)
     ap.add_argument("--self-check", action="store_true", help="verify every proof on the host (pairing check) before posting it")
@@ -302,18 +391,33 @@ def main(argv=None):
     def toxic(kind):
         return b"".join(L.host_scalar_new(hashlib.sha3_256(f"{a.dev_toxic}/{kind}/{i}".encode()).digest() * 2) for i in range(5))
 
-    bzk = L.Bzk(a.device)  # raises without a gfx950 device: there is no CPU prover
     if bool(a.dev_toxic) == bool(a.params):
         ap.error("exactly one of --dev-toxic / --params")
-    keys = BellmanKeys(bzk, dict(enumerate(a.params))) if a.params else DevSetup(bzk, {k: toxic(k) for k in range(3)})
-    w = Worker(bzk, address, (host, int(port)), keys, flags=1 if a.sig_len_prefixed else 0, self_check=a.self_check)
+    devices = [int(x) for x in a.devices.split(",")] if a.devices else [a.device]
+
+    def key_source(bzk):
+        return BellmanKeys(bzk, dict(enumerate(a.params))) if a.params else DevSetup(bzk, {k: toxic(k) for k in range(3)})
+
+    slots, closers = [], []
+    for d in devices:
+        first_bzk = L.Bzk(d)  # raises without a gfx950 device: there is no CPU prover
+        first_keys = key_source(first_bzk)
+        slots.append((first_bzk, first_keys))
+        closers += [first_keys, first_bzk]
+        for _ in range(max(1, a.slots_per_device) - 1):
+            bz = L.Bzk(d)
+            sk = SlotKeys(bz, first_keys)
+            slots.append((bz, sk))
+            closers = [sk, bz] + closers   # slots go before the keys they share
+    w = Worker(slots[0][0], address, (host, int(port)), slots[0][1], flags=1 if a.sig_len_prefixed else 0, self_check=a.self_check,
+               extra_slots=slots[1:])
     try:
         w.register()
         w.run_forever(a.poll, a.rounds)
     finally:
         print(w.stats)
-        keys.close()
-        bzk.close()
+        for c in closers:
+            c.close()
 
 
 if __name__ == "__main__":

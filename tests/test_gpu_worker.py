@@ -128,3 +128,38 @@ def test_worker_with_bellman_parameter_files(bzk, tmp_path):
         node.close()
         keys.close()
         dev.close()
+
+
+def test_multi_slot_worker_proves_a_round_side_by_side(bzk):
+    """replicas: a worker with three prover slots (two further contexts on this GPU sharing the first one's device-resident keys through
+    bzk_params_slot - on a multi-GPU node the extra slots sit on other devices) proves the works of a round concurrently; the node
+    accepts all of them and more than one slot did work"""
+    from bazuka_amd import Bzk
+    keys = W.DevSetup(bzk, {k: fr_bytes(fr_list(5, 9100 + k)) for k in range(3)})
+    vks = [keys.keys(k, 3, 3, 1)[1] for k in range(3)]
+    w = L.MpnWorld(3, 3)
+    for i in range(6):
+        w.add_account(i, b"slot%d" % i, ZIESHA, 10 ** 9)
+    w.set_height(5)
+    blobs = {}
+    for k in range(6):   # six update works over consecutive states
+        w.push_tx(k % 6, (k + 1) % 6, ZIESHA, 10 + k, ZIESHA, 1)
+        w.push_tx((k + 2) % 6, (k + 3) % 6, ZIESHA, 20 + k, ZIESHA, 0)
+        blobs[k] = w.make_work(2, vks, 50 + k).encode()
+    node = MockNode(blobs)
+    extra_ctx = [Bzk(0), Bzk(0)]
+    extra = [(c, W.SlotKeys(c, keys)) for c in extra_ctx]
+    try:
+        worker = W.Worker(bzk, ALICE, ("127.0.0.1", node.port), keys, self_check=True, extra_slots=extra)
+        assert worker.run_once() == 6
+        assert node.solved == {k: ALICE for k in range(6)}
+        st = worker.stats
+        assert st["proved"] == 6 and sum(st["proved_by_slot"]) == 6 and sum(1 for x in st["proved_by_slot"] if x) >= 2
+        assert st["self_check_failed"] == 0 and st["unsat"] == 0
+    finally:
+        node.close()
+        for _, sk in extra:
+            sk.close()
+        keys.close()
+        for c in extra_ctx:
+            c.close()
