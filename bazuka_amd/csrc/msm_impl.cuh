@@ -544,6 +544,114 @@ __device__ __forceinline__ typename C::Pt block_tree_sum(typename C::Pt acc, typ
     return sh[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// 7b. (round 3) cooperative general addition for the latency-bound window-sum trees, G1 only.  A general XYZZ addition is 14
+//     products of which at most 4 are ever independent: a QUAD of lanes computes them side by side - 4 product steps instead of 14 -
+//     and hands the results round with quad shuffles.  All four lanes hold both operands and end with the same result, which is
+//     limb-identical to g1x28::add_full(a, b) (same products, same subtractions, same normalisations).
+//        step 1  X1 ZZ2 | X2 ZZ1 | Y1 ZZZ2 | Y2 ZZZ1          -> U1 U2 S1 S2 ; P = U2 - U1, R = S2 - S1
+//        step 2  P P    | R R    | ZZ1 ZZ2 | ZZZ1 ZZZ2        -> PP RR ZZ12 ZZZ12
+//        step 3  P PP   | U1 PP  | ZZ12 PP | -                 -> PPP Q ZZ3 ; X3 = RR - PPP - 2 Q
+//        step 4  R (Q - X3) | S1 PPP | ZZZ12 PPP | -           -> Y3 = difference, ZZZ3
+//     A link of a tree is then ~5 us instead of ~15.6 us.
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+// lane SRC of the quad broadcasts its value: a DPP quad_perm move per limb (VALU, no trip through the LDS crossbar as __shfl's
+// ds_bpermute would take)
+template <int SRC>
+__device__ __forceinline__ Fp28 quad_get(const Fp28& v) {
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);  // quad_perm:[SRC, SRC, SRC, SRC]
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], ctrl, 0xf, 0xf, false);
+        __asm__ volatile("" : "+v"(r.l[i]));  // keep the move a move: no folding of the DPP operand into the consuming instruction
+    }
+    return r;
+}
+__device__ __forceinline__ Fp28 sel4(int q, const Fp28& a, const Fp28& b, const Fp28& c, const Fp28& d) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) r.l[i] = q == 0 ? a.l[i] : (q == 1 ? b.l[i] : (q == 2 ? c.l[i] : d.l[i]));
+    return r;
+}
+// The products are CALLS (fp28::mul): the callee's last VALU write of a result register may sit one instruction (its s_setpc) before the
+// caller's first DPP read of it, and a DPP source needs two wait states after a VALU write - the compiler's hazard recogniser does
+// not look across the call boundary (first GPU run of the DPP form: wrong sums).  An explicit s_nop closes the gap.
+#define BZK_DPP_AFTER_CALL() __asm__ volatile("s_nop 3" ::: "memory")
+// every lane of the (aligned) quad passes the same a and b and receives a + b
+__device__ __forceinline__ G1X28 g1_add_quad(G1X28 a, const G1X28& b) {
+    using namespace fp28;
+    const int q = (int)(threadIdx.x & 3u);
+    if (g1x28::is_identity(b)) return a;  // quad-uniform: all four lanes hold the same operands
+    if (g1x28::is_identity(a)) return b;
+    const Fp28 r1 = mul(sel4(q, a.X, b.X, a.Y, b.Y), sel4(q, b.ZZ, a.ZZ, b.ZZZ, a.ZZZ));
+    BZK_DPP_AFTER_CALL();
+    const Fp28 U1 = quad_get<0>(r1), U2 = quad_get<1>(r1), S1 = quad_get<2>(r1), S2 = quad_get<3>(r1);
+    const Fp28 Pp = sub<3>(U2, U1), R = sub<3>(S2, S1);  // k 5
+    const Fp28 r2 = mul(sel4(q, Pp, R, a.ZZ, a.ZZZ), sel4(q, Pp, R, b.ZZ, b.ZZZ));
+    BZK_DPP_AFTER_CALL();
+    const Fp28 PP = quad_get<0>(r2), RR = quad_get<1>(r2), Z12 = quad_get<2>(r2), Z123 = quad_get<3>(r2);
+    if (mulout_is_zero(PP)) {  // same x (doubling or cancellation; practically never between partial sums): the serial formula, by every lane
+        g1x28::add_full(a, b);
+        return a;
+    }
+    const Fp28 r3 = mul(sel4(q, Pp, U1, Z12, Z12), PP);
+    BZK_DPP_AFTER_CALL();
+    const Fp28 PPP = quad_get<0>(r3), Q = quad_get<1>(r3), ZZ3 = quad_get<2>(r3);
+    G1X28 o;
+    o.X = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));
+    const Fp28 r4 = mul(sel4(q, R, S1, Z123, Z123), sel4(q, sub<12>(Q, o.X), PPP, PPP, PPP));
+    BZK_DPP_AFTER_CALL();
+    const Fp28 m0 = quad_get<0>(r4), m1 = quad_get<1>(r4);
+    o.Y = norm(sub<3>(m0, m1));
+    o.ZZ = ZZ3;
+    o.ZZZ = quad_get<2>(r4);
+    return o;
+}
+#endif
+// tree over `count` (a power of two <= THREADS) points in sh[], quads of lanes per addition; result in sh[0]
+template <int THREADS>
+__device__ __forceinline__ void g1_quad_tree(G1X28* sh, int count) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int quad = (int)(threadIdx.x >> 2), n_quads = THREADS / 4;
+    for (int s = count / 2; s > 0; s >>= 1) {
+        for (int p = quad; p < s; p += n_quads) {
+            const G1X28 r = g1_add_quad(sh[p], sh[p + s]);
+            if ((threadIdx.x & 3u) == 0) sh[p] = r;
+        }
+        __syncthreads();
+    }
+#endif
+}
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_window_partial_quad_kernel(const G1X28* __restrict__ chunk_out, uint32_t per_win, uint32_t groups,
+                                                                         G1X28* __restrict__ partial_out) {
+    __shared__ G1X28 sh[THREADS];
+    const uint32_t w = blockIdx.x / groups, g = blockIdx.x % groups;
+    const uint32_t i = g * THREADS + threadIdx.x;
+    sh[threadIdx.x] = i < per_win ? chunk_out[(size_t)w * per_win + i] : g1x28::identity();
+    __syncthreads();
+    g1_quad_tree<THREADS>(sh, THREADS);
+    if (threadIdx.x == 0) partial_out[(size_t)w * groups + g] = sh[0];
+}
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_window_sum_quad_kernel(const G1X28* __restrict__ partials, uint32_t groups,
+                                                                      XyzzT<FpOps>* __restrict__ win_out) {
+    __shared__ G1X28 sh[THREADS];
+    const uint32_t w = blockIdx.x;
+    const G1X28* src = partials + (size_t)w * groups;
+    int active = 1;
+    while (active < THREADS && (uint32_t)active < groups) active <<= 1;
+    // groups <= THREADS partials (more: folded serially into the first THREADS slots by their owners)
+    G1X28 acc = threadIdx.x < groups ? src[threadIdx.x] : g1x28::identity();
+    for (uint32_t i = threadIdx.x + THREADS; i < groups; i += THREADS) g1x28::add_full(acc, src[i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    g1_quad_tree<THREADS>(sh, active);
+    if (threadIdx.x == 0) win_out[w] = g1x28::to_std(sh[0]);
+}
+
 template <class C, int THREADS>
 __global__ void __launch_bounds__(THREADS) msm_window_partial_kernel(const typename C::Pt* __restrict__ chunk_out, uint32_t per_win,
                                                                      uint32_t groups, typename C::Pt* __restrict__ partial_out) {
@@ -1214,9 +1322,23 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         const uint32_t groups = (per_win_out + WT - 1) / WT;
         auto k_wp = msm_window_partial_kernel<C, WT>;
         auto k_ws = msm_window_sum_kernel<C, WT>;
-        BZK_LAUNCH(ctx, "msm_window_partial", k_wp, dim3((unsigned)n_red_win * groups), dim3(WT), 0, chunk_out, per_win_out, groups, wpart);
         StdPt* const win_dst = wout ? (StdPt*)wout->d_win + ((table && !folded) ? 0 : wb - w_begin) : win_out;
-        BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_dst);
+        // G1: the two trees on quads of lanes (7b); env BZK_MSM_QUAD_TREE=0: the one-lane-per-point form (A/B runs).  G2 keeps the latter
+        static const bool quad_tree = [] { const char* e = getenv("BZK_MSM_QUAD_TREE"); return !(e && atoi(e) == 0); }();
+        if constexpr (!C::PARK_REDUCE) {
+            if (quad_tree) {
+                BZK_LAUNCH(ctx, "msm_window_partial", (msm_window_partial_quad_kernel<WT>), dim3((unsigned)n_red_win * groups), dim3(WT), 0,
+                           (const G1X28*)chunk_out, per_win_out, groups, (G1X28*)wpart);
+                BZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum_quad_kernel<WT>), dim3((unsigned)n_red_win), dim3(WT), 0, (const G1X28*)wpart, groups,
+                           (XyzzT<FpOps>*)win_dst);
+            } else {
+                BZK_LAUNCH(ctx, "msm_window_partial", k_wp, dim3((unsigned)n_red_win * groups), dim3(WT), 0, chunk_out, per_win_out, groups, wpart);
+                BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_dst);
+            }
+        } else {
+            BZK_LAUNCH(ctx, "msm_window_partial", k_wp, dim3((unsigned)n_red_win * groups), dim3(WT), 0, chunk_out, per_win_out, groups, wpart);
+            BZK_LAUNCH(ctx, "msm_window_sum", k_ws, dim3((unsigned)n_red_win), dim3(WT), 0, wpart, groups, win_dst);
+        }
         if (wout) {
             if (table && !folded) return BZK_OK;
             continue;  // window sums stay on the device, in stream order; the caller reads them back and combines
