@@ -21,6 +21,7 @@
 
 #include "bzk_curve.cuh"
 #include "bzk_internal.h"
+#include "host_fp64.h"
 
 // The CRS of one circuit on one device, shared (reference-counted, read-only once prepared) by every prover SLOT of that device:
 // a slot = bzk_params = the shared CRS + its own per-proof scratch.  Four slots per GPU (bench.py) used to hold four CRS copies and
@@ -94,15 +95,83 @@ int32_t groth16_h(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m) {
     return BZK_OK;
 }
 
-template <class F>
-static XyzzT<F> host_mul_fr(const XyzzT<F>& p, const Fr& k_mont) {
-    Fr k = fe_from_mont<FrParams>(k_mont);
-    XyzzT<F> r = xyzz_identity<F>();
-    for (int i = 254; i >= 0; --i) {
-        r = xyzz_dbl<F>(r);
-        if ((k.l[i >> 5] >> (i & 31)) & 1) xyzz_add<F>(r, p);
+// ---- proof assembly on the host (bellman prover.rs: g_a = alpha + a + r delta, g_b = beta + b + s delta,
+// g_c = h + l + s g_a + r (beta_g1 + b_g1)): a handful of 255-bit scalar multiplications that nothing overlaps with once the
+// MSMs are in.  They run on the 64-bit-limb host field (host_fp64.h); the two that depend only on (r, s) and the verifying key are
+// computed on a lane thread while the device still works, the other two share one doubling chain (Shamir), and the three final
+// inversions share one.  Round 3: with full-size (r, s) this was 2.4 ms at the end of every proof (six G1 + one G2 double-and-add
+// chains on the 32-bit-limb field code); now ~0.3 ms.
+typedef XyzzT<HFpOps> HG1;
+typedef XyzzT<HFp2Ops> HG2;
+
+static inline int fr_bit(const Fr& k, int i) { return (int)((k.l[i >> 5] >> (i & 31)) & 1u); }
+static inline int fr_top_bit(const Fr& k) {
+    for (int i = 254; i >= 0; --i)
+        if (fr_bit(k, i)) return i;
+    return -1;
+}
+// k * p, k canonical (not Montgomery)
+template <class H>
+static XyzzT<H> host_mul_fr(const XyzzT<H>& p, const Fr& k) {
+    XyzzT<H> r = xyzz_identity<H>();
+    for (int i = fr_top_bit(k); i >= 0; --i) {
+        r = xyzz_dbl<H>(r);
+        if (fr_bit(k, i)) xyzz_add<H>(r, p);
     }
     return r;
+}
+// k * p + l * q on one doubling chain
+template <class H>
+static XyzzT<H> host_mul2_fr(const XyzzT<H>& p, const Fr& k, const XyzzT<H>& q, const Fr& l) {
+    XyzzT<H> pq = p;
+    xyzz_add<H>(pq, q);
+    const XyzzT<H>* tab[4] = {nullptr, &p, &q, &pq};
+    XyzzT<H> r = xyzz_identity<H>();
+    const int top = fr_top_bit(k) > fr_top_bit(l) ? fr_top_bit(k) : fr_top_bit(l);
+    for (int i = top; i >= 0; --i) {
+        r = xyzz_dbl<H>(r);
+        const int sel = fr_bit(k, i) | (fr_bit(l, i) << 1);
+        if (sel) xyzz_add<H>(r, *tab[sel]);
+    }
+    return r;
+}
+// (g_a, g_b, g_c) -> the 387-byte packed proof; one field inversion for the three points (Montgomery's trick; the G2 denominator
+// through its norm).  An identity point packs as (0, 1, flag) like PointIO::pack.
+static void pack_proof(const HG1& ga, const HG2& gb, const HG1& gc, uint8_t* proof) {
+    typedef HFpOps F;
+    const bool fa = !xyzz_is_identity<HFpOps>(ga), fb = !xyzz_is_identity<HFp2Ops>(gb), fc = !xyzz_is_identity<HFpOps>(gc);
+    const HFp nb = F::add(F::sqr(gb.ZZZ.c0), F::sqr(gb.ZZZ.c1));  // |ZZZ_b|^2
+    const HFp d0 = fa ? ga.ZZZ : F::one(), d1 = fb ? nb : F::one(), d2 = fc ? gc.ZZZ : F::one();
+    const HFp d01 = F::mul(d0, d1);
+    const HFp iall = F::inv(F::mul(d01, d2));
+    const HFp i2 = F::mul(iall, d01);      // 1 / d2
+    const HFp i01 = F::mul(iall, d2);      // 1 / (d0 d1)
+    const HFp i0 = F::mul(i01, d1), i1 = F::mul(i01, d0);
+    auto g1_out = [](const HG1& p, const HFp& i3, bool fin, uint8_t* out) {
+        HFp x = F::zero(), y = F::one();
+        if (fin) {
+            const HFp iz2 = F::mul(F::sqr(p.ZZ), F::sqr(i3));  // 1/ZZ = ZZ^2 / ZZZ^2
+            x = F::mul(p.X, iz2);
+            y = F::mul(p.Y, i3);
+        }
+        memcpy(out, x.l, 48);
+        memcpy(out + 48, y.l, 48);
+        out[96] = fin ? 0 : 1;
+    };
+    g1_out(ga, i0, fa, proof);
+    g1_out(gc, i2, fc, proof + 290);
+    HFp2 x = HFp2Ops::zero(), y = HFp2Ops::one();
+    if (fb) {
+        const HFp2 i3 = {F::mul(gb.ZZZ.c0, i1), F::mul(F::neg(gb.ZZZ.c1), i1)};  // conj(ZZZ) / |ZZZ|^2
+        const HFp2 iz2 = HFp2Ops::mul(HFp2Ops::sqr(gb.ZZ), HFp2Ops::sqr(i3));
+        x = HFp2Ops::mul(gb.X, iz2);
+        y = HFp2Ops::mul(gb.Y, i3);
+    }
+    memcpy(proof + 97, x.c0.l, 48);
+    memcpy(proof + 97 + 48, x.c1.l, 48);
+    memcpy(proof + 97 + 96, y.c0.l, 48);
+    memcpy(proof + 97 + 144, y.c1.l, 48);
+    proof[97 + 192] = fb ? 0 : 1;
 }
 
 static G1Xyzz unpack_g1(const uint8_t* in) {
@@ -120,22 +189,6 @@ static G2Xyzz unpack_g2(const uint8_t* in) {
     memcpy(a.y.c0.l, in + 96, 48);
     memcpy(a.y.c1.l, in + 144, 48);
     return xyzz_from_affine<Fp2Ops>(a);
-}
-static void pack_g1(const G1Xyzz& p, uint8_t* out) {
-    G1Affine a;
-    bool fin = xyzz_to_affine<FpOps>(p, a);
-    memcpy(out, a.x.l, 48);
-    memcpy(out + 48, a.y.l, 48);
-    out[96] = fin ? 0 : 1;
-}
-static void pack_g2(const G2Xyzz& p, uint8_t* out) {
-    G2Affine a;
-    bool fin = xyzz_to_affine<Fp2Ops>(p, a);
-    memcpy(out, a.x.c0.l, 48);
-    memcpy(out + 48, a.x.c1.l, 48);
-    memcpy(out + 96, a.y.c0.l, 48);
-    memcpy(out + 144, a.y.c1.l, 48);
-    out[192] = fin ? 0 : 1;
 }
 
 }  // namespace bzk
@@ -448,6 +501,31 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     };
     double lane_done_ms[4] = {0, 0, 0, 0};  // BZK_TIMING: when each lane's host thread returned, relative to t0
     auto stamp = [&](int i) { lane_done_ms[i] = std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    // the (r, s)-only part of the assembly: host work on a thread of its own (one past the MSM lanes) while the device computes
+    Fr r_canon, s_canon;
+    {
+        Fr r, s;
+        memcpy(r.l, r32, 32);
+        memcpy(s.l, s32, 32);
+        r_canon = fe_from_mont<FrParams>(r);
+        s_canon = fe_from_mont<FrParams>(s);
+    }
+    // g_c = s g_a + r (beta_g1 + b_g1) + h + l = [s (alpha + r delta) + r beta_g1] + s a + r b_g1 + h + l: the bracket needs no MSM
+    // result (job_pre), s a and r b_g1 are computed by the lane threads that own a and b_g1 as soon as their MSM has returned -
+    // what is left after the join is seven point additions and the packing.
+    HG1 ga_pre, gc_pre, s_a, r_b1;
+    HG2 gb_pre;
+    auto job_pre = [&] {
+        const uint8_t* vk = p->vk;
+        const HG1 alpha = to_host_fast<FpOps>(unpack_g1(vk)), beta1 = to_host_fast<FpOps>(unpack_g1(vk + 97));
+        ga_pre = host_mul_fr<HFpOps>(to_host_fast<FpOps>(unpack_g1(vk + 580)), r_canon);  // r delta_g1 + alpha
+        xyzz_add<HFpOps>(ga_pre, alpha);
+        gc_pre = host_mul2_fr<HFpOps>(ga_pre, s_canon, beta1, r_canon);
+        gb_pre = host_mul_fr<HFp2Ops>(to_host_fast<Fp2Ops>(unpack_g2(vk + 677)), s_canon);  // s delta_g2 + beta_g2
+        xyzz_add<HFp2Ops>(gb_pre, to_host_fast<Fp2Ops>(unpack_g2(vk + 194)));
+    };
+    auto after_a = [&] { if (st[2] == BZK_OK) s_a = host_mul_fr<HFpOps>(to_host_fast<FpOps>(unpack_g1(pA)), s_canon); };
+    auto after_b1 = [&](int lane_i) { if (st[lane_i] == BZK_OK) r_b1 = host_mul_fr<HFpOps>(to_host_fast<FpOps>(unpack_g1(pB1)), r_canon); };
     auto job0 = [&] {
         (void)hipSetDevice(dev);
         st[0] = p->rb2 ? bzk_msm_g2_bases_run_dev(lane[0], p->rb2, slot->d_sb, p->n_b, wflags, pB2)
@@ -461,16 +539,19 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
         job1a();
         if (n_lanes == 3) job1b();
         stamp(1);
+        if (n_lanes == 3) after_b1(1);
     };
     auto job3 = [&] {  // four-lane form: b_g1 beside l
         (void)hipSetDevice(dev);
         st[3] = g1(lane[3], p->rb1, p->b_g1, slot->d_sb, p->n_b, wflags, pB1);
         stamp(3);
+        after_b1(3);
     };
     auto job2 = [&] {
         (void)hipSetDevice(dev);
         st[2] = g1(lane[2], p->ra, p->a, slot->d_sa, p->n_a, wflags, pA);
         stamp(2);
+        after_a();
     };
     if (serial) {
         auto dump = [&](int i, const char* what) {
@@ -487,12 +568,15 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
         (void)hipSetDevice(dev);
         job1a(); dump(1, "l");
         job1b(); dump(1, "b_g1");
+        after_b1(1);
         job2(); dump(2, "a");
+        job_pre();
     } else {
         bzk::lane_post(ctx, 0, job0);
         bzk::lane_post(ctx, 1, job1);
         bzk::lane_post(ctx, 2, job2);
         if (n_lanes == 4) bzk::lane_post(ctx, 3, job3);
+        bzk::lane_post(ctx, (size_t)n_lanes, job_pre);
     }
     // main stream: stage the evaluations, h polynomial, h MSM
     int32_t st_main = BZK_OK;
@@ -512,7 +596,7 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     st_main = main_part();
     const auto t3 = clk::now();
     if (!serial)
-        for (size_t i = 0; i < (size_t)n_lanes; ++i) bzk::lane_wait(ctx, i);  // always: the jobs reference this frame
+        for (size_t i = 0; i <= (size_t)n_lanes; ++i) bzk::lane_wait(ctx, i);  // always: the jobs reference this frame
     const auto t4 = clk::now();
     if (st_main != BZK_OK) return st_main;
     for (int i = 0; i < n_lanes; ++i)
@@ -520,33 +604,18 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
             ctx->last_error = "lane " + std::to_string(i) + ": " + lane[i]->last_error;
             return st[i];
         }
-    // assembly (host)
-    Fr r, s;
-    memcpy(r.l, r32, 32);
-    memcpy(s.l, s32, 32);
-    Fr rs = fe_mul<FrParams>(r, s);
-    const uint8_t* vk = p->vk;
-    G1Xyzz alpha = unpack_g1(vk), beta1 = unpack_g1(vk + 97), delta1 = unpack_g1(vk + 580);
-    G2Xyzz beta2 = unpack_g2(vk + 194), delta2 = unpack_g2(vk + 677);
-    G1Xyzz H = unpack_g1(pH), L = unpack_g1(pL), A = unpack_g1(pA), B1 = unpack_g1(pB1);
-    G2Xyzz B2 = unpack_g2(pB2);
-    G1Xyzz ga = host_mul_fr<FpOps>(delta1, r);
-    xyzz_add<FpOps>(ga, alpha);
-    xyzz_add<FpOps>(ga, A);
-    G2Xyzz gb = host_mul_fr<Fp2Ops>(delta2, s);
-    xyzz_add<Fp2Ops>(gb, beta2);
-    xyzz_add<Fp2Ops>(gb, B2);
-    G1Xyzz gc = host_mul_fr<FpOps>(delta1, rs);
-    G1Xyzz t;
-    t = host_mul_fr<FpOps>(alpha, s);  xyzz_add<FpOps>(gc, t);
-    t = host_mul_fr<FpOps>(beta1, r);  xyzz_add<FpOps>(gc, t);
-    t = host_mul_fr<FpOps>(A, s);      xyzz_add<FpOps>(gc, t);
-    t = host_mul_fr<FpOps>(B1, r);     xyzz_add<FpOps>(gc, t);
-    xyzz_add<FpOps>(gc, H);
-    xyzz_add<FpOps>(gc, L);
-    pack_g1(ga, proof);
-    pack_g2(gb, proof + 97);
-    pack_g1(gc, proof + 290);
+    // assembly (host): g_a = (alpha + r delta) + a;  g_b = (beta + s delta) + b;  g_c = gc_pre + s a + r b_g1 + h + l
+    // (= bellman's h + l + s g_a + r g_b1 - r s delta with g_b1 = beta_g1 + b_g1 + s delta)
+    HG1 ga = ga_pre;
+    xyzz_add<HFpOps>(ga, to_host_fast<FpOps>(unpack_g1(pA)));
+    HG2 gb = gb_pre;
+    xyzz_add<HFp2Ops>(gb, to_host_fast<Fp2Ops>(unpack_g2(pB2)));
+    HG1 gc = gc_pre;
+    xyzz_add<HFpOps>(gc, s_a);
+    xyzz_add<HFpOps>(gc, r_b1);
+    xyzz_add<HFpOps>(gc, to_host_fast<FpOps>(unpack_g1(pH)));
+    xyzz_add<HFpOps>(gc, to_host_fast<FpOps>(unpack_g1(pL)));
+    pack_proof(ga, gb, gc, proof);
     if (ctx->timing) {
         auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[bzk] groth16_prove: z staged %.2f ms, lanes started %.2f, h chain %.2f, lanes joined +%.2f, assembly %.2f; lanes done at "

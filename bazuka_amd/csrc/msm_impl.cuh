@@ -31,6 +31,7 @@
 #include <cstring>
 
 #include "bzk_internal.h"
+#include "host_fp64.h"
 #include "msm_policy.cuh"
 
 namespace bzk {
@@ -575,39 +576,71 @@ __device__ __forceinline__ Fp28 sel4(int q, const Fp28& a, const Fp28& b, const 
     for (int i = 0; i < 14; ++i) r.l[i] = q == 0 ? a.l[i] : (q == 1 ? b.l[i] : (q == 2 ? c.l[i] : d.l[i]));
     return r;
 }
-// The products are CALLS (fp28::mul): the callee's last VALU write of a result register may sit one instruction (its s_setpc) before the
-// caller's first DPP read of it, and a DPP source needs two wait states after a VALU write - the compiler's hazard recogniser does
-// not look across the call boundary (first GPU run of the DPP form: wrong sums).  An explicit s_nop closes the gap.
-#define BZK_DPP_AFTER_CALL() __asm__ volatile("s_nop 3" ::: "memory")
+// The products are INLINED (fp28::mul_body), not the library's calls (fp28::mul): (1) a call makes the caller save every live limb
+// around it - the first forms of these functions kept 0.5 - 1.3 KB of scratch per lane busy - and (2) the callee's last VALU write of a
+// result register may sit one instruction (its s_setpc) before the caller's first DPP read of it, while a DPP source needs two wait
+// states after a VALU write; the compiler's hazard recogniser does not look across the call boundary (first GPU run of the DPP form
+// with calls: wrong sums, cured then by an s_nop after each call).  Inlined, both problems are the compiler's own.
 // every lane of the (aligned) quad passes the same a and b and receives a + b
 __device__ __forceinline__ G1X28 g1_add_quad(G1X28 a, const G1X28& b) {
     using namespace fp28;
     const int q = (int)(threadIdx.x & 3u);
     if (g1x28::is_identity(b)) return a;  // quad-uniform: all four lanes hold the same operands
     if (g1x28::is_identity(a)) return b;
-    const Fp28 r1 = mul(sel4(q, a.X, b.X, a.Y, b.Y), sel4(q, b.ZZ, a.ZZ, b.ZZZ, a.ZZZ));
-    BZK_DPP_AFTER_CALL();
+    const Fp28 r1 = mul_body(sel4(q, a.X, b.X, a.Y, b.Y), sel4(q, b.ZZ, a.ZZ, b.ZZZ, a.ZZZ));
     const Fp28 U1 = quad_get<0>(r1), U2 = quad_get<1>(r1), S1 = quad_get<2>(r1), S2 = quad_get<3>(r1);
     const Fp28 Pp = sub<3>(U2, U1), R = sub<3>(S2, S1);  // k 5
-    const Fp28 r2 = mul(sel4(q, Pp, R, a.ZZ, a.ZZZ), sel4(q, Pp, R, b.ZZ, b.ZZZ));
-    BZK_DPP_AFTER_CALL();
+    const Fp28 r2 = mul_body(sel4(q, Pp, R, a.ZZ, a.ZZZ), sel4(q, Pp, R, b.ZZ, b.ZZZ));
     const Fp28 PP = quad_get<0>(r2), RR = quad_get<1>(r2), Z12 = quad_get<2>(r2), Z123 = quad_get<3>(r2);
     if (mulout_is_zero(PP)) {  // same x (doubling or cancellation; practically never between partial sums): the serial formula, by every lane
         g1x28::add_full(a, b);
         return a;
     }
-    const Fp28 r3 = mul(sel4(q, Pp, U1, Z12, Z12), PP);
-    BZK_DPP_AFTER_CALL();
+    const Fp28 r3 = mul_body(sel4(q, Pp, U1, Z12, Z12), PP);
     const Fp28 PPP = quad_get<0>(r3), Q = quad_get<1>(r3), ZZ3 = quad_get<2>(r3);
     G1X28 o;
     o.X = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));
-    const Fp28 r4 = mul(sel4(q, R, S1, Z123, Z123), sel4(q, sub<12>(Q, o.X), PPP, PPP, PPP));
-    BZK_DPP_AFTER_CALL();
+    const Fp28 r4 = mul_body(sel4(q, R, S1, Z123, Z123), sel4(q, sub<12>(Q, o.X), PPP, PPP, PPP));
     const Fp28 m0 = quad_get<0>(r4), m1 = quad_get<1>(r4);
     o.Y = norm(sub<3>(m0, m1));
     o.ZZ = ZZ3;
     o.ZZZ = quad_get<2>(r4);
     return o;
+}
+// 2 p on a quad (dbl-2008-s-1, the products of g1x28::dbl in three steps):
+//        step 1  U U | X X | - | -                       (U = 2 Y)   -> V, XX ; M = 3 XX
+//        step 2  U V | X V | V ZZ | M M                              -> W, S, ZZ3, MM ; X3 = MM - 2 S
+//        step 3  M (S - X3) | W Y | W ZZZ | -                        -> Y3 = difference, ZZZ3
+__device__ __forceinline__ G1X28 g1_dbl_quad(const G1X28& p) {
+    using namespace fp28;
+    if (g1x28::is_identity(p)) return p;
+    const int q = (int)(threadIdx.x & 3u);
+    const Fp28 U = add(p.Y, p.Y);  // k 10
+    const Fp28 f1 = (q & 1) ? p.X : U;
+    const Fp28 r1 = mul_body(f1, f1);
+    const Fp28 V = quad_get<0>(r1), xx = quad_get<1>(r1);
+    const Fp28 M = add(add(xx, xx), xx);
+    const Fp28 r2 = mul_body(sel4(q, U, p.X, V, M), sel4(q, V, V, p.ZZ, M));
+    const Fp28 Wv = quad_get<0>(r2), S = quad_get<1>(r2), MM = quad_get<3>(r2);
+    G1X28 o;
+    o.ZZ = quad_get<2>(r2);
+    o.X = norm(sub<3>(sub<3>(MM, S), S));
+    const Fp28 r3 = mul_body(sel4(q, M, Wv, Wv, Wv), sel4(q, sub<12>(S, o.X), p.Y, p.ZZZ, p.ZZZ));
+    const Fp28 m0 = quad_get<0>(r3), m1 = quad_get<1>(r3);
+    o.Y = norm(sub<3>(m0, m1));
+    o.ZZZ = quad_get<2>(r3);
+    return o;
+}
+// The same two operations on points that stay in memory (LDS or global), as CALLS: one copy of the ~3 000-instruction bodies per
+// code object, nothing live in the caller across them.  *dst = *pa + *pb (dst may be pa); lane 0 of the quad stores, and a later read
+// of *dst by the whole quad is ordered behind that store (one wave, LDS and the vector memory path are in order per wave).
+static __device__ __noinline__ void g1_add_quad_mem(G1X28* dst, const G1X28* pa, const G1X28* pb) {
+    const G1X28 r = g1_add_quad(*pa, *pb);
+    if ((threadIdx.x & 3u) == 0) *dst = r;
+}
+static __device__ __noinline__ void g1_dbl_quad_mem(G1X28* dst, const G1X28* pa) {
+    const G1X28 r = g1_dbl_quad(*pa);
+    if ((threadIdx.x & 3u) == 0) *dst = r;
 }
 #endif
 // tree over `count` (a power of two <= THREADS) points in sh[], quads of lanes per addition; result in sh[0]
@@ -650,6 +683,49 @@ __global__ void __launch_bounds__(THREADS) msm_window_sum_quad_kernel(const G1X2
     __syncthreads();
     g1_quad_tree<THREADS>(sh, active);
     if (threadIdx.x == 0) win_out[w] = g1x28::to_std(sh[0]);
+}
+
+// Level 2 of the two-level bucket reduction (section 6) on quads, G1: out = 2^post_dbl * sum_{j < ch2} (lo + j + 1) T[lo + j].  The
+// level has per_win / ch2 chunks per window - 8 192 lanes for a 2^20-point MSM in the one-lane form, a pure chain of 16 + ~25 + 3
+// point operations of ~15 us (0.56 ms, as long as level 1 with its 16x the work); here a chunk is a quad, its chain the same links
+// at ~7 / ~5 us (addition / doubling), and ch2 may be smaller (more, shorter chains) because the lanes are there.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_reduce_l2_quad_kernel(const G1X28* __restrict__ tot, uint32_t per_win, uint32_t ch2,
+                                                                     uint32_t n_chunks2, G1X28* __restrict__ out, uint32_t out_stride,
+                                                                     uint32_t out_off, uint32_t post_dbl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a quad's three points (run, acc, m) live in LDS between the calls: 42 KB per 256 lanes
+    __shared__ G1X28 park[THREADS / 4][3];
+    const uint32_t t = (blockIdx.x * THREADS + threadIdx.x) >> 2;
+    if (t >= n_chunks2) return;  // whole quads leave (no workgroup barrier below)
+    const uint32_t per2 = per_win / ch2;
+    const uint32_t w = t / per2, k = t % per2, lo = k * ch2;
+    const G1X28* b = tot + (size_t)w * per_win + lo;
+    G1X28* const run = &park[threadIdx.x >> 2][0];
+    G1X28* const acc = run + 1;
+    G1X28* const m = run + 2;
+    const bool lead = (threadIdx.x & 3u) == 0;
+    if (lead) {
+        const G1X28 first = b[ch2 - 1];
+        *run = first;
+        *acc = first;
+    }
+#pragma nounroll
+    for (int j = (int)ch2 - 2; j >= 0; --j) {
+        g1_add_quad_mem(run, run, &b[j]);
+        g1_add_quad_mem(acc, acc, run);
+    }
+    // m = lo * run by double-and-add below lo's top bit; lo is a multiple of ch2 >= 2, so its bit 0 is clear and the last bit step
+    // takes `acc` in instead; then the post-doublings
+    if (lead) *m = lo ? *run : *acc;
+    const int top = lo ? 31 - __clz((int)lo) : 0;
+#pragma nounroll
+    for (int i = top - 1; i >= -(int)post_dbl; --i) {
+        g1_dbl_quad_mem(m, m);
+        if (i > 0 ? ((lo >> i) & 1u) != 0 : (i == 0)) g1_add_quad_mem(m, m, i == 0 ? acc : run);
+    }
+    if (lead) out[(size_t)w * out_stride + out_off + k] = *m;
+#endif
 }
 
 template <class C, int THREADS>
@@ -741,8 +817,8 @@ template <>
 struct PointIO<FpOps> {
     static constexpr int RAW = 96, PACKED = 97;
     static void pack(const XyzzT<FpOps>& p, uint8_t* out) {
-        G1Affine a;
-        bool fin = xyzz_to_affine<FpOps>(p, a);
+        AffineT<HFpOps> a;  // the inversion on the 64-bit-limb host field (host_fp64.h)
+        bool fin = xyzz_to_affine<HFpOps>(to_host_fast<FpOps>(p), a);
         memcpy(out, a.x.l, 48);
         memcpy(out + 48, a.y.l, 48);
         out[96] = fin ? 0 : 1;
@@ -759,8 +835,8 @@ template <>
 struct PointIO<Fp2Ops> {
     static constexpr int RAW = 192, PACKED = 193;
     static void pack(const XyzzT<Fp2Ops>& p, uint8_t* out) {
-        G2Affine a;
-        bool fin = xyzz_to_affine<Fp2Ops>(p, a);
+        AffineT<HFp2Ops> a;
+        bool fin = xyzz_to_affine<HFp2Ops>(to_host_fast<Fp2Ops>(p), a);
         memcpy(out, a.x.c0.l, 48);
         memcpy(out + 48, a.x.c1.l, 48);
         memcpy(out + 96, a.y.c0.l, 48);
@@ -1036,16 +1112,18 @@ struct MsmWinOut {
     bool single = false;                             // full static table: d_win[0] is the result itself
 };
 
-// Horner over window sums (host, 64-bit limbs behind xyzz_*<F>): result = sum_k 2^(c (w0 + k)) S[k]
+// Horner over window sums on the host: result = sum_k 2^(c (w0 + k)) S[k].  c * (count + w0) doublings that nothing can overlap
+// with - they run on the 6 x 64-bit host field of host_fp64.h (round 3: 0.63 -> 0.45 us per doubling, same values).
 template <class F>
 static XyzzT<F> msm_horner_host(const XyzzT<F>* S, int count, int c, int w0) {
-    XyzzT<F> acc = xyzz_identity<F>();
+    typedef typename HostFast<F>::Ops H;
+    XyzzT<H> acc = xyzz_identity<H>();
     for (int k = count - 1; k >= 0; --k) {
-        for (int d = 0; d < c; ++d) acc = xyzz_dbl<F>(acc);
-        xyzz_add<F>(acc, S[k]);
+        for (int d = 0; d < c; ++d) acc = xyzz_dbl<H>(acc);
+        xyzz_add<H>(acc, to_host_fast<F>(S[k]));
     }
-    for (int d = 0; d < c * w0; ++d) acc = xyzz_dbl<F>(acc);
-    return acc;
+    for (int d = 0; d < c * w0; ++d) acc = xyzz_dbl<H>(acc);
+    return from_host_fast<F>(acc);
 }
 
 template <class C>
@@ -1079,7 +1157,16 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const uint32_t per_win = half / ch;
     // two-level bucket reduction (see msm_reduce_kernel): ctx->msm_reduce2 > 0 forces it, < 0 forbids it, 0 = the caller's hint
     // BZK_F_THROUGHPUT (set by bzk_groth16_prove for its overlapping MSMs)
-    const uint32_t ch2 = std::min<uint32_t>(8u, per_win);
+    // level-2 chunk: 8 in the one-lane form; the quad form of G1 (msm_reduce_l2_quad_kernel) takes shorter chunks (env BZK_MSM_L2_CH,
+    // BZK_MSM_QUAD_L2=0 for the one-lane form: A/B runs)
+    static const bool quad_l2_on = [] { const char* e = getenv("BZK_MSM_QUAD_L2"); return !(e && atoi(e) == 0); }();
+    static const uint32_t quad_l2_ch = [] {
+        const char* e = getenv("BZK_MSM_L2_CH");
+        const int v = e ? atoi(e) : 4;
+        return (uint32_t)((v == 2 || v == 4 || v == 8 || v == 16) ? v : 4);
+    }();
+    const bool quad_l2 = quad_l2_on && !C::PARK_REDUCE;
+    const uint32_t ch2 = std::min<uint32_t>(quad_l2 ? quad_l2_ch : 8u, per_win);
     const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && (flags & BZK_F_THROUGHPUT)));
     const uint32_t per_win_out = two_level ? per_win + per_win / ch2 : per_win;  // chunk results per window handed to the window sums
     const bool dedup = (flags & BZK_F_DEDUP) && C::CONVERT_BASES && !table && n >= 4096 && n < ((uint64_t)1 << 30);
@@ -1312,8 +1399,17 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             const uint32_t n_chunks2 = (uint32_t)n_red_win * (per_win / ch2);
             BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out, per_win_out, 0u,
                        chunk_tot, 0u);
-            BZK_LAUNCH(ctx, "msm_reduce_l2", k_red, dim3((n_chunks2 + 63) / 64), dim3(64), 0, (const Pt*)chunk_tot, per_win, ch2, n_chunks2,
-                       chunk_out, per_win_out, per_win, (Pt*)nullptr, (uint32_t)lg);
+            bool l2_done = false;
+            if constexpr (!C::PARK_REDUCE) {
+                if (quad_l2) {
+                    BZK_LAUNCH(ctx, "msm_reduce_l2", (msm_reduce_l2_quad_kernel<256>), dim3((n_chunks2 * 4 + 255) / 256), dim3(256), 0,
+                               (const G1X28*)chunk_tot, per_win, ch2, n_chunks2, (G1X28*)chunk_out, per_win_out, per_win, (uint32_t)lg);
+                    l2_done = true;
+                }
+            }
+            if (!l2_done)
+                BZK_LAUNCH(ctx, "msm_reduce_l2", k_red, dim3((n_chunks2 + 63) / 64), dim3(64), 0, (const Pt*)chunk_tot, per_win, ch2, n_chunks2,
+                           chunk_out, per_win_out, per_win, (Pt*)nullptr, (uint32_t)lg);
         } else {
             BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out, per_win, 0u,
                        (Pt*)nullptr, 0u);
