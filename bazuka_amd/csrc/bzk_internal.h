@@ -50,6 +50,10 @@ struct bzk_ctx {
     // conversion) runs here beside digits / sort; fork / join through the two events.  Created on first use.
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // env BZK_PROVE_H_PRIO=1 (A/B runs, measured neutral): highest-priority side stream of bzk_groth16_prove for the h polynomial
+    // (evaluations staged + seven transforms).  Created on first use.
+    hipStream_t hprio = nullptr;
+    hipEvent_t ev_h = nullptr;
 };
 
 #define BZK_HIP(ctx, call)                                                                  \

@@ -231,6 +231,11 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->hprio) {
+        (void)hipStreamSynchronize(ctx->hprio);
+        (void)hipStreamDestroy(ctx->hprio);
+    }
+    if (ctx->ev_h) (void)hipEventDestroy(ctx->ev_h);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

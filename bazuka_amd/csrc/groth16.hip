@@ -36,6 +36,8 @@ struct CrsShared {
     uint32_t *a_idx = nullptr, *b_idx = nullptr;                                       // variable index of each dense entry
     // resident internal forms of the queries (bzk_msm_bases: converted once, no per-proof conversion), built on first use
     bzk_msm_bases *rl = nullptr, *ra = nullptr, *rb1 = nullptr, *rb2 = nullptr, *rh = nullptr;
+    // [l | b_g1] as ONE base set: l + r b_g1 is then one MSM over (z_aux | r z_b) - see groth16_prove_impl (round 3)
+    bzk_msm_bases* rlb1 = nullptr;
     // static-base table of the h query: the h bases never change and their scalars are never de-duplicated, so all windows can share one
     // bucket set at a window size of ~log2 m (fewer windows = fewer additions)
     bzk_msm_table* h_table = nullptr;
@@ -61,6 +63,13 @@ __global__ void __launch_bounds__(256) g16_gather_kernel(const Fr* __restrict__ 
                                                          Fr* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = z[idx[i]];
+}
+
+// out[i] = k * z[idx[i]] (Montgomery forms): the scalars of r b_g1 inside the merged l + r b_g1 MSM
+__global__ void __launch_bounds__(256) g16_gather_mul_kernel(const Fr* __restrict__ z, const uint32_t* __restrict__ idx, uint32_t n, Fr k,
+                                                             Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fe_mul<FrParams>(z[idx[i]], k);
 }
 
 static Fr host_fr_pow(Fr b, uint64_t e) {
@@ -200,7 +209,7 @@ extern "C" {
 static void crs_release(bzk_ctx* ctx, CrsShared* c) {
     if (!c || c->refs.fetch_sub(1) != 1) return;
     if (c->h_table) bzk_msm_table_free(ctx, c->h_table);
-    for (bzk_msm_bases* b : {c->rl, c->ra, c->rb1, c->rb2, c->rh})
+    for (bzk_msm_bases* b : {c->rl, c->ra, c->rb1, c->rb2, c->rh, c->rlb1})
         if (b) bzk_msm_bases_free(ctx, b);
     void* bufs[] = {c->h, c->l, c->a, c->b_g1, c->b_g2, c->a_idx, c->b_idx};
     for (void* b : bufs)
@@ -229,7 +238,8 @@ static int32_t slot_alloc(bzk_ctx* ctx, CrsShared* c, bzk_params** out) {
     p->crs = c;
     const uint64_t m = (uint64_t)1 << c->log_m, nv = (uint64_t)c->n_in + c->n_aux;
     struct Al { void** dst; size_t bytes; };
-    Al als[] = {{&p->d_z, (size_t)nv * 32}, {&p->d_a, (size_t)m * 32}, {&p->d_b, (size_t)m * 32}, {&p->d_c, (size_t)m * 32},
+    // d_z = [inputs | aux | r z_b]: the third part is written per proof when l and b_g1 run as one MSM (scalars = aux | r z_b, contiguous)
+    Al als[] = {{&p->d_z, (size_t)(nv + c->n_b) * 32}, {&p->d_a, (size_t)m * 32}, {&p->d_b, (size_t)m * 32}, {&p->d_c, (size_t)m * 32},
                 {&p->d_sa, (size_t)c->n_a * 32}, {&p->d_sb, (size_t)c->n_b * 32}};
     for (auto& a : als) {
         if (hipMalloc(a.dst, a.bytes ? a.bytes : 32) != hipSuccess) {
@@ -310,6 +320,15 @@ int32_t bzk_params_slot(bzk_ctx* ctx, const bzk_params* src, bzk_params** out) {
 // Memory policy: a resident form is only built when hipMemGetInfo shows its size plus a reserve for the provers' grow-only
 // workspaces free; anything that does not fit is simply not built (the per-call pipeline on the raw bases works without it), and
 // bzk_groth16_prove drops the table and retries once if a workspace allocation fails later while it is the CRS's only user.
+// env BZK_PROVE_MERGE_LB1=0: l and b_g1 as two MSMs (the round-2 form; A/B runs).  BZK_PROVE_LANES=4 implies it (b_g1 has its own lane there).
+static bool prove_merge_lb1() {
+    static const bool on = [] {
+        const char* e = getenv("BZK_PROVE_MERGE_LB1");
+        const char* l = getenv("BZK_PROVE_LANES");
+        return !(e && atoi(e) == 0) && !(l && atoi(l) == 4);
+    }();
+    return on;
+}
 static bool crs_fits(size_t need, size_t reserve) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -338,9 +357,23 @@ static void crs_prepare(bzk_ctx* ctx, CrsShared* c) {
         }
     }
     if (!want_res) return;
+    // l and b_g1 as one set (prove_merge_lb1): [l | b_g1] concatenated in a temporary raw buffer, converted once
+    if (prove_merge_lb1() && c->l && c->b_g1 && c->n_aux && c->n_b) {
+        const size_t n_cat = (size_t)c->n_aux + c->n_b;
+        void* cat = nullptr;
+        if (crs_fits(n_cat * (96 + 112), reserve) && hipMalloc(&cat, n_cat * 96) == hipSuccess) {
+            bool ok = hipMemcpyAsync(cat, c->l, (size_t)c->n_aux * 96, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                      hipMemcpyAsync((char*)cat + (size_t)c->n_aux * 96, c->b_g1, (size_t)c->n_b * 96, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+            if (ok) ok = bzk_msm_g1_bases_load_dev(ctx, cat, n_cat, &c->rlb1) == BZK_OK;
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(cat);
+            if (!ok) c->rlb1 = nullptr;
+        }
+        (void)hipGetLastError();
+    }
     struct Q { const void* raw; uint64_t n; bzk_msm_bases** dst; bool g2; };
-    Q qs[] = {{c->b_g2, c->n_b, &c->rb2, true}, {c->l, c->n_aux, &c->rl, false}, {c->a, c->n_a, &c->ra, false}, {c->b_g1, c->n_b, &c->rb1, false},
-              {c->h_table ? nullptr : c->h, m - 1, &c->rh, false}};
+    Q qs[] = {{c->b_g2, c->n_b, &c->rb2, true}, {c->rlb1 ? nullptr : c->l, c->n_aux, &c->rl, false}, {c->a, c->n_a, &c->ra, false},
+              {c->rlb1 ? nullptr : c->b_g1, c->n_b, &c->rb1, false}, {c->h_table ? nullptr : c->h, m - 1, &c->rh, false}};
     for (auto& q : qs) {
         if (!q.raw || !q.n) continue;
         if (!crs_fits((size_t)q.n * (q.g2 ? 224 : 112), reserve)) continue;
@@ -400,6 +433,7 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
         // the caller frees (re-uses) the assignment arrays as soon as this returns: no copy out of them may still be in
         // flight, on the main stream or on a lane
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->hprio) (void)hipStreamSynchronize(ctx->hprio);
         for (bzk_ctx* c : ctx->lanes) (void)hipStreamSynchronize(c->stream);
         (void)hipGetLastError();
     };
@@ -477,6 +511,16 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
         BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_a + 255) / 256), dim3(256), 0, (const Fr*)slot->d_z, p->a_idx, p->n_a, (Fr*)slot->d_sa);
     if (p->n_b)
         BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_b + 255) / 256), dim3(256), 0, (const Fr*)slot->d_z, p->b_idx, p->n_b, (Fr*)slot->d_sb);
+    // l + r b_g1 as ONE MSM over the base set [l | b_g1] with the scalars (z_aux | r z_b), laid out contiguously behind z: one bucket
+    // reduction, one set of window sums, one de-duplication pass and one read-back instead of two (a witness MSM of this size is
+    // ~1.2 ms of accumulation inside ~3.8 ms of mostly latency-bound phases), and r b_g1 needs no host scalar multiplication.
+    const bool merged_lb1 = p->rlb1 != nullptr && n_lanes == 3;
+    if (merged_lb1) {
+        Fr r_mont;
+        memcpy(r_mont.l, r32, 32);
+        BZK_LAUNCH(ctx, "g16_gather_mul", g16_gather_mul_kernel, dim3((p->n_b + 255) / 256), dim3(256), 0, (const Fr*)slot->d_z, p->b_idx, p->n_b,
+                   r_mont, (Fr*)slot->d_z + nv);
+    }
     if (!ctx->ev_z) BZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming));
     const hipEvent_t z_ready = ctx->ev_z;
     BZK_HIP(ctx, hipEventRecord(z_ready, ctx->stream));
@@ -532,14 +576,21 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
                        : bzk_msm_g2_dev(lane[0], p->b_g2, slot->d_sb, p->n_b, wflags, pB2);
         stamp(0);
     };
-    auto job1a = [&] { st[1] = g1(lane[1], p->rl, p->l, z_aux, p->n_aux, wflags, pL); };
-    auto job1b = [&] { if (st[1] == BZK_OK) st[1] = g1(lane[1], p->rb1, p->b_g1, slot->d_sb, p->n_b, wflags, pB1); };
+    auto job1a = [&] {
+        if (merged_lb1) {  // pL = l + r b_g1
+            st[1] = bzk_msm_g1_bases_run_dev(lane[1], p->rlb1, z_aux, (uint64_t)p->n_aux + p->n_b, wflags, pL);
+            r_b1 = xyzz_identity<HFpOps>();
+        } else {
+            st[1] = g1(lane[1], p->rl, p->l, z_aux, p->n_aux, wflags, pL);
+        }
+    };
+    auto job1b = [&] { if (!merged_lb1 && st[1] == BZK_OK) st[1] = g1(lane[1], p->rb1, p->b_g1, slot->d_sb, p->n_b, wflags, pB1); };
     auto job1 = [&] {
         (void)hipSetDevice(dev);
         job1a();
         if (n_lanes == 3) job1b();
         stamp(1);
-        if (n_lanes == 3) after_b1(1);
+        if (n_lanes == 3 && !merged_lb1) after_b1(1);
     };
     auto job3 = [&] {  // four-lane form: b_g1 beside l
         (void)hipSetDevice(dev);
@@ -568,7 +619,7 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
         (void)hipSetDevice(dev);
         job1a(); dump(1, "l");
         job1b(); dump(1, "b_g1");
-        after_b1(1);
+        if (!merged_lb1) after_b1(1);
         job2(); dump(2, "a");
         job_pre();
     } else {
@@ -580,15 +631,57 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     }
     // main stream: stage the evaluations, h polynomial, h MSM
     int32_t st_main = BZK_OK;
+    // BZK_TIMING: device-side marks on the main stream (start of the proof, evaluations staged, h polynomial done)
+    struct Marks {
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Marks() {
+            for (auto& x : e)
+                if (x) (void)hipEventDestroy(x);
+        }
+    } marks;
+    hipEvent_t* const tm = marks.e;
+    if (ctx->timing)
+        for (auto& e : marks.e)
+            if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    // env BZK_PROVE_H_PRIO=1: the h polynomial on a highest-priority side stream.  Measured (profiles/r03_run21...): the transforms then
+    // finish 2.2 ms into the proof instead of 11 ms, the h MSM behind them takes the time back (a proof is ~17 ms of throughput-bound
+    // work on four streams whichever order it runs in): single proof and 4-slot rate unchanged, so the default stays the plain stream
+    static const bool h_prio = [] { const char* e = getenv("BZK_PROVE_H_PRIO"); return e && atoi(e) != 0; }();
+    if (h_prio && !ctx->hprio) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&ctx->hprio, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_h, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ctx->hprio) (void)hipStreamDestroy(ctx->hprio);
+            ctx->hprio = nullptr;  // no side stream: everything on the main stream
+        }
+    }
     auto main_part = [&]() -> int32_t {
         void* ev[3] = {slot->d_a, slot->d_b, slot->d_c};
         const uint8_t* hv[3] = {asg->az, asg->bz, asg->cz};
+        // the evaluations and the transforms on the high-priority side stream (BZK_LAUNCH and the transform code work on ctx->stream: it
+        // is pointed at the side stream for this stretch); d_a/d_b/d_c are this slot's own and idle since the last proof's final sync
+        struct StreamSwap {
+            bzk_ctx* c;
+            hipStream_t saved;
+            StreamSwap(bzk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { if (s) c->stream = s; }
+            ~StreamSwap() { c->stream = saved; }
+        };
+        const bool side = h_prio && ctx->hprio;
+        {
+        StreamSwap swap(ctx, side ? ctx->hprio : nullptr);
+        if (tm[0]) (void)hipEventRecord(tm[0], ctx->stream);
         for (int k = 0; k < 3; ++k) {
             BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
             if (m > asg->n_rows)
                 BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
         }
+        if (tm[1]) (void)hipEventRecord(tm[1], ctx->stream);
         BZK_TRY(groth16_h(ctx, slot->d_a, slot->d_b, slot->d_c, p->log_m));
+        if (tm[2]) (void)hipEventRecord(tm[2], ctx->stream);
+        if (side) BZK_HIP(ctx, hipEventRecord(ctx->ev_h, ctx->stream));
+        }
+        if (side) BZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h, 0));
         if (p->h_table) return bzk_msm_g1_table_run_dev(ctx, p->h_table, slot->d_a, m - 1, tflag, pH);
         return g1(ctx, p->rh, p->h, slot->d_a, m - 1, tflag, pH);
     };
@@ -622,7 +715,14 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
                         "b_g2 %.2f, l%s %.2f, a %.2f, b_g1 %.2f, main %.2f ms\n",
                 ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, clk::now()), lane_done_ms[0], n_lanes == 3 ? "+b_g1" : "", lane_done_ms[1],
                 lane_done_ms[2], lane_done_ms[3], ms(t0, t3));
+        if (tm[0] && tm[1] && tm[2]) {
+            float e01 = 0, e12 = 0;
+            (void)hipEventElapsedTime(&e01, tm[0], tm[1]);
+            (void)hipEventElapsedTime(&e12, tm[1], tm[2]);
+            fprintf(stderr, "[bzk] groth16_prove main stream: az/bz/cz staged in %.2f ms after z and the gathers, h polynomial %.2f ms, h MSM the rest\n", e01, e12);
+        }
     }
+
     return BZK_OK;
 }
 
