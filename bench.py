@@ -74,6 +74,14 @@ def _fr_blind(k: int) -> bytes:
 MSM_KERNEL_SOURCES = ("msm_impl.cuh", "msm_policy.cuh", "msm_g1.hip", "bzk_fp28.cuh", "bzk_curve.cuh", "bzk_field.cuh")
 
 
+def quota_binds(quota) -> bool:
+    """True when the cgroup CPU quota is smaller than the thread count of the pipelined-proof section (8 producers x 8 workers + ~20 prover
+    threads): host waits then sleep instead of spinning (BZK_SYNC_BLOCKING=1).  env BZK_BENCH_BLOCKING_WAITS=0|1 overrides."""
+    if "BZK_BENCH_BLOCKING_WAITS" in os.environ:
+        return os.environ["BZK_BENCH_BLOCKING_WAITS"] != "0"
+    return quota is not None and quota < 84
+
+
 def cpu_quota():
     """CPUs the container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), None when unlimited.  The GPU box shows 256
     logical CPUs but runs this job inside a 16-CPU quota (profiles/r02_run37_46_host_interference.txt): `cores` of a cpu_baseline is the
@@ -199,6 +207,18 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     synth_s = []
     q = queue.Queue(maxsize=4)
     stop = threading.Event()
+    # Host CPU is the scarce resource of this pipeline on a quota'd box (the GPU pool runs the job inside cgroup cpu.max = 16 CPUs while
+    # showing 256): a proof's witness is ~0.23 CPU-seconds, so ~55 proofs/s keep ~13 CPUs busy, and the provers' ~20 host threads SPINNING in
+    # their waits are charged against the same budget.  When the quota is smaller than the threads this pipeline starts, the provers wait
+    # on interrupts instead - libbzk's BZK_SYNC_BLOCKING=1 (same-box A/B, profiles/r03_run23...: 49.9 / 54.1 -> 57.5 / 57.8 proofs/s with 4
+    # worker threads per producer; the MSM headline of the same runs is unchanged within the box noise).  The runtime flag behind it is
+    # process-wide and has to be in place before the first context exists (flipping it later hung the process, profiles/r03_run23...):
+    # main() sets the variable at start-up when the quota binds.
+    quota = cpu_quota()
+    waits_blocking = os.environ.get("BZK_SYNC_BLOCKING", "0") != "0"  # main() decides (before the first context is created)
+    throttled = quota_binds(quota)
+    if throttled and "BZK_BENCH_PROD_THREADS" not in os.environ:
+        prod_threads = min(prod_threads, 4)
 
     prod_dev = os.environ.get("BZK_BENCH_PRODUCER_DEV", "0") != "0"
 
@@ -268,6 +288,8 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     out["producer_synth_s_mean_under_load"] = round(sum(synth_s) / len(synth_s), 4)
     out["pipeline"] = (f"{n_prod} host producers ({prod_threads} worker threads each{', tree hashing on the device' if prod_dev else ''}) -> {len(slots)} prover slots on 1 GPU, "
                        f"{n_pipe} proofs timed (after {n_warm}, before the last {n_drain})")
+    out["host_waits"] = {"mode": "blocking (BZK_SYNC_BLOCKING=1: hipDeviceScheduleBlockingSync)" if waits_blocking else "spin (runtime default)", "cpu_quota": quota,
+                         "why": "CPU quota below the pipeline's thread count" if throttled else "no binding CPU quota"}
     stop.set()
     for th in threads:
         th.join()
@@ -524,6 +546,8 @@ def main():
     if dry:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    if not args.no_proofs and "BZK_SYNC_BLOCKING" not in os.environ and quota_binds(cpu_quota()):
+        os.environ["BZK_SYNC_BLOCKING"] = "1"  # read by libbzk when the first context is created (full_prove_section explains)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         if dry:
@@ -711,6 +735,13 @@ def main():
     if dry:
         out["dryrun"] = (f"ranks share GPUs (rendezvous over {dry}; window sums exchanged through libbzk's shared-memory transport, RCCL refuses "
                          "two ranks on one device): a rehearsal of the code path, NOT a measurement")
+    # the other single-GPU configurations: before the proofs section (which may switch the process to blocking host waits)
+    others = None
+    if world == 1 and rank == 0 and not args.no_others:
+        try:
+            others = other_configs_section(ctx, dev)
+        except Exception as e:  # the headline line must still be printed
+            others = {"error": repr(e)}
     # Second half of the metric: full Groth16 proofs/s.  Every rank proves its own batches (replicas).
     proofs, rates = None, []
     if not args.no_proofs:
@@ -778,11 +809,8 @@ def main():
                                              f"(min {dts[0]:.2f} s, median {dt:.2f} s, max {dts[-1]:.2f} s), window-per-thread Pippenger "
                                              "(bellman-equivalent)",
                                    "parity": "bit-exact (97-byte affine result)"}
-        if world == 1 and not args.no_others:
-            try:
-                out["other_configs"] = other_configs_section(ctx, dev)
-            except Exception as e:  # the headline line must still be printed
-                out["other_configs"] = {"error": repr(e)}
+        if others is not None:
+            out["other_configs"] = others
         if proofs is not None and isinstance(proofs.get("proofs_per_s_pipelined"), float):
             gbs = PROOF_ALG_BYTES * proofs["proofs_per_s_pipelined"] / 1e9
             proofs["proof_roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
