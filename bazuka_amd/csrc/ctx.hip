@@ -167,9 +167,10 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     // env BZK_SYNC_BLOCKING=1: host threads that wait for the GPU sleep on an interrupt instead of spinning.  A prover keeps ~4 host
     // threads per slot waiting most of the time; inside a CPU-quota'd container (cgroup cpu.max) their spinning is charged against the
     // same budget as the witness producers' work (profiles/r02_run37_45_host_interference.txt)
-    if (const char* e = getenv("BZK_SYNC_BLOCKING")) {
-        if (atoi(e) != 0 && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
-    }
+    // The variable is read ONCE, by the first context of the process: switching the device to blocking waits after contexts and streams
+    // exist hung the process (profiles/r03_run23_27...: waits on streams created in the other mode never return).
+    static const bool blocking_waits = [] { const char* e = getenv("BZK_SYNC_BLOCKING"); return e && atoi(e) != 0; }();
+    if (blocking_waits && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     bzk_ctx* ctx = new (std::nothrow) bzk_ctx();
     if (!ctx) return BZK_E_ALLOC;
     ctx->device = device_id;

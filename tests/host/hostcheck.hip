@@ -4,6 +4,7 @@
 #include "../../bazuka_amd/csrc/bzk_fp28.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon29.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon_opt.h"
+#include "../../bazuka_amd/csrc/host_fp64.h"
 #include <string.h>
 using namespace bzk;
 
@@ -311,6 +312,60 @@ int hc_g2_sum_mixed(const uint8_t* pts, int n, uint8_t* out193) {
     G2Xyzz acc = xyzz_identity<Fp2Ops>();
     for (int i = 0; i < n; ++i) xyzz_add_mixed<Fp2Ops>(acc, ld_g2(pts + 192 * i));
     st_g2(out193, acc);
+    return 0;
+}
+
+// host_fp64.h: the 6 x 64-bit-limb host field of the Horner / to-affine / proof-assembly code (op codes of field_op)
+int hc_hfp_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    HFp x, y = HFpOps::zero(), r;
+    memcpy(x.l, a, 48);
+    if (b) memcpy(y.l, b, 48);
+    switch (op) {
+        case 0: r = HFpOps::add(x, y); break;
+        case 1: r = HFpOps::sub(x, y); break;
+        case 2: r = HFpOps::mul(x, y); break;
+        case 3: r = HFpOps::inv(x); break;
+        case 6: r = HFpOps::neg(x); break;
+        case 7: r = HFpOps::dbl(x); break;
+        case 8: r = HFpOps::sqr(x); break;
+        default: return -1;
+    }
+    memcpy(out, r.l, 48);
+    return 0;
+}
+// k * p (+ q at the end) by double-and-add with the XYZZ formulas over the fast host fields, packed like libbzk packs a result
+int hc_hfp_g1_mul_add(const uint8_t* p96, const uint32_t* k8, const uint8_t* q96, uint8_t* out97) {
+    typedef XyzzT<HFpOps> H;
+    const H P = to_host_fast<FpOps>(xyzz_from_affine<FpOps>(ld_g1(p96)));
+    H r = xyzz_identity<HFpOps>();
+    for (int i = 255; i >= 0; --i) {
+        r = xyzz_dbl<HFpOps>(r);
+        if ((k8[i >> 5] >> (i & 31)) & 1) xyzz_add<HFpOps>(r, P);
+    }
+    if (q96) xyzz_add<HFpOps>(r, to_host_fast<FpOps>(xyzz_from_affine<FpOps>(ld_g1(q96))));
+    AffineT<HFpOps> a;
+    const bool fin = xyzz_to_affine<HFpOps>(r, a);
+    memcpy(out97, a.x.l, 48);
+    memcpy(out97 + 48, a.y.l, 48);
+    out97[96] = fin ? 0 : 1;
+    return 0;
+}
+int hc_hfp_g2_mul_add(const uint8_t* p192, const uint32_t* k8, const uint8_t* q192, uint8_t* out193) {
+    typedef XyzzT<HFp2Ops> H;
+    const H P = to_host_fast<Fp2Ops>(xyzz_from_affine<Fp2Ops>(ld_g2(p192)));
+    H r = xyzz_identity<HFp2Ops>();
+    for (int i = 255; i >= 0; --i) {
+        r = xyzz_dbl<HFp2Ops>(r);
+        if ((k8[i >> 5] >> (i & 31)) & 1) xyzz_add<HFp2Ops>(r, P);
+    }
+    if (q192) xyzz_add<HFp2Ops>(r, to_host_fast<Fp2Ops>(xyzz_from_affine<Fp2Ops>(ld_g2(q192))));
+    AffineT<HFp2Ops> a;
+    const bool fin = xyzz_to_affine<HFp2Ops>(r, a);
+    memcpy(out193, a.x.c0.l, 48);
+    memcpy(out193 + 48, a.x.c1.l, 48);
+    memcpy(out193 + 96, a.y.c0.l, 48);
+    memcpy(out193 + 144, a.y.c1.l, 48);
+    out193[192] = fin ? 0 : 1;
     return 0;
 }
 }

@@ -253,3 +253,37 @@ def test_poseidon29_device_function_on_host_matches_oracle(hc, co, pr):
             out = C.create_string_buffer(32)
             assert hc.hc_poseidon29(ib, arity, consts, len(consts) // 32, 8, rp, out) == 0
             assert out.raw == co.poseidon_batch(ib, arity), arity
+
+
+def test_host_fp64_field_and_curve_match_oracle(hc, co, pr):
+    """bazuka_amd/csrc/host_fp64.h (64-bit-limb host field of the window Horner, the to-affine inversion and the proof assembly, round 3)
+    against the oracle: field operations on random and edge values, then 255-bit scalar multiples + one addition through the generic XYZZ
+    formulas instantiated on it, G1 and G2 (Fp2 by Karatsuba), packed exactly as libbzk packs a result."""
+    rnd = random.Random(64)
+    cases = [(rnd.randrange(pr.P_MOD), rnd.randrange(pr.P_MOD)) for _ in range(200)]
+    cases += [(a, b) for a in (0, 1, 2, pr.P_MOD - 1, pr.P_MOD - 2, (1 << 380) - 1) for b in (0, 1, pr.P_MOD - 1, (1 << 64) - 1, 1 << 64)]
+    for a, b in cases:
+        A, B = pr.fp_to_mont_bytes(a), pr.fp_to_mont_bytes(b)
+        for o in (0, 1, 2, 3, 6):
+            assert _op(hc.hc_hfp_op, o, A, B, 48) == co.fp_op(o, A, B), ("hfp", o, a, b)
+        assert _op(hc.hc_hfp_op, 7, A, B, 48) == co.fp_op(0, A, A), ("hfp dbl", a)
+        assert _op(hc.hc_hfp_op, 8, A, B, 48) == co.fp_op(2, A, A), ("hfp sqr", a)
+    n = 4
+    b1, b2 = co.g1_bases(11, 0, n + 1), co.g2_bases(11, 0, n + 1)
+    ks = [rnd.randrange(pr.R_MOD) for _ in range(n - 2)] + [1, pr.R_MOD - 1]
+    for i, k in enumerate(ks):
+        kw = (C.c_uint32 * 8)(*[(k >> (32 * j)) & 0xffffffff for j in range(8)])
+        sc = k.to_bytes(32, "little") + (1).to_bytes(32, "little")
+        P, Q = b1[96 * i:96 * (i + 1)], b1[96 * (i + 1):96 * (i + 2)]
+        out = C.create_string_buffer(97)
+        assert hc.hc_hfp_g1_mul_add(P, kw, Q, out) == 0
+        assert out.raw == co.msm_g1(P + Q, sc, mont=False, naive=True), ("g1", k)
+        P2, Q2 = b2[192 * i:192 * (i + 1)], b2[192 * (i + 1):192 * (i + 2)]
+        out2 = C.create_string_buffer(193)
+        assert hc.hc_hfp_g2_mul_add(P2, kw, Q2, out2) == 0
+        assert out2.raw == co.msm_g2(P2 + Q2, sc, mont=False, naive=True), ("g2", k)
+    # k P - P... the identity packs as (0, 1, flag): (r - 1) P + P
+    kw = (C.c_uint32 * 8)(*[((pr.R_MOD - 1) >> (32 * j)) & 0xffffffff for j in range(8)])
+    out = C.create_string_buffer(97)
+    assert hc.hc_hfp_g1_mul_add(b1[:96], kw, b1[:96], out) == 0
+    assert out.raw == pr.g1_to_bytes(None)
