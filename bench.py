@@ -129,7 +129,8 @@ def _pmc_traffic(log_n):
     return None, f"stale: no profiles/*pmc_traffic*.json carries source stamp {stamp} (re-run tools/runs/pmc passes)"
 
 
-def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: int = 16, cpu_baseline: bool = False):
+def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: int = 16, cpu_baseline: bool = False, helper: bool = False,
+                       second_process: bool = False):
     """Second half of BASELINE.json's metric: Groth16 proofs/s for the 2^20-constraint MPN class =
     UpdateCircuit(L=15, T=3, B=2): 16 signed transactions, 903 037 constraints, 2^20 NTT domain.
     Product code only: host witness/R1CS generator (C++ worker threads), CRS generated on the GPU
@@ -260,31 +261,119 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     # the slots keep proving n_drain more proofs after the timed ones, so that the last timed proofs do not run on a draining GPU
     # (the timed window is steady state on both sides: n_warm completions before it, every slot still busy at its end)
     n_drain = len(slots)
-    done = {"n": 0}
-    finished = []
     lock = threading.Lock()
 
-    def consumer(slot):
-        c, p = slots[slot]
-        k = 0
+    def run_pipeline(n_warm, n_pipe, until=None, finished=None):
+        """n_warm + n_pipe + n_drain proofs through the slots (or, with `until`, proofs until that event is set); returns the sorted
+        completion times"""
+        done = {"n": 0}
+        finished = [] if finished is None else finished
+
+        def consumer(slot):
+            c, p = slots[slot]
+            k = 0
+            while True:
+                with lock:
+                    if (until.is_set() if until is not None else done["n"] >= n_warm + n_pipe + n_drain):
+                        return
+                    done["n"] += 1
+                rr = q.get()
+                c.groth16_prove(p, rr.raw("z"), rr.raw("az"), rr.raw("bz"), rr.raw("cz"), _fr_blind(1000 + 2 * k), _fr_blind(1001 + 2 * k))
+                k += 1
+                with lock:
+                    finished.append(time.perf_counter())
+
+        cons = [threading.Thread(target=consumer, args=(i,)) for i in range(len(slots))]
+        for th in cons:
+            th.start()
+        return cons, finished
+
+    def join_all(cons):
+        for th in cons:
+            th.join()
+
+    if helper:
+        # second prover process of `proofs.two_processes` (see below): prove until told to stop; protocol on stdin / stdout:
+        # -> "READY" once n_warm proofs are through; <- "START": mark; <- "STOP": mark, report the proofs between the marks, leave
+        until = threading.Event()
+        fin = []
+        cons, fin = run_pipeline(0, 0, until=until, finished=fin)
         while True:
             with lock:
-                if done["n"] >= n_warm + n_pipe + n_drain:
-                    return
-                done["n"] += 1
-            rr = q.get()
-            c.groth16_prove(p, rr.raw("z"), rr.raw("az"), rr.raw("bz"), rr.raw("cz"), _fr_blind(1000 + 2 * k), _fr_blind(1001 + 2 * k))
-            k += 1
-            with lock:
-                finished.append(time.perf_counter())
-
-    cons = [threading.Thread(target=consumer, args=(i,)) for i in range(len(slots))]
-    for th in cons:
-        th.start()
-    for th in cons:
-        th.join()
+                if len(fin) >= n_warm:
+                    break
+            time.sleep(0.01)
+        print("READY", flush=True)
+        marks = []
+        for line in sys.stdin:
+            cmd = line.strip()
+            if cmd in ("START", "STOP"):
+                with lock:
+                    marks.append((time.perf_counter(), len(fin)))
+            if cmd == "STOP":
+                break
+        until.set()
+        join_all(cons)
+        if len(marks) >= 2:
+            print(json.dumps({"helper_proofs": marks[-1][1] - marks[0][1], "helper_seconds": marks[-1][0] - marks[0][0]}), flush=True)
+        stop.set()
+        for th in threads:
+            th.join()
+        for cx, px in slots[1:]:
+            cx.params_free(px)
+            cx.close()
+        ctx.params_free(ph)
+        return {}
+    cons, finished = run_pipeline(n_warm, n_pipe)
+    join_all(cons)
     finished.sort()  # completion times: rate over the n_pipe completions after the first n_warm
     out["proofs_per_s_pipelined"] = round(n_pipe / (finished[n_warm + n_pipe - 1] - finished[n_warm - 1]), 3)
+    if second_process:
+        # Informational (never `proofs_per_s_pipelined`): the same pipeline once more while a SECOND prover process - its own HIP runtime,
+        # CRS, producers and slots - proves on the same GPU.  One process tops out below what the GPU can take (the N = 2 rehearsal with
+        # both ranks on one GPU gave 65 proofs/s against 56 from one process, profiles/r03_run29...): a deployment runs two workers per GPU.
+        import subprocess
+        hp = None
+        try:
+            hp = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--prover-helper"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL, text=True, bufsize=1)
+            ready = {"ok": False}
+
+            def wait_ready():
+                for line in hp.stdout:
+                    if line.strip() == "READY":
+                        ready["ok"] = True
+                        return
+
+            wr = threading.Thread(target=wait_ready, daemon=True)
+            wr.start()
+            wr.join(timeout=120.0)
+            if not ready["ok"]:
+                raise RuntimeError("helper process not ready within 120 s")
+            hp.stdin.write("START\n")
+            hp.stdin.flush()
+            cons2, fin2 = run_pipeline(8, n_pipe)
+            join_all(cons2)
+            hp.stdin.write("STOP\n")
+            hp.stdin.flush()
+            fin2.sort()
+            mine = n_pipe / (fin2[8 + n_pipe - 1] - fin2[8 - 1])
+            rep = {}
+            for line in hp.stdout:
+                line = line.strip()
+                if line.startswith("{"):
+                    rep = json.loads(line)
+                    break
+            hp.wait(timeout=60)
+            theirs = rep["helper_proofs"] / rep["helper_seconds"]
+            out["two_processes"] = {"proofs_per_s": round(mine + theirs, 3), "this_process": round(mine, 3), "helper_process": round(theirs, 3),
+                                    "how": f"informational: a second prover process ({n_prod} producers -> {len(slots)} slots, own CRS) on the same GPU while this "
+                                           f"one repeats its {n_pipe}-proof measurement; the helper's rate over the enclosing START..STOP interval"}
+        except Exception as e:
+            out["two_processes"] = {"error": repr(e)}
+        finally:
+            if hp is not None and hp.poll() is None:
+                hp.kill()
     out["producer_synth_s_mean_under_load"] = round(sum(synth_s) / len(synth_s), 4)
     out["pipeline"] = (f"{n_prod} host producers ({prod_threads} worker threads each{', tree hashing on the device' if prod_dev else ''}) -> {len(slots)} prover slots on 1 GPU, "
                        f"{n_pipe} proofs timed (after {n_warm}, before the last {n_drain})")
@@ -499,7 +588,22 @@ def main():
                     help="N > 1: windows = the north star's scalar-window ranges over all points (default); points = every rank runs "
                          "all windows over its own slice of the points (no rank converts or recodes another rank's points); same "
                          "single all-gather + fold, same result")
+    ap.add_argument("--prover-helper", action="store_true",
+                    help="internal: the second prover process of proofs.two_processes (proves until told to stop on stdin; prints no bench line)")
     args = ap.parse_args()
+
+    if args.prover_helper:
+        import torch
+        from bazuka_amd import Bzk
+        dev_i = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(dev_i)
+        if "BZK_SYNC_BLOCKING" not in os.environ and quota_binds(cpu_quota()):
+            os.environ["BZK_SYNC_BLOCKING"] = "1"
+        hctx = Bzk(dev_i)
+        full_prove_section(hctx, n_prod=int(os.environ.get("BZK_BENCH_PRODUCERS", "8")), prod_threads=int(os.environ.get("BZK_BENCH_PROD_THREADS", "8")),
+                           helper=True)
+        hctx.close()
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` with no launcher (how the driver may call it): become the launcher - one process per GPU under
@@ -752,7 +856,8 @@ def main():
             n_prod = int(os.environ.get("BZK_BENCH_PRODUCERS", "8"))
             pt = 8 if world == 1 else max(2, min(8, (os.cpu_count() or 64) // world // n_prod))
             pt = int(os.environ.get("BZK_BENCH_PROD_THREADS", str(pt)))
-            proofs = full_prove_section(ctx, n_prod=n_prod, prod_threads=pt, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+            proofs = full_prove_section(ctx, n_prod=n_prod, prod_threads=pt, cpu_baseline=(world == 1 and not args.no_cpu_baseline),
+                                        second_process=(world == 1 and os.environ.get("BZK_BENCH_TWO_PROCS", "1") != "0"))
         except Exception as e:  # the headline MSM line must still be printed
             proofs = {"error": repr(e)}
         if world > 1:
