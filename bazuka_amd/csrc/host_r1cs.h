@@ -19,6 +19,7 @@
 #include <utility>
 #include <vector>
 
+#include "host_fr64.h"
 #include "host_zk.h"
 
 namespace bzk {
@@ -518,7 +519,51 @@ static inline std::vector<Number> g_product_mds(const std::vector<Number>& vals,
         for (int k = 0; k < t; ++k) res[j] = res[j].plus_scaled(P.mds[j * t + k], vals[k]);
     return res;
 }
+// Witness-only synthesis (lc_tracking() off: every LC is empty, only values are recorded): the same allocations and constraints in the
+// same order as the LC form below - per S-box  x2 = x x, x4 = x2 x2, x5 = x x4  (three variables, three constraints), per idle lane of a
+// partial round  v = v * 1  - on plain field values, the MDS rows as dot products with one reduction each (host_fr64.h).  The Poseidon
+// gadget is ~2/3 of a transaction's witness time; this form needs no vector<Number> traffic and ~0.6 of the word multiplications.
+static inline Number g_poseidon_values(ConstraintSystem& cs, const std::vector<Number>& vals) {
+    static const LC none;
+    const int t = (int)vals.size() + 1;
+    const PoseidonHostParams P = poseidon_host_params(t);
+    Fr e[17], nw[17];
+    e[0] = Fr::zero();
+    for (int i = 1; i < t; ++i) e[i] = vals[i - 1].val;
+    const Fr one = Fr::one();
+    auto sbox = [&](const Fr& x) {
+        const Fr x2 = hfr::mul(x, x);
+        cs.alloc(x2);
+        cs.enforce(none, x, none, x, none, x2);
+        const Fr x4 = hfr::mul(x2, x2);
+        cs.alloc(x4);
+        cs.enforce(none, x2, none, x2, none, x4);
+        const Fr x5 = hfr::mul(x, x4);
+        cs.alloc(x5);
+        cs.enforce(none, x, none, x4, none, x5);
+        return x5;
+    };
+    int off = 0;
+    for (int rnd = 0; rnd < P.rf + P.rp; ++rnd) {
+        for (int i = 0; i < t; ++i) e[i] = fe_add<FrParams>(e[i], P.rc[off + i]);
+        off += t;
+        const bool full = rnd < P.rf / 2 || rnd >= P.rf / 2 + P.rp;
+        if (full) {
+            for (int i = 0; i < t; ++i) e[i] = sbox(e[i]);
+        } else {
+            e[0] = sbox(e[0]);
+            for (int i = 1; i < t; ++i) {  // Number::compress: v * 1 = v
+                cs.alloc(e[i]);
+                cs.enforce(none, e[i], none, one, none, e[i]);
+            }
+        }
+        for (int j = 0; j < t; ++j) nw[j] = hfr::dot(P.mds + (size_t)j * t, e, t);
+        for (int j = 0; j < t; ++j) e[j] = nw[j];
+    }
+    return {LC(), e[1]};
+}
 static inline Number g_poseidon(ConstraintSystem& cs, const std::vector<Number>& vals) {
+    if (!lc_tracking()) return g_poseidon_values(cs, vals);
     std::vector<Number> e;
     e.push_back(Number::zero());
     for (auto& v : vals) e.push_back(v);

@@ -1,5 +1,6 @@
 // Host-side ZkScalar helpers, Poseidon, SHA3-256 and Jubjub/EdDSA (see host_zk.h for the mapping to
 // the reference's src/zk and src/crypto/jubjub).
+#include "host_fr64.h"
 #include "host_zk.h"
 
 #include <mutex>
@@ -144,11 +145,7 @@ Fr hash_sparse(const SparseConsts& S, int t, const Fr* in) {
     for (int i = 1; i < t; ++i) st[i] = in[i - 1];
     auto full_round = [&](const Fr* rc) {
         for (int i = 0; i < t; ++i) st[i] = sbox5(fe_add<FrParams>(st[i], rc[i]));
-        for (int j = 0; j < t; ++j) {
-            Fr acc = Fr::zero();
-            for (int k = 0; k < t; ++k) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(mds[j * t + k], st[k]));
-            nw[j] = acc;
-        }
+        for (int j = 0; j < t; ++j) nw[j] = hfr::dot(mds + (size_t)j * t, st, t);  // one reduction per row (host_fr64.h)
         for (int i = 0; i < t; ++i) st[i] = nw[i];
     };
     for (int r = 0; r < half; ++r) full_round(rc1 + (size_t)r * t);
@@ -156,16 +153,11 @@ Fr hash_sparse(const SparseConsts& S, int t, const Fr* in) {
     for (int i = 0; i < S.rp; ++i) {
         const Fr* c = part + (size_t)i * 2 * t;  // s_i, row0[t], what[t-1]
         st[0] = fe_add<FrParams>(sbox5(st[0]), c[0]);
-        Fr n0 = Fr::zero();
-        for (int k = 0; k < t; ++k) n0 = fe_add<FrParams>(n0, fe_mul<FrParams>(c[1 + k], st[k]));
+        const Fr n0 = hfr::dot(c + 1, st, t);
         for (int j = 1; j < t; ++j) st[j] = fe_add<FrParams>(st[j], fe_mul<FrParams>(c[t + j], st[0]));
         st[0] = n0;
     }
-    for (int j = 0; j < t - 1; ++j) {
-        Fr acc = Fr::zero();
-        for (int k = 0; k < t - 1; ++k) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(dmat[j * (t - 1) + k], st[k + 1]));
-        nw[j] = acc;
-    }
+    for (int j = 0; j < t - 1; ++j) nw[j] = hfr::dot(dmat + (size_t)j * (t - 1), st + 1, t - 1);
     for (int j = 1; j < t; ++j) st[j] = nw[j - 1];
     for (int r = 0; r < half; ++r) full_round(rc2 + (size_t)r * t);
     return st[1];
