@@ -5,6 +5,7 @@
 #include "../../bazuka_amd/csrc/bzk_poseidon29.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon_opt.h"
 #include "../../bazuka_amd/csrc/host_fp64.h"
+#include "../../bazuka_amd/csrc/host_fr64.h"
 #include <string.h>
 using namespace bzk;
 
@@ -366,6 +367,22 @@ int hc_hfp_g2_mul_add(const uint8_t* p192, const uint32_t* k8, const uint8_t* q1
     memcpy(out193 + 96, a.y.c0.l, 48);
     memcpy(out193 + 144, a.y.c1.l, 48);
     out193[192] = fin ? 0 : 1;
+    return 0;
+}
+
+// host_fr64.h: the witness generator's Fr product and its dot product with one reduction
+int hc_hfr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    st<FrParams>(out, hfr::mul(ld<FrParams>(a), ld<FrParams>(b)));
+    return 0;
+}
+int hc_hfr_dot(const uint8_t* a, const uint8_t* b, int n, uint8_t* out) {
+    Fr x[32], y[32];
+    if (n < 0 || n > 32) return -1;
+    for (int k = 0; k < n; ++k) {
+        x[k] = ld<FrParams>(a + 32 * k);
+        y[k] = ld<FrParams>(b + 32 * k);
+    }
+    st<FrParams>(out, hfr::dot(x, y, n));
     return 0;
 }
 }

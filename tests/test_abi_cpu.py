@@ -287,3 +287,31 @@ def test_host_fp64_field_and_curve_match_oracle(hc, co, pr):
     out = C.create_string_buffer(97)
     assert hc.hc_hfp_g1_mul_add(b1[:96], kw, b1[:96], out) == 0
     assert out.raw == pr.g1_to_bytes(None)
+
+
+def test_host_fr64_product_and_dot_match_oracle(hc, co, pr):
+    """bazuka_amd/csrc/host_fr64.h (witness generator, round 3): the unrolled Fr product and the dot product with ONE Montgomery reduction
+    (column-wise accumulation of up to 32 512-bit products) against the oracle's field arithmetic - random values and the extremes that
+    stress the final reduction (every operand r - 1: the accumulated value is largest there)."""
+    rnd = random.Random(464)
+    M = pr.R_MOD
+    for _ in range(300):
+        a, b = rnd.randrange(M), rnd.randrange(M)
+        A, B = pr.fr_to_mont_bytes(a), pr.fr_to_mont_bytes(b)
+        out = C.create_string_buffer(32)
+        assert hc.hc_hfr_mul(A, B, out) == 0
+        assert out.raw == co.fr_op(2, A, B)
+    for n in list(range(0, 33)):
+        for mode in ("rand", "max", "mixed"):
+            if mode == "rand":
+                xs = [rnd.randrange(M) for _ in range(n)]; ys = [rnd.randrange(M) for _ in range(n)]
+            elif mode == "max":
+                xs = [M - 1] * n; ys = [M - 1] * n
+            else:
+                xs = [rnd.choice((0, 1, M - 1, rnd.randrange(M))) for _ in range(n)]; ys = [rnd.choice((0, 1, M - 1, rnd.randrange(M))) for _ in range(n)]
+            A = b"".join(pr.fr_to_mont_bytes(x) for x in xs)
+            B = b"".join(pr.fr_to_mont_bytes(y) for y in ys)
+            out = C.create_string_buffer(32)
+            assert hc.hc_hfr_dot(A, B, n, out) == 0
+            want = sum(x * y for x, y in zip(xs, ys)) % M
+            assert out.raw == pr.fr_to_mont_bytes(want), (n, mode)
