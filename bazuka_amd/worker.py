@@ -363,6 +363,24 @@ class Worker:
             time.sleep(poll_s)
 
 
+def cpu_quota():
+    """CPUs this container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota); None when unlimited"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        return None if q == "max" else int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def main(argv=None):
     """python -m bazuka_amd.worker --node 127.0.0.1:8765 --address <64 hex> --dev-toxic <seed>
     Dev-mode worker: proving keys are generated on the GPU from a toxic-waste seed shared with the node's setup
@@ -394,6 +412,13 @@ def main(argv=None):
     if bool(a.dev_toxic) == bool(a.params):
         ap.error("exactly one of --dev-toxic / --params")
     devices = [int(x) for x in a.devices.split(",")] if a.devices else [a.device]
+    # A prover slot keeps ~5 host threads waiting on the GPU.  Inside a CPU-quota'd container (cgroup cpu.max) spinning waits are charged
+    # against the same budget as the witness generation: when the quota is smaller than the threads this worker runs, the waits sleep on
+    # interrupts instead (libbzk reads BZK_SYNC_BLOCKING once, when the first context is created - so it is set here, before any exists;
+    # measured + 4 - 7 % proofs/s under a 16-CPU quota, profiles/r03_run23_27...).
+    quota = cpu_quota()
+    if quota is not None and quota < len(devices) * a.slots_per_device * 5 + (os.cpu_count() or 1) // 2:
+        os.environ.setdefault("BZK_SYNC_BLOCKING", "1")
 
     def key_source(bzk):
         return BellmanKeys(bzk, dict(enumerate(a.params))) if a.params else DevSetup(bzk, {k: toxic(k) for k in range(3)})
