@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-3 run 32: the default bench of the last commit, exactly as the driver runs it (bounded)
+# round-3 run 32 / 36: the default bench of the last commit, exactly as the driver runs it (bounded); O overridable
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03_run32; mkdir -p $O
+O=${O:-gpurun_out/r03_run32}; mkdir -p $O
 timeout 420 python bench.py > $O/bench.txt 2> $O/bench_err.txt; echo "rc=$?"
 python - <<PY
 import json
