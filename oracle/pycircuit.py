@@ -706,8 +706,8 @@ def _header(cs, commitment, height, state, aux_data, next_state, fee_token=None)
 # ---------------------------------------------------------------------------------------------------------------------
 # src/mpn/circuits/update_circuit.rs:49-494
 # ---------------------------------------------------------------------------------------------------------------------
-def update_circuit(log4_tree, log4_token_tree, commitment, height, state, aux_data, next_state, fee_token, transitions):
-    cs = ConstraintSystem()
+def update_circuit(log4_tree, log4_token_tree, commitment, height, state, aux_data, next_state, fee_token, transitions, cs=None):
+    cs = ConstraintSystem() if cs is None else cs
     L, T = log4_tree, log4_token_tree
     state_wit, accepted_fee_token, aux_wit, claimed_next_state_wit = _header(cs, commitment, height, state, aux_data, next_state,
                                                                              fee_token)
@@ -833,8 +833,8 @@ def update_circuit(log4_tree, log4_token_tree, commitment, height, state, aux_da
 # ---------------------------------------------------------------------------------------------------------------------
 # src/mpn/circuits/deposit_circuit.rs:47-293
 # ---------------------------------------------------------------------------------------------------------------------
-def deposit_circuit(log4_tree, log4_token_tree, log4_batch, commitment, height, state, aux_data, next_state, transitions):
-    cs = ConstraintSystem()
+def deposit_circuit(log4_tree, log4_token_tree, log4_batch, commitment, height, state, aux_data, next_state, transitions, cs=None):
+    cs = ConstraintSystem() if cs is None else cs
     L, T = log4_tree, log4_token_tree
     state_wit, _, aux_wit, claimed_next_state_wit = _header(cs, commitment, height, state, aux_data, next_state)
     state_model = ("list", log4_batch, ("struct", ["scalar"] * 4))
@@ -904,8 +904,8 @@ def deposit_circuit(log4_tree, log4_token_tree, log4_batch, commitment, height, 
 # src/mpn/circuits/withdraw_circuit.rs:50-413
 # ---------------------------------------------------------------------------------------------------------------------
 def withdraw_circuit(log4_tree, log4_token_tree, log4_batch, commitment, height, state, aux_data, next_state, transitions,
-                     encode_contract_withdraw):
-    cs = ConstraintSystem()
+                     encode_contract_withdraw, cs=None):
+    cs = ConstraintSystem() if cs is None else cs
     L, T = log4_tree, log4_token_tree
     state_wit, _, aux_wit, claimed_next_state_wit = _header(cs, commitment, height, state, aux_data, next_state)
     state_model = ("list", log4_batch, ("struct", ["scalar"] * 7))
@@ -1085,7 +1085,7 @@ def null_withdraw_transition(L, T):
             "fee_balance_proof": _null_proof(T)}
 
 
-def circuit_of_work(work, commitment, fee_token=1, encode_contract_withdraw=None):
+def circuit_of_work(work, commitment, fee_token=1, encode_contract_withdraw=None, cs=None):
     """The circuit instance a prover builds for a decoded `MpnWork` (tests/bincode_ref.py dict): transitions padded with
     `::null` to 4^batch, public inputs [commitment, height, state, aux_data, next_state] (the external prover's side of
     src/mpn/mod.rs:263-295; fee_token = the accepted fee token, Ziesha on the network: src/mpn/mod.rs:156-158, 400)."""
@@ -1096,14 +1096,14 @@ def circuit_of_work(work, commitment, fee_token=1, encode_contract_withdraw=None
     if kind == "Update":
         n = 1 << (2 * c["log4_update_batch_size"])
         trs = list(trs) + [null_update_transition(L, T)] * (n - len(trs))
-        return update_circuit(L, T, *args, fee_token, trs)
+        return update_circuit(L, T, *args, fee_token, trs, cs=cs)
     if kind == "Deposit":
         B = c["log4_deposit_batch_size"]
         trs = list(trs) + [null_deposit_transition(L, T)] * ((1 << (2 * B)) - len(trs))
-        return deposit_circuit(L, T, B, *args, trs)
+        return deposit_circuit(L, T, B, *args, trs, cs=cs)
     B = c["log4_withdraw_batch_size"]
     trs = list(trs) + [null_withdraw_transition(L, T)] * ((1 << (2 * B)) - len(trs))
-    return withdraw_circuit(L, T, B, *args, trs, encode_contract_withdraw)
+    return withdraw_circuit(L, T, B, *args, trs, encode_contract_withdraw, cs=cs)
 
 
 def first_unsatisfied(cs):
@@ -1142,6 +1142,88 @@ def all_views(cs):
     for which in "ABC":
         out["val" + which], out["col" + which], out["rp" + which] = csr_bytes(cs, which)
     return out
+
+
+class StreamingConstraintSystem(ConstraintSystem):
+    """The same recording, folded into running sha256 states the moment a constraint is enforced instead of being kept:
+    what `all_views` + `first_unsatisfied` compute from a stored instance, for circuits too large to store as Python lists
+    (the production shapes of src/config/blockchain.rs:22-26 - Update (15,3,4) is 14.4 M constraints).  Every value a row
+    refers to is allocated before the row is enforced, so <A,z>, <B,z>, <C,z> are known then; the flat index of an aux
+    variable needs the FINAL input count, which the caller states up front (6 for the three MPN circuits: ONE + five
+    `inputize`d values) and `finish` asserts.  tests/test_pycircuit_cpu.py checks that this class and the stored form
+    give the same 15 hashes on the small scenarios."""
+
+    def __init__(self, n_in_final):
+        super().__init__()
+        self._nin = n_in_final
+        self._h = {k: hashlib.sha256() for k in ("az", "bz", "cz", "valA", "valB", "valC", "colA", "colB", "colC", "rpA", "rpB", "rpC")}
+        self._nnz = {"A": 0, "B": 0, "C": 0}
+        for w in "ABC":
+            self._h["rp" + w].update(b"\0\0\0\0")
+        self._dens = {"A": bytearray(), "B": bytearray()}
+        self._mont = {}
+        self.n_rows = 0
+        self.unsat = -1
+
+    def flat(self, v):
+        return -v - 1 if v < 0 else self._nin + v
+
+    def _mb(self, c):
+        b = self._mont.get(c)
+        if b is None:
+            from oracle.pyref import fr_to_mont_bytes
+            b = fr_to_mont_bytes(c)
+            if len(self._mont) < 1 << 16:
+                self._mont[c] = b
+        return b
+
+    def _row(self, which, lc):
+        from oracle.pyref import fr_to_mont_bytes
+        dens = self._dens.get(which)
+        acc, ev = {}, 0
+        for v, c in lc:
+            c %= R_MOD
+            f = -v - 1 if v < 0 else self._nin + v
+            if c:
+                ev += c * (self.inputs[-v - 1] if v < 0 else self.aux[v])
+                if dens is not None:
+                    if len(dens) <= f:
+                        dens.extend(bytes(f + 1 - len(dens)))
+                    dens[f] = 1
+            acc[f] = (acc.get(f, 0) + c) % R_MOD
+        terms = [(f, c) for f, c in acc.items() if c]
+        self._h["val" + which].update(b"".join(self._mb(c) for _, c in terms))
+        self._h["col" + which].update(b"".join(f.to_bytes(4, "little") for f, _ in terms))
+        self._nnz[which] += len(terms)
+        self._h["rp" + which].update(self._nnz[which].to_bytes(4, "little"))
+        ev %= R_MOD
+        self._h[which.lower() + "z"].update(fr_to_mont_bytes(ev))
+        return ev
+
+    def enforce(self, a, b, c):
+        ea, eb, ec = self._row("A", a), self._row("B", b), self._row("C", c)
+        if self.unsat < 0 and (ea * eb - ec) % R_MOD:
+            self.unsat = self.n_rows
+        self.n_rows += 1
+
+    def finish(self):
+        """-> (n_in, n_aux, n_constraints incl. the input rows, first unsatisfied row or -1, {view name: sha256 hex})"""
+        from oracle.pyref import fr_to_mont_bytes
+        assert len(self.inputs) == self._nin, "final input count differs from the one flat indices were computed with"
+        for i in range(self._nin):          # bellman appends `input_i * 0 = 0` per input after synthesis
+            self.enforce([(-i - 1, 1)], [], [])
+        n = self._nin + len(self.aux)
+        hz = hashlib.sha256()
+        hz.update(b"".join(fr_to_mont_bytes(x) for x in self.inputs))
+        for lo in range(0, len(self.aux), 1 << 16):
+            hz.update(b"".join(fr_to_mont_bytes(x) for x in self.aux[lo:lo + (1 << 16)]))
+        out = {k: h.hexdigest() for k, h in self._h.items()}
+        out["z"] = hz.hexdigest()
+        for w, name in (("A", "a_density"), ("B", "b_density")):
+            d = self._dens[w]
+            d.extend(bytes(n - len(d)))
+            out[name] = hashlib.sha256(bytes(d)).hexdigest()
+        return self._nin, len(self.aux), self.n_rows, self.unsat, out
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ def test_msm_g2_2p20_equals_oracle(bzk, co):
     assert bzk.msm_g2_dev(bases, sc, n, dedup=True) == want
 
 
-@pytest.mark.parametrize("name", list(S.SCENARIOS))
+@pytest.mark.parametrize("name", [n for n in S.SCENARIOS if n not in S.PRODUCTION])   # the production shapes: test_gpu_production.py
 def test_r1cs_fixture_replay_on_the_gpu_box(name):
     """the generator is host code, but it is THIS build on THIS box that proves: replay the pinned hashes here too"""
     blob = S.make_work(name)

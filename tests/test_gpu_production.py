@@ -1,0 +1,60 @@
+"""Row g: the shapes a real node accepts - Deposit(15,3,3), Withdraw(15,3,3), Update(15,3,4)
+(/root/reference/src/config/blockchain.rs:22-26, one work of each per block :326-328) - through the whole path on the GPU box:
+
+  validator-side `MpnWork` bytes (49 / 49 / 193 enabled transitions, the rest `::null`)  ==  the committed work hash
+  worker-side synthesis: all 15 arrays (z, A.z, B.z, C.z, densities, CSR of A, B, C)     ==  sha256 fixtures made by the independent
+        Python restatement ALONE (oracle/pycircuit.py streaming form; tests/golden/make_r1cs_fixtures.py)
+  CRS on the GPU (bzk_groth16_setup), proof on the GPU (2^21 / 2^22 / 2^24 domains)
+  387 proof bytes == the CPU oracle prover's on the same (CRS, witness, r, s)             Deposit, Withdraw always;
+        Update (2^24: minutes of host time, ~25 GB) with BZK_TEST_PRODUCTION_BYTES=1 - run on a builder lease, result in profiles/
+  pairing check (product `bzk_groth16_verify` and the oracle's Python verifier): accepts; rejects a wrong public input."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import r1cs_scenarios as S
+from bazuka_amd import lib as L
+from oracle import pyref as pr
+from util import fr_bytes, fr_list
+
+pytestmark = pytest.mark.gpu
+U = pr.fr_from_mont_bytes
+FIX = json.load(open(os.path.join(S.G, "r1cs_sha256.json")))
+LOG_M = {"deposit_15_3_3": 21, "withdraw_15_3_3": 22, "update_15_3_4": 24}
+
+
+@pytest.mark.parametrize("name", S.PRODUCTION)
+def test_production_shape_proof_equals_oracle_and_verifies(name, bzk, co):
+    fix = FIX[name]
+    blob = S.make_work(name)
+    assert hashlib.sha256(blob).hexdigest() == fix["work_sha256"]
+    dec, r, sha = S.product_hashes(blob)
+    assert r.satisfied and r.accepted == fix["n_enabled"] and (r.n_in, r.n_aux, r.n_constraints) == (fix["n_in"], fix["n_aux"], fix["n_constraints"])
+    assert (r.n_constraints - 1).bit_length() == LOG_M[name]
+    assert sha == fix["sha256"]
+    csr = [(r.n_constraints, r.raw("rp" + w), r.raw("col" + w), r.raw("val" + w)) for w in "ABC"]
+    seed = 4000 + LOG_M[name]
+    ph, vkb = bzk.groth16_setup(csr, r.n_in, r.n_aux, fr_bytes(fr_list(5, seed)))
+    rs = fr_bytes(fr_list(2, seed + 1))
+    z, az, bz, cz = (r.raw(k) for k in ("z", "az", "bz", "cz"))
+    proof = bzk.groth16_prove(ph, z, az, bz, cz, rs[:32], rs[32:])
+    inputs = bytes(z[32:32 * 6])
+    pub = [U(inputs[32 * i:32 * i + 32]) for i in range(5)]
+    assert pub[0] == U(dec.commitment(S.PROVER)) and pub[1] == 11 and pub[2] == U(dec.state) and pub[4] == U(dec.next_state)
+    # the node's check (src/zk/groth16/mod.rs:67-121) by the product's host verifier and by the oracle's independent pairing
+    assert L.groth16_verify(vkb, inputs, proof)
+    assert not L.groth16_verify(vkb, inputs[:128] + pr.fr_to_mont_bytes(pub[4] + 1), proof)
+    vk = pr.vk_from_bytes(vkb)
+    assert pr.groth16_verify(vk, pub, pr.proof_from_bytes(proof))
+    assert not pr.groth16_verify(vk, [pub[0] + 1] + pub[1:], pr.proof_from_bytes(proof))
+    if name != "update_15_3_4" or os.environ.get("BZK_TEST_PRODUCTION_BYTES") == "1":
+        op = {"n_in": r.n_in, "n_aux": r.n_aux, "log_m": LOG_M[name], "a_density": r.view("a_density"), "b_density": r.view("b_density")}
+        for which, key in ((0, "vk"), (1, "h"), (2, "l"), (3, "a"), (4, "b_g1"), (5, "b_g2")):
+            op[key] = bzk.params_read(ph, which)
+        op["n_a"], op["n_b"] = sum(op["a_density"]), sum(op["b_density"])
+        want = co.groth16_prove(op, bytes(z), bytes(az), bytes(bz), bytes(cz), rs[:32], rs[32:], nthreads=co.ncpu())
+        assert proof == want
+    bzk.params_free(ph)
+    r.free()
