@@ -45,6 +45,15 @@ namespace {
 
 constexpr int MG_MAX_W = 64;          // windows of a call (c >= 4 -> W <= 64)
 constexpr size_t MG_SLOT_G2 = 384;    // bytes of one standard-limb XYZZ window sum (G2; G1 = 192)
+// every rank's block of an exchange ends in this record, so that a rank whose local stage failed still TAKES PART and every rank
+// returns an error - instead of the peers blocking in ncclAllGather / spinning on the shared-memory barrier, or (worse) combining
+// the stale sums of an earlier call
+struct MgHdr {
+    uint64_t seq;
+    int32_t status, c_bits;
+};
+constexpr size_t MG_HDR = sizeof(MgHdr);
+static_assert(MG_HDR == 16, "exchange record");
 
 struct RcclApi {
     void* lib = nullptr;
@@ -117,7 +126,7 @@ struct bzk_mg {
 // proof pool: `slots` prover slots (context + lanes + scratch) per local device over one shared CRS per device; one host thread per
 // slot takes proofs from a common queue - whichever slot is free next, on whichever device (replicas: proofs do not shard)
 struct MgProofJob {
-    const bzk_assignment* asg;
+    bzk_assignment asg;  // by value: the caller's 48-byte struct may be gone by the time a slot takes the job (only the ARRAYS must live)
     uint8_t r[32], s[32];
     uint8_t* out;
     uint64_t ticket;
@@ -130,6 +139,7 @@ struct bzk_mg_params {
     std::condition_variable cv_work, cv_done;
     std::deque<MgProofJob> queue;
     std::vector<std::pair<uint64_t, int32_t>> finished;  // (ticket, status)
+    std::set<uint64_t> outstanding;                      // submitted and not yet handed back by bzk_mg_prove_wait
     std::vector<std::pair<uint64_t, std::string>> errors;
     uint64_t next_ticket = 1;
     bool quit = false;
@@ -168,7 +178,9 @@ void worker_loop(Worker* w, int device) {
 int32_t run_all(bzk_mg* mg, const std::function<int32_t(int)>& fn) {
     if (mg->n_local == 1) {
         (void)hipSetDevice(mg->devices[0]);
-        return fn(0);
+        const int32_t st = fn(0);
+        if (st != BZK_OK && !mg->ctxs.empty()) mg->last_error = "device " + std::to_string(mg->devices[0]) + ": " + mg->ctxs[0]->last_error;
+        return st;
     }
     for (int i = 0; i < mg->n_local; ++i) {
         Worker* w = mg->workers[i];
@@ -198,14 +210,14 @@ void window_range(int W, int rank, int world, int* lo, int* hi) {
 int slots_per_rank(int W, int world) { return (W + world - 1) / world; }
 
 int32_t mg_alloc_buffers(bzk_mg* mg) {
-    const size_t slot_all = (size_t)mg->world * MG_MAX_W * MG_SLOT_G2;
+    const size_t slot_all = (size_t)mg->world * (MG_MAX_W * MG_SLOT_G2 + MG_HDR);
     mg->d_send.assign(mg->n_local, nullptr);
     mg->d_all.assign(mg->n_local, nullptr);
     mg->d_stage.assign(mg->n_local, nullptr);
     mg->d_stage_bytes.assign(mg->n_local, 0);
     for (int i = 0; i < mg->n_local; ++i) {
         if (hipSetDevice(mg->devices[i]) != hipSuccess) return mg_fail(mg, BZK_E_DEVICE, "hipSetDevice");
-        if (hipMalloc(&mg->d_send[i], (size_t)MG_MAX_W * MG_SLOT_G2) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "exchange buffer");
+        if (hipMalloc(&mg->d_send[i], (size_t)MG_MAX_W * MG_SLOT_G2 + MG_HDR) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "exchange buffer");
         if (hipMalloc(&mg->d_all[i], slot_all) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "exchange buffer");
     }
     if (hipHostMalloc((void**)&mg->h_win, slot_all, hipHostMallocPortable) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "pinned exchange buffer");
@@ -226,7 +238,7 @@ int32_t mg_open_shm(bzk_mg* mg, const uint8_t uid[BZK_MG_UID_BYTES]) {
         for (int b = 0; b < 16; ++b) name[o++] = hx[(h[k] >> (4 * b)) & 15];
     name[o] = 0;
     mg->shm_name = name;
-    mg->shm_bytes = sizeof(ShmHeader) + 2 * (size_t)mg->world * MG_MAX_W * MG_SLOT_G2;
+    mg->shm_bytes = sizeof(ShmHeader) + 2 * (size_t)mg->world * (MG_MAX_W * MG_SLOT_G2 + MG_HDR);
     const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
     if (fd < 0) return mg_fail(mg, BZK_E_DEVICE, std::string("shm_open ") + name);
     if (ftruncate(fd, (off_t)mg->shm_bytes) != 0) { close(fd); return mg_fail(mg, BZK_E_DEVICE, "ftruncate shm"); }
@@ -344,63 +356,112 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
     const int W = (int)bzk_msm_window_count(n ? n : 1);
     if (W > MG_MAX_W) return mg_fail(mg, BZK_E_INTERNAL, "window count");
     const int spr = slots_per_rank(W, mg->world);
+    const size_t blk = (size_t)spr * sz;  // a rank's sums in an exchange; the RCCL / shared-memory block carries an MgHdr after them
     const uint64_t seq = ++mg->seq;
     std::vector<int32_t> cs(mg->n_local, 0);
+    std::vector<MgHdr> hdr(mg->n_local);
     const uint32_t x = mg->exchange;
+    const bool shm = mg->multi_process && x == BZK_MG_X_HOST;
     int32_t st = run_all(mg, [&](int i) -> int32_t {
         bzk_ctx* c = mg->ctxs[i];
         const int rank = mg->rank0 + i;
         int lo, hi;
         window_range(W, rank, mg->world, &lo, &hi);
-        const void* sc = scalars_dev ? scalars_dev[i] : nullptr;
-        if (!scalars_dev && n) BZK_TRY(stage_scalars(mg, i, scalars_host, n, &sc));
-        int32_t info[4] = {0, 0, 0, 0};
-        // a rank without windows (world > W) still takes part in the exchange
-        if (hi > lo && n) {
-            BZK_TRY(windows(c, B->per_dev[i], nullptr, sc, n, flags, lo, hi, mg->d_send[i], info));
-            if (info[1] != W) { c->last_error = "bzk_mg: window count disagrees with bzk_msm_window_count"; return BZK_E_INTERNAL; }
-            cs[i] = info[0];
-        }
-        const size_t mine = (size_t)(hi - lo) * sz;
+        // local stage; its status travels with the exchange (RCCL, shared memory: the peers cannot see it otherwise)
+        const int32_t lst = [&]() -> int32_t {
+            // test hook (tests/test_gpu_mg.py): "rank:call" makes that rank's local stage of that call of the group fail
+            static const char* fault = getenv("BZK_MG_TEST_FAULT");
+            if (fault) {
+                int fr = -1;
+                unsigned long long fs = 0;
+                if (sscanf(fault, "%d:%llu", &fr, &fs) == 2 && fr == rank && fs == seq) { c->last_error = "bzk_mg: injected fault"; return BZK_E_ALLOC; }
+            }
+            const void* sc = scalars_dev ? scalars_dev[i] : nullptr;
+            if (!scalars_dev && n) BZK_TRY(stage_scalars(mg, i, scalars_host, n, &sc));
+            int32_t info[4] = {0, 0, 0, 0};
+            // a rank without windows (world > W) still takes part in the exchange
+            if (hi > lo && n) {
+                BZK_TRY(windows(c, B->per_dev[i], nullptr, sc, n, flags, lo, hi, mg->d_send[i], info));
+                if (info[1] != W) { c->last_error = "bzk_mg: window count disagrees with bzk_msm_window_count"; return BZK_E_INTERNAL; }
+                cs[i] = info[0];
+            }
+            return BZK_OK;
+        }();
+        hdr[i] = MgHdr{seq, lst, cs[i]};
+        const size_t mine = lst == BZK_OK ? (size_t)(hi - lo) * sz : 0;
         if (x == BZK_MG_X_RCCL) {
             RcclApi* R = rccl_api();
-            const ncclResult_t r = R->AllGather(mg->d_send[i], mg->d_all[i], (size_t)spr * sz, ncclUint8, mg->comms[i], c->stream);
-            if (r != ncclSuccess) { c->last_error = std::string("ncclAllGather: ") + (R->GetErrorString ? R->GetErrorString(r) : "error"); return BZK_E_DEVICE; }
-            if (i == 0) BZK_HIP(c, hipMemcpyAsync(mg->h_win, mg->d_all[0], (size_t)mg->world * spr * sz, hipMemcpyDeviceToHost, c->stream));
+            if (hipMemcpyAsync((char*)mg->d_send[i] + blk, &hdr[i], MG_HDR, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                (void)hipGetLastError();  // the stream is gone: nothing can be told to the peers through it
+                if (lst == BZK_OK) c->last_error = "bzk_mg: exchange record upload";
+                return lst != BZK_OK ? lst : BZK_E_DEVICE;
+            }
+            const ncclResult_t r = R->AllGather(mg->d_send[i], mg->d_all[i], blk + MG_HDR, ncclUint8, mg->comms[i], c->stream);
+            if (r != ncclSuccess) {
+                if (lst == BZK_OK) c->last_error = std::string("ncclAllGather: ") + (R->GetErrorString ? R->GetErrorString(r) : "error");
+                return lst != BZK_OK ? lst : BZK_E_DEVICE;
+            }
+            if (i == 0) BZK_HIP(c, hipMemcpyAsync(mg->h_win, mg->d_all[0], (size_t)mg->world * (blk + MG_HDR), hipMemcpyDeviceToHost, c->stream));
         } else if (x == BZK_MG_X_PEER) {
             if (mine)
-                BZK_HIP(c, hipMemcpyPeerAsync((char*)mg->d_all[0] + (size_t)rank * spr * sz, mg->devices[0], mg->d_send[i], mg->devices[i], mine, c->stream));
+                BZK_HIP(c, hipMemcpyPeerAsync((char*)mg->d_all[0] + (size_t)rank * blk, mg->devices[0], mg->d_send[i], mg->devices[i], mine, c->stream));
         } else if (mine) {  // HOST: straight into the shared pinned array (one process) / this rank's staging (shared memory below)
-            BZK_HIP(c, hipMemcpyAsync(mg->h_win + (size_t)rank * spr * sz, mg->d_send[i], mine, hipMemcpyDeviceToHost, c->stream));
+            BZK_HIP(c, hipMemcpyAsync(mg->h_win + (size_t)rank * blk, mg->d_send[i], mine, hipMemcpyDeviceToHost, c->stream));
         }
-        BZK_HIP(c, hipStreamSynchronize(c->stream));
-        return BZK_OK;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (lst == BZK_OK) c->last_error = "bzk_mg: exchange synchronisation";
+            return lst != BZK_OK ? lst : BZK_E_DEVICE;
+        }
+        return lst;
     });
-    if (st != BZK_OK) return st;
+    if (st != BZK_OK && !shm) return st;   // (RCCL: the peers read this rank's status from the gathered records below)
+    if (x == BZK_MG_X_RCCL) {
+        // compact the gathered blocks [sums | record] into the plain per-rank layout the combine below reads
+        for (int r = 0; r < mg->world; ++r) {
+            MgHdr h;
+            memcpy(&h, mg->h_win + (size_t)r * (blk + MG_HDR) + blk, MG_HDR);
+            if (h.seq != seq || h.status != BZK_OK)
+                return mg_fail(mg, BZK_E_DEVICE, "bzk_mg: rank " + std::to_string(r) + (h.seq != seq ? " is at another call of the group" : " failed its local stage (status " + std::to_string(h.status) + ")"));
+            if (r) memmove(mg->h_win + (size_t)r * blk, mg->h_win + (size_t)r * (blk + MG_HDR), blk);
+        }
+    }
     if (x == BZK_MG_X_PEER) {
         bzk_ctx* c = mg->ctxs[0];
         (void)hipSetDevice(mg->devices[0]);
-        if (hipMemcpyAsync(mg->h_win, mg->d_all[0], (size_t)mg->world * spr * sz, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        if (hipMemcpyAsync(mg->h_win, mg->d_all[0], (size_t)mg->world * blk, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess)
             return mg_fail(mg, BZK_E_DEVICE, "peer gather read-back");
     }
     // the window size, like the window count, is a function of n alone for calls that name a window range
     const int c_bits = bzk::msm_window_bits(n);
-    for (int v : cs)
-        if (v && v != c_bits) return mg_fail(mg, BZK_E_INTERNAL, "window size disagrees with msm_window_bits");
-    if (mg->multi_process && x == BZK_MG_X_HOST) {
-        // shared-memory all-gather: own sums (+ the window size this rank ran with) into slot [parity][rank], sequence-numbered arrival
+    if (st == BZK_OK)
+        for (int v : cs)
+            if (v && v != c_bits) { st = mg_fail(mg, BZK_E_INTERNAL, "window size disagrees with msm_window_bits"); break; }
+    if (shm) {
+        // shared-memory all-gather: [record | own sums] into slot [parity][rank], sequence-numbered arrival.  A rank that failed
+        // locally still arrives - with its status in the record - so every rank of the group returns an error for this call
         uint8_t* data = (uint8_t*)(mg->shm + 1);
-        const size_t rank_bytes = (size_t)MG_MAX_W * MG_SLOT_G2;
+        const size_t rank_bytes = (size_t)MG_MAX_W * MG_SLOT_G2 + MG_HDR;
         uint8_t* mine = data + ((seq & 1) * mg->world + mg->rank0) * rank_bytes;
         int lo, hi;
         window_range(W, mg->rank0, mg->world, &lo, &hi);
-        memcpy(mine, mg->h_win + (size_t)mg->rank0 * spr * sz, (size_t)(hi - lo) * sz);
-        BZK_TRY(shm_barrier(mg, seq));
+        const MgHdr h0{seq, st, cs[0]};
+        memcpy(mine, &h0, MG_HDR);
+        if (st == BZK_OK) memcpy(mine + MG_HDR, mg->h_win + (size_t)mg->rank0 * blk, (size_t)(hi - lo) * sz);
+        const int32_t bst = shm_barrier(mg, seq);
+        if (st != BZK_OK) return st;
+        BZK_TRY(bst);
         for (int r = 0; r < mg->world; ++r) {
             if (r == mg->rank0) continue;
+            const uint8_t* theirs = data + ((seq & 1) * mg->world + r) * rank_bytes;
+            MgHdr h;
+            memcpy(&h, theirs, MG_HDR);
+            // arrive[r] >= seq let us through; the record says whether what lies in the slot belongs to THIS call and is a result
+            if (h.seq != seq || h.status != BZK_OK)
+                return mg_fail(mg, BZK_E_DEVICE, "bzk_mg: rank " + std::to_string(r) + (h.seq != seq ? " is at another call of the group (stale slot)" : " failed its local stage (status " + std::to_string(h.status) + ")"));
             window_range(W, r, mg->world, &lo, &hi);
-            memcpy(mg->h_win + (size_t)r * spr * sz, data + ((seq & 1) * mg->world + r) * rank_bytes, (size_t)(hi - lo) * sz);
+            memcpy(mg->h_win + (size_t)r * blk, theirs + MG_HDR, (size_t)(hi - lo) * sz);
         }
     }
     // compact the per-rank slots into window order and combine
@@ -409,7 +470,7 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
         for (int r = 0; r < mg->world; ++r) {
             int lo, hi;
             window_range(W, r, mg->world, &lo, &hi);
-            memcpy(S.data() + (size_t)lo * sz, mg->h_win + (size_t)r * spr * sz, (size_t)(hi - lo) * sz);
+            memcpy(S.data() + (size_t)lo * sz, mg->h_win + (size_t)r * blk, (size_t)(hi - lo) * sz);
         }
     }
     return horner(S.data(), n ? W : 0, c_bits, 0, out);
@@ -591,7 +652,7 @@ static void mg_slot_main(bzk_mg_params* P, bzk_mg_params::Slot* sl) {
             job = P->queue.front();
             P->queue.pop_front();
         }
-        const int32_t st = bzk_groth16_prove(sl->ctx, sl->params, job.asg, job.r, job.s, job.out);
+        const int32_t st = bzk_groth16_prove(sl->ctx, sl->params, &job.asg, job.r, job.s, job.out);
         {
             std::lock_guard<std::mutex> lk(P->m);
             ++sl->proofs;
@@ -665,11 +726,12 @@ int32_t bzk_mg_prove_submit(bzk_mg* mg, bzk_mg_params* P, const bzk_assignment* 
     if (!mg || !P || !asg || !r || !s || !proof_out || !ticket || P->mg != mg) return BZK_E_ARG;
     std::lock_guard<std::mutex> lk(P->m);
     MgProofJob j;
-    j.asg = asg;
+    j.asg = *asg;
     memcpy(j.r, r, 32);
     memcpy(j.s, s, 32);
     j.out = proof_out;
     j.ticket = *ticket = P->next_ticket++;
+    P->outstanding.insert(j.ticket);
     P->queue.push_back(j);
     P->cv_work.notify_one();
     return BZK_OK;
@@ -678,12 +740,13 @@ int32_t bzk_mg_prove_submit(bzk_mg* mg, bzk_mg_params* P, const bzk_assignment* 
 int32_t bzk_mg_prove_wait(bzk_mg* mg, bzk_mg_params* P, uint64_t ticket) {
     if (!mg || !P || P->mg != mg) return BZK_E_ARG;
     std::unique_lock<std::mutex> lk(P->m);
-    if (ticket == 0 || ticket >= P->next_ticket) return BZK_E_ARG;
+    if (ticket == 0 || ticket >= P->next_ticket || !P->outstanding.count(ticket)) return BZK_E_ARG;  // unknown or already consumed
     for (;;) {
         for (size_t i = 0; i < P->finished.size(); ++i) {
             if (P->finished[i].first != ticket) continue;
             const int32_t st = P->finished[i].second;
             P->finished.erase(P->finished.begin() + (long)i);
+            P->outstanding.erase(ticket);
             for (size_t e = 0; e < P->errors.size(); ++e)
                 if (P->errors[e].first == ticket) {
                     mg->last_error = P->errors[e].second;

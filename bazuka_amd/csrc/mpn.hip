@@ -466,9 +466,11 @@ struct DevBatch {
             if (it != init_cache.end()) return it->second;
             return init_cache[k] = P.upload(w.accounts->get(lv, i));
         });
-        const int32_t st = P.run(w.dev);
+        // test hook (tests/test_gpu_mpn_devtree.py): read per call, so a test can fail one batch and run the next
+        const char* fault = getenv("BZK_MPN_TEST_FAULT");
+        const int32_t st = fault && fault[0] == '1' ? BZK_E_DEVICE : P.run(w.dev);
         if (st != BZK_OK) {
-            w.dev_error = bzk_last_error(w.dev);
+            w.dev_error = fault && fault[0] == '1' ? "injected fault" : bzk_last_error(w.dev);
             return st;
         }
         // bring the host-side sparse account tree up to date: every event's leaf and ancestors, in time order (the last write wins)
@@ -491,6 +493,27 @@ struct DevBatch {
 };
 }  // namespace
 
+// The device builders decide a batch on account data first (balances, nonces, queue) and hash afterwards in one batched step.  If that
+// step fails (allocation, HIP error) the decision must not stay behind - the Merkle tree was not advanced, so every later root, proof
+// or work of this handle would silently disagree with its accounts.  First-touch copies of the accounts; the caller keeps
+// the old queue in `rest` after the swap.
+struct AcctUndo {
+    bzk_mpn& w;
+    std::map<uint64_t, std::pair<bool, MpnAccount>> before;  // slot -> (existed, contents)
+    explicit AcctUndo(bzk_mpn& w_) : w(w_) {}
+    void note(uint64_t i) {
+        if (before.count(i)) return;
+        auto it = w.acct.find(i);
+        before[i] = {it != w.acct.end(), it != w.acct.end() ? it->second : MpnAccount()};
+    }
+    void rollback() {
+        for (auto& kv : before) {
+            if (kv.second.first) w.acct[kv.first] = kv.second.second;
+            else w.acct.erase(kv.first);
+        }
+    }
+};
+
 // update::update (src/mpn/update.rs:8-299) with the Merkle work batched on the device; same acceptance rules, same transitions
 static int32_t build_transitions_dev(bzk_mpn& w, int log4_batch, const ZkScalar& fee_token, std::vector<UpdateTransition>& out,
                                      uint64_t& fee_sum, uint64_t& rejected) {
@@ -498,6 +521,7 @@ static int32_t build_transitions_dev(bzk_mpn& w, int log4_batch, const ZkScalar&
     fee_sum = 0;
     rejected = 0;
     DevBatch B(w);
+    AcctUndo undo(w);
     struct Rec { size_t ev_sti, ev_sfi, ev_dti, leaf_src, leaf_dst; };
     std::vector<Rec> recs;
     std::vector<MpnTx> rest;
@@ -548,6 +572,7 @@ static int32_t build_transitions_dev(bzk_mpn& w, int log4_batch, const ZkScalar&
         r.ev_sti = B.token_write(src_index, sti, src_after.tokens[sti]);
         src_after.tokens[sfi].amount -= tx.fee.amount;
         r.ev_sfi = B.token_write(src_index, sfi, src_after.tokens[sfi]);
+        undo.note(src_index);
         w.acct[src_index] = src_after;
         r.leaf_src = B.account_write(src_index, src_after, r.ev_sfi);
         MpnAccount dst_before = w.get(dst_index);  // read AFTER the sender update (matters when src == dst)
@@ -559,6 +584,7 @@ static int32_t build_transitions_dev(bzk_mpn& w, int log4_batch, const ZkScalar&
         dst_after.tokens[dti].amount += tx.amount.amount;
         B.touch(dst_index, dst_before);
         r.ev_dti = B.token_write(dst_index, dti, dst_after.tokens[dti]);
+        undo.note(dst_index);
         w.acct[dst_index] = dst_after;
         r.leaf_dst = B.account_write(dst_index, dst_after, r.ev_dti);
         fee_sum += tx.fee.amount;
@@ -567,7 +593,12 @@ static int32_t build_transitions_dev(bzk_mpn& w, int log4_batch, const ZkScalar&
     }
     w.mempool.swap(rest);
     if (recs.empty()) return BZK_OK;
-    BZK_TRY(B.run());
+    if (const int32_t st = B.run(); st != BZK_OK) {  // nothing of the batch stays: accounts, queue and (untouched) tree agree again
+        undo.rollback();
+        w.mempool.swap(rest);
+        out.resize(out.size() - recs.size());
+        return st;
+    }
     const size_t first = out.size() - recs.size();
     for (size_t k = 0; k < recs.size(); ++k) {
         UpdateTransition& t = out[first + k];
@@ -959,6 +990,7 @@ static int32_t build_deposits_dev(bzk_mpn& w, int log4_batch, std::vector<Deposi
     const size_t cap = (size_t)1 << (2 * log4_batch);
     rejected = 0;
     DevBatch B(w);
+    AcctUndo undo(w);
     struct Rec { size_t ev_tok, leaf; bool had_tokens; };
     std::vector<Rec> recs;
     std::vector<DepositTx> rest;
@@ -990,6 +1022,7 @@ static int32_t build_deposits_dev(bzk_mpn& w, int log4_batch, std::vector<Deposi
         Rec r;
         B.touch(index, acc);
         r.ev_tok = B.token_write(index, ti, upd.tokens[ti]);
+        undo.note(index);
         w.acct[index] = upd;
         r.leaf = B.account_write(index, upd, r.ev_tok);
         out.push_back(std::move(t));
@@ -997,7 +1030,12 @@ static int32_t build_deposits_dev(bzk_mpn& w, int log4_batch, std::vector<Deposi
     }
     w.deposit_queue.swap(rest);
     if (recs.empty()) return BZK_OK;
-    BZK_TRY(B.run());
+    if (const int32_t st = B.run(); st != BZK_OK) {  // see AcctUndo: nothing of the batch stays behind
+        undo.rollback();
+        w.deposit_queue.swap(rest);
+        out.resize(out.size() - recs.size());
+        return st;
+    }
     const size_t first = out.size() - recs.size();
     for (size_t k = 0; k < recs.size(); ++k) {
         DepositTransition& t = out[first + k];
@@ -1148,6 +1186,7 @@ static int32_t build_withdraws_dev(bzk_mpn& w, int log4_batch, std::vector<Withd
     const size_t cap = (size_t)1 << (2 * log4_batch);
     rejected = 0;
     DevBatch B(w);
+    AcctUndo undo(w);
     struct Rec { size_t ev_ti, ev_fi, leaf; };
     std::vector<Rec> recs;
     std::vector<WithdrawTx> rest;
@@ -1186,6 +1225,7 @@ static int32_t build_withdraws_dev(bzk_mpn& w, int log4_batch, std::vector<Withd
         r.ev_ti = B.token_write(index, ti, upd.tokens[ti]);
         upd.tokens[fi].amount -= tx.fee.amount;
         r.ev_fi = B.token_write(index, fi, upd.tokens[fi]);
+        undo.note(index);
         w.acct[index] = upd;
         r.leaf = B.account_write(index, upd, r.ev_fi);
         out.push_back(std::move(t));
@@ -1193,7 +1233,12 @@ static int32_t build_withdraws_dev(bzk_mpn& w, int log4_batch, std::vector<Withd
     }
     w.withdraw_queue.swap(rest);
     if (recs.empty()) return BZK_OK;
-    BZK_TRY(B.run());
+    if (const int32_t st = B.run(); st != BZK_OK) {  // see AcctUndo: nothing of the batch stays behind
+        undo.rollback();
+        w.withdraw_queue.swap(rest);
+        out.resize(out.size() - recs.size());
+        return st;
+    }
     const size_t first = out.size() - recs.size();
     for (size_t k = 0; k < recs.size(); ++k) {
         WithdrawTransition& t = out[first + k];

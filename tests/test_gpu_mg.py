@@ -170,6 +170,35 @@ def test_mg_process_per_gpu_shared_memory_exchange(bzk, co, world, g2):
         assert o[1] == str(r) and o[2] == "host" and bytes.fromhex(o[3]) == want
 
 
+def test_mg_local_failure_reaches_every_rank_and_the_group_survives(bzk, co):
+    """a rank whose local stage fails (allocation, window error) must still take part in the exchange so that EVERY
+    rank returns an error for that call - not block, and never combine the stale sums of an earlier call - and the next call of
+    the group works again.  Fault injected into rank 1's local stage of the group's 3rd sequence number (1 = the creation barrier,
+    so the 2nd MSM call): 4 calls per rank -> 3 results equal to the single-GPU bytes + 1 error, on both ranks."""
+    from bazuka_amd import mg_unique_id
+    n, seed, world = 20000, 78, 2
+    uid = mg_unique_id().hex()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BZK_MG_TEST_FAULT="1:3", BZK_MG_TIMEOUT_S="60")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "mg_rank.py"), str(r), str(world), uid, str(n), str(seed),
+                               "0", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    d = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(seed, 0, n, d)
+    bzk.sync()
+    want = co.msm_g1(dev_bytes(d), rand_scalars_bytes(n, seed), nthreads=co.ncpu())
+    for r, p in enumerate(procs):
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-2000:]
+        res = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0].split()
+        err = [ln for ln in o.splitlines() if ln.startswith("ERROR")]
+        assert bytes.fromhex(res[3]) == want and res[4:] == ["3", "1"], o
+        assert len(err) == 1 and ("injected fault" in err[0] if r == 1 else "rank 1 failed its local stage" in err[0]), err
+
+
 def test_mg_proof_pool_replicas(bzk, co, pr):
     """bzk_mg_params_load / bzk_mg_prove_submit / _wait: a pool of prover slots over the group's devices (one CRS upload per device)
     proves a queue of different (r, s) pairs; every proof equals the oracle's and more than one slot did work"""

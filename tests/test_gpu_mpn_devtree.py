@@ -73,3 +73,27 @@ def test_shared_accounts_follow_up_batches_and_circuit_instance(bzk):
     assert len(host) == len(dev)
     for k, (a, b) in enumerate(zip(host, dev)):
         assert a == b, f"item {k} differs between the host and the device builder"
+
+
+def test_failed_device_step_leaves_the_world_untouched(bzk, monkeypatch):
+    """the device builders decide a batch (balances, nonces, queue) BEFORE the batched hashing step; if that step fails
+    nothing of the decision may stay behind.  One injected failure per work kind, then the same call again: the works must equal the
+    ones of a world that never saw a failure, and so must the roots."""
+    def run(fail):
+        w, idx = _world(15, 3, 8, bzk)
+        out = []
+        for kind, push in ((2, lambda: [w.push_tx(idx[t], idx[t + 1], ZIESHA, 100 + t, ZIESHA, 1) for t in range(5)]),
+                           (0, lambda: [w.push_deposit(idx[2], ZIESHA, 500), w.push_deposit(4 ** 15 - 5, F(4242), 9)]),
+                           (1, lambda: [w.push_withdraw(idx[4], ZIESHA, 40, ZIESHA, 1), w.push_withdraw(idx[4], ZIESHA, 41, ZIESHA, 1)])):
+            push()
+            if fail:
+                root = w.root()
+                monkeypatch.setenv("BZK_MPN_TEST_FAULT", "1")
+                with pytest.raises(L.BzkError):
+                    w.make_work(kind, sc.VKS, 10, log4_batches=(1, 1, 2))
+                monkeypatch.delenv("BZK_MPN_TEST_FAULT")
+                assert w.root() == root
+            out.append(w.make_work(kind, sc.VKS, 10, log4_batches=(1, 1, 2)).encode())
+            out.append(w.root())
+        return out
+    assert run(True) == run(False)

@@ -23,9 +23,15 @@ def main():
     sc = to_dev(rand_scalars_bytes(n, seed))
     torch.cuda.synchronize()
     hb = mg.bases_load_dev([bases], n, g2=bool(g2))
-    outs = [mg.msm_dev(hb, [sc], n, g2=bool(g2)) for _ in range(3)]  # several calls: the double-buffered exchange is re-used
-    assert outs[0] == outs[1] == outs[2]
-    print("RESULT", rank, mg.exchange, outs[0].hex(), flush=True)
+    outs, errs = [], 0
+    for _ in range(4 if os.environ.get("BZK_MG_TEST_FAULT") else 3):  # several calls: the double-buffered exchange is re-used
+        try:
+            outs.append(mg.msm_dev(hb, [sc], n, g2=bool(g2)))
+        except Exception as e:   # an injected fault on ANY rank must surface on EVERY rank, for that call only
+            errs += 1
+            print("ERROR", rank, str(e).replace("\n", " "), flush=True)
+    assert all(o == outs[0] for o in outs)
+    print("RESULT", rank, mg.exchange, outs[0].hex(), len(outs), errs, flush=True)
     mg.bases_free(hb)
     mg.close()
     ctx.close()
