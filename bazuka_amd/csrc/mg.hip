@@ -500,6 +500,19 @@ int32_t bzk_mg_unique_id(uint8_t uid[BZK_MG_UID_BYTES]) {
     return got == BZK_MG_UID_BYTES ? BZK_OK : BZK_E_DEVICE;
 }
 
+int32_t bzk_mg_probe(int32_t device_id) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
+    int32_t mask = 0;
+    if (device_id >= 0 && device_id < n_dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && strstr(prop.gcnArchName, "gfx950")) mask |= 1;
+        else (void)hipGetLastError();
+    }
+    if (n_dev > 0 && rccl_api()->ok()) mask |= 2;
+    return mask;
+}
+
 int32_t bzk_mg_create(const int32_t* device_ids, int32_t n_devices, uint32_t exchange, bzk_mg** out) {
     if (!out) return BZK_E_ARG;
     *out = nullptr;

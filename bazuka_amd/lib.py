@@ -141,6 +141,7 @@ SIGNATURES = {
     "bzk_msm_g1_bases_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "bzk_msm_g2_bases_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "bzk_mg_unique_id": (_i32, [_vp]),
+    "bzk_mg_probe": (_i32, [_i32]),
     "bzk_mg_create": (_i32, [C.POINTER(_i32), _i32, _u32, C.POINTER(_vp)]),
     "bzk_mg_create_rank": (_i32, [_i32, _i32, _i32, _vp, _u32, C.POINTER(_vp)]),
     "bzk_mg_destroy": (None, [_vp]),
@@ -624,6 +625,14 @@ class Bzk:
 # --------------------------------------------------------------------------------------------------
 MG_X_AUTO, MG_X_HOST, MG_X_PEER, MG_X_RCCL = 0, 1, 2, 3
 MG_X_NAMES = {MG_X_HOST: "host", MG_X_PEER: "peer", MG_X_RCCL: "rccl"}
+
+
+def mg_probe(device: int) -> int:
+    """bit 0: the device is a usable gfx950; bit 1: librccl loads with everything the RCCL exchange needs (bzk_mg_probe)"""
+    st = load_library().bzk_mg_probe(device)
+    if st < 0:
+        raise BzkError(f"bzk_mg_probe: {load_library().bzk_strerror(st).decode()}")
+    return st
 
 
 def mg_unique_id() -> bytes:

@@ -463,6 +463,11 @@ int32_t bzk_msm_g2_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, c
 typedef struct bzk_mg bzk_mg;
 typedef struct bzk_mg_bases bzk_mg_bases;
 int32_t bzk_mg_unique_id(uint8_t uid[BZK_MG_UID_BYTES]);
+/* what THIS process could contribute to a group on `device_id`, without creating anything that a peer would wait for: a bit mask,
+ * bit 0 = the device exists and is a gfx950, bit 1 = librccl is loadable with every entry point the RCCL exchange needs.  A
+ * process-per-GPU host publishes the answer of every rank (by its own means) BEFORE calling bzk_mg_create_rank with BZK_MG_X_RCCL:
+ * ncclCommInitRank blocks until all ranks arrive, so a rank that cannot take part must be known beforehand.  Negative: BZK_E_*. */
+int32_t bzk_mg_probe(int32_t device_id);
 int32_t bzk_mg_create(const int32_t* device_ids, int32_t n_devices, uint32_t exchange, bzk_mg** out);
 int32_t bzk_mg_create_rank(int32_t device_id, int32_t rank, int32_t world, const uint8_t uid[BZK_MG_UID_BYTES], uint32_t exchange, bzk_mg** out);
 void bzk_mg_destroy(bzk_mg* mg);

@@ -29,6 +29,14 @@ def child(mode, log_n):
         ms = timeit(lambda: ctx.msm_g1_windows_dev(bases, sc, n, 0, w1))
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_g1_windows_dev(bases, sc, n, 0, w1); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
         print(json.dumps({"mode": mode, "log_n": log_n, "windows": [0, w1], "of": W, "ms": round(ms, 3), "prof": prof}))
+    elif mode == "g1winres":  # the same on a RESIDENT base set (what bzk_mg_msm_g1_dev runs per rank since round 3): conversion is load-time work
+        bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
+        hb = ctx.msm_bases_load_dev(bases, n)
+        W = ctx.msm_window_count(n); w1 = max(1, W // int(os.environ.get("SHARDS", "8")))
+        ms = timeit(lambda: ctx.msm_bases_windows_dev(hb, sc, n, 0, w1))
+        ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_bases_windows_dev(hb, sc, n, 0, w1); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
+        print(json.dumps({"mode": mode, "log_n": log_n, "windows": [0, w1], "of": W, "ms": round(ms, 3), "prof": prof}))
+        ctx.msm_bases_free(hb)
     elif mode == "g1tab":
         bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
         lv = int(os.environ.get("TAB_LEVELS", "0"))
@@ -109,6 +117,8 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r4rank8",):  # round 4: what one rank of 8 / 4 / 2 does at 2^23 / 2^22 / 2^21 points (weak scaling), raw and resident bases
+        run("g1win", 23); run("g1winres", 23); run("g1winres", 22, {"SHARDS": "4"}); run("g1winres", 21, {"SHARDS": "2"}); run("g1", 20)
     if what in ("r39",):
         run("tree", 24); run("tree", 20); run("tree", 16); run("tree", 12)
     if what in ("r36",):
