@@ -35,6 +35,7 @@ struct bzk_ctx {
     // MSM tuning overrides (0 = automatic); settable through env BZK_MSM_C / BZK_MSM_CHUNK
     int msm_c_override = 0;
     int msm_chunk_override = 0;
+    bool msm_no_endo = false;  // env BZK_MSM_NO_ENDO=1 (and the device groups' contexts): resident base sets without endomorphism images, plain windows
     int msm_reduce2 = 0;  // env BZK_MSM_REDUCE2: 1 forces the two-level bucket reduction, -1 forbids it, 0 = per call (BZK_F_THROUGHPUT)
     bool debug = false;  // env BZK_DEBUG=1: synchronise + log after every launch (hang localisation)
     // NTT twiddle cache: per log_n, forward and inverse tables

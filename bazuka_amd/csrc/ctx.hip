@@ -77,6 +77,7 @@ bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
     c->msm_c_override = ctx->msm_c_override;
     c->msm_chunk_override = ctx->msm_chunk_override;
     c->msm_reduce2 = ctx->msm_reduce2;
+    c->msm_no_endo = ctx->msm_no_endo;
     return c;
 }
 
@@ -194,6 +195,7 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     if (const char* e = getenv("BZK_MSM_C")) ctx->msm_c_override = atoi(e);
     if (const char* e = getenv("BZK_MSM_CHUNK")) ctx->msm_chunk_override = atoi(e);
     if (const char* e = getenv("BZK_MSM_REDUCE2")) ctx->msm_reduce2 = atoi(e);
+    if (const char* e = getenv("BZK_MSM_NO_ENDO")) ctx->msm_no_endo = atoi(e) != 0;
     if (const char* e = getenv("BZK_DEBUG")) ctx->debug = atoi(e) != 0;
     if (const char* e = getenv("BZK_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char* e = getenv("BZK_NO_COOP")) ctx->no_coop = atoi(e) != 0;

@@ -272,6 +272,7 @@ int32_t mg_finish_create(bzk_mg* mg, uint32_t exchange, const uint8_t* uid) {
         bzk_ctx* c = nullptr;
         const int32_t st = bzk_ctx_create(mg->devices[i], nullptr, &c);
         if (st != BZK_OK) return mg_fail(mg, st, "bzk_ctx_create(device " + std::to_string(mg->devices[i]) + ")");
+        c->msm_no_endo = true;  // the group shards PLAIN windows: its resident sets carry no endomorphism images (E x the memory for nothing)
         mg->ctxs.push_back(c);
     }
     BZK_TRY(mg_alloc_buffers(mg));

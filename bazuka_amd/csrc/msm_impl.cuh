@@ -171,6 +171,94 @@ static __global__ void __launch_bounds__(256) msm_digits_kernel(const U128* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1b. digits of the endomorphism form (bzk_endo.cuh; round 4): the canonical scalar is split into E signed sub-scalars (G2: four
+// of < 2^63 in base X, G1: two of < 2^127 in base X^2), each recoded into w_sub signed c-bit digits.  Window j of sub-scalar m feeds
+// bucket set j with the image m of its base: the value's index field is  (m << ibits) | base index.  Window-in-value pairs, emitted
+// window-major with the E images of a window adjacent, so that the stable sort leaves every (bucket, window) run contiguous.
+// ------------------------------------------------------------------------------------------------
+template <int E>
+static __global__ void __launch_bounds__(256) msm_digits_endo_kernel(const U128* __restrict__ scalars, uint64_t n, int mont, int c, int w_sub,
+                                                                     int ibits, const uint32_t* __restrict__ rep, uint32_t* __restrict__ keys,
+                                                                     uint32_t* __restrict__ vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s;
+    {
+        U128 a = scalars[2 * i], b = scalars[2 * i + 1];
+        s.l[0] = a.x; s.l[1] = a.y; s.l[2] = a.z; s.l[3] = a.w;
+        s.l[4] = b.x; s.l[5] = b.y; s.l[6] = b.z; s.l[7] = b.w;
+    }
+    if (mont) {
+        s = fe_from_mont<FrParams>(s);
+    } else {  // the split needs k < r (2^256 < 3 r)
+        fe_reduce_once<FrParams>(s);
+        fe_reduce_once<FrParams>(s);
+    }
+    constexpr int ML = E == 4 ? 2 : 4;  // limbs of a sub-scalar's magnitude
+    uint32_t mag[E][ML];
+    bool sneg[E];
+    if constexpr (E == 4) {
+        int64_t sv[4];
+        endo::decompose4(s.l, sv);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            sneg[m] = sv[m] < 0;
+            const uint64_t a = (uint64_t)(sneg[m] ? -sv[m] : sv[m]);
+            mag[m][0] = (uint32_t)a;
+            mag[m][1] = (uint32_t)(a >> 32);
+        }
+    } else {
+        endo::decompose2(s.l, mag, sneg);
+    }
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    const uint32_t base = rep ? rep[i] : (uint32_t)i;
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        uint64_t buf = 0;
+        int cnt = 0, w = 0;
+        uint32_t carry = 0;
+        auto emit = [&](uint32_t raw) {
+            uint32_t d = raw + carry;
+            uint32_t neg = sneg[m] ? 1u : 0u;
+            if (d > half) {
+                d = (1u << c) - d;
+                neg ^= 1u;
+                carry = 1;
+            } else {
+                carry = 0;
+            }
+            const uint64_t o = ((uint64_t)w * E + m) * n + i;
+            keys[o] = d ? (d - 1) : half;
+            vals[o] = (((uint32_t)m << ibits) | base) | ((uint32_t)w << 27) | (neg << 31);
+            ++w;
+        };
+#pragma unroll
+        for (int j = 0; j < ML; ++j) {
+            buf |= (uint64_t)mag[m][j] << cnt;
+            cnt += 32;
+            while (cnt >= c && w < w_sub) {
+                emit((uint32_t)buf & mask);
+                buf >>= c;
+                cnt -= c;
+            }
+        }
+        while (w < w_sub) {
+            emit((uint32_t)buf & mask);
+            buf >>= c;
+        }
+    }
+}
+
+// images X^m P (m = 1 .. E - 1) of `count` points in the internal affine form: data[m * stride + i] from data[i]
+template <class C>
+__global__ void __launch_bounds__(128) msm_endo_images_kernel(typename C::DevAff* __restrict__ data, uint64_t count, uint64_t stride) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    C::endo_images(data[i], data + i, (size_t)stride);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3. bucket boundaries
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) msm_offsets_kernel(const uint32_t* __restrict__ keys, uint64_t len, uint32_t nb,
@@ -304,12 +392,18 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
                                                              const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t t_max,
                                                              uint32_t seg, typename C::Pt* __restrict__ buckets,
                                                              typename C::Pt* __restrict__ partial, uint32_t vmask,
-                                                             const void* __restrict__ bases2, uint32_t n_split) {
+                                                             const void* __restrict__ bases2, uint32_t n_split, uint32_t ibits,
+                                                             uint32_t stride1, uint32_t stride2) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= t_max) return;
     // base indices >= n_split name entries of a SECOND array (the de-duplication's group sums, which live in the call's workspace
-    // while the bases proper may be a resident, shared, read-only set - MsmBases): one compare + select per gather
-    auto ld = [&](uint32_t idx) { return idx >= n_split ? C::load(bases2, idx - n_split) : C::load(bases, idx); };
+    // while the bases proper may be a resident, shared, read-only set - MsmBases): one compare + select per gather.  Endomorphism
+    // form: the bits above `ibits` of the index select the image m of the base (array m of either set; ibits = 31 otherwise: m = 0)
+    const uint32_t imask = (1u << ibits) - 1u;
+    auto ld = [&](uint32_t idx) {
+        const uint32_t m = idx >> ibits, b = idx & imask;
+        return b >= n_split ? C::load(bases2, m * stride2 + (b - n_split)) : C::load(bases, m * stride1 + b);
+    };
     // last sorted position i with tbase[i] <= t
     uint32_t lo = 0, hi = nb;
     while (lo + 1 < hi) {
@@ -985,7 +1079,8 @@ struct BucketArrays {
 template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
                                  uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
-                                 bool group_sums = false, uint32_t wiv_half = 0, const void* bases2 = nullptr, uint32_t n_split = 0xffffffffu) {
+                                 bool group_sums = false, uint32_t wiv_half = 0, const void* bases2 = nullptr, uint32_t n_split = 0xffffffffu,
+                                 uint32_t ibits = 31, uint32_t stride1 = 0, uint32_t stride2 = 0) {
     // start[] and count[] are taken from the workspace back to back: one fill covers both
     if ((const char*)A.count > (const char*)A.start && (size_t)((const char*)A.count - (const char*)A.start) <= (size_t)nb * 4 + 256) {
         BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)((const char*)A.count - (const char*)A.start) + (size_t)nb * 4, ctx->stream));
@@ -1026,10 +1121,10 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     auto k_fold_small = msm_fold_small_kernel<C>;
     if (group_sums) {
         BZK_LAUNCH(ctx, "dedup_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
-                   nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split);
+                   nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split, ibits, stride1, stride2);
     } else {
         BZK_LAUNCH(ctx, "msm_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
-                   nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split);
+                   nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split, ibits, stride1, stride2);
     }
     // only sorted positions < len / seg can hold a multi-task bucket; of those only the first
     // len / (seg * MSM_FOLD_SMALL) can need the workgroup-wide fold
@@ -1099,9 +1194,10 @@ struct MsmTable {
 // Groth16 CRS query - is loaded, shared read-only by every later call (and by every rank of a window-sharded MSM: no rank converts
 // anything per call).  bzk_msm_g*_bases_*.
 struct MsmBases {
-    void* data = nullptr;  // DevAff[n]
+    void* data = nullptr;  // DevAff[endo][n]: the set itself, then (endo > 1) its images X^m P, m = 1 .. endo - 1 (bzk_endo.cuh)
     uint64_t n = 0;
     int device = 0;
+    int endo = 1;
 };
 // Where a call that must not finish on this host thread leaves its window sums: `d_win` receives, in DEVICE memory and in stream
 // order, the (w_end - w_begin) window sums S_w as standard-limb XYZZ points; no read-back, no Horner, no synchronisation.  The
@@ -1143,7 +1239,23 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     // bzk_msm_window_count(n), i.e. with the plain pick
     if (!table && (flags & BZK_F_DEDUP) && w_end < 0 && w_begin == 0 && !(ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20))
         c = msm_pick_c_witness<C>(n, c);
-    const int w_total = msm_windows_for(c);
+    const bool dedup = (flags & BZK_F_DEDUP) && C::CONVERT_BASES && !table && n >= 4096 && n < ((uint64_t)1 << 30);
+    const uint32_t m_max = dedup ? (uint32_t)(n / 2 + 1) : 0;  // group sums: at most n / 2 groups of >= 2 members
+    // window-in-value pairs (msm_digits): per-window bucket sets of up to 16 windows per pass over fewer than 2^27 bases
+    static const bool wiv_off = [] { const char* e = getenv("BZK_MSM_NO_WIV"); return e && atoi(e) != 0; }();
+    // Endomorphism form (bzk_endo.cuh, round 4) for whole MSMs over a resident set that carries its images: E sub-scalars per scalar
+    // whose windows share w_sub = ENDO_BITS / c bucket sets (c = 16: 8 on G1, 4 on G2, instead of 16) - the same additions, 1 / 2
+    // resp. 1 / 4 of the buckets to reduce.  Calls that name a window range or leave their window sums on the device (the
+    // multi-GPU entry points) keep the plain form: their partition is defined over the plain windows.
+    int E = 1, ibits = 31;
+    if (prep && prep->endo > 1 && !table && !wout && w_begin == 0 && w_end < 0 && !ctx->msm_no_endo && !wiv_off) {
+        const int e = prep->endo, ib = 27 - (e == 4 ? 2 : 1), ws = (C::ENDO_BITS + c - 1) / c;
+        if (e == C::ENDO && (uint64_t)n + m_max < ((uint64_t)1 << ib) && ws <= 16 && (uint64_t)ws * n * e < ((uint64_t)1 << 30)) {
+            E = e;
+            ibits = ib;
+        }
+    }
+    const int w_total = E > 1 ? (C::ENDO_BITS + c - 1) / c : msm_windows_for(c);
     const bool folded = table && table->wpl > 1;  // bucket sets [w_begin, w_end) of a folded table, fed by every level
     const int levels = table ? table->levels : 1;
     if (w_end < 0) w_end = folded ? table->wpl : w_total;
@@ -1169,16 +1281,14 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const uint32_t ch2 = std::min<uint32_t>(quad_l2 ? quad_l2_ch : 8u, per_win);
     const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && (flags & BZK_F_THROUGHPUT)));
     const uint32_t per_win_out = two_level ? per_win + per_win / ch2 : per_win;  // chunk results per window handed to the window sums
-    const bool dedup = (flags & BZK_F_DEDUP) && C::CONVERT_BASES && !table && n >= 4096 && n < ((uint64_t)1 << 30);
     if (wout) { wout->c = c; wout->w_total = w_total; wout->w_begin = w_begin; wout->w_end = w_end; wout->single = table && !folded; }
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
     int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w_end - w_begin), ((uint64_t)1 << 30) / n));
-    if (table) group = w_end - w_begin;  // shared bucket sets: all requested windows in one pass
-    const uint64_t len_max = (uint64_t)group * n * (folded ? (uint64_t)levels : 1);
+    if (table || E > 1) group = w_end - w_begin;  // shared bucket sets: all requested windows in one pass
+    const uint64_t len_max = (uint64_t)group * n * (folded ? (uint64_t)levels : (uint64_t)E);
     if (len_max >= ((uint64_t)1 << 31)) return BZK_E_ARG;
     const uint32_t nb_max = (table && !folded) ? half : (uint32_t)group * half;
-    const uint32_t m_max = dedup ? (uint32_t)(n / 2 + 1) : 0;  // group sums: at most n / 2 groups of >= 2 members
     const uint32_t nb_alloc = std::max(nb_max, m_max);
 
     // rocPRIM temp sizes
@@ -1204,7 +1314,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const size_t tmp = std::max(std::max(tmp1, tmp2), std::max(tmp3, tmp4));
     // serial run length per lane: ~4x the mean bucket population, within [32, 256] - short enough that the
     // few over-full buckets of a degenerate top window do not set the kernel's critical path at small n
-    uint32_t seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n / half + 1)));
+    uint32_t seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n * E / half + 1)));
     if (table) seg = 64;  // shared buckets are all heavily populated: short runs keep every SIMD busy
     if (folded) seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (len_max / nb_max + 1)));
     // few, heavily populated buckets (a rank of a window-sharded MSM owns 2 windows of 2^23 points: 65 536 buckets of
@@ -1229,7 +1339,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (two_level) total += ws_pad((size_t)group * per_win * sizeof(Pt));
     total += ws_pad(((size_t)group * (per_win_out / C::WSUM_THREADS + 1)) * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(StdPt));
-    if (C::CONVERT_BASES && !table) total += ws_pad((size_t)((prep ? 0 : n) + m_max) * sizeof(typename C::DevAff));
+    if (C::CONVERT_BASES && !table) total += ws_pad((size_t)((prep ? 0 : n) + (size_t)m_max * E) * sizeof(typename C::DevAff));
     if (dedup) {
         total += 11 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
     }
@@ -1261,7 +1371,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     AuxJoin aux(ctx);
     if (prep) {
         bases = prep->data;  // resident internal form: nothing to convert
-        if (m_max) sums_aff = cur.take<typename C::DevAff>(m_max);
+        if (m_max) sums_aff = cur.take<typename C::DevAff>((size_t)m_max * E);  // group sums, then (endomorphism form) their images
     } else if (C::CONVERT_BASES && !table) {
         conv = cur.take<typename C::DevAff>(n + m_max);
         sums_aff = conv + n;
@@ -1363,26 +1473,33 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             auto k_aff = dedup_affine_kernel<C>;
             BZK_LAUNCH(ctx, "dedup_affine", k_aff, dim3((unsigned)(((M + K - 1) / K + 63) / 64)), dim3(64), 0, (const Pt*)buckets, M, K, pref,
                        sums_aff, (const uint32_t*)gof, scal2);
+            if (E > 1) {  // images X^m S of the group sums (an identity sum has a zeroed scalar: its slot is never gathered)
+                auto k_img = msm_endo_images_kernel<C>;
+                BZK_LAUNCH(ctx, "dedup_images", k_img, dim3((M + 127) / 128), dim3(128), 0, sums_aff, (uint64_t)M, (uint64_t)m_max);
+            }
         }
         n_eff = G;
         scal_eff = scal2;
-        seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n_eff / half + 1)));
-        seg = std::min(seg, enough_tasks(seg, (uint64_t)group * n_eff, nb_max));
+        seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n_eff * E / half + 1)));
+        seg = std::min(seg, enough_tasks(seg, (uint64_t)group * n_eff * E, nb_max));
     }
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;
-    // window-in-value pairs (msm_digits): per-window bucket sets of up to 16 windows per pass over fewer than 2^27 bases
-    static const bool wiv_off = [] { const char* e = getenv("BZK_MSM_NO_WIV"); return e && atoi(e) != 0; }();
     const bool wiv = !wiv_off && !table && group <= 16 && (uint64_t)n + m_max < ((uint64_t)1 << 27);
     std::vector<StdPt> wsum((size_t)(w_end - w_begin));
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
-        const uint64_t len = (uint64_t)wc * n_eff * (folded ? (uint64_t)levels : 1);
+        const uint64_t len = (uint64_t)wc * n_eff * (folded ? (uint64_t)levels : (uint64_t)E);
         const uint32_t nb = (table && !folded) ? half : (uint32_t)wc * half;
         const int n_red_win = (table && !folded) ? 1 : wc;  // bucket sets to reduce
-        BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
-                   mont, c, folded ? levels * table->wpl : w_total, wb, wc, (uint32_t)(table ? table->n : 0), table ? table->wpl : 1,
-                   (const uint32_t*)(dedup ? rep : nullptr), wiv ? 1 : 0, keys, vals);
+        if (E > 1) {
+            BZK_LAUNCH(ctx, "msm_digits", (msm_digits_endo_kernel<C::ENDO>), dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff,
+                       n_eff, mont, c, w_total, ibits, (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
+        } else {
+            BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,
+                       mont, c, folded ? levels * table->wpl : w_total, wb, wc, (uint32_t)(table ? table->n : 0), table ? table->wpl : 1,
+                       (const uint32_t*)(dedup ? rep : nullptr), wiv ? 1 : 0, keys, vals);
+        }
         {
             ProfScope ps(ctx, "msm_sort_pairs");
             size_t t = tmp;
@@ -1390,7 +1507,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         aux.join();
-        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, wiv ? half : 0u, sums_aff, n_split));
+        BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, wiv ? half : 0u, sums_aff, n_split,
+                                     (uint32_t)ibits, E > 1 ? (uint32_t)prep->n : 0u, E > 1 ? m_max : 0u));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         if (two_level) {
@@ -1550,7 +1668,19 @@ static int32_t msm_bases_load(bzk_ctx* ctx, const void* bases_raw, uint64_t n, M
     if (!b) return BZK_E_ALLOC;
     b->n = n;
     b->device = ctx->device;
-    hipError_t e = hipMalloc(&b->data, (size_t)n * sizeof(typename C::DevAff));
+    // with its endomorphism images (E x the memory) unless the context opts out or the device has no room for them beside a reserve
+    b->endo = ctx->msm_no_endo ? 1 : C::ENDO;
+    if (b->endo > 1) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if ((size_t)b->endo * n * sizeof(typename C::DevAff) + ((size_t)8 << 30) > free_b) b->endo = 1;
+    }
+    hipError_t e = hipMalloc(&b->data, (size_t)b->endo * n * sizeof(typename C::DevAff));
+    if (e != hipSuccess && b->endo > 1) {
+        (void)hipGetLastError();
+        b->endo = 1;
+        e = hipMalloc(&b->data, (size_t)n * sizeof(typename C::DevAff));
+    }
     if (e != hipSuccess) {
         ctx->last_error = std::string("bases alloc: ") + hipGetErrorString(e);
         (void)hipGetLastError();
@@ -1558,6 +1688,13 @@ static int32_t msm_bases_load(bzk_ctx* ctx, const void* bases_raw, uint64_t n, M
         return BZK_E_ALLOC;
     }
     int32_t st = msm_convert_launch<C>(ctx, bases_raw, n, (typename C::DevAff*)b->data);
+    if (st == BZK_OK && b->endo > 1) {
+        auto k_img = msm_endo_images_kernel<C>;
+        st = [&]() -> int32_t {
+            BZK_LAUNCH(ctx, "msm_endo_images", k_img, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (typename C::DevAff*)b->data, n, n);
+            return BZK_OK;
+        }();
+    }
     if (st == BZK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = BZK_E_DEVICE;
     if (st != BZK_OK) {
         (void)hipFree(b->data);

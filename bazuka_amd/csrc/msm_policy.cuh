@@ -4,6 +4,7 @@
 //             call to the internal 112-byte form (x, y in 14 x 28-bit limbs, Montgomery 2^392)
 //   G2Fast  - the same over Fp2 = Fp28[u]/(u^2+1) with the generic XYZZ formulas (buckets 448 B, bases 224 B)
 #pragma once
+#include "bzk_endo.cuh"
 #include "bzk_fp28.cuh"
 
 namespace bzk {
@@ -26,6 +27,9 @@ struct G1Fast {
 #define BZK_G1_ACC_OCC 2  // waves per SIMD the accumulate kernel is compiled for (A/B builds)
 #endif
     static constexpr int ACC_OCC = BZK_G1_ACC_OCC;
+    // endomorphism form (bzk_endo.cuh): scalars split into ENDO signed sub-scalars of ENDO_BITS bits over the images X^(2 m) P
+    static constexpr int ENDO = 2, ENDO_BITS = 128;
+    __device__ static __forceinline__ void endo_images(const DevAff& p, DevAff* out, size_t stride) { out[stride] = endo::g1_image(p); }
 #ifndef BZK_G1_PARK_REDUCE
 #define BZK_G1_PARK_REDUCE 0
 #endif
@@ -100,6 +104,13 @@ struct G2Fast {
     // waves per SIMD the accumulate kernel is compiled for: 2 -> 256 VGPRs, 402 spilled to scratch; 1 -> 512 (VGPR + AGPR),
     // 35 spilled (profiles/r01_run15: 12.7 ms vs 13.0 ms at 2^20)
     static constexpr int ACC_OCC = BZK_G2_ACC_OCC;
+    // endomorphism form (bzk_endo.cuh): four signed 64-bit sub-scalars over the images X^m P, m = 0 .. 3
+    static constexpr int ENDO = 4, ENDO_BITS = 64;
+    __device__ static __forceinline__ void endo_images(const DevAff& p, DevAff* out, size_t stride) {
+        out[stride] = endo::g2_image<1>(p);
+        out[2 * stride] = endo::g2_image<2>(p);
+        out[3 * stride] = endo::g2_image<3>(p);
+    }
     __device__ static __forceinline__ Pt identity() { return xyzz_identity<Fp2x28Ops>(); }
     template <class Pre>
     __device__ static __forceinline__ void add_mixed_pre(Pt& acc, const DevAff& p_in, bool neg, Pre&& pre) {

@@ -2,6 +2,7 @@
 // so that limb-level logic is checked against the oracle in this GPU-less container.
 #define BZK_FP28_CHECK 1
 #include "../../bazuka_amd/csrc/bzk_fp28.cuh"
+#include "../../bazuka_amd/csrc/bzk_endo.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon29.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon_opt.h"
 #include "../../bazuka_amd/csrc/host_fp64.h"
@@ -233,6 +234,42 @@ int hc_g2x28_lincomb_mem(const uint8_t* pts, const uint32_t* k, const uint8_t* n
     return 0;
 }
 // Fr in 9 x 29-bit limbs
+// ---- bzk_endo.cuh: scalar split and point images of the endomorphism form of the MSM (round 4)
+// k: 8 x u32 canonical scalar -> G2 split: 4 x int64
+int hc_endo_decompose4(const uint32_t* k, int64_t* s4) {
+    endo::decompose4(k, s4);
+    return 0;
+}
+// -> G1 split: mag[2][4] (u32 limbs) and neg[2]
+int hc_endo_decompose2(const uint32_t* k, uint32_t* mag8, uint8_t* neg2) {
+    uint32_t mag[2][4];
+    bool neg[2];
+    endo::decompose2(k, mag, neg);
+    for (int m = 0; m < 2; ++m) {
+        for (int i = 0; i < 4; ++i) mag8[4 * m + i] = mag[m][i];
+        neg2[m] = neg[m] ? 1 : 0;
+    }
+    return 0;
+}
+// image X^2 P of a G1 point / X^m P of a G2 point in the internal form, handed back through ONE mixed addition (what the accumulation
+// does with an image): out = packed affine point.  neg: add -image
+int hc_endo_g1_image(const uint8_t* p96, int neg, uint8_t* out97) {
+    const G1A28 a = g1x28::affine_to28(ld_g1(p96));
+    G1X28 acc = g1x28::identity();
+    g1x28::add_mixed(acc, endo::g1_image(a), neg != 0);
+    st_g1(out97, g1x28::to_std(acc));
+    return 0;
+}
+// twice: image added to the point itself first (exercises the bounds of an image as the affine operand of a REAL addition)
+int hc_endo_g2_image(const uint8_t* p192, int m, int neg, int onto_self, uint8_t* out193) {
+    const G2A28 a = g2x28::affine_to28(ld_g2(p192));
+    const G2A28 im = m == 1 ? endo::g2_image<1>(a) : m == 2 ? endo::g2_image<2>(a) : endo::g2_image<3>(a);
+    G2X28 acc = xyzz_identity<Fp2x28Ops>();
+    if (onto_self) g2x28::add_mixed(acc, a, false);
+    g2x28::add_mixed(acc, im, neg != 0);
+    st_g2(out193, g2x28::to_std(acc));
+    return 0;
+}
 int hc_fr29_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     st<FrParams>(out, fr29::from29(fr29::mul(fr29::to29(ld<FrParams>(a)), fr29::to29(ld<FrParams>(b)))));
     return 0;
