@@ -1248,7 +1248,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     // resp. 1 / 4 of the buckets to reduce.  Calls that name a window range or leave their window sums on the device (the
     // multi-GPU entry points) keep the plain form: their partition is defined over the plain windows.
     int E = 1, ibits = 31;
-    if (prep && prep->endo > 1 && !table && !wout && w_begin == 0 && w_end < 0 && !ctx->msm_no_endo && !wiv_off) {
+    static const int endo_mode = [] { const char* e = getenv(C::ENDO_ENV); return e ? atoi(e) : C::ENDO_DEFAULT; }();
+    const bool endo_wanted = endo_mode == 1 || (endo_mode == 2 && (flags & BZK_F_THROUGHPUT));
+    if (endo_wanted && prep && prep->endo > 1 && !table && !wout && w_begin == 0 && w_end < 0 && !ctx->msm_no_endo && !wiv_off) {
         const int e = prep->endo, ib = 27 - (e == 4 ? 2 : 1), ws = (C::ENDO_BITS + c - 1) / c;
         if (e == C::ENDO && (uint64_t)n + m_max < ((uint64_t)1 << ib) && ws <= 16 && (uint64_t)ws * n * e < ((uint64_t)1 << 30)) {
             E = e;
@@ -1321,7 +1323,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     // 256 entries): one task per bucket would leave the machine under-filled and the kernel as long as its longest
     // run.  Cut the runs so that there are at least ~4 tasks per resident lane (131 072 lanes at 2 waves/SIMD).
     auto enough_tasks = [&](uint32_t sg, uint64_t len_, uint32_t nb_) {
-        const uint64_t target = 4ull * 131072;
+        // endomorphism form: E x fewer, E x fuller buckets - two tasks per resident lane are enough (cutting every other bucket of a
+        // 262 144-bucket call in two bought partial sums and folds, not balance: r04 run 3)
+        const uint64_t target = (E > 1 ? 2ull : 4ull) * 131072;
         if (nb_ >= target || len_ / sg + nb_ >= target) return sg;
         return (uint32_t)std::max<uint64_t>(32, len_ / (target - nb_));
     };

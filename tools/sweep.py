@@ -37,6 +37,18 @@ def child(mode, log_n):
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_bases_windows_dev(hb, sc, n, 0, w1); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.05}
         print(json.dumps({"mode": mode, "log_n": log_n, "windows": [0, w1], "of": W, "ms": round(ms, 3), "prof": prof}))
         ctx.msm_bases_free(hb)
+    elif mode in ("g1res", "g2res"):  # whole MSM over a RESIDENT set (endomorphism form where the set carries its images; env BZK_MSM_ENDO_G1 / _G2)
+        g2 = mode == "g2res"
+        bases = torch.empty(n * (192 if g2 else 96), dtype=torch.uint8, device="cuda")
+        (ctx.g2_synth_bases_dev if g2 else ctx.g1_synth_bases_dev)(1, 0, n, bases); sc = rand_fr(n)
+        hb = ctx.msm_bases_load_dev(bases, n, g2=g2)
+        thr = os.environ.get("THROUGHPUT", "0") == "1"
+        ms = timeit(lambda: ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr), reps=3)
+        same = ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr) == (ctx.msm_g2_dev if g2 else ctx.msm_g1_dev)(bases, sc, n)
+        ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.04}
+        print(json.dumps({"mode": mode, "log_n": log_n, "endo_g1": os.environ.get("BZK_MSM_ENDO_G1"), "endo_g2": os.environ.get("BZK_MSM_ENDO_G2"), "throughput": thr,
+                          "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 2), "same_as_raw": same, "prof": prof}))
+        ctx.msm_bases_free(hb)
     elif mode == "g1tab":
         bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda"); ctx.g1_synth_bases_dev(1, 0, n, bases); sc = rand_fr(n)
         lv = int(os.environ.get("TAB_LEVELS", "0"))
@@ -117,6 +129,11 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r4endo",):  # round 4: endomorphism form vs plain form on resident sets, stand-alone (latency form) and with the throughput hint
+        for e in ("0", "1"):
+            run("g1res", 20, {"BZK_MSM_ENDO_G1": e}); run("g1res", 20, {"BZK_MSM_ENDO_G1": e, "THROUGHPUT": "1"})
+            run("g2res", 20, {"BZK_MSM_ENDO_G2": e}); run("g2res", 20, {"BZK_MSM_ENDO_G2": e, "THROUGHPUT": "1"})
+        run("g1res", 22, {"BZK_MSM_ENDO_G1": "0"}); run("g1res", 22, {"BZK_MSM_ENDO_G1": "1"})
     if what in ("r4rank8",):  # round 4: what one rank of 8 / 4 / 2 does at 2^23 / 2^22 / 2^21 points (weak scaling), raw and resident bases
         run("g1win", 23); run("g1winres", 23); run("g1winres", 22, {"SHARDS": "4"}); run("g1winres", 21, {"SHARDS": "2"}); run("g1", 20)
     if what in ("r39",):
