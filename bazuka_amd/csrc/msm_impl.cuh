@@ -1330,6 +1330,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         return (uint32_t)std::max<uint64_t>(32, len_ / (target - nb_));
     };
     if (!table || folded) seg = std::min(seg, enough_tasks(seg, len_max, nb_max));
+    static const uint32_t seg_override = [] { const char* e = getenv("BZK_MSM_SEG"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 8 && v <= 256 ? v : 0); }();
+    if (seg_override) seg = seg_override;  // A/B runs
     const uint32_t seg_dd = 8;  // group sums are latency-bound (a 7 k-member group of bits is one bucket): short serial runs
     // capacity of the per-task partial sums: sized for the shortest run length any later adjustment can pick (32; 64 for tables)
     const uint64_t t_cap = std::max<uint64_t>((uint64_t)nb_max + len_max / std::min<uint32_t>(seg, 32u) + 1,
@@ -1486,6 +1488,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         scal_eff = scal2;
         seg = (uint32_t)std::min<uint64_t>(MSM_SEG_MAX, std::max<uint64_t>(32, 4 * (n_eff * E / half + 1)));
         seg = std::min(seg, enough_tasks(seg, (uint64_t)group * n_eff * E, nb_max));
+        if (seg_override) seg = seg_override;
     }
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;

@@ -30,7 +30,10 @@ struct G1Fast {
     // endomorphism form (bzk_endo.cuh): scalars split into ENDO signed sub-scalars of ENDO_BITS bits over the images X^(2 m) P
     static constexpr int ENDO = 2, ENDO_BITS = 128;
     static constexpr int ENDO_DEFAULT = 2;
-    static constexpr const char* ENDO_ENV = "BZK_MSM_ENDO_G1";  // 0: plain form for this curve, 1: always, 2: only calls with BZK_F_THROUGHPUT (A/B runs)
+    // 0: plain form for this curve, 1: every whole-MSM call over a set with images, 2 (default): only calls with BZK_F_THROUGHPUT - the
+    // prover's overlapping MSMs, where fewer buckets mean less WORK for the reduction.  A stand-alone call gains nothing: its bucket
+    // reduction is as long as one lane's chain whatever the bucket count, and fuller buckets balance worse (profiles/r04_run4_5_endo_ab.txt)
+    static constexpr const char* ENDO_ENV = "BZK_MSM_ENDO_G1";
     __device__ static __forceinline__ void endo_images(const DevAff& p, DevAff* out, size_t stride) { out[stride] = endo::g1_image(p); }
 #ifndef BZK_G1_PARK_REDUCE
 #define BZK_G1_PARK_REDUCE 0
@@ -108,7 +111,7 @@ struct G2Fast {
     static constexpr int ACC_OCC = BZK_G2_ACC_OCC;
     // endomorphism form (bzk_endo.cuh): four signed 64-bit sub-scalars over the images X^m P, m = 0 .. 3
     static constexpr int ENDO = 4, ENDO_BITS = 64;
-    static constexpr int ENDO_DEFAULT = 1;
+    static constexpr int ENDO_DEFAULT = 2;
     static constexpr const char* ENDO_ENV = "BZK_MSM_ENDO_G2";
     __device__ static __forceinline__ void endo_images(const DevAff& p, DevAff* out, size_t stride) {
         out[stride] = endo::g2_image<1>(p);

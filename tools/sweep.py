@@ -129,6 +129,18 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r4endo2",):  # round 4: why the endomorphism form's accumulation is slower - task length and reduction chunk
+        for sg in ("32", "64", "128", "256"):
+            run("g2res", 20, {"BZK_MSM_ENDO_G2": "1", "BZK_MSM_SEG": sg})
+        for sg in ("16", "32", "64"):
+            run("g2res", 20, {"BZK_MSM_ENDO_G2": "0", "BZK_MSM_SEG": sg})
+        for ch in ("2", "4"):
+            run("g2res", 20, {"BZK_MSM_ENDO_G2": "1", "BZK_MSM_CHUNK": ch, "BZK_MSM_SEG": "64"})
+        for sg in ("32", "64", "128"):
+            run("g1res", 20, {"BZK_MSM_ENDO_G1": "1", "BZK_MSM_SEG": sg})
+        for ch in ("2", "4"):
+            run("g1res", 20, {"BZK_MSM_ENDO_G1": "1", "BZK_MSM_CHUNK": ch})
+        run("g1res", 20, {"BZK_MSM_ENDO_G1": "0", "BZK_MSM_SEG": "16"})
     if what in ("r4endo",):  # round 4: endomorphism form vs plain form on resident sets, stand-alone (latency form) and with the throughput hint
         for e in ("0", "1"):
             run("g1res", 20, {"BZK_MSM_ENDO_G1": e}); run("g1res", 20, {"BZK_MSM_ENDO_G1": e, "THROUGHPUT": "1"})
