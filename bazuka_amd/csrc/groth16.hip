@@ -469,8 +469,14 @@ int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* p, int32_t on) {
         const uint64_t m = (uint64_t)1 << c->log_m;
         if (c->log_m < 16 || m <= 1) return BZK_E_ARG;
         const uint32_t cw = c->log_m > 20 ? 20u : c->log_m;
-        const int32_t st = bzk_msm_g1_table_build_c(ctx, c->h, m - 1, cw, &c->h_table);
-        if (st != BZK_OK) c->h_table = nullptr;
+        // built into a local and published once complete and synchronised: other slots of this CRS read c->h_table without the lock
+        //  - they see either no table or a finished one
+        bzk_msm_table* t = nullptr;
+        const int32_t st = bzk_msm_g1_table_build_c(ctx, c->h, m - 1, cw, &t);
+        if (st == BZK_OK) {
+            std::atomic_thread_fence(std::memory_order_release);
+            c->h_table = t;
+        }
         return st;
     }
     std::lock_guard<std::mutex> lk(c->m);

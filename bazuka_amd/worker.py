@@ -12,16 +12,17 @@ Everything that computes is libbzk: `bzk_mpn_work_decode` / `_synthesize` (host 
 This module is the plumbing around it: HTTP, the HashMap framing of the two messages, the proving-key cache.  It needs a
 GPU context (`Bzk`); there is no CPU prover to fall back to.
 
-Proving keys: the reference's provers load bellman `Parameters` files produced by the network's setup; this build has no
-reader for that file format yet (bellman is not vendored in the reference), so the key source is a callable
-`params_for(work) -> bzk_params handle` - e.g. `DevSetup`, which generates the CRS on the GPU from the circuit's
-matrices and a given toxic waste, as the reference's dev-mode setup does (src/config/blockchain.rs:355-417).
+Proving keys: the reference's provers load bellman `Parameters` files produced by the network's setup.  The key source is a
+callable `params_for(work) -> bzk_params handle`: `BellmanKeys` reads those files (`--params DEPOSIT WITHDRAW UPDATE`;
+`bzk_params_load_bellman`, bazuka_amd/csrc/host_bellman.hip), `DevSetup` generates the CRS on the GPU from the circuit's
+matrices and a given toxic waste, as the reference's dev-mode setup does (src/config/blockchain.rs:355-417; `--dev-toxic`).
 """
 from __future__ import annotations
 
 import http.client
 import os
 import struct
+import sys
 import time
 
 from . import lib as L
@@ -335,8 +336,11 @@ class Worker:
                         return
                     try:
                         p = self.prove(work, slot)
-                    except L.BzkError as e:  # reported after the round; the other slots keep going
+                    except Exception as e:  # noqa: BLE001 - counted and reported; the slot keeps taking works, the others keep going
                         errors.append(e)
+                        with self._lock:
+                            self.stats["slot_errors"] = self.stats.get("slot_errors", 0) + 1
+                            self.stats["last_slot_error"] = f"slot {slot}, work {wid}: {e!r}"
                         continue
                     if p is not None:
                         with self._lock:
@@ -347,8 +351,11 @@ class Worker:
                 t.start()
             for t in th:
                 t.join()
+            if errors:
+                print(f"[worker] {len(errors)} of {len(works)} works failed this round ({self.stats.get('last_slot_error')})", file=sys.stderr, flush=True)
             if errors and not proofs:
-                raise errors[0]
+                e = errors[0]
+                raise e if isinstance(e, L.BzkError) else L.BzkError(f"slot failure: {e!r}")
         return self.submit(proofs) if proofs else 0
 
     def run_forever(self, poll_s: float = 1.0, rounds: int | None = None):

@@ -143,6 +143,32 @@ def _pmc_traffic(log_n):
     return None, f"stale: no profiles/*pmc_traffic*.json carries source stamp {stamp} (re-run tools/runs/pmc passes)"
 
 
+OTHER_KERNEL_SOURCES = ("ntt.hip", "poseidon.hip", "bzk_fr29.cuh", "bzk_poseidon29.cuh", "msm_impl.cuh", "msm_policy.cuh", "msm_g2.hip", "bzk_fp28.cuh")
+
+
+def other_source_stamp():
+    import hashlib
+    h = hashlib.sha256()
+    for f in OTHER_KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "bazuka_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_other(name):
+    """HBM-side bytes of one of the other kernels (tools/pmc_kernels.py over tools/pmc_ops.py), only if taken on THIS build's sources"""
+    import glob
+    stamp = other_source_stamp()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_other_kernels*.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        k = doc.get("kernels", {}).get(name)
+        if doc.get("source_stamp") == stamp and k and "traffic_bytes_per_launch" in k:
+            return k["traffic_bytes_per_launch"], f"{os.path.basename(path)} ({k['per']}; {k['correction']})"
+    return None, f"no profiles/*pmc_other_kernels*.json carries source stamp {stamp}"
+
+
 def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: int = 16, cpu_baseline: bool = False, helper: bool = False,
                        second_process: bool = False, world: int = 1, ring_k: int = 6):
     """Second half of BASELINE.json's metric: Groth16 proofs/s for the 2^20-constraint MPN class =
@@ -474,6 +500,7 @@ def other_configs_section(ctx, dev):
                                 "note": "integer-ALU bound: 9 x 29-bit Fr, sparse partial rounds; ~131 k multiply-adds per arity-4 hash "
                                         "(DESIGN 3.3) against the measured instruction ceiling"},
                         "kernel_ms": kernels(lambda: ctx.merkle4_root_dev(leaves, 12))}
+    out["tree_2p24"]["roofline"]["traffic"], out["tree_2p24"]["roofline"]["traffic_source"] = _pmc_other("tree_2p24")
     del leaves
     # configs[4], secondary instance: the MPN-shaped state - 4^9 accounts x (64 H2 + 21 H4 + 1 H5) + the account tree
     n_acct, ts = 1 << 18, 64
@@ -494,6 +521,8 @@ def other_configs_section(ctx, dev):
         out[f"ntt_2p{lg}"] = {"ms": round(ms, 4), "coset_ms": round(ms_coset, 4), "roofline": hbm(64.0 * (1 << lg), ms),
                               "alu": {"fr_products": (lg * (1 << lg)) // 2, "G_per_s": round(lg * (1 << lg) / 2 / ms / 1e6, 2), "peak": 162.9,
                                       "peak_source": "Fr29 product as dependent calls, profiles/r01_ubench_int.txt"}}
+        if lg == 24:
+            out["ntt_2p24"]["roofline"]["traffic"], out["ntt_2p24"]["roofline"]["traffic_source"] = _pmc_other("ntt_2p24")
         del d
     a, b, c = rand_fr(1 << 20, 1), rand_fr(1 << 20, 2), rand_fr(1 << 20, 3)
     ms = timeit(lambda: ctx.groth16_h_dev(a, b, c, 20))
@@ -570,6 +599,7 @@ def other_configs_section(ctx, dev):
     if acc:
         W = ctx.msm_window_count(n)
         sec["roofline"] = dict(hbm(224.0 * n, acc), kernel="msm_accumulate<G2>", avg_launch_ms=round(acc, 4))
+        sec["roofline"]["traffic"], sec["roofline"]["traffic_source"] = _pmc_other("msm_accumulate_g2")
         g = n * W * FP_MULS_PER_G2_MIXED_ADD / (acc * 1e-3) / 1e9
         sec["alu"] = {"achieved": round(g, 2), "peak": 60.1, "unit": "G Fp-mul/s", "frac": round(g / 60.1, 4),
                       "peak_source": "library product at 1 wave/SIMD (the G2 kernel's occupancy), profiles/r01_ubench_int.txt"}
