@@ -1,6 +1,6 @@
 // Host-side Fr (BLS12-381 scalar field) on 4 x 64-bit limbs for the witness generator and the host hasher: a Groth16 witness of the
 // 16-tx Update circuit is ~0.2 CPU-seconds, more than half of it field products (profile of bzk_mpn_update_synthesize), and the host
-// CPUs are the scarce resource of the pipelined prover on a quota'd box.  Same Montgomery form and byte layout as `Fr`
+// CPUs are the scarce resource of the pipelined prover on a quota'd box (HISTORY.md 6b).  Same Montgomery form and byte layout as `Fr`
 // (8 x 32-bit limbs, little endian), canonical results - so every value is identical to what fe_mul<FrParams> returns.
 //   mul : fully unrolled CIOS product on unsigned __int128
 //   dot : sum_k a[k] b[k] with ONE Montgomery reduction (column-wise accumulation of the 512-bit products): the dense MDS rows of

@@ -162,7 +162,7 @@ struct Wide17 {
     uint32_t v[17];
 };
 // by-value argument (17 VGPRs): never hand a noinline device function a pointer into the caller's
-// private arrays - that form hung on gfx950 / ROCm 7.2 in the first GPU session
+// private arrays - that form hung on gfx950 / ROCm 7.2 in the first GPU session (HISTORY.md 3.1)
 __device__ __noinline__ Fr wide_reduce(Wide17 acc_in) {
     uint32_t a[18];
 #pragma unroll

@@ -498,7 +498,7 @@ def other_configs_section(ctx, dev):
                                 "achieved": round(hashes * 131000 / ms / 1e9, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s",
                                 "frac": round(hashes * 131000 / ms / 1e9 / MAD_PEAK_T, 4),
                                 "note": "integer-ALU bound: 9 x 29-bit Fr, sparse partial rounds; ~131 k multiply-adds per arity-4 hash "
-                                        "(DESIGN 3.3) against the measured instruction ceiling"},
+                                        "(DESIGN 3.4) against the measured instruction ceiling"},
                         "kernel_ms": kernels(lambda: ctx.merkle4_root_dev(leaves, 12))}
     out["tree_2p24"]["roofline"]["traffic"], out["tree_2p24"]["roofline"]["traffic_source"] = _pmc_other("tree_2p24")
     del leaves
