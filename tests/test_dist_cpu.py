@@ -58,3 +58,73 @@ def test_allgather_fold_world2_gloo():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2]  # every rank holds the same folded point
+
+
+# ---- the group-building protocol of bench.py --gpus N (bazuka_amd/dist.py::build_device_group) on gloo, world 2, with stub groups ----
+class _StubGroup:
+    def __init__(self, exchange):
+        self.exchange = exchange
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+def _group_worker(rank, world, port, scenario, q):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch.distributed as dist
+    from bazuka_amd.dist import build_device_group
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def new_uid():
+        box = [os.urandom(16) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def make_group(uid, exchange):
+        calls.append(exchange)
+        if scenario == "rccl_init_hangs_on_rank1" and exchange != 1 and rank == 1:
+            time.sleep(30)                       # what a peer that never arrives looks like from inside ncclCommInitRank
+        if scenario == "rccl_init_raises_on_rank0" and exchange != 1 and rank == 0:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        if scenario == "nothing_works" and rank == 1:
+            raise RuntimeError("no transport")
+        return _StubGroup(exchange)
+
+    probe = 1 if (scenario == "rank1_has_no_rccl" and rank == 1) else 3
+    t0 = time.perf_counter()
+    try:
+        mg, x, notes = build_device_group(make_group, probe, rank, 0, 2.0, vote_group=None, new_uid=new_uid)
+        q.put((rank, scenario, "ok", x, calls, round(time.perf_counter() - t0, 1)))
+    except RuntimeError as e:
+        q.put((rank, scenario, "error", str(e), calls, round(time.perf_counter() - t0, 1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario,want", [("all_fine", ("ok", 0, [0])), ("rank1_has_no_rccl", ("ok", 1, [1])),
+                                           ("rccl_init_hangs_on_rank1", ("ok", 1, [0, 1])), ("rccl_init_raises_on_rank0", ("ok", 1, [0, 1])),
+                                           ("nothing_works", ("error", None, None))])
+def test_device_group_protocol_never_hangs_and_falls_back_together(scenario, want):
+    """every rank must reach the same decision: RCCL when all can, the shared-memory transport when ONE rank cannot (capability vote before
+    the blocking init, or a bounded wait inside it), an error on every rank when nothing works - and never a hang"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, 2, port, scenario, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, sc_, status, x, calls, secs in got:
+        assert status == want[0], got
+        assert secs < 20, got
+        if status == "ok":
+            assert x == want[1] and calls == want[2], got
