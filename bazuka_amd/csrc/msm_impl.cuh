@@ -1500,7 +1500,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         const uint32_t nb = (table && !folded) ? half : (uint32_t)wc * half;
         const int n_red_win = (table && !folded) ? 1 : wc;  // bucket sets to reduce
         if (E > 1) {
-            BZK_LAUNCH(ctx, "msm_digits", (msm_digits_endo_kernel<C::ENDO>), dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff,
+            BZK_LAUNCH(ctx, "msm_digits_endo", (msm_digits_endo_kernel<C::ENDO>), dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff,
                        n_eff, mont, c, w_total, ibits, (const uint32_t*)(dedup ? rep : nullptr), keys, vals);
         } else {
             BZK_LAUNCH(ctx, "msm_digits", msm_digits_kernel, dim3((unsigned)((n_eff + 255) / 256)), dim3(256), 0, (const U128*)scal_eff, n_eff,

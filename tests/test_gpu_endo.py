@@ -60,10 +60,11 @@ def test_endo_form_equals_plain_form_and_oracle(bzk, plain, co, n, g2):
     db = to_dev(bases)
     torch.cuda.synchronize()
     h, hp = bzk.msm_bases_load_dev(db, n, g2=g2), plain.msm_bases_load_dev(db, n, g2=g2)
-    for name, scb, kw in (("uniform", rand_scalars_bytes(n, n + 7), {}),
-                          ("edges", fr_bytes(_edge_scalars(n)), {}),
-                          ("witness-like + dedup", _witness_like(n, 13), {"dedup": True}),
-                          ("witness-like + dedup + throughput", _witness_like(n, 14), {"dedup": True, "throughput": True})):
+    # the endomorphism form is taken by whole-MSM calls with the throughput hint (the prover's; msm_policy.cuh ENDO_DEFAULT = 2)
+    for name, scb, kw in (("uniform", rand_scalars_bytes(n, n + 7), {"throughput": True}),
+                          ("edges", fr_bytes(_edge_scalars(n)), {"throughput": True}),
+                          ("witness-like + dedup", _witness_like(n, 13), {"dedup": True, "throughput": True}),
+                          ("witness-like, latency form (plain windows on both contexts)", _witness_like(n, 14), {"dedup": True})):
         sc = to_dev(scb)
         torch.cuda.synchronize()
         want = msm(bases, scb, nthreads=co.ncpu())
@@ -75,12 +76,12 @@ def test_endo_form_equals_plain_form_and_oracle(bzk, plain, co, n, g2):
     sc = to_dev(scb)
     torch.cuda.synchronize()
     want = msm(bases, fr_bytes([v % R for v in can[:n]]), nthreads=co.ncpu())
-    assert bzk.msm_bases_run_dev(h, sc, n, g2=g2, canonical=True) == want
+    assert bzk.msm_bases_run_dev(h, sc, n, g2=g2, canonical=True, throughput=True) == want
     # a prefix of the set (the images of the set are strided by the SET's size, not by the call's n)
     m = max(1, n // 3)
     scm = to_dev(rand_scalars_bytes(m, 99))
     torch.cuda.synchronize()
-    assert bzk.msm_bases_run_dev(h, scm, m, g2=g2) == msm(bases[:m * (192 if g2 else 96)], dev_bytes(scm), nthreads=co.ncpu())
+    assert bzk.msm_bases_run_dev(h, scm, m, g2=g2, throughput=True) == msm(bases[:m * (192 if g2 else 96)], dev_bytes(scm), nthreads=co.ncpu())
     bzk.msm_bases_free(h)
     plain.msm_bases_free(hp)
 
@@ -96,7 +97,36 @@ def test_endo_form_2p20_g1_and_g2(bzk, plain, co):
         torch.cuda.synchronize()
         want = (co.msm_g2 if g2 else co.msm_g1)(dev_bytes(d), scb, nthreads=co.ncpu())
         h = bzk.msm_bases_load_dev(d, n, g2=g2)
-        assert bzk.msm_bases_run_dev(h, sc, n, g2=g2) == want
-        assert bzk.msm_bases_run_dev(h, sc, n, g2=g2, dedup=True) == want
+        assert bzk.msm_bases_run_dev(h, sc, n, g2=g2, throughput=True) == want
+        assert bzk.msm_bases_run_dev(h, sc, n, g2=g2, dedup=True, throughput=True) == want
+        assert bzk.msm_bases_run_dev(h, sc, n, g2=g2) == want      # latency form: plain windows over the same set
         bzk.msm_bases_free(h)
         del d
+
+
+def test_the_endomorphism_form_is_the_path_taken(bzk, plain, co):
+    """no silent fall-back: a throughput call over a set with images runs the split digits kernel, a latency-form call and a set
+    without images do not (the launch labels of the per-kernel event table say which)"""
+    n = 30000
+    db = to_dev(co.g1_bases(5, 0, n, nthreads=co.ncpu()))
+    sc = to_dev(rand_scalars_bytes(n, 5))
+    torch.cuda.synchronize()
+
+    scw = to_dev(_witness_like(n, 3))   # repeats: the de-duplication has group sums to make images of
+    torch.cuda.synchronize()
+
+    def labels(ctx, h, **kw):
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        ctx.msm_bases_run_dev(h, scw if kw.get("dedup") else sc, n, **kw)
+        out = set(ctx.prof_dump())
+        ctx.prof_enable(False)
+        return out
+
+    h, hp = bzk.msm_bases_load_dev(db, n), plain.msm_bases_load_dev(db, n)
+    assert "msm_digits_endo" in labels(bzk, h, throughput=True)
+    assert "dedup_images" in labels(bzk, h, throughput=True, dedup=True)
+    assert "msm_digits_endo" not in labels(bzk, h) and "msm_digits" in labels(bzk, h)
+    assert "msm_digits_endo" not in labels(plain, hp, throughput=True)
+    bzk.msm_bases_free(h)
+    plain.msm_bases_free(hp)

@@ -58,6 +58,11 @@ def main(seconds=60, seed=1):
                 torch.cuda.synchronize()
                 hb = ctx.msm_bases_load_dev(db, n, g2=g2)
                 assert ctx.msm_bases_run_dev(hb, ds, n, g2=g2, dedup=dd) == want, (kind, n, g2, dd)
+                # round 4: the endomorphism form (whole-MSM calls with the throughput hint over a set that carries its images)
+                assert ctx.msm_bases_run_dev(hb, ds, n, g2=g2, dedup=dd, throughput=True) == want, (kind, "endo", n, g2, dd)
+                m = rnd.randrange(1, n + 1)   # a prefix of the set
+                assert ctx.msm_bases_run_dev(hb, ds, m, g2=g2, dedup=rnd.random() < 0.5, throughput=True) == \
+                    (co.msm_g2 if g2 else co.msm_g1)(bases[:m * (192 if g2 else 96)], sc[:32 * m], nthreads=nt), (kind, "endo prefix", n, m, g2)
                 W = ctx.msm_window_count(n)
                 cut = sorted({0, W, rnd.randrange(W + 1)})
                 parts = b"".join(ctx.msm_bases_windows_dev(hb, ds, n, a, b, g2=g2) for a, b in zip(cut, cut[1:]))
