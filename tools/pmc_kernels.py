@@ -39,12 +39,15 @@ if __name__ == "__main__":
     for spec in specs:
         name, sub = spec.split("=", 1)
         pattern, runs = "stream", 0
-        parts = sub.split(":")
-        sub = parts[0]
-        if len(parts) > 1:
-            pattern = parts[1]
-        if len(parts) > 2:
-            runs = int(parts[2])
+        # trailing ":stream" / ":gather" and ":<operations>" are options; the substring itself may hold "::" (C++ names)
+        while True:
+            head, sep, tail = sub.rpartition(":")
+            if sep and tail.isdigit():
+                runs, sub = int(tail), head
+            elif sep and tail in ("stream", "gather"):
+                pattern, sub = tail, head
+            else:
+                break
         f = [v for k, v in fr if sub in k]
         w = [v for k, v in wr if sub in k]
         if not f or not w:
