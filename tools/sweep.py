@@ -129,6 +129,11 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r4ntt",):  # round 4: 32-byte inter-pass elements (BZK_NTT_IP32) vs the 48-byte padded limb form
+        for ip in ("0", "1"):
+            for lg in (20, 22, 24):
+                run("ntt", lg, {"BZK_NTT_IP32": ip})
+            run("h", 20, {"BZK_NTT_IP32": ip}); run("h", 24, {"BZK_NTT_IP32": ip})
     if what in ("r4endo2",):  # round 4: why the endomorphism form's accumulation is slower - task length and reduction chunk
         for sg in ("32", "64", "128", "256"):
             run("g2res", 20, {"BZK_MSM_ENDO_G2": "1", "BZK_MSM_SEG": sg})
