@@ -34,13 +34,32 @@ BZK_HD Fr29 row_dot(const Fr29* __restrict__ m, const Fr29* v) {
     }
     return acc;
 }
+#ifndef BZK_POSEIDON_ROWS_STRAIGHT
+#define BZK_POSEIDON_ROWS_STRAIGHT 1  // 0: the MDS rows of a full round as a loop the compiler may keep rolled (A/B builds: it did, and wrote the
+#endif                                //    row results through scratch with a dynamic index - 192 B per lane, 2.2 GB of HBM writes per 2^24-leaf tree)
+// rows J - 1 .. 0 as straight-line code: every nw[] index is a compile-time constant, the results stay in registers
+template <int T, int J>
+struct MdsRows {  // T = row length = row stride
+    BZK_HD static void run(Fr29* nw, const Fr29* __restrict__ mds, const Fr29* st) {
+        MdsRows<T, J - 1>::run(nw, mds, st);
+        nw[J - 1] = row_dot<T>(mds + (J - 1) * T, st);
+    }
+};
+template <int T>
+struct MdsRows<T, 0> {
+    BZK_HD static void run(Fr29*, const Fr29* __restrict__, const Fr29*) {}
+};
 template <int T>
 BZK_HD void full_round(Fr29* st, const Fr29* __restrict__ rc, const Fr29* __restrict__ mds) {
 #pragma unroll
     for (int k = 0; k < T; ++k) st[k] = fr29::sbox5(fr29::norm(fr29::add(st[k], rc[k])));
     Fr29 nw[T];
+#if BZK_POSEIDON_ROWS_STRAIGHT
+    MdsRows<T, T>::run(nw, mds, st);
+#else
 #pragma unroll
     for (int j = 0; j < T; ++j) nw[j] = row_dot<T>(mds + j * T, st);
+#endif
 #pragma unroll
     for (int k = 0; k < T; ++k) st[k] = nw[k];
 }
@@ -94,8 +113,12 @@ BZK_HD Fr poseidon29_hash(const Fr* __restrict__ in, const Fr29* __restrict__ co
         Fr29 v[T > 2 ? T - 1 : 1], nw[T > 2 ? T - 1 : 1];
 #pragma unroll
         for (int j = 1; j < T; ++j) v[j - 1] = since ? fr29::mul(st[j], one) : st[j];
+#if BZK_POSEIDON_ROWS_STRAIGHT
+        p29::MdsRows<T - 1, T - 1>::run(nw, dmat, v);
+#else
 #pragma unroll
         for (int j = 0; j < T - 1; ++j) nw[j] = p29::row_dot<T - 1>(dmat + j * (T - 1), v);
+#endif
 #pragma unroll
         for (int j = 1; j < T; ++j) st[j] = nw[j - 1];
     }

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbzk.so")
+# BZK_LIBBZK: another build of the same library (A/B runs of compile-time switches: the gitignored pattern bazuka_amd/libbzk.so.* travels to the GPU box)
+LIB_PATH = os.environ.get("BZK_LIBBZK") or os.path.join(_HERE, "libbzk.so")
 
 BZK_F_CANONICAL = 1
 BZK_F_DEDUP = 2

@@ -129,6 +129,13 @@ if __name__ == "__main__":
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
             run("g1", 22, {"BZK_MSM_ACC_OCC": str(occ)})
+    if what in ("r4pos",):  # round 4: MDS rows as straight-line code (no scratch) vs the rolled loop (bazuka_amd/libbzk.so.rows0, built with -DBZK_POSEIDON_ROWS_STRAIGHT=0)
+        alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bazuka_amd", "libbzk.so.rows0")
+        for lib in (alt, ""):
+            env = {"BZK_LIBBZK": lib} if lib else {}
+            run("tree", 24, env); run("tree", 20, env)
+            for ar in ("2", "3", "4", "5", "7"):
+                run("hash", 22, dict(env, ARITY=ar))
     if what in ("r4ntt",):  # round 4: 32-byte inter-pass elements (BZK_NTT_IP32) vs the 48-byte padded limb form
         for ip in ("0", "1"):
             for lg in (20, 22, 24):
