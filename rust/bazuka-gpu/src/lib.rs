@@ -253,6 +253,12 @@ impl DeviceGroup {
     pub fn world(&self) -> i32 {
         unsafe { sys::bzk_mg_world(self.0) }
     }
+    /// what this process could contribute to a process-per-GPU group on `device`: bit 0 = usable gfx950 device, bit 1 = librccl loadable.
+    /// A host collects the answers of all ranks BEFORE creating a group on the RCCL transport (`ncclCommInitRank` blocks until every
+    /// rank arrives; include/bzk.h)
+    pub fn probe(device: i32) -> i32 {
+        unsafe { sys::bzk_mg_probe(device) }
+    }
     fn fail(&self, st: i32) -> GpuError {
         GpuError::Status(st, unsafe { CStr::from_ptr(sys::bzk_mg_last_error(self.0)).to_string_lossy().into_owned() })
     }

@@ -315,3 +315,12 @@ def test_host_fr64_product_and_dot_match_oracle(hc, co, pr):
             assert hc.hc_hfr_dot(A, B, n, out) == 0
             want = sum(x * y for x, y in zip(xs, ys)) % M
             assert out.raw == pr.fr_to_mont_bytes(want), (n, mode)
+
+
+def test_mg_probe_without_a_device_reports_nothing_usable():
+    """bzk_mg_probe creates nothing and computes nothing: on a GPU-less host both capability bits are clear (the GPU suite sees 1 or 3)"""
+    from bazuka_amd import mg_probe
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    assert mg_probe(0) == 0 and mg_probe(-1) == 0
