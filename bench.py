@@ -37,13 +37,13 @@ sys.path.insert(0, ROOT)
 
 LOG_N = 20
 # micro-benchmarked peak of the library's own Fp product (chains of dependent calls, all CUs busy):
-# tools/ubench_int "Fp28 lib mul", profiles/r01_ubench_int.txt.  An XYZZ mixed add is 8 products + 2 squares; since round 2 its Y
+# tools/ubench_int "Fp28 lib mul", profiles/r04_ubench_int.txt.  An XYZZ mixed add is 8 products + 2 squares; since round 2 its Y
 # coordinate R (Q - X3) - Y PPP is two multiplications under ONE Montgomery reduction (fp28::mul_sub2_body) = 1.5 products
 FP_MUL_PEAK_G = 76.2
 MULS_PER_MIXED_ADD = 9.5
 # integer multiply-adds actually issued by one XYZZ mixed addition: 6 products of 394 v_mad_u64_u32 + 2 squares of 301
 # (profiles/r01_run56_fp28_square.txt) + the fused Y (2 x 196 + 196 + 2), against the measured v_mad_u64_u32 ceiling of the whole
-# chip (profiles/r01_ubench_int.txt)
+# chip (profiles/r04_ubench_int.txt)
 MADS_PER_MIXED_ADD = 6 * 394 + 2 * 301 + (3 * 196 + 2)
 MAD_PEAK_T = 31.4
 # G2: 6 Fp2 products (3 Fp products each) + 2 Fp2 squares (2 Fp products each) + the fused Y (8 multiplications under 2 reductions
@@ -520,7 +520,7 @@ def other_configs_section(ctx, dev):
         ms_coset = timeit(lambda: ctx.ntt_dev(d, lg, False, True))
         out[f"ntt_2p{lg}"] = {"ms": round(ms, 4), "coset_ms": round(ms_coset, 4), "roofline": hbm(64.0 * (1 << lg), ms),
                               "alu": {"fr_products": (lg * (1 << lg)) // 2, "G_per_s": round(lg * (1 << lg) / 2 / ms / 1e6, 2), "peak": 162.9,
-                                      "peak_source": "Fr29 product as dependent calls, profiles/r01_ubench_int.txt"}}
+                                      "peak_source": "Fr29 product as dependent calls, profiles/r04_ubench_int.txt"}}
         if lg == 24:
             out["ntt_2p24"]["roofline"]["traffic"], out["ntt_2p24"]["roofline"]["traffic_source"] = _pmc_other("ntt_2p24")
         del d
@@ -602,7 +602,7 @@ def other_configs_section(ctx, dev):
         sec["roofline"]["traffic"], sec["roofline"]["traffic_source"] = _pmc_other("msm_accumulate_g2")
         g = n * W * FP_MULS_PER_G2_MIXED_ADD / (acc * 1e-3) / 1e9
         sec["alu"] = {"achieved": round(g, 2), "peak": 60.1, "unit": "G Fp-mul/s", "frac": round(g / 60.1, 4),
-                      "peak_source": "library product at 1 wave/SIMD (the G2 kernel's occupancy), profiles/r01_ubench_int.txt"}
+                      "peak_source": "library product at 1 wave/SIMD (the G2 kernel's occupancy), profiles/r04_ubench_int.txt"}
     out["msm_g2_2p20"] = sec
     # static bases (a Groth16 CRS is static): full table at c = 20 - 13 windows sharing one bucket set, no host Horner.  Informational:
     # `value` of the headline stays the per-call pipeline on raw bases
@@ -1035,12 +1035,12 @@ def main():
             gmul = pairs * MULS_PER_MIXED_ADD / (per_launch_ms * 1e-3) / 1e9
             out["roofline"]["alu"] = {"achieved": round(gmul, 2), "peak": FP_MUL_PEAK_G, "unit": "G Fp-mul/s",
                                       "frac": round(gmul / FP_MUL_PEAK_G, 4),
-                                      "peak_source": "tools/ubench_int.hip, library product as dependent calls (profiles/)"}
+                                      "peak_source": "tools/ubench_int.hip, library product as dependent calls (profiles/r04_ubench_int.txt: 76.2 G/s, as in round 1)"}
             tmad = pairs * MADS_PER_MIXED_ADD / (per_launch_ms * 1e-3) / 1e12
             out["roofline"]["alu_mad"] = {"achieved": round(tmad, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s",
                                           "frac": round(tmad / MAD_PEAK_T, 4),
                                           "how": f"{MADS_PER_MIXED_ADD} mads issued per mixed add (6 x 394 + 2 x 301 + 590 for the fused Y) against the "
-                                                 "micro-benchmarked instruction ceiling (profiles/r01_ubench_int.txt)"}
+                                                 "micro-benchmarked instruction ceiling (profiles/r04_ubench_int.txt)"}
         out["kernel_ms_per_step"] = {k: round(v[1] / n_break, 4) for k, v in sorted(prof_all.items())}
         out["kernel_ms_per_step_how"] = f"{n_break} extra untimed steps with every launch instrumented (HIP events)"
         if overlapped:
