@@ -28,14 +28,16 @@ class PyMpnState:
             a["tokens"][slot] = (tid, bal)
 
     @staticmethod
-    def _levels(leaves, depth, defaults):
-        """maps {index: hash} for depth `depth` down to 0 from the populated leaves"""
+    def _levels(leaves, depth, defaults, hasher=None):
+        """maps {index: hash} for depth `depth` down to 0 from the populated leaves.  hasher: the `ZkHasher` (default Poseidon; the
+        reference's own membership-proof test runs the state manager over an additive SumHasher, src/zk/test/mod.rs:7-18)"""
+        hasher = hasher or pr.poseidon
         lv = [None] * (depth + 1)
         lv[depth] = dict(leaves)
         for k in range(depth - 1, -1, -1):
             cur = {}
             for p in {i >> 2 for i in lv[k + 1]}:
-                cur[p] = pr.poseidon([lv[k + 1].get(4 * p + j, defaults[k + 1]) for j in range(4)])
+                cur[p] = hasher([lv[k + 1].get(4 * p + j, defaults[k + 1]) for j in range(4)])
             lv[k] = cur
         return lv
 

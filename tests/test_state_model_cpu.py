@@ -40,3 +40,25 @@ def test_malformed_models_are_refused():
     out = C.create_string_buffer(32)
     for blob in (b"", b"\x03\0\0\0", (1).to_bytes(4, "little") + (0).to_bytes(8, "little"), (2).to_bytes(4, "little") + bytes([40]) + (0).to_bytes(4, "little")):
         assert lib.bzk_state_model_default(blob, len(blob), out) == -1
+
+
+def test_membership_proof_structure_against_the_reference_sum_hasher_constant():
+    """The reference's own state-manager test (src/zk/test/mod.rs:7-18, 43-70) swaps Poseidon for an ADDITIVE hasher, fills a
+    `List{log4_size: 4, Scalar}` with item i = i and asserts that every leaf plus all the values of its membership proof sums to
+    32640 = sum(0..255): a reference-held constant for the SHAPE of a proof - log4_size levels, exactly the three siblings of the node
+    on the path at each level.  The restatement the GPU trees are compared with (pystate `_levels` / `_prove`; tests/test_gpu_tree4.py,
+    test_gpu_mpn_tree.py) run over that hasher must reproduce it."""
+    add = lambda vals: sum(vals) % pr.R_MOD  # noqa: E731 - SumHasher::hash
+    depth = 4
+    defaults = [0] * (depth + 1)      # compress_default under the additive hasher: sums of zeros
+    lv = ps.PyMpnState._levels({i: i for i in range(256)}, depth, defaults, hasher=add)
+    assert lv[0][0] == 32640
+    for i in range(256):
+        proof = ps.PyMpnState._prove(lv, depth, defaults, i)
+        assert len(proof) == depth and all(len(part) == 3 for part in proof)
+        assert (i + sum(v for part in proof for v in part)) % pr.R_MOD == 32640
+    # a sparse tree: missing nodes take the default of their level (zero here), the constant becomes the sum of what is populated
+    some = {3: 30, 77: 700, 200: 9}
+    lv = ps.PyMpnState._levels(some, depth, defaults, hasher=add)
+    for i, v in some.items():
+        assert (v + sum(x for part in ps.PyMpnState._prove(lv, depth, defaults, i) for x in part)) % pr.R_MOD == 739
