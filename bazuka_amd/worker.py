@@ -273,13 +273,18 @@ class Worker:
     def prove(self, work: L.MpnWork, slot: int = 0) -> bytes | None:
         """387 proof bytes for the work, or None when the work's witness does not satisfy its circuit (a proof of it
         could only be rejected by the node).  slot: which prover slot runs it."""
-        bzk, params_for = self.slots[slot]
         t0 = time.perf_counter()
         r1cs = work.synthesize(self.address, threads=self.threads)
+        return self._prove_synthesized(work, r1cs, time.perf_counter() - t0, slot)
+
+    def _prove_synthesized(self, work: L.MpnWork, r1cs, synth_s: float, slot: int = 0) -> bytes | None:
+        """the GPU half of `prove`: the witness arrays are already there (run_once synthesizes the next work on a host thread while the
+        GPU proves this one)"""
+        bzk, params_for = self.slots[slot]
         t1 = time.perf_counter()
         if not r1cs.satisfied:
             with self._lock:
-                self.stats["synth_s"] += t1 - t0
+                self.stats["synth_s"] += synth_s
                 self.stats["unsat"] += 1
             return None
         ph = params_for(work)
@@ -287,7 +292,7 @@ class Worker:
         proof = bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
         ok = (not self.self_check) or work.verify(self.address, proof)   # MpnWork::verify: the node's own acceptance test
         with self._lock:
-            self.stats["synth_s"] += t1 - t0
+            self.stats["synth_s"] += synth_s
             self.stats["prove_s"] += time.perf_counter() - t1
             self.stats["proved"] += 1
             self.stats["proved_by_slot"][slot] += 1
@@ -301,18 +306,19 @@ class Worker:
         return acc
 
     def run_once(self) -> int:
-        """one round: fetch the works assigned to this address, prove them (side by side when there are several slots), post the
-        solutions; returns `accepted`"""
+        """one round: fetch the works assigned to this address, prove them, post the solutions; returns `accepted`.
+        Witness synthesis (host threads inside libbzk, GIL released) runs AHEAD of the proofs: a producer thread synthesizes work k + 1
+        while the GPU proves work k - a one-slot worker is then bound by max(synthesis, proof) per work instead of their sum (the bench's
+        `proofs_per_s_serial` vs `proofs_per_s_pipelined`) - and with several slots the works are proved side by side,
+        one host thread per slot taking synthesized works from the common queue."""
+        import queue
+        import threading
         works = self.fetch()
         proofs = {}
-        if len(self.slots) == 1 or len(works) <= 1:
-            for wid, work in works.items():
-                p = self.prove(work)
-                if p is not None:
-                    proofs[wid] = p
-        else:
-            import queue
-            import threading
+        if not works:
+            return 0
+        n_slots = min(len(self.slots), len(works))
+        if n_slots > 1:
             # key sources generate / load a shape's CRS on THEIR context the first time it is asked for: do that here, before the slot
             # threads start, so that no context is used from two threads (further slots of a device only add a scratch set: SlotKeys)
             warmed = set()
@@ -323,39 +329,58 @@ class Worker:
                     for _, params_for in self.slots:
                         if not isinstance(params_for, SlotKeys):
                             params_for(work)
-            todo = queue.Queue()
-            for item in works.items():
-                todo.put(item)
-            errors = []
+        ready = queue.Queue(maxsize=n_slots)   # synthesized ahead: at most one witness per slot waits (they are 0.1 - 2 GB of pinned memory)
+        errors = []
 
-            def run(slot):
-                while True:
-                    try:
-                        wid, work = todo.get_nowait()
-                    except queue.Empty:
-                        return
-                    try:
-                        p = self.prove(work, slot)
-                    except Exception as e:  # noqa: BLE001 - counted and reported; the slot keeps taking works, the others keep going
-                        errors.append(e)
-                        with self._lock:
-                            self.stats["slot_errors"] = self.stats.get("slot_errors", 0) + 1
-                            self.stats["last_slot_error"] = f"slot {slot}, work {wid}: {e!r}"
-                        continue
-                    if p is not None:
-                        with self._lock:
-                            proofs[wid] = p
+        def failed(where, wid, e):
+            errors.append(e)
+            with self._lock:
+                self.stats["slot_errors"] = self.stats.get("slot_errors", 0) + 1
+                self.stats["last_slot_error"] = f"{where}, work {wid}: {e!r}"
 
-            th = [threading.Thread(target=run, args=(k,)) for k in range(min(len(self.slots), len(works)))]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            if errors:
-                print(f"[worker] {len(errors)} of {len(works)} works failed this round ({self.stats.get('last_slot_error')})", file=sys.stderr, flush=True)
-            if errors and not proofs:
-                e = errors[0]
-                raise e if isinstance(e, L.BzkError) else L.BzkError(f"slot failure: {e!r}")
+        def producer():
+            for wid, work in works.items():
+                t0 = time.perf_counter()
+                try:
+                    r1cs = work.synthesize(self.address, threads=self.threads)
+                except Exception as e:  # noqa: BLE001 - counted and reported; the other works go on
+                    failed("synthesis", wid, e)
+                    continue
+                ready.put((wid, work, r1cs, time.perf_counter() - t0))
+            for _ in range(n_slots):
+                ready.put(None)
+
+        def consumer(slot):
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                wid, work, r1cs, synth_s = item
+                try:
+                    p = self._prove_synthesized(work, r1cs, synth_s, slot)
+                except Exception as e:  # noqa: BLE001 - the slot keeps taking works, the others keep going
+                    failed(f"slot {slot}", wid, e)
+                    continue
+                finally:
+                    r1cs.free()   # hand the pinned witness arrays back to the pool before the next one is taken
+                if p is not None:
+                    with self._lock:
+                        proofs[wid] = p
+
+        prod = threading.Thread(target=producer, daemon=True)
+        prod.start()
+        th = [threading.Thread(target=consumer, args=(k,)) for k in range(1, n_slots)]
+        for t in th:
+            t.start()
+        consumer(0)   # slot 0 proves on the calling thread
+        for t in th:
+            t.join()
+        prod.join()
+        if errors:
+            print(f"[worker] {len(errors)} of {len(works)} works failed this round ({self.stats.get('last_slot_error')})", file=sys.stderr, flush=True)
+        if errors and not proofs:
+            e = errors[0]
+            raise e if isinstance(e, L.BzkError) else L.BzkError(f"worker failure: {e!r}")
         return self.submit(proofs) if proofs else 0
 
     def run_forever(self, poll_s: float = 1.0, rounds: int | None = None):
