@@ -268,7 +268,10 @@ int32_t bzk_groth16_setup(bzk_ctx* ctx, const bzk_csr* A, const bzk_csr* B, cons
         hipMemcpy(h_vk1.data(), d_vk1, h_vk1.size(), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(h_vk2.data(), d_vk2, h_vk2.size(), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(BZK_E_DEVICE);
-    if (flag) return fail(BZK_E_INTERNAL);  // an identity point in the CRS (a polynomial vanished at tau)
+    if (flag) {  // an identity point in the CRS: a query polynomial vanished at tau (tau on the evaluation domain, a zero in the toxic waste)
+        ctx->last_error = "bzk_groth16_setup: a CRS element is the identity for this toxic waste (tau on the evaluation domain, or a zero among alpha / beta / gamma / delta)";
+        return fail(BZK_E_ARG);
+    }
     // vk: alpha_g1 | beta_g1 | beta_g2 | gamma_g2 | delta_g1 | delta_g2 (packed, inf flag 0)
     uint8_t vk[870];
     memset(vk, 0, sizeof vk);
