@@ -5,4 +5,4 @@ for gfx950 under ``bazuka_amd/csrc``.  This Python package is only the thin ctyp
 tests/ and bench.py (device memory and process-group plumbing come from PyTorch-ROCm).  There is
 no CPU fallback anywhere in this package: if the library or a gfx950 device is missing, calls fail.
 """
-from .lib import Bzk, BzkError, Mg, load_library, mg_probe, mg_unique_id, LIB_PATH  # noqa: F401
+from .lib import Bzk, BzkError, DeviceState, Mg, load_library, mg_probe, mg_unique_id, LIB_PATH  # noqa: F401

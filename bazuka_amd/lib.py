@@ -44,6 +44,14 @@ SIGNATURES = {
     "bzk_state_compress": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp, C.POINTER(_u64)]),
     "bzk_state_compress_bincode": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp]),
     "bzk_state_model_default": (_i32, [_vp, _u64, _vp]),
+    "bzk_state_create": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "bzk_state_free": (None, [_vp]),
+    "bzk_state_update": (_i32, [_vp, _vp, _vp, _vp, _u64, _u64, _vp, C.POINTER(_u64), _vp]),
+    "bzk_state_update_bincode": (_i32, [_vp, _vp, _u64, _u64, _vp]),
+    "bzk_state_root": (_i32, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "bzk_state_get": (_i32, [_vp, _vp, _vp, _u64, _vp]),
+    "bzk_state_prove": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u32)]),
+    "bzk_state_stats": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "bzk_ntt": (_i32, [_vp, _vp, _u32, _i32, _i32]),
     "bzk_ntt_dev": (_i32, [_vp, _vp, _u32, _i32, _i32]),
     "bzk_msm_g1": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
@@ -1007,6 +1015,82 @@ def mpn_circuit_empty(kind, L, T, B, commitment, height, state, aux, next_state,
     _st(load_library().bzk_mpn_circuit_empty(kind, L, T, B, _ptr(commitment), height, _ptr(state), _ptr(aux), _ptr(next_state),
                                              int(record_matrices), C.byref(h)), "circuit_empty")
     return R1cs(h)
+
+
+def _csr(locators):
+    off, loc = [0], []
+    for l in locators:
+        loc.extend(int(x) for x in l)
+        off.append(len(loc))
+    return (_u64 * len(off))(*off), (_u64 * max(1, len(loc)))(*loc)
+
+
+class DeviceState:
+    """`KvStoreStateManager` for one contract with the values resident on the device (bzk_state_*): update / root / get / prove"""
+
+    def __init__(self, ctx: "Bzk", model_bincode: bytes):
+        self.ctx, self.lib, self.h = ctx, ctx.lib, _vp()
+        ctx._ck(self.lib.bzk_state_create(ctx.h, _ptr(model_bincode), len(model_bincode), C.byref(self.h)), "state_create")
+
+    def close(self):
+        if self.h:
+            self.lib.bzk_state_free(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            import sys
+            if not sys.is_finalizing():    # at interpreter exit the HIP runtime may be gone already; the process frees the memory
+                self.close()
+        except Exception:
+            pass
+
+    def update(self, pairs, target_height: int, want_rollback=False):
+        """pairs: iterable of (locator, 32-byte Montgomery scalar; zero = remove) -> (state_hash, state_size[, previous values])"""
+        pairs = list(pairs)
+        o, lo = _csr(l for l, _ in pairs)
+        vals = b"".join(v for _, v in pairs)
+        out, size = C.create_string_buffer(32), _u64()
+        prev = C.create_string_buffer(max(1, 32 * len(pairs))) if want_rollback else None
+        self.ctx._ck(self.lib.bzk_state_update(self.h, o, lo, _ptr(vals), len(pairs), target_height, out, C.byref(size), prev), "state_update")
+        if want_rollback:
+            return out.raw, size.value, [prev.raw[32 * i:32 * i + 32] for i in range(len(pairs))]
+        return out.raw, size.value
+
+    def update_bincode(self, delta_bincode: bytes, target_height: int) -> bytes:
+        out = C.create_string_buffer(40)
+        self.ctx._ck(self.lib.bzk_state_update_bincode(self.h, _ptr(delta_bincode), len(delta_bincode), target_height, out), "state_update_bincode")
+        return out.raw
+
+    def root(self):
+        """-> (state_hash, state_size, height)"""
+        out, size, height = C.create_string_buffer(32), _u64(), _u64()
+        self.ctx._ck(self.lib.bzk_state_root(self.h, out, C.byref(size), C.byref(height)), "state_root")
+        return out.raw, size.value, height.value
+
+    def get(self, locators) -> list:
+        locators = list(locators)
+        o, lo = _csr(locators)
+        out = C.create_string_buffer(max(1, 32 * len(locators)))
+        self.ctx._ck(self.lib.bzk_state_get(self.h, o, lo, len(locators), out), "state_get")
+        return [out.raw[32 * i:32 * i + 32] for i in range(len(locators))]
+
+    def prove(self, tree_loc, indices) -> list:
+        """-> per index: log4_size levels (leaf level first) of three 32-byte siblings"""
+        tree_loc, indices = [int(x) for x in tree_loc], [int(x) for x in indices]
+        tl = (_u64 * max(1, len(tree_loc)))(*tree_loc)
+        ix = (_u64 * max(1, len(indices)))(*indices)
+        log4 = _u32()
+        self.ctx._ck(self.lib.bzk_state_prove(self.h, tl, len(tree_loc), None, 0, None, C.byref(log4)), "state_prove")  # the depth
+        out = C.create_string_buffer(max(1, len(indices) * log4.value * 96))
+        self.ctx._ck(self.lib.bzk_state_prove(self.h, tl, len(tree_loc), ix, len(indices), out, C.byref(log4)), "state_prove")
+        L, raw = log4.value, out.raw
+        return [[[raw[((i * L + d) * 3 + j) * 32:((i * L + d) * 3 + j) * 32 + 32] for j in range(3)] for d in range(L)] for i in range(len(indices))]
+
+    def stats(self) -> dict:
+        a, b, c = _u64(), _u64(), _u64()
+        self.ctx._ck(self.lib.bzk_state_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "state_stats")
+        return {"slots": a.value, "device_bytes": b.value, "keys": c.value}
 
 
 def state_model_default(model_bincode: bytes) -> bytes:

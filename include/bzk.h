@@ -155,6 +155,36 @@ int32_t bzk_state_compress_bincode(bzk_ctx* ctx, const uint8_t* model, uint64_t 
                                    uint8_t compressed_out[40]);
 int32_t bzk_state_model_default(const uint8_t* model, uint64_t model_len, uint8_t out[32]);
 
+/* PERSISTENT device state of one contract, any model: `KvStoreStateManager::{update_contract, set_data, get_data, prove, root}`
+ * (src/zk/state/mod.rs:286-308, 310-420, 422-438, 218-264, 274-284) with the values resident in HBM.  The reference walks
+ * root-wards once per written scalar, one hash and four KV reads per level; here one update is ONE plan - the union of the
+ * root-ward paths of every written scalar, each node once, grouped by (height, arity): per group one gather, one batched
+ * Poseidon launch, one scatter, in place on the device.  Only the written scalars go up, only the root comes back.
+ *   bzk_state_update   = `update_contract(db, id, &ZkDeltaPairs, target_height)`: n (locator, value) pairs, a zero value = the
+ *                        reference's `None` (remove).  All or nothing: every locator is checked before a slot changes.
+ *                        state_hash / state_size = the new `ZkCompressedState` (either may be NULL).
+ *                        prev_values_out (n x 32 B, or NULL) = what the named scalars held before, zero where nothing was stored:
+ *                        the rollback delta `ZkState::push_delta` records (src/zk/mod.rs:521-530); feeding it back undoes the update.
+ *   _bincode           delta = bincode(ZkDeltaPairs) (HashMap<ZkDataLocator, Option<ZkScalar>>), out = bincode(ZkCompressedState)
+ *   bzk_state_root     = `root` (+ `height_of`)
+ *   bzk_state_get      = `get_data` for n locators: scalar, or the value of the struct / list named; defaults where untouched
+ *   bzk_state_prove    = `prove(db, id, tree_loc, index)` for n indices of ONE list: per index log4_size x 3 scalars, leaf level
+ *                        first, the three siblings of a level in ascending position (`Vec<[ZkScalar; 3]>`)
+ * Errors as bzk_state_compress (BZK_E_ARG + bzk_last_error(ctx) naming the reference's error); BZK_E_DEVICE after a device
+ * failure in the middle of an update (the handle is then unusable).  A handle is bound to its ctx; one thread at a time. */
+typedef struct bzk_state bzk_state;
+int32_t bzk_state_create(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, bzk_state** out);
+void bzk_state_free(bzk_state* st);
+int32_t bzk_state_update(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, const uint8_t* values, uint64_t n,
+                         uint64_t target_height, uint8_t state_hash[32], uint64_t* state_size, uint8_t* prev_values_out);
+int32_t bzk_state_update_bincode(bzk_state* st, const uint8_t* delta, uint64_t delta_len, uint64_t target_height,
+                                 uint8_t compressed_out[40]);
+int32_t bzk_state_root(bzk_state* st, uint8_t state_hash[32], uint64_t* state_size, uint64_t* height);
+int32_t bzk_state_get(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, uint64_t n, uint8_t* values_out);
+int32_t bzk_state_prove(bzk_state* st, const uint64_t* tree_loc, uint64_t tree_loc_len, const uint64_t* indices, uint64_t n,
+                        uint8_t* proof_out, uint32_t* log4_size);
+int32_t bzk_state_stats(bzk_state* st, uint64_t* slots, uint64_t* device_bytes, uint64_t* keys);
+
 /* ---- K3: radix-2 NTT over Fr -----------------------------------------------------------------
  * bellman 0.14 `EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}` (third-party crate; reached
  * from `create_random_proof`, src/mpn/circuits/test.rs:135,175,215).  In place, natural order in and

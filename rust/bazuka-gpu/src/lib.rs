@@ -9,6 +9,8 @@
 //!   * `GpuPoseidonHasher`      - `impl ZkHasher` (src/zk/mod.rs:152-155, 496-511) + the BULK path `hash_batch`
 //!   * `groth16_prove`          - beside `groth16_verify` (src/zk/groth16/mod.rs:67-75), same argument order
 //!   * `compress`               - `ZkStateModel::compress::<H>(&data)` (src/zk/mod.rs:392-399)
+//!   * `DeviceStateManager`     - `KvStoreStateManager::{update_contract, root, get_data, prove}` (src/zk/state/mod.rs:218-438) for one
+//!                                contract with the values resident on the GPU
 //!   * `prove_work`             - an `MpnWork` (src/mpn/mod.rs:263-270) -> the `ZkProof` that `MpnWork::verify` (:281-295) accepts
 //!   * `DeviceGroup`            - 1..8 GPUs of a node: window-sharded MSM + a proof pool (no torch, no Python)
 //!
@@ -17,7 +19,9 @@
 use bazuka::core::Address;
 use bazuka::mpn::MpnWork;
 use bazuka::zk::groth16::Groth16Proof;
-use bazuka::zk::{StateManagerError, ZkCompressedState, ZkDataPairs, ZkHasher, ZkLocatorError, ZkProof, ZkScalar, ZkStateModel};
+use bazuka::zk::{
+    StateManagerError, ZkCompressedState, ZkDataLocator, ZkDataPairs, ZkDeltaPairs, ZkHasher, ZkLocatorError, ZkProof, ZkScalar, ZkStateModel,
+};
 use bzk_sys as sys;
 use std::ffi::CStr;
 use std::ptr;
@@ -94,6 +98,94 @@ impl Gpu {
 impl Drop for Gpu {
     fn drop(&mut self) {
         unsafe { sys::bzk_ctx_destroy(self.0) }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// `KvStoreStateManager<H>` (src/zk/state/mod.rs:29-31) for ONE contract, values resident on the device.  The reference's functions
+// are static over a `KvStore` and a `ContractId`; here the handle IS the contract's store.  One `update_contract` is one batched
+// plan on the GPU (every touched node hashed once) instead of depth-many hashes and KV reads per pair.
+// ---------------------------------------------------------------------------------------------------------------------------
+pub struct DeviceStateManager<'g> {
+    st: *mut sys::bzk_state,
+    gpu: &'g Gpu,
+}
+unsafe impl Send for DeviceStateManager<'_> {}
+
+fn locator_error(st: i32) -> StateManagerError {
+    match st {
+        // refused exactly where the reference returns LocatorError / NonScalarLocatorError / NonTreeLocatorError
+        sys::BZK_E_ARG => StateManagerError::LocatorError(ZkLocatorError::InvalidLocator),
+        e => panic!("libbzk device state: status {}", e),
+    }
+}
+
+impl<'g> DeviceStateManager<'g> {
+    /// an empty contract of this model (`ZkCompressedState::empty::<H>(model)`, src/zk/mod.rs:557-562)
+    pub fn new(gpu: &'g Gpu, model: &ZkStateModel) -> Result<Self, GpuError> {
+        let m = bincode::serialize(model)?;
+        let mut st = ptr::null_mut();
+        check(gpu.0, unsafe { sys::bzk_state_create(gpu.0, m.as_ptr(), m.len() as u64, &mut st) })?;
+        Ok(DeviceStateManager { st, gpu })
+    }
+
+    /// `update_contract(db, id, patch, target_height)` (src/zk/state/mod.rs:286-308): all or nothing
+    pub fn update_contract(&mut self, patch: &ZkDeltaPairs, target_height: u64) -> Result<ZkCompressedState, StateManagerError> {
+        let d = bincode::serialize(patch).expect("ZkDeltaPairs serialises");
+        let mut out = [0u8; 40];
+        match unsafe { sys::bzk_state_update_bincode(self.st, d.as_ptr(), d.len() as u64, target_height, out.as_mut_ptr()) } {
+            sys::BZK_OK => Ok(bincode::deserialize(&out).expect("40-byte ZkCompressedState")),
+            e => Err(locator_error(e)),
+        }
+    }
+
+    /// `root` (:274-284) and `height_of` (:210-216)
+    pub fn root(&self) -> (ZkCompressedState, u64) {
+        let (mut hash, mut size, mut height) = (ZkScalar::default(), 0u64, 0u64);
+        let st = unsafe { sys::bzk_state_root(self.st, &mut hash as *mut _ as *mut u8, &mut size, &mut height) };
+        assert_eq!(st, sys::BZK_OK);
+        (ZkCompressedState::new(hash, size), height)
+    }
+
+    /// `get_data` (:422-438) for many locators in one device read
+    pub fn get_data(&self, locators: &[ZkDataLocator]) -> Result<Vec<ZkScalar>, StateManagerError> {
+        let mut off = vec![0u64];
+        let mut flat = Vec::new();
+        for l in locators {
+            flat.extend_from_slice(&l.0);
+            off.push(flat.len() as u64);
+        }
+        let mut out = vec![ZkScalar::default(); locators.len()];
+        match unsafe { sys::bzk_state_get(self.st, off.as_ptr(), flat.as_ptr(), locators.len() as u64, out.as_mut_ptr() as *mut u8) } {
+            sys::BZK_OK => Ok(out),
+            e => Err(locator_error(e)),
+        }
+    }
+
+    /// `prove(db, id, tree_loc, index)` (:218-264): `Vec<[ZkScalar; 3]>`, leaf level first
+    pub fn prove(&self, tree_loc: &ZkDataLocator, index: u64) -> Result<Vec<[ZkScalar; 3]>, StateManagerError> {
+        let mut log4 = 0u32;
+        let st = unsafe { sys::bzk_state_prove(self.st, tree_loc.0.as_ptr(), tree_loc.0.len() as u64, ptr::null(), 0, ptr::null_mut(), &mut log4) };
+        if st != sys::BZK_OK {
+            return Err(if st == sys::BZK_E_ARG { StateManagerError::NonTreeLocatorError } else { locator_error(st) });
+        }
+        let mut out = vec![[ZkScalar::default(); 3]; log4 as usize];
+        match unsafe {
+            sys::bzk_state_prove(self.st, tree_loc.0.as_ptr(), tree_loc.0.len() as u64, &index, 1, out.as_mut_ptr() as *mut u8, &mut log4)
+        } {
+            sys::BZK_OK => Ok(out),
+            e => Err(locator_error(e)),
+        }
+    }
+
+    pub fn gpu(&self) -> &Gpu {
+        self.gpu
+    }
+}
+
+impl Drop for DeviceStateManager<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::bzk_state_free(self.st) }
     }
 }
 

@@ -167,3 +167,117 @@ def mpn_model(L, T):
     """`MpnConfig::state_model` (src/mpn/mod.rs:218-241)"""
     S = ("scalar",)
     return ("list", L, ("struct", [S, S, S, S, ("list", T, ("struct", [S, S]))]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# `KvStoreStateManager` over a plain dict (test infrastructure for the persistent device state, bzk_state_*): a restatement of
+# /root/reference/src/zk/state/mod.rs - `set_data` :310-420 (one pair at a time: the scalar, then every enclosing list / struct up to
+# the root; nodes that equal their default are REMOVED from the store; size_diff bookkeeping on zero <-> non-zero), `get_data`
+# :422-438, `prove` :218-264, `root` :274-284, `update_contract` :286-308, and of `ZkState::push_delta` (src/zk/mod.rs:521-530: the
+# rollback of a delta = the previous value of every key it names, None where there was none).  Store keys:
+#   ("v", locator)            scalar / struct / list value at a locator        (keys::local_value)
+#   ("a", locator, heap idx)  inner node of the list at `locator`, heap index (4^k - 1) / 3 + i at depth k   (keys::local_tree_aux)
+# ---------------------------------------------------------------------------------------------------------------------------
+class PyKvState:
+    def __init__(self, model, hasher=None):
+        self.model, self.db, self.H, self._dflt = model, {}, hasher or pr.poseidon, {}
+        self.hash, self.size, self.height = self._default(model), 0, 0
+
+    def _default(self, model):
+        """`compress_default` (memoised per sub-model object: the reference recomputes it, the value is the same)"""
+        if model[0] == "scalar":
+            return 0
+        if id(model) not in self._dflt:
+            if model[0] == "struct":
+                d = self.H([self._default(f) for f in model[1]])
+            else:
+                d = self._default(model[2])
+                for _ in range(model[1]):
+                    d = self.H([d] * 4)
+            self._dflt[id(model)] = d
+        return self._dflt[id(model)]
+
+    def get_data(self, locator):
+        locator = tuple(locator)
+        return self.db.get(("v", locator), self._default(model_locate(self.model, locator)))
+
+    def set_data(self, locator, value):
+        locator, value = list(locator), value % pr.R_MOD
+        if model_locate(self.model, locator)[0] != "scalar":
+            raise ValueError("NonScalarLocatorError")
+        prev = self.get_data(locator)
+        if prev == value:
+            return self.get_data(())
+        if value == 0:
+            self.size -= 1 if prev else 0
+            self.db.pop(("v", tuple(locator)), None)
+        else:
+            self.size += 0 if prev else 1
+            self.db[("v", tuple(locator))] = value
+        while locator:
+            at = locator.pop()
+            here = model_locate(self.model, locator)
+            if here[0] == "list":
+                log4, dflt, cur = here[1], self._default(here[2]), at
+                for layer in range(log4 - 1, -1, -1):
+                    first = cur - cur % 4
+                    kids = []
+                    for j in range(first, first + 4):
+                        if j == cur:
+                            kids.append(value)
+                        elif layer == log4 - 1:
+                            kids.append(self.get_data(locator + [j]))
+                        else:
+                            kids.append(self.db.get(("a", tuple(locator), (4 ** (layer + 1) - 1) // 3 + j), dflt))
+                    value, dflt, cur = self.H(kids), self.H([dflt] * 4), cur // 4
+                    if layer > 0:
+                        key = ("a", tuple(locator), (4 ** layer - 1) // 3 + cur)
+                        if value == dflt:
+                            self.db.pop(key, None)
+                        else:
+                            self.db[key] = value
+            else:
+                value = self.H([value if f == at else self.get_data(locator + [f]) for f in range(len(here[1]))])
+            if value == self._default(here):
+                self.db.pop(("v", tuple(locator)), None)
+            else:
+                self.db[("v", tuple(locator))] = value
+        return value
+
+    def update_contract(self, delta, target_height):
+        """delta: {locator: int or None}.  All or nothing, like the reference's mirror / fork.  -> the rollback delta"""
+        for loc in delta:
+            if model_locate(self.model, loc)[0] != "scalar":
+                raise ValueError("NonScalarLocatorError")
+        rollback = {tuple(loc): self.db.get(("v", tuple(loc))) for loc in delta}
+        for loc, v in delta.items():
+            self.hash = self.set_data(loc, v or 0)
+        self.height = target_height
+        return rollback
+
+    def root(self):
+        return self.hash, self.size
+
+    def prove(self, tree_loc, index):
+        here = model_locate(self.model, tree_loc)
+        if here[0] != "list":
+            raise ValueError("NonTreeLocatorError")
+        log4, dflt, cur, out = here[1], self._default(here[2]), index, []
+        for layer in range(log4 - 1, -1, -1):
+            first, part = cur - cur % 4, []
+            for j in range(first, first + 4):
+                if j != cur:
+                    part.append(self.get_data(list(tree_loc) + [j]) if layer == log4 - 1
+                                else self.db.get(("a", tuple(tree_loc), (4 ** (layer + 1) - 1) // 3 + j), dflt))
+            out.append(part)
+            cur, dflt = cur // 4, self.H([dflt] * 4)
+        return out
+
+
+def delta_bincode(delta) -> bytes:
+    """bincode of `ZkDeltaPairs(HashMap<ZkDataLocator, Option<ZkScalar>>)`: u64 count; per entry Vec<u64>, u8 Option tag, the limbs"""
+    out = len(delta).to_bytes(8, "little")
+    for loc, v in delta.items():
+        out += len(loc).to_bytes(8, "little") + b"".join(int(x).to_bytes(8, "little") for x in loc)
+        out += b"\x00" if v is None else b"\x01" + pr.fr_to_mont_bytes(v % pr.R_MOD)
+    return out

@@ -62,3 +62,53 @@ def test_membership_proof_structure_against_the_reference_sum_hasher_constant():
     lv = ps.PyMpnState._levels(some, depth, defaults, hasher=add)
     for i, v in some.items():
         assert (v + sum(x for part in ps.PyMpnState._prove(lv, depth, defaults, i) for x in part)) % pr.R_MOD == 739
+
+
+def test_state_manager_restatement_replays_the_reference_membership_test():
+    """`test_zk_list_membership_proof` (src/zk/test/mod.rs:43-62) replayed LITERALLY on the pair-at-a-time restatement of the state
+    manager (pystate.PyKvState: `update_contract` -> `set_data`, then `prove`) over the additive hasher: Struct{Scalar, List{4, Scalar}},
+    256 deltas of one pair, and leaf + proof = 32640 for every index - the constant the reference asserts."""
+    add = lambda vals: sum(vals) % pr.R_MOD  # noqa: E731
+    st = ps.PyKvState(("struct", [S, ("list", 4, S)]), hasher=add)
+    for i in range(256):
+        st.update_contract({(1, i): i}, i + 1)
+    for i in range(256):
+        proof = st.prove((1,), i)
+        assert len(proof) == 4 and (i + sum(v for part in proof for v in part)) % pr.R_MOD == 32640
+    assert st.root() == (32640, 255) and st.get_data((1,)) == 32640      # item 0 holds zero: 255 stored scalars
+
+
+def test_state_manager_restatement_equals_one_shot_compress():
+    """pair-at-a-time updates (with removals, overwrites and nodes falling back to their defaults) end at the value the one-shot
+    `compress` restatement gives for the surviving pairs; the rollback deltas bring every earlier root back"""
+    rnd = random.Random(9)
+    m = ("list", 2, ("struct", [S, ("list", 1, S), ("struct", [S, S]), ("list", 0, S)]))
+    st = ps.PyKvState(m)
+    live, roots, rollbacks = {}, [st.root()], []
+    for step in range(12):
+        delta = {}
+        for _ in range(rnd.randint(1, 4)):
+            i, f = rnd.randrange(5), rnd.randrange(4)
+            loc = {0: (i, 0), 1: (i, 1, rnd.randrange(4)), 2: (i, 2, rnd.randrange(2)), 3: (i, 3, 0)}[f]
+            delta[loc] = rnd.choice([None, 0, rnd.randrange(1, pr.R_MOD)])
+        rollbacks.append(st.update_contract(delta, step + 1))
+        for k, v in delta.items():
+            if v:
+                live[k] = v
+            else:
+                live.pop(k, None)
+        assert st.root() == ps.compress(m, live)
+        roots.append(st.root())
+    for rb in reversed(rollbacks):
+        roots.pop()
+        st.update_contract(rb, 0)
+        assert st.root() == roots[-1]
+    assert st.db == {} and st.root() == (ps.model_default(m), 0)
+
+
+def test_delta_bincode_layout():
+    blob = ps.delta_bincode({(3, 1): 5, (2,): None})
+    assert blob[:8] == (2).to_bytes(8, "little")
+    assert blob[8:16] == (2).to_bytes(8, "little") and blob[16:32] == (3).to_bytes(8, "little") + (1).to_bytes(8, "little")
+    assert blob[32] == 1 and blob[33:65] == pr.fr_to_mont_bytes(5)
+    assert blob[65:73] == (1).to_bytes(8, "little") and blob[73:81] == (2).to_bytes(8, "little") and blob[81:] == b"\x00"
