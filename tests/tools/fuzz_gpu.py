@@ -1,6 +1,7 @@
 """Differential fuzzing of the C ABI against the CPU oracle on random shapes (run on a GPU box):
 MSM G1/G2 (plain, de-duplicated, window partitions, witness-like / degenerate scalar mixes, repeated and negated bases),
-NTT (all four modes, every log size up to 14), Poseidon batches (every arity), 4-ary trees, tree updates.
+NTT (all four modes, every log size up to 14), Poseidon batches (every arity), 4-ary trees, tree updates, the general state seam one-shot and
+device-resident (random models under random deltas).
 usage: python tests/tools/fuzz_gpu.py [seconds=60] [seed=1]"""
 import json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,7 +43,7 @@ def main(seconds=60, seed=1):
     t_end = time.time() + seconds
     while time.time() < t_end:
         kind = rnd.choice(("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows", "table", "window_size",
-                           "bases", "mg", "h_chain", "state"))
+                           "bases", "mg", "h_chain", "state", "state_dev"))
         counts[kind] = counts.get(kind, 0) + 1
         if kind in ("bases", "mg"):  # round 3: resident base sets, device groups (several contexts on this one GPU)
             import torch
@@ -87,6 +88,41 @@ def main(seconds=60, seed=1):
             ctx.groth16_h_dev(d[0], d[1], d[2], lg)
             torch.cuda.synchronize()
             assert bytes(d[0].cpu().numpy().tobytes())[: 32 * (m - 1)] == co.groth16_h(az, bz, cz, lg, nthreads=nt), (kind, lg, rows)
+            continue
+        if kind == "state_dev":  # round 4: the persistent device state against the pair-at-a-time restatement of the reference's state manager
+            import pystate as ps
+            from bazuka_amd import DeviceState
+            def rmodel(depth):
+                k = rnd.random()
+                if depth == 0 or k < 0.3:
+                    return ("scalar",)
+                if k < 0.65:
+                    return ("struct", [rmodel(depth - 1) for _ in range(rnd.randint(1, 4))])
+                return ("list", rnd.randint(0, 3), rmodel(depth - 1))
+            def rloc(model, stop=0.0, span=5):
+                loc = []
+                while model[0] != "scalar" and rnd.random() >= stop:
+                    if model[0] == "struct":
+                        f = rnd.randrange(len(model[1])); loc.append(f); model = model[1][f]
+                    else:
+                        loc.append(rnd.randrange(min(span, 4 ** model[1]))); model = model[2]
+                return tuple(loc), model
+            model = rmodel(3)
+            dev, ref = DeviceState(ctx, ps.model_bincode(model)), ps.PyKvState(model)
+            for height in range(1, rnd.randrange(2, 6)):
+                delta = {rloc(model)[0]: rnd.choice((None, 0, 1, rnd.randrange(pr.R_MOD))) for _ in range(rnd.choice((1, 2, 6, 25)))}
+                rb = ref.update_contract(delta, height)
+                ps_ = [(k, pr.fr_to_mont_bytes((v or 0) % pr.R_MOD)) for k, v in delta.items()]
+                h, n, prev = dev.update(ps_, height, want_rollback=True)
+                assert (h, n) == (pr.fr_to_mont_bytes(ref.hash), ref.size), (kind, model, delta)
+                assert prev == [pr.fr_to_mont_bytes(rb[k] or 0) for k, _ in ps_], (kind, "rollback", model, delta)
+                locs = [rloc(model, stop=0.3)[0] for _ in range(6)]
+                assert dev.get(locs) == [pr.fr_to_mont_bytes(ref.get_data(l)) for l in locs], (kind, "get", model, locs)
+                tl, sub = rloc(model, stop=0.4)
+                if sub[0] == "list":
+                    ix = [rnd.randrange(4 ** sub[1]) for _ in range(2)]
+                    assert dev.prove(tl, ix) == [[[pr.fr_to_mont_bytes(x) for x in part] for part in ref.prove(tl, i)] for i in ix], (kind, "prove", model, tl, ix)
+            dev.close()
             continue
         if kind == "state":  # general ZkStateModel::compress against the general Python restatement (small cases: pure-Python Poseidon)
             import pystate as ps
