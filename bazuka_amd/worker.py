@@ -413,6 +413,13 @@ def cpu_quota():
         return None
 
 
+def dev_toxic(seed: str, kind: int) -> bytes:
+    """the dev-mode toxic waste of circuit `kind` under `--dev-toxic SEED` (tau | alpha | beta | gamma | delta): scalar i =
+    ZkScalar::new(sha3_256("SEED/kind/i") twice).  bazuka_amd/csrc/worker_main.cpp derives the same bytes."""
+    import hashlib
+    return b"".join(L.host_scalar_new(hashlib.sha3_256(f"{seed}/{kind}/{i}".encode()).digest() * 2) for i in range(5))
+
+
 def main(argv=None):
     """python -m bazuka_amd.worker --node 127.0.0.1:8765 --address <64 hex> --dev-toxic <seed>
     Dev-mode worker: proving keys are generated on the GPU from a toxic-waste seed shared with the node's setup
@@ -439,7 +446,7 @@ def main(argv=None):
         ap.error("--address must be 32 bytes of hex")
 
     def toxic(kind):
-        return b"".join(L.host_scalar_new(hashlib.sha3_256(f"{a.dev_toxic}/{kind}/{i}".encode()).digest() * 2) for i in range(5))
+        return dev_toxic(a.dev_toxic, kind)
 
     if bool(a.dev_toxic) == bool(a.params):
         ap.error("exactly one of --dev-toxic / --params")

@@ -163,3 +163,84 @@ def test_multi_slot_worker_proves_a_round_side_by_side(bzk):
         keys.close()
         for c in extra_ctx:
             c.close()
+
+
+# ---- the NATIVE worker (bazuka_amd/bzk-worker: C++ over the C ABI, no Python in the loop) ------------------------------------------------
+def _native(args, timeout=600):
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([os.path.join(root, "bazuka_amd", "bzk-worker")] + args, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1]), p.stderr
+
+
+def _block_of_works(vks, reward0=100):
+    w = L.MpnWorld(3, 3)
+    for i in range(4):
+        w.add_account(i, b"acct%d" % i, ZIESHA, 10 ** 9)
+    w.add_key(7, b"newcomer")
+    w.set_height(21)
+    blobs = {}
+    w.push_deposit(0, ZIESHA, 1000)
+    w.push_deposit(7, ZIESHA, 55)
+    blobs[0] = w.make_work(0, vks, reward0).encode()
+    w.push_withdraw(1, ZIESHA, 400, ZIESHA, 2)
+    blobs[1] = w.make_work(1, vks, reward0 + 100).encode()
+    w.push_tx(0, 1, ZIESHA, 1000, ZIESHA, 7)
+    w.push_tx(7, 2, ZIESHA, 5, ZIESHA, 1)
+    blobs[2] = w.make_work(2, vks, reward0 + 200).encode()
+    for k in range(3, 6):    # three more update batches: work for a second slot
+        w.push_tx(2, 3, ZIESHA, 10 + k, ZIESHA, 0)
+        blobs[k] = w.make_work(2, vks, reward0 + 100 * k).encode()
+    return blobs
+
+
+def test_native_worker_proves_a_block_and_the_node_accepts(bzk):
+    """the same round as the first test, run by the native program: it registers, fetches the six works over HTTP, derives the dev-mode
+    keys from the seed on the GPU (bzk_groth16_setup), synthesizes ahead of the proofs, proves on two slots sharing the CRS, checks every
+    proof with the work's own key and posts; the node accepts a solution iff the ORACLE's pairing check passes"""
+    seed = "native-dev"
+    keys = W.DevSetup(bzk, {k: W.dev_toxic(seed, k) for k in range(3)})   # what a node set up with this seed holds
+    vks = [keys.keys(k, 3, 3, 1)[1] for k in range(3)]
+    keys.close()
+    blobs = _block_of_works(vks)
+    node = MockNode(blobs)
+    try:
+        st, err = _native(["--node", f"127.0.0.1:{node.port}", "--address", ALICE.hex(), "--dev-toxic", seed, "--slots-per-device", "2",
+                           "--self-check", "--rounds", "2", "--poll", "0.05"])
+        assert st["fetched"] == 6 and st["proved"] == 6 and st["accepted"] == 6 and st["unsat"] == 0 and st["self_check_failed"] == 0 and st["errors"] == 0, (st, err)
+        assert sum(st["proved_by_slot"]) == 6 and len(st["proved_by_slot"]) == 2
+        assert node.solved == {k: ALICE for k in blobs}
+        assert [e[0] for e in node.log] == ["worker", "work", "solution", "work"]      # second round: nothing left
+        # a worker set up with ANOTHER seed holds other keys: it refuses the works (their VK is not its key's) and posts nothing
+        node2 = MockNode({0: blobs[2]})
+        try:
+            st2, err2 = _native(["--node", f"127.0.0.1:{node2.port}", "--address", ALICE.hex(), "--dev-toxic", "another-seed", "--rounds", "1"])
+            assert st2["accepted"] == 0 and st2["proved"] == 0 and st2["errors"] == 1 and "verifying key" in st2["last_error"] and not node2.solved
+        finally:
+            node2.close()
+    finally:
+        node.close()
+
+
+def test_native_worker_with_bellman_parameter_files(bzk, tmp_path):
+    dev = W.DevSetup(bzk, {k: fr_bytes(fr_list(5, 9300 + k)) for k in range(3)})
+    paths, vks = [], []
+    for kind in range(3):
+        ph, vk = dev.keys(kind, 3, 3, 1)
+        vks.append(vk)
+        parts = [bzk.params_read(ph, which) for which in range(6)]
+        path = tmp_path / f"kind{kind}.params"
+        path.write_bytes(L.bellman_params_encode(parts[0], vk[878:], *parts[1:]))
+        paths.append(str(path))
+    dev.close()
+    blobs = _block_of_works(vks, reward0=7)
+    node = MockNode(blobs)
+    try:
+        st, err = _native(["--node", f"127.0.0.1:{node.port}", "--address", ALICE.hex(), "--params"] + paths + ["--self-check", "--rounds", "1"])
+        assert st["accepted"] == 6 and st["proved"] == 6 and st["self_check_failed"] == 0 and st["errors"] == 0, (st, err)
+        assert node.solved == {k: ALICE for k in blobs}
+    finally:
+        node.close()

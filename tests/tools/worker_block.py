@@ -2,8 +2,10 @@
 a mock node (tests/mock_node.py) hands out a deposit work (64 tx, 2^21), a withdraw work (64 tx, 2^22) and an update work (256 tx, 2^24)
 over consecutive states as bincode `GetMpnWorkResponse`; bazuka_amd/worker.py decodes them, synthesizes ahead of the proofs, proves on
 the GPU, checks every proof with the work's own key (--self-check) and posts `PostMpnSolutionRequest`; the node accepts a solution iff
-the ORACLE's pairing check passes.  Run on a GPU box: python tests/tools/worker_block.py"""
-import json, os, sys, time
+the ORACLE's pairing check passes.  Run on a GPU box: python tests/tools/worker_block.py [--native]
+--native: the round is run by the native program bazuka_amd/bzk-worker (C++ over the C ABI; --dev-toxic SEED, so it derives the same
+dev-mode keys on the GPU itself) instead of bazuka_amd/worker.py."""
+import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from bazuka_amd import Bzk, lib as L, worker as W
@@ -19,7 +21,10 @@ def main():
     ctx = Bzk(0)
     out = {}
     t0 = time.perf_counter()
-    keys = W.DevSetup(ctx, {k: b"".join(F(1234567 * (k + 1) + 7919 * j + 11) for j in range(5)) for k in range(3)})
+    native = "--native" in sys.argv
+    seed = "production-block"
+    keys = W.DevSetup(ctx, {k: W.dev_toxic(seed, k) for k in range(3)} if native else
+                      {k: b"".join(F(1234567 * (k + 1) + 7919 * j + 11) for j in range(5)) for k in range(3)})
     vks = [keys.keys(0, 15, 3, 3)[1], keys.keys(1, 15, 3, 3)[1], keys.keys(2, 15, 3, 4)[1]]
     out["crs_three_shapes_s"] = round(time.perf_counter() - t0, 1)
     w = L.MpnWorld(15, 3)
@@ -44,6 +49,22 @@ def main():
     out["wire_bytes"] = {k: len(v) for k, v in blobs.items()}
     node = MockNode(blobs)
     try:
+        if native:
+            w.close()
+            keys.close()          # the native worker generates its own CRS from the seed: free this process's copy first
+            ctx.close()
+            t0 = time.perf_counter()
+            p = subprocess.run([os.path.join(ROOT, "bazuka_amd", "bzk-worker"), "--node", f"127.0.0.1:{node.port}", "--address", ADDR.hex(),
+                                "--dev-toxic", seed, "--self-check", "--rounds", "1"], capture_output=True, text=True, timeout=900)
+            out["native_wall_s_incl_crs_generation"] = round(time.perf_counter() - t0, 1)
+            out["native_stderr"] = [l for l in p.stderr.splitlines() if l.startswith("[bzk-worker]")]
+            assert p.returncode == 0, p.stderr[-2000:]
+            out["worker_stats"] = json.loads(p.stdout.strip().splitlines()[-1])
+            out["accepted"] = out["worker_stats"]["accepted"]
+            out["node_solved"] = sorted(node.solved)
+            assert out["accepted"] == 3 and node.solved == {0: ADDR, 1: ADDR, 2: ADDR}
+            print(json.dumps(out))
+            return
         wk = W.Worker(ctx, ADDR, ("127.0.0.1", node.port), keys, self_check=True)
         assert wk.register()
         t0 = time.perf_counter()
