@@ -400,9 +400,11 @@ __device__ __forceinline__ Fr29 sel29(bool c, const Fr29& a, const Fr29& b) {
     return r;
 }
 
-// in: the node's four children (read by lanes 1..4); returns the hash in lane 1 of the group (other lanes: garbage)
-__device__ Fr poseidon29_coop5(const Fr* __restrict__ in, const Fr29* __restrict__ consts, int rf, int rp) {
-    constexpr int T = 5;
+// in: the node's T - 1 inputs (read by lanes 1..T-1); returns the hash in lane 1 of the group (other lanes: garbage).  Any width
+// 2 <= T <= 8 (eight lanes per node): T = 5 is the tree node, the others are the struct hashes of a state model (round 4)
+template <int T>
+__device__ Fr poseidon29_coop(const Fr* __restrict__ in, const Fr29* __restrict__ consts, int rf, int rp) {
+    static_assert(T >= 2 && T <= 8, "eight lanes per node");
     const int lane = threadIdx.x & 63, j = lane & 7, g0 = lane & ~7;
     const int jj = j < T ? j : T - 1;  // idle lanes mirror lane 4 (their values are never used)
     const int half_f = rf / 2;
@@ -427,11 +429,11 @@ __device__ Fr poseidon29_coop5(const Fr* __restrict__ in, const Fr29* __restrict
     st = fr29::norm(fr29::add(st, pre[jj]));
 #pragma unroll 1
     for (int i = 0; i < rp; ++i) {
-        const Fr29* c = part + (size_t)i * 2 * T;  // s_i, row0[5], what[4]
+        const Fr29* c = part + (size_t)i * 2 * T;  // s_i, row0[T], what[T - 1]
         // lane 0: S-box and the scalar constant (the other lanes run the same instructions on values that are dropped)
         const Fr29 sb = fr29::norm(fr29::add(fr29::sbox5(j == 0 ? st : one), c[0]));
         const Fr29 s0 = shfl29(sb, g0);
-        // row 0: one product per lane, butterfly sum over the group (lanes 5..7 contribute zero)
+        // row 0: one product per lane, butterfly sum over the group (lanes T..7 contribute zero)
         Fr29 prod = fr29::mul(c[1 + jj], j == 0 ? s0 : st);
         if (j >= T) prod = fr29::zero();
         prod = fr29::norm(fr29::add(prod, shfl29_xor(prod, 1)));
@@ -461,8 +463,36 @@ __global__ void __launch_bounds__(64) poseidon29_coop5_kernel(const Fr* __restri
     const uint64_t node = (uint64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
     const uint64_t clamped = node < n ? node : n - 1;  // whole groups stay convergent for the shuffles
     const uint64_t p = parents ? parents[clamped] : clamped;
-    const Fr h = poseidon29_coop5(in + 4 * p, consts, rf, rp);
+    const Fr h = poseidon29_coop<5>(in + 4 * p, consts, rf, rp);
     if (node < n && (threadIdx.x & 7) == 1) out[p] = h;
+}
+
+// the same for any width: node i hashes in[(T - 1) i .. (T - 1) i + T - 2]
+template <int T>
+__global__ void __launch_bounds__(64) poseidon29_coop_kernel(const Fr* __restrict__ in, uint64_t n, const Fr29* __restrict__ consts, int rf, int rp,
+                                                             Fr* __restrict__ out) {
+    const uint64_t node = (uint64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+    const uint64_t p = node < n ? node : n - 1;  // whole groups stay convergent for the shuffles
+    const Fr h = poseidon29_coop<T>(in + (uint64_t)(T - 1) * p, consts, rf, rp);
+    if (node < n && (threadIdx.x & 7) == 1) out[p] = h;
+}
+typedef void (*poseidon29_coop_fn)(const Fr*, uint64_t, const Fr29*, int, int, Fr*);
+static poseidon29_coop_fn poseidon29_coop_table(int t) {
+    switch (t) {
+        case 2: return poseidon29_coop_kernel<2>;
+        case 3: return poseidon29_coop_kernel<3>;
+        case 4: return poseidon29_coop_kernel<4>;
+        case 6: return poseidon29_coop_kernel<6>;
+        case 7: return poseidon29_coop_kernel<7>;
+        case 8: return poseidon29_coop_kernel<8>;
+        default: return nullptr;
+    }
+}
+
+// env BZK_POSEIDON_COOP_ANY=0: widths other than 5 keep the one-lane-per-hash kernel for small batches too (A/B runs)
+static bool poseidon_coop_any_off() {
+    static const bool off = [] { const char* e = getenv("BZK_POSEIDON_COOP_ANY"); return e && atoi(e) == 0; }();
+    return off;
 }
 
 int32_t poseidon_launch(bzk_ctx* ctx, const void* in_dev, uint32_t arity, uint64_t n, void* out_dev) {
@@ -477,6 +507,11 @@ int32_t poseidon_launch(bzk_ctx* ctx, const void* in_dev, uint32_t arity, uint64
     if (t == 5 && n <= COOP_MAX_NODES && !ctx->no_coop) {  // too few nodes to fill the machine: shorten the chain instead
         BZK_LAUNCH(ctx, "poseidon_coop", poseidon29_coop5_kernel, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, (const Fr*)in_dev, n,
                    (const uint64_t*)nullptr, (const Fr29*)consts, rf, rp, (Fr*)out_dev);
+        return BZK_OK;
+    }
+    if (t <= 8 && n <= COOP_MAX_NODES && !ctx->no_coop && !poseidon_coop_any_off()) {  // the struct hashes of small batches: same reasoning
+        poseidon29_coop_fn k = poseidon29_coop_table(t);
+        BZK_LAUNCH(ctx, "poseidon_coop", k, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, (const Fr*)in_dev, n, (const Fr29*)consts, rf, rp, (Fr*)out_dev);
         return BZK_OK;
     }
     if (t <= 8) {

@@ -525,6 +525,40 @@ def state_seam_section(ctx, out):
 
 
 
+def make_work_section(ctx, out=None):
+    """validator-side work preparation (f-3); fills and returns out[...]"""
+    out = {} if out is None else out
+    # validator-side work preparation (f-3): 256 update transactions at the production shape, host walk vs device batches
+    try:
+        from bazuka_amd import lib as L_
+        import json as _json
+        vks = [bytes.fromhex(h) for h in _json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))["verifying_keys_bincode_hex"]]
+        Z_ = _fr(1)
+        res = {}
+        for key, dev_on in (("host_s", False), ("device_s", True)):
+            w_ = L_.MpnWorld(15, 3)
+            if dev_on:
+                w_.set_device(ctx)
+            for i in range(512):
+                w_.add_account((i * 7919 + 1) % 4 ** 15, b"a%d" % i, Z_, 10 ** 12)
+            ts = []
+            for k in range(2):
+                for i in range(256):
+                    w_.push_tx((i * 7919 + 1) % 4 ** 15, ((256 + i) * 7919 + 1) % 4 ** 15, Z_, 100 + i + k, Z_, i % 7)
+                t = time.perf_counter()
+                wk = w_.make_work(2, vks, 1, log4_batches=(1, 1, 4))
+                ts.append(time.perf_counter() - t)
+                if k == 0:
+                    res[key + "_bytes"] = wk.encode()
+            res[key] = round(min(ts), 4)
+        out["mpn_make_work_256tx"] = {"what": "one update work of `prepare_works` (256 transactions, L = 15, T = 3): transitions with their Merkle proofs; "
+                                              "host = per-transaction walk of the sparse tree, device = bzk_mpn_set_device (one batched Poseidon launch per level)",
+                                      "host_s": res["host_s"], "device_s": res["device_s"], "same_work_bytes": res["host_s_bytes"] == res["device_s_bytes"]}
+    except Exception as e:
+        out["mpn_make_work_256tx"] = {"error": repr(e)}
+    return out
+
+
 def other_configs_section(ctx, dev):
     """BASELINE.json's other single-GPU configurations and the proof's remaining kernels, timed by the driver's own run
     (VERDICT r1 item 3): inputs resident in HBM, best of 3 after one warm-up, plus the HIP-event time of the dominant kernel and
@@ -607,34 +641,7 @@ def other_configs_section(ctx, dev):
                            "roofline": hbm(7 * 64.0 * (1 << 20) + 128.0 * (1 << 20), ms)}
     del a, b, c
     state_seam_section(ctx, out)
-    # validator-side work preparation (f-3): 256 update transactions at the production shape, host walk vs device batches
-    try:
-        from bazuka_amd import lib as L_
-        import json as _json
-        vks = [bytes.fromhex(h) for h in _json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))["verifying_keys_bincode_hex"]]
-        Z_ = _fr(1)
-        res = {}
-        for key, dev_on in (("host_s", False), ("device_s", True)):
-            w_ = L_.MpnWorld(15, 3)
-            if dev_on:
-                w_.set_device(ctx)
-            for i in range(512):
-                w_.add_account((i * 7919 + 1) % 4 ** 15, b"a%d" % i, Z_, 10 ** 12)
-            ts = []
-            for k in range(2):
-                for i in range(256):
-                    w_.push_tx((i * 7919 + 1) % 4 ** 15, ((256 + i) * 7919 + 1) % 4 ** 15, Z_, 100 + i + k, Z_, i % 7)
-                t = time.perf_counter()
-                wk = w_.make_work(2, vks, 1, log4_batches=(1, 1, 4))
-                ts.append(time.perf_counter() - t)
-                if k == 0:
-                    res[key + "_bytes"] = wk.encode()
-            res[key] = round(min(ts), 4)
-        out["mpn_make_work_256tx"] = {"what": "one update work of `prepare_works` (256 transactions, L = 15, T = 3): transitions with their Merkle proofs; "
-                                              "host = per-transaction walk of the sparse tree, device = bzk_mpn_set_device (one batched Poseidon launch per level)",
-                                      "host_s": res["host_s"], "device_s": res["device_s"], "same_work_bytes": res["host_s_bytes"] == res["device_s_bytes"]}
-    except Exception as e:
-        out["mpn_make_work_256tx"] = {"error": repr(e)}
+    make_work_section(ctx, out)
     # G2 MSM (a6): 224 algorithmic bytes per (point, scalar) pair
     n = 1 << 20
     bases = torch.empty(n * 192, dtype=torch.uint8, device=dev)

@@ -15,11 +15,13 @@ def test_poseidon_reference_kats(bzk, pr):
         assert pr.fr_from_mont_bytes(out) == POSEIDON_KAT[k - 1], k
 
 
-@pytest.mark.parametrize("arity", [1, 2, 4, 5, 7, 16])
+@pytest.mark.parametrize("arity", [1, 2, 3, 4, 5, 6, 7, 16])
 def test_poseidon_batch_vs_oracle(bzk, co, arity):
-    n = 1000 if arity < 10 else 200
-    inp = rand_scalars_bytes(n * arity, arity)
-    assert bzk.poseidon_batch(inp, arity) == co.poseidon_batch(inp, arity, nthreads=co.ncpu())
+    """widths <= 8 take the cooperative kernel (eight lanes per hash) up to 8192 hashes and the one-lane-per-hash kernel beyond: both
+    sides of the switch, group sizes that are not multiples of eight, and a single hash"""
+    for n in ((1, 7, 9, 1000, 8192, 8193, 9001) if arity < 10 else (1, 200)):
+        inp = rand_scalars_bytes(n * arity, arity + 31 * n)
+        assert bzk.poseidon_batch(inp, arity) == co.poseidon_batch(inp, arity, nthreads=co.ncpu()), (arity, n)
 
 
 def test_poseidon_bad_arity(bzk):
