@@ -324,3 +324,17 @@ def test_mg_probe_without_a_device_reports_nothing_usable():
     if torch.cuda.is_available():
         pytest.skip("a GPU is visible")
     assert mg_probe(0) == 0 and mg_probe(-1) == 0
+
+
+def test_header_is_plain_c99_and_cxx11(tmp_path):
+    """the boundary is a C ABI: include/bzk.h must compile as C99 (-pedantic) and as C++11 on its own - what a cgo / JNI / Rust-bindgen
+    consumer feeds it to"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "bzk.h"\nint main(void) { return (int)sizeof(bzk_params_desc) == 0; }\n')
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror"], ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-x", "c++"]):
+        subprocess.check_call(cmd + ["-I", os.path.join(root, "include"), "-c", str(src), "-o", str(tmp_path / "hdr.o")])
