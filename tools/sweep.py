@@ -158,6 +158,9 @@ if __name__ == "__main__":
             run("g1res", 20, {"BZK_MSM_ENDO_G1": e}); run("g1res", 20, {"BZK_MSM_ENDO_G1": e, "THROUGHPUT": "1"})
             run("g2res", 20, {"BZK_MSM_ENDO_G2": e}); run("g2res", 20, {"BZK_MSM_ENDO_G2": e, "THROUGHPUT": "1"})
         run("g1res", 22, {"BZK_MSM_ENDO_G1": "0"}); run("g1res", 22, {"BZK_MSM_ENDO_G1": "1"})
+    if what in ("r4strong",):  # round 4: SURVEY C4 (i) on one GPU: the whole 2^26-point MSM, and what one rank of 8 / 4 / 2 does of it (its window share)
+        run("g1res", 26); run("g1winres", 26); run("g1winres", 26, {"SHARDS": "4"}); run("g1winres", 26, {"SHARDS": "2"})
+        run("g1res", 24); run("g1winres", 24); run("g1winres", 24, {"SHARDS": "4"}); run("g1winres", 24, {"SHARDS": "2"})
     if what in ("r4rank8",):  # round 4: what one rank of 8 / 4 / 2 does at 2^23 / 2^22 / 2^21 points (weak scaling), raw and resident bases
         run("g1win", 23); run("g1winres", 23); run("g1winres", 22, {"SHARDS": "4"}); run("g1winres", 21, {"SHARDS": "2"}); run("g1", 20)
     if what in ("r39",):
