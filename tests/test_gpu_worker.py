@@ -244,3 +244,21 @@ def test_native_worker_with_bellman_parameter_files(bzk, tmp_path):
         assert node.solved == {k: ALICE for k in blobs}
     finally:
         node.close()
+
+
+def test_native_worker_over_several_devices(bzk):
+    """`--devices a,b`: one key source and one prover slot per device (replicas).  A one-GPU box names its device twice - two independent
+    contexts with their own CRS, the code path of a multi-GPU node"""
+    seed = "native-two-devices"
+    keys = W.DevSetup(bzk, {k: W.dev_toxic(seed, k) for k in range(3)})
+    vks = [keys.keys(k, 3, 3, 1)[1] for k in range(3)]
+    keys.close()
+    blobs = _block_of_works(vks, reward0=11)
+    node = MockNode(blobs)
+    try:
+        st, err = _native(["--node", f"127.0.0.1:{node.port}", "--address", ALICE.hex(), "--dev-toxic", seed, "--devices", "0,0", "--self-check", "--rounds", "1"])
+        assert st["accepted"] == 6 and st["proved"] == 6 and st["errors"] == 0 and len(st["proved_by_slot"]) == 2 and sum(st["proved_by_slot"]) == 6, (st, err)
+        assert err.count("proving key for kind 2") == 2      # each device generated its own
+        assert node.solved == {k: ALICE for k in blobs}
+    finally:
+        node.close()
