@@ -281,3 +281,41 @@ def delta_bincode(delta) -> bytes:
         out += len(loc).to_bytes(8, "little") + b"".join(int(x).to_bytes(8, "little") for x in loc)
         out += b"\x00" if v is None else b"\x01" + pr.fr_to_mont_bytes(v % pr.R_MOD)
     return out
+
+
+def delta_decode(blob: bytes) -> dict:
+    """inverse of delta_bincode with the checks a bincode reader of `ZkDeltaPairs` makes (ValueError on anything else): count, Vec<u64>
+    locators, the Option tag, 32-byte limbs below r, no trailing bytes; a HashMap holds a key once"""
+    def u64(pos):
+        if pos + 8 > len(blob):
+            raise ValueError("truncated")
+        return int.from_bytes(blob[pos:pos + 8], "little"), pos + 8
+    n, pos = u64(0)
+    if n > len(blob):
+        raise ValueError("implausible count")
+    out = {}
+    for _ in range(n):
+        k, pos = u64(pos)
+        if k > 64:
+            raise ValueError("implausible locator")
+        loc = []
+        for _ in range(k):
+            x, pos = u64(pos)
+            loc.append(x)
+        if pos >= len(blob) or blob[pos] > 1:
+            raise ValueError("bad Option tag")
+        tag, pos = blob[pos], pos + 1
+        v = None
+        if tag:
+            if pos + 32 > len(blob):
+                raise ValueError("truncated")
+            limbs = int.from_bytes(blob[pos:pos + 32], "little")
+            if limbs >= pr.R_MOD:
+                raise ValueError("not a field element")
+            v, pos = pr.fr_from_mont_bytes(blob[pos:pos + 32]), pos + 32
+        if tuple(loc) in out:
+            raise ValueError("duplicate key")
+        out[tuple(loc)] = v
+    if pos != len(blob):
+        raise ValueError("trailing bytes")
+    return out

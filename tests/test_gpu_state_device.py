@@ -220,3 +220,47 @@ def test_growth_past_the_first_allocation(bzk):
         h, n = dev.update(_pairs(delta), height)
         assert (h, n) == bzk.state_compress(ps.model_bincode(model), _pairs(allp))
     assert dev.stats()["slots"] > 4096
+
+
+def test_mutated_delta_blobs_are_applied_or_refused_never_half(bzk):
+    """differential fuzzing of the bincode entry: byte flips, truncations and splices of valid `ZkDeltaPairs` blobs either decode to a delta
+    the model accepts - then the device state moves exactly as the restatement does - or are refused with the state untouched"""
+    rnd = random.Random(99)
+    model = ("list", 2, ("struct", [S, ("list", 1, S), ("struct", [S, S])]))
+    b = Both(bzk, model)
+    applied = refused = 0
+    for case in range(250):
+        delta = {}
+        for _ in range(rnd.randint(1, 4)):
+            i, f = rnd.randrange(16), rnd.randrange(3)
+            loc = {0: (i, 0), 1: (i, 1, rnd.randrange(4)), 2: (i, 2, rnd.randrange(2))}[f]
+            delta[loc] = rnd.choice([None, 0, rnd.randrange(1, pr.R_MOD)])
+        blob = bytearray(ps.delta_bincode(delta))
+        mode = rnd.randrange(4)
+        if mode == 1:
+            for _ in range(rnd.randint(1, 3)):
+                blob[rnd.randrange(len(blob))] ^= 1 << rnd.randrange(8)
+        elif mode == 2:
+            blob = blob[:rnd.randrange(len(blob))]
+        elif mode == 3:
+            at = rnd.randrange(len(blob))
+            blob = blob[:at] + bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 9))) + blob[at:]
+        try:
+            want = ps.delta_decode(bytes(blob))
+            for loc in want:
+                if ps.model_locate(model, loc)[0] != "scalar":
+                    raise ValueError("NonScalarLocatorError")
+        except (ValueError, IndexError):
+            want = None
+        if want is None:
+            with pytest.raises(BzkError):
+                b.dev.update_bincode(bytes(blob), b.h + 1)
+            refused += 1
+        else:
+            b.h += 1
+            b.ref.update_contract(want, b.h)
+            assert b.dev.update_bincode(bytes(blob), b.h) == F(b.ref.hash) + b.ref.size.to_bytes(8, "little"), (case, mode, want)
+            applied += 1
+        b.check_root()
+    assert applied > 60 and refused > 60
+    b.check_get([(i, 0) for i in range(16)] + [(i,) for i in range(16)] + [()])
