@@ -375,6 +375,14 @@ struct bzk_state {
     uint8_t root_hash[32];
     bool poisoned = false;  // a device error in the middle of an update: the slots no longer describe one state
     std::mutex m;
+    // every call that used the store has synchronised its stream before returning, and the context is not touched here: a host that
+    // tears its handles down in arbitrary order (a garbage collector) may already have destroyed it
+    ~bzk_state() {
+        if (d_vals) {
+            (void)hipSetDevice(device);
+            (void)hipFree(d_vals);
+        }
+    }
 };
 
 namespace {
@@ -833,14 +841,7 @@ int32_t bzk_state_create(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len,
 }
 
 void bzk_state_free(bzk_state* st) {
-    if (!st) return;
-    // every call that used the store has synchronised its stream before returning, and the context is not touched here: a
-    // host that tears its handles down in arbitrary order (a garbage collector) may already have destroyed it
-    if (st->d_vals) {
-        (void)hipSetDevice(st->device);
-        (void)hipFree(st->d_vals);
-    }
-    delete st;
+    delete st;  // frees the value store (see ~bzk_state)
 }
 
 int32_t bzk_state_update(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, const uint8_t* values, uint64_t n, uint64_t target_height,
