@@ -65,6 +65,24 @@ inline Fr mul(const Fr& a_, const Fr& b_) {
     return finish(t0, t1, t2, t3, 0);  // r < 2^255: the running value stays below 2 r < 2^256
 }
 inline Fr sqr(const Fr& a) { return mul(a, a); }
+// a^(r-2) by the same square-and-multiply ladder as fe_inv<FrParams> (inv(0) = 0), on the 64-bit-limb product: the same canonical value
+inline Fr inv(const Fr& a) {
+    uint32_t e[8];
+    {
+        uint64_t borrow = 2;
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t d = (uint64_t)FrParams::MOD[i] - borrow;
+            e[i] = (uint32_t)d;
+            borrow = (d >> 63) & 1;
+        }
+    }
+    Fr r = Fr::one();
+    for (int i = 255; i >= 0; --i) {
+        r = mul(r, r);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = mul(r, a);
+    }
+    return r;
+}
 
 // sum_{k < n} a[k * sa] * b[k * sb], n <= 32 (Montgomery forms in, Montgomery form out)
 inline Fr dot(const Fr* a, size_t sa, const Fr* b, size_t sb, int n) {

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "host_fr64.h"
+#include "host_fr_ifma.h"
 #include "host_zk.h"
 
 namespace bzk {
@@ -53,7 +54,7 @@ struct LC {
     LC& sub_var(Var v) { return add(v, fe_neg<FrParams>(Fr::one())); }
     LC& add_scaled(const LC& o, const Fr& k) {
         if (!lc_tracking()) return *this;
-        for (auto& e : o.t) add(e.first, fe_mul<FrParams>(e.second, k));
+        for (auto& e : o.t) add(e.first, hfr::mul(e.second, k));
         return *this;
     }
     LC& add_lc(const LC& o) {
@@ -149,7 +150,7 @@ class ConstraintSystem {
     const Fr& value(Var v) const { return (v & VAR_AUX) ? aux[v & ~VAR_AUX] : inputs[v]; }
     Fr eval(const LC& lc) const {
         Fr acc = Fr::zero();
-        for (auto& e : lc.t) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(e.second, value(e.first)));
+        for (auto& e : lc.t) acc = fe_add<FrParams>(acc, hfr::mul(e.second, value(e.first)));
         return acc;
     }
     size_t num_constraints() const { return win_aux ? win_n_con : az.size(); }
@@ -196,13 +197,13 @@ class ConstraintSystem {
 
     bool is_satisfied() const {
         for (size_t k = 0; k < az.size(); ++k)
-            if (!fe_mul<FrParams>(az[k], bz[k]).equals(cz[k])) return false;
+            if (!hfr::mul(az[k], bz[k]).equals(cz[k])) return false;
         return true;
     }
     // first violated constraint or -1
     long first_unsatisfied() const {
         for (size_t k = 0; k < az.size(); ++k)
-            if (!fe_mul<FrParams>(az[k], bz[k]).equals(cz[k])) return (long)k;
+            if (!hfr::mul(az[k], bz[k]).equals(cz[k])) return (long)k;
         return -1;
     }
     uint32_t flat_index(Var v) const { return (v & VAR_AUX) ? (uint32_t)inputs.size() + (v & ~VAR_AUX) : v; }
@@ -264,7 +265,7 @@ static inline void num_inputize(ConstraintSystem& cs, const Num& n) {
 }
 
 static inline Num num_mul(ConstraintSystem& cs, const Num& a, const Num& b) {  // AllocatedNum::mul
-    Num r = num_alloc(cs, fe_mul<FrParams>(a.val, b.val));
+    Num r = num_alloc(cs, hfr::mul(a.val, b.val));
     cs.enforce(LC::of(a.var), a.val, LC::of(b.var), b.val, LC::of(r.var), r.val);
     return r;
 }
@@ -366,7 +367,7 @@ struct Number {
     static Number one() { return {LC::one(), Fr::one()}; }
     static Number constant(const Fr& v) { return {LC().add(VAR_ONE, v), v}; }
     static Number from(const Num& n) { return {LC::of(n.var), n.val}; }
-    static Number from_scaled(const Fr& k, const Num& n) { return {LC().add(n.var, k), fe_mul<FrParams>(n.val, k)}; }
+    static Number from_scaled(const Fr& k, const Num& n) { return {LC().add(n.var, k), hfr::mul(n.val, k)}; }
     static Number from(const Bit& b) { return {LC::of(b.var), fr_from_bool(b.val)}; }
     void add_constant(const Fr& c) {
         lc.add(VAR_ONE, c);
@@ -374,7 +375,7 @@ struct Number {
     }
     void add_num(const Fr& coeff, const Num& n) {
         lc.add(n.var, coeff);
-        val = fe_add<FrParams>(val, fe_mul<FrParams>(n.val, coeff));
+        val = fe_add<FrParams>(val, hfr::mul(n.val, coeff));
     }
     Number plus(const Number& o) const {
         Number r = *this;
@@ -385,7 +386,7 @@ struct Number {
     Number plus_scaled(const Fr& k, const Number& o) const {
         Number r = *this;
         r.lc.add_scaled(o.lc, k);
-        r.val = fe_add<FrParams>(val, fe_mul<FrParams>(k, o.val));
+        r.val = fe_add<FrParams>(val, hfr::mul(k, o.val));
         return r;
     }
     Number minus(const Number& o) const {
@@ -395,7 +396,7 @@ struct Number {
         return r;
     }
     Num mul(ConstraintSystem& cs, const Number& o) const {  // number.rs:48-65
-        Num r = num_alloc(cs, fe_mul<FrParams>(val, o.val));
+        Num r = num_alloc(cs, hfr::mul(val, o.val));
         cs.enforce(lc, val, o.lc, o.val, LC::of(r.var), r.val);
         return r;
     }
@@ -403,7 +404,7 @@ struct Number {
     Bool is_zero(ConstraintSystem& cs) const {                            // :75-111
         const bool z = val.is_zero();
         Bit isz = bit_alloc(cs, z);
-        Num inv = num_alloc(cs, z ? Fr::zero() : fe_inv<FrParams>(val));
+        Num inv = num_alloc(cs, z ? Fr::zero() : hfr::inv(val));
         cs.enforce(LC().sub_lc(lc), fe_neg<FrParams>(val), LC::of(inv.var), inv.val, LC::of(isz.var).sub_var(VAR_ONE),
                    fe_sub<FrParams>(fr_from_bool(z), Fr::one()));
         cs.enforce(LC::of(isz.var), fr_from_bool(z), lc, val, LC(), Fr::zero());
@@ -526,7 +527,8 @@ static inline std::vector<Number> g_product_mds(const std::vector<Number>& vals,
 static inline Number g_poseidon_values(ConstraintSystem& cs, const std::vector<Number>& vals) {
     static const LC none;
     const int t = (int)vals.size() + 1;
-    const PoseidonHostParams P = poseidon_host_params(t);
+    const PoseidonHostParams P = poseidon_host_params_cached(t);
+    const hfr::MdsTable& mds_tab = poseidon_mds_table(t);
     Fr e[17], nw[17];
     e[0] = Fr::zero();
     for (int i = 1; i < t; ++i) e[i] = vals[i - 1].val;
@@ -557,7 +559,7 @@ static inline Number g_poseidon_values(ConstraintSystem& cs, const std::vector<N
                 cs.enforce(none, e[i], none, one, none, e[i]);
             }
         }
-        for (int j = 0; j < t; ++j) nw[j] = hfr::dot(P.mds + (size_t)j * t, e, t);
+        hfr::mds_mul(mds_tab, e, nw);  // all t rows of the dense MDS at once (AVX-512 IFMA lanes; one dot product per row without it)
         for (int j = 0; j < t; ++j) e[j] = nw[j];
     }
     return {LC(), e[1]};
@@ -652,14 +654,14 @@ struct APoint {
         }
         APoint sum = alloc(cs, sumv);
         const Fr bx = b.x.v, by = b.y.v;
-        const Fr dbb = fe_mul<FrParams>(fe_mul<FrParams>(jubjub_d().v, bx), by);
+        const Fr dbb = hfr::mul(hfr::mul(jubjub_d().v, bx), by);
         Num common = num_mul(cs, x, y);
-        const Fr kx = fe_mul<FrParams>(dbb, common.val);
+        const Fr kx = hfr::mul(dbb, common.val);
         cs.enforce(LC::one().add(common.var, dbb), fe_add<FrParams>(Fr::one(), kx), LC::of(sum.x.var), sum.x.val,
-                   LC().add(x.var, by).add(y.var, bx), fe_add<FrParams>(fe_mul<FrParams>(x.val, by), fe_mul<FrParams>(y.val, bx)));
+                   LC().add(x.var, by).add(y.var, bx), fe_add<FrParams>(hfr::mul(x.val, by), hfr::mul(y.val, bx)));
         // y_1 - y_2: by*y - (A*bx)*x with A = -1
         cs.enforce(LC::one().add(common.var, fe_neg<FrParams>(dbb)), fe_sub<FrParams>(Fr::one(), kx), LC::of(sum.y.var), sum.y.val,
-                   LC().add(y.var, by).add(x.var, bx), fe_add<FrParams>(fe_mul<FrParams>(y.val, by), fe_mul<FrParams>(x.val, bx)));
+                   LC().add(y.var, by).add(x.var, bx), fe_add<FrParams>(hfr::mul(y.val, by), hfr::mul(x.val, bx)));
         return sum;
     }
     APoint add(ConstraintSystem& cs, const APoint& o, const PointAffine* hint = nullptr) const {  // :125-172
@@ -674,7 +676,7 @@ struct APoint {
         const Fr d = jubjub_d().v;
         Num common = num_mul(cs, num_mul(cs, num_mul(cs, x, o.x), y), o.y);
         Num x1 = num_mul(cs, x, o.y), x2 = num_mul(cs, y, o.x);
-        const Fr kd = fe_mul<FrParams>(d, common.val);
+        const Fr kd = hfr::mul(d, common.val);
         cs.enforce(LC::one().add(common.var, d), fe_add<FrParams>(Fr::one(), kd), LC::of(sum.x.var), sum.x.val,
                    LC::of(x1.var).add_var(x2.var), fe_add<FrParams>(x1.val, x2.val));
         Num y1 = num_mul(cs, y, o.y), y2 = num_mul(cs, x, o.x);

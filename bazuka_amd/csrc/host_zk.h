@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "bzk_field.cuh"
+#include "host_fr64.h"
 
 namespace bzk {
 
@@ -49,11 +50,11 @@ struct ZkScalar {
     bool operator!=(const ZkScalar& o) const { return !v.equals(o.v); }
     ZkScalar operator+(const ZkScalar& o) const { return ZkScalar(fe_add<FrParams>(v, o.v)); }
     ZkScalar operator-(const ZkScalar& o) const { return ZkScalar(fe_sub<FrParams>(v, o.v)); }
-    ZkScalar operator*(const ZkScalar& o) const { return ZkScalar(fe_mul<FrParams>(v, o.v)); }
+    ZkScalar operator*(const ZkScalar& o) const { return ZkScalar(hfr::mul(v, o.v)); }  // 64-bit-limb product (host_fr64.h): same canonical value
     ZkScalar operator-() const { return ZkScalar(fe_neg<FrParams>(v)); }
-    ZkScalar square() const { return ZkScalar(fe_sqr<FrParams>(v)); }
+    ZkScalar square() const { return ZkScalar(hfr::mul(v, v)); }
     ZkScalar dbl() const { return ZkScalar(fe_dbl<FrParams>(v)); }
-    ZkScalar invert() const { return ZkScalar(fe_inv<FrParams>(v)); }  // 0 -> 0 (callers check)
+    ZkScalar invert() const { return ZkScalar(hfr::inv(v)); }  // 0 -> 0 (callers check)
     ZkScalar pow(const uint32_t* e, int nlimbs) const;
     bool sqrt(ZkScalar* out) const;  // Tonelli-Shanks (2-adicity 32); false if non-residue
     void to_bytes(uint8_t out[32]) const { memcpy(out, v.l, 32); }  // Montgomery limbs = wire form
@@ -71,6 +72,9 @@ struct PoseidonHostParams {
     const Fr* mds;  // t * t row-major
 };
 PoseidonHostParams poseidon_host_params(int t);              // poseidon.hip
+PoseidonHostParams poseidon_host_params_cached(int t);       // host_zk.hip: the same, without a lock after the first call per width
+namespace hfr { struct MdsTable; }
+const hfr::MdsTable& poseidon_mds_table(int t);              // host_zk.hip: the dense MDS of width t in the lane layout of host_fr_ifma.h
 ZkScalar poseidon_hash(const ZkScalar* vals, int arity);      // `ZkHasher::hash` (sparse-partial-round evaluation)
 ZkScalar poseidon_hash_plain(const ZkScalar* vals, int arity);  // the reference's round function, literally
 inline ZkScalar poseidon_hash(const std::vector<ZkScalar>& v) { return poseidon_hash(v.data(), (int)v.size()); }

@@ -1,8 +1,10 @@
 // Host-side ZkScalar helpers, Poseidon, SHA3-256 and Jubjub/EdDSA (see host_zk.h for the mapping to
 // the reference's src/zk and src/crypto/jubjub).
 #include "host_fr64.h"
+#include "host_fr_ifma.h"
 #include "host_zk.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -106,12 +108,12 @@ ZkScalar poseidon_hash_plain(const ZkScalar* vals, int arity) {
         const bool full = rnd < P.rf / 2 || rnd >= P.rf / 2 + P.rp;
         const int ns = full ? t : 1;
         for (int i = 0; i < ns; ++i) {
-            Fr x2 = fe_sqr<FrParams>(st[i]);
-            st[i] = fe_mul<FrParams>(fe_sqr<FrParams>(x2), st[i]);
+            Fr x2 = hfr::sqr(st[i]);
+            st[i] = hfr::mul(hfr::sqr(x2), st[i]);
         }
         for (int j = 0; j < t; ++j) {
             Fr acc = Fr::zero();
-            for (int k = 0; k < t; ++k) acc = fe_add<FrParams>(acc, fe_mul<FrParams>(P.mds[j * t + k], st[k]));
+            for (int k = 0; k < t; ++k) acc = fe_add<FrParams>(acc, hfr::mul(P.mds[j * t + k], st[k]));
             nw[j] = acc;
         }
         for (int i = 0; i < t; ++i) st[i] = nw[i];
@@ -124,13 +126,14 @@ struct SparseConsts {
     bool ready = false, usable = false;
     int rf = 0, rp = 0;
     std::vector<Fr> flat;  // layout of poseidon_optimize()
+    hfr::MdsTable mds_tab, dmat_tab;  // the two dense blocks in the lane layout of host_fr_ifma.h
 };
 std::mutex g_sparse_mu;
 SparseConsts g_sparse[18];
 
-inline Fr sbox5(const Fr& x) {
-    Fr x2 = fe_sqr<FrParams>(x);
-    return fe_mul<FrParams>(fe_sqr<FrParams>(x2), x);
+inline Fr sbox5(const Fr& x) {  // 64-bit-limb products (host_fr64.h): canonical, the values of fe_sqr / fe_mul
+    const Fr x2 = hfr::mul(x, x);
+    return hfr::mul(hfr::mul(x2, x2), x);
 }
 Fr hash_sparse(const SparseConsts& S, int t, const Fr* in) {
     const int half = S.rf / 2;
@@ -145,43 +148,84 @@ Fr hash_sparse(const SparseConsts& S, int t, const Fr* in) {
     for (int i = 1; i < t; ++i) st[i] = in[i - 1];
     auto full_round = [&](const Fr* rc) {
         for (int i = 0; i < t; ++i) st[i] = sbox5(fe_add<FrParams>(st[i], rc[i]));
-        for (int j = 0; j < t; ++j) nw[j] = hfr::dot(mds + (size_t)j * t, st, t);  // one reduction per row (host_fr64.h)
+        hfr::mds_mul(S.mds_tab, st, nw);  // t rows side by side on AVX-512 IFMA where the CPU has it, else one dot product per row
         for (int i = 0; i < t; ++i) st[i] = nw[i];
     };
+    (void)mds;
     for (int r = 0; r < half; ++r) full_round(rc1 + (size_t)r * t);
     for (int i = 0; i < t; ++i) st[i] = fe_add<FrParams>(st[i], pre[i]);
     for (int i = 0; i < S.rp; ++i) {
         const Fr* c = part + (size_t)i * 2 * t;  // s_i, row0[t], what[t-1]
         st[0] = fe_add<FrParams>(sbox5(st[0]), c[0]);
         const Fr n0 = hfr::dot(c + 1, st, t);
-        for (int j = 1; j < t; ++j) st[j] = fe_add<FrParams>(st[j], fe_mul<FrParams>(c[t + j], st[0]));
+        for (int j = 1; j < t; ++j) st[j] = fe_add<FrParams>(st[j], hfr::mul(c[t + j], st[0]));
         st[0] = n0;
     }
-    for (int j = 0; j < t - 1; ++j) nw[j] = hfr::dot(dmat + (size_t)j * (t - 1), st + 1, t - 1);
+    if (t > 2) {
+        hfr::mds_mul(S.dmat_tab, st + 1, nw);
+    } else {
+        nw[0] = hfr::dot(dmat, st + 1, 1);
+    }
     for (int j = 1; j < t; ++j) st[j] = nw[j - 1];
     for (int r = 0; r < half; ++r) full_round(rc2 + (size_t)r * t);
     return st[1];
 }
+std::atomic<bool> g_sparse_ready[18];
 const SparseConsts& sparse_consts(int t) {
-    std::lock_guard<std::mutex> lk(g_sparse_mu);
     SparseConsts& S = g_sparse[t];
+    if (g_sparse_ready[t].load(std::memory_order_acquire)) return S;  // no lock on the path every host hash takes
+    std::lock_guard<std::mutex> lk(g_sparse_mu);
     if (S.ready) return S;
     PoseidonHostParams P = poseidon_host_params(t);
     S.rf = P.rf;
     S.rp = P.rp;
     std::vector<Fr> rc(P.rc, P.rc + (size_t)t * (P.rf + P.rp)), mds(P.mds, P.mds + (size_t)t * t);
     S.usable = poseidon_optimize(t, P.rf, P.rp, rc, mds, S.flat);
+    if (S.usable) {
+        const int half = S.rf / 2;
+        const Fr* dmat = S.flat.data() + (size_t)half * t + t + (size_t)S.rp * 2 * t;
+        const Fr* mds_flat = dmat + (size_t)(t - 1) * (t - 1) + (size_t)half * t;
+        hfr::mds_table_build(S.mds_tab, mds_flat, t);
+        if (t > 2) hfr::mds_table_build(S.dmat_tab, dmat, t - 1);
+    }
     if (S.usable) {  // probe: the derived constants must reproduce the plain function
         ZkScalar probe[16];
-        for (int k = 0; k < t - 1; ++k) probe[k] = ZkScalar(fe_mul<FrParams>(P.mds[k % (t * t)], P.rc[k]));
+        for (int k = 0; k < t - 1; ++k) probe[k] = ZkScalar(hfr::mul(P.mds[k % (t * t)], P.rc[k]));
         Fr in[16];
         for (int k = 0; k < t - 1; ++k) in[k] = probe[k].v;
         S.usable = hash_sparse(S, t, in).equals(poseidon_hash_plain(probe, t - 1).v);
     }
     S.ready = true;
+    g_sparse_ready[t].store(true, std::memory_order_release);
     return S;
 }
+std::mutex g_mds_mu;
+hfr::MdsTable g_mds_tab[18];
+std::atomic<bool> g_mds_ready[18];
 }  // namespace
+
+// poseidon_host_params takes a lock on every call (poseidon.hip); the witness generator asks once per hash from several threads
+PoseidonHostParams poseidon_host_params_cached(int t) {
+    static PoseidonHostParams cache[18];
+    static std::atomic<bool> ready[18];
+    if (ready[t].load(std::memory_order_acquire)) return cache[t];
+    std::lock_guard<std::mutex> lk(g_mds_mu);
+    if (!ready[t].load(std::memory_order_relaxed)) {
+        cache[t] = poseidon_host_params(t);
+        ready[t].store(true, std::memory_order_release);
+    }
+    return cache[t];
+}
+
+const hfr::MdsTable& poseidon_mds_table(int t) {
+    if (g_mds_ready[t].load(std::memory_order_acquire)) return g_mds_tab[t];
+    std::lock_guard<std::mutex> lk(g_mds_mu);
+    if (!g_mds_ready[t].load(std::memory_order_relaxed)) {
+        hfr::mds_table_build(g_mds_tab[t], poseidon_host_params(t).mds, t);
+        g_mds_ready[t].store(true, std::memory_order_release);
+    }
+    return g_mds_tab[t];
+}
 
 ZkScalar poseidon_hash(const ZkScalar* vals, int arity) {
     const int t = arity + 1;

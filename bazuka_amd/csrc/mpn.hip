@@ -1693,8 +1693,8 @@ int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]) {
         std::vector<long> first((size_t)nt, -1);
         auto scan = [&](unsigned t) {
             const size_t lo = nrows * t / nt, hi = nrows * (t + 1) / nt;
-            for (size_t k = lo; k < hi; ++k)
-                if (!fe_mul<FrParams>(cs.az[k], cs.bz[k]).equals(cs.cz[k])) { first[t] = (long)k; return; }
+            // eight rows per step on AVX-512 IFMA where the CPU has it, the 64-bit-limb product otherwise (host_fr_ifma.h)
+            first[t] = hfr::products_first_mismatch(cs.az.data(), cs.bz.data(), cs.cz.data(), lo, hi);
         };
         std::vector<std::thread> th;
         for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);

@@ -7,7 +7,9 @@
 #include "../../bazuka_amd/csrc/bzk_poseidon_opt.h"
 #include "../../bazuka_amd/csrc/host_fp64.h"
 #include "../../bazuka_amd/csrc/host_fr64.h"
+#include "../../bazuka_amd/csrc/host_fr_ifma.h"
 #include <string.h>
+#include <vector>
 using namespace bzk;
 
 template <class P> static Fe<P> ld(const uint8_t* p) { Fe<P> a; memcpy(a.l, p, 4 * P::N); return a; }
@@ -421,5 +423,40 @@ int hc_hfr_dot(const uint8_t* a, const uint8_t* b, int n, uint8_t* out) {
     }
     st<FrParams>(out, hfr::dot(x, y, n));
     return 0;
+}
+int hc_hfr_inv(const uint8_t* a, uint8_t* out) {
+    st<FrParams>(out, hfr::inv(ld<FrParams>(a)));
+    return 0;
+}
+int hc_host_ifma_available() { return hfr::ifma_available() ? 1 : 0; }
+// host_fr_ifma.h: first row k < n with a_k b_k != c_k, or -1 (the witness's satisfaction scan)
+long hc_products_first_mismatch(const uint8_t* a, const uint8_t* b, const uint8_t* c, int n) {
+    std::vector<Fr> x((size_t)n), y((size_t)n), z((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        x[k] = ld<FrParams>(a + 32 * k);
+        y[k] = ld<FrParams>(b + 32 * k);
+        z[k] = ld<FrParams>(c + 32 * k);
+    }
+    return hfr::products_first_mismatch(x.data(), y.data(), z.data(), 0, (size_t)n);
+}
+// host_fr_ifma.h: out = M s for a t x t matrix; mode 0 = the dispatching entry (AVX-512 IFMA where the CPU has it), 1 = one hfr::dot per
+// row.  Returns 1 when the IFMA path ran, 0 when the scalar one did.
+int hc_mds_mul(int t, const uint8_t* m, const uint8_t* s, int mode, uint8_t* out) {
+    if (t < 1 || t > 17) return -1;
+    static Fr M[17 * 17];
+    static hfr::MdsTable T;
+    Fr x[17], y[17];
+    for (int i = 0; i < t * t; ++i) M[i] = ld<FrParams>(m + 32 * i);
+    for (int k = 0; k < t; ++k) x[k] = ld<FrParams>(s + 32 * k);
+    int used = 0;
+    if (mode == 0) {
+        hfr::mds_table_build(T, M, t);
+        hfr::mds_mul(T, x, y);
+        used = T.ifma ? 1 : 0;
+    } else {
+        for (int j = 0; j < t; ++j) y[j] = hfr::dot(M + (size_t)j * t, x, t);
+    }
+    for (int j = 0; j < t; ++j) st<FrParams>(out + 32 * j, y[j]);
+    return used;
 }
 }

@@ -317,6 +317,43 @@ def test_host_fr64_product_and_dot_match_oracle(hc, co, pr):
             assert out.raw == pr.fr_to_mont_bytes(want), (n, mode)
 
 
+def test_host_ifma_mds_product_and_satisfaction_scan(hc, pr):
+    """bazuka_amd/csrc/host_fr_ifma.h (round 4): the dense MDS product of a Poseidon round with its rows in AVX-512 IFMA lanes (five 52-bit
+    limbs, one Montgomery reduction by 2^260 on a table scaled by 16) and the eight-rows-at-a-time satisfaction scan a_k b_k = c_k: equal to
+    the 64-bit scalar forms AND to plain integer arithmetic for every width 1..17, with the operands that stress the reduction (r - 1
+    everywhere, zeros, small values).  On a CPU without the instructions both entries take their scalar form (the test then compares that
+    with the integers); BZK_HOST_IFMA=0 forces it."""
+    import ctypes
+    hc.hc_products_first_mismatch.restype = ctypes.c_long
+    rnd = random.Random(808)
+    M, F = pr.R_MOD, pr.fr_to_mont_bytes
+    took_ifma = set()
+    for t in range(1, 18):
+        for case in range(12):
+            pick = [lambda: rnd.randrange(M), lambda: M - 1, lambda: rnd.choice((0, 1, 2, M - 1, M - 2)), lambda: rnd.randrange(1 << 64)][case % 4]
+            mat, vec = [pick() for _ in range(t * t)], [pick() for _ in range(t)]
+            mb, sb = b"".join(F(x) for x in mat), b"".join(F(x) for x in vec)
+            o0, o1 = C.create_string_buffer(32 * t), C.create_string_buffer(32 * t)
+            took_ifma.add(hc.hc_mds_mul(t, mb, sb, 0, o0))
+            assert hc.hc_mds_mul(t, mb, sb, 1, o1) == 0 and o0.raw == o1.raw, (t, case)
+            assert o0.raw == b"".join(F(sum(mat[j * t + k] * vec[k] for k in range(t)) % M) for j in range(t)), (t, case)
+    assert took_ifma <= {0, 1} and (1 in took_ifma) == bool(hc.hc_host_ifma_available())
+    for n in (0, 1, 7, 8, 9, 64, 1001):
+        for bad_at in (None, 0, n // 2, n - 1):
+            if bad_at is not None and n == 0:
+                continue
+            a = [rnd.choice((0, 1, M - 1, rnd.randrange(M), rnd.randrange(M))) for _ in range(n)]
+            b = [rnd.choice((0, 1, M - 1, rnd.randrange(M), rnd.randrange(M))) for _ in range(n)]
+            c = [x * y % M for x, y in zip(a, b)]
+            if bad_at is not None:
+                c[bad_at] = (c[bad_at] + rnd.choice((1, M - 1, 1 << 200))) % M
+            got = hc.hc_products_first_mismatch(b"".join(F(x) for x in a), b"".join(F(x) for x in b), b"".join(F(x) for x in c), n)
+            assert got == (-1 if bad_at is None else bad_at), (n, bad_at, got)
+    for x in (0, 1, 2, M - 1, rnd.randrange(M), rnd.randrange(M)):
+        out = C.create_string_buffer(32)
+        assert hc.hc_hfr_inv(F(x), out) == 0 and out.raw == F(pow(x, M - 2, M)), x
+
+
 def test_mg_probe_without_a_device_reports_nothing_usable():
     """bzk_mg_probe creates nothing and computes nothing: on a GPU-less host both capability bits are clear (the GPU suite sees 1 or 3)"""
     from bazuka_amd import mg_probe
