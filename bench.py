@@ -349,10 +349,17 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
             rr = w.update_synthesize(b, _fr(99), ZIESHA)
             assert rr.satisfied
             ring.append(rr)
+        import resource as _res
+        ru0, tr0 = _res.getrusage(_res.RUSAGE_SELF), time.perf_counter()
         cons, fin = run_pipeline(8, n_pipe, ring=ring)
         join_all(cons)
+        ru1, tr1 = _res.getrusage(_res.RUSAGE_SELF), time.perf_counter()
         fin.sort()
         out["proofs_per_s_ring"] = round(n_pipe / (fin[8 + n_pipe - 1] - fin[8 - 1]), 3)
+        # what the PROVER side costs the host per proof (lane threads, staging, Horner, assembly, waits) - no witness is made in this leg:
+        # user + system seconds of the process over all proofs of the leg (warm-up and drain included)
+        out["prover_host_cpu_s_per_proof"] = round(((ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)) / (8 + n_pipe + n_drain), 4)
+        out["prover_host_cpu_cores_busy"] = round(((ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)) / (tr1 - tr0), 2)
         out["ring"] = f"{ring_k} pre-synthesised witnesses of the 16-tx circuit round-robin -> {len(slots)} prover slots, {n_pipe} proofs timed (after 8, before the last {n_drain}); distinct (r, s) per proof"
         for rr in ring:
             rr.free()
