@@ -84,6 +84,22 @@ BZK_HD bool limbs_all_zero(const Fp28& a) {
     return o == 0;
 }
 
+// ---- the quotient digit of one Montgomery step: (lo * PINV) mod 2^28.  v_mul_lo_u32 issues at 18.3 Top/s on gfx950, v_mad_u64_u32 at
+// 31.2 (profiles/r04_ubench_int.txt): the low half of a multiply-add with a zero addend is the same number, 3.6 cycles sooner.  The
+// compiler narrows any C++ spelling of that back to v_mul_lo_u32, hence the asm (BZK_MONT_M_MAD = 0: plain C++, A/B builds).
+#ifndef BZK_MONT_M_MAD
+#define BZK_MONT_M_MAD 1
+#endif
+BZK_HD uint32_t mont_m(uint32_t lo) {
+#if defined(__HIP_DEVICE_COMPILE__) && BZK_MONT_M_MAD
+    uint64_t t, carry_out;
+    __asm__("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=&v"(t), "=s"(carry_out) : "v"(lo), "s"(PINV));
+    return (uint32_t)t & MASK;
+#else
+    return (lo * PINV) & MASK;
+#endif
+}
+
 // ---- the product (see bounds in the header comment)
 BZK_HD Fp28 mul_body(const Fp28& a, const Fp28& b) {
 #if defined(BZK_FP28_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
@@ -105,7 +121,7 @@ BZK_HD Fp28 mul_body(const Fp28& a, const Fp28& b) {
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+        const uint32_t m = mont_m((uint32_t)c[i]);
 #pragma unroll
         for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P.v[j];
         c[i + 1] += c[i] >> W;
@@ -146,7 +162,7 @@ BZK_HD Fp28 sqr_body(const Fp28& a) {
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+        const uint32_t m = mont_m((uint32_t)c[i]);
 #pragma unroll
         for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P.v[j];
         c[i + 1] += c[i] >> W;
@@ -204,7 +220,7 @@ BZK_HD Fp28 mul_sub2_body(const Fp28& a, const Fp28& b, const Fp28& cc, const Fp
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+        const uint32_t m = mont_m((uint32_t)c[i]);
 #pragma unroll
         for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P.v[j];
         c[i + 1] += c[i] >> W;
@@ -263,7 +279,7 @@ BZK_HD Fp28 mul4_body(const Fp28& a0, const Fp28& b0, const Fp28& a1, const Fp28
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+        const uint32_t m = mont_m((uint32_t)c[i]);
 #pragma unroll
         for (int j = 0; j < N; ++j) c[i + j] += (uint64_t)m * P.v[j];
         c[i + 1] += c[i] >> W;
@@ -747,8 +763,18 @@ BZK_HD G1X28 dbl(const G1X28& p) {  // dbl-2008-s-1
 struct NoPre {
     BZK_HD void operator()() const {}
 };
-template <class Pre = NoPre>
-BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q, Pre&& pre = Pre()) {
+// how the formula's products are issued: as calls to the resident product functions (default), or inlined into the caller
+// (BZK_G1_ACC_INLINE: the accumulation's hot loop without the call ABI's argument moves - A/B builds)
+struct MulCalls {
+    BZK_HD static Fp28 mul(const Fp28& a, const Fp28& b) { return fp28::mul(a, b); }
+    BZK_HD static Fp28 sqr(const Fp28& a) { return fp28::sqr(a); }
+};
+struct MulInline {
+    BZK_HD static Fp28 mul(const Fp28& a, const Fp28& b) { return mul_body(a, b); }
+    BZK_HD static Fp28 sqr(const Fp28& a) { return sqr_body(a); }
+};
+template <class Pre = NoPre, class M = MulCalls>
+BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q, Pre&& pre = Pre(), M = M()) {
     G1A28 q = q_in;
     if (neg_q) q.y = norm(sub<3>(zero(), q.y));  // 3p - y, k 3
     if (is_identity(acc)) {
@@ -756,10 +782,10 @@ BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q, Pre&& pre = Pre
         acc = {q.x, q.y, one(), one()};
         return;
     }
-    Fp28 U2 = mul(q.x, acc.ZZ), S2 = mul(q.y, acc.ZZZ);
+    Fp28 U2 = M::mul(q.x, acc.ZZ), S2 = M::mul(q.y, acc.ZZZ);
     Fp28 Pp = sub<12>(U2, acc.X);  // k 14
     Fp28 R = sub<6>(S2, acc.Y);    // k 8
-    Fp28 PP = sqr(Pp);
+    Fp28 PP = M::sqr(Pp);
     if (mulout_is_zero(PP)) {  // same x: doubling or cancellation (rare)
         Fp28 RR = sqr(R);
         if (mulout_is_zero(RR)) acc = dbl_affine(q);
@@ -767,10 +793,10 @@ BZK_HD void add_mixed(G1X28& acc, const G1A28& q_in, bool neg_q, Pre&& pre = Pre
         pre();
         return;
     }
-    Fp28 PPP = mul(Pp, PP), Q = mul(acc.X, PP), RR = sqr(R);
+    Fp28 PPP = M::mul(Pp, PP), Q = M::mul(acc.X, PP), RR = M::sqr(R);
     Fp28 X3 = norm(sub<3>(sub<3>(sub<3>(RR, PPP), Q), Q));             // k 11
-    acc.ZZ = mul(acc.ZZ, PP);
-    acc.ZZZ = mul(acc.ZZZ, PPP);
+    acc.ZZ = M::mul(acc.ZZ, PP);
+    acc.ZZZ = M::mul(acc.ZZZ, PPP);
     pre();
 #if BZK_G1_FUSED_Y
     acc.Y = mul_sub2_body(R, sub<12>(Q, X3), PPP, acc.Y);              // R (Q - X3) - Y PPP, one reduction; k 2

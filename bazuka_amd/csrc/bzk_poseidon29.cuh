@@ -17,6 +17,18 @@
 namespace bzk {
 
 namespace p29 {
+#ifndef BZK_POSEIDON_PARTIAL_INLINE
+#define BZK_POSEIDON_PARTIAL_INLINE 6  // widths up to this value run the products of a PARTIAL round inlined into the round loop (7 products + one row, ~17 KB of
+#endif                                 // code for width 5) instead of calling the resident product functions: no argument / result moves, - 7 % instructions per
+                                       // partial round.  Widths 7 and 8 keep the calls: inlined they need 410 registers and scratch (one wave per SIMD).  0: calls everywhere
+// products of the partial-round loop: calls (as everywhere else) or inlined bodies
+template <int T>
+struct PartialOps {
+    static constexpr bool INL = T <= BZK_POSEIDON_PARTIAL_INLINE;
+    BZK_HD static Fr29 mul(const Fr29& a, const Fr29& b) { return INL ? fr29::mul_body(a, b) : fr29::mul(a, b); }
+    BZK_HD static Fr29 sqr(const Fr29& a) { return INL ? fr29::sqr_body(a) : fr29::sqr(a); }
+    BZK_HD static Fr29 sbox5(const Fr29& x) { return mul(sqr(sqr(x)), x); }
+};
 // dense row product: out = sum_k m[k] * v[k], n <= 8 operands, groups of <= 6 per reduction; operands k <= 5
 template <int N>
 BZK_HD Fr29 row_dot(const Fr29* __restrict__ m, const Fr29* v) {
@@ -49,8 +61,15 @@ template <int T>
 struct MdsRows<T, 0> {
     BZK_HD static void run(Fr29*, const Fr29* __restrict__, const Fr29*) {}
 };
+#ifndef BZK_POSEIDON_MDS_RELOAD
+#define BZK_POSEIDON_MDS_RELOAD 0  // 1: the MDS matrix is re-read (scalar loads) in every full round instead of being hoisted out of the round loop:
+#endif                             //    hoisted it is T*T*9 scalars - more than the SGPR file - and the compiler parks them in VGPR lanes (v_readlane per use)
 template <int T>
-BZK_HD void full_round(Fr29* st, const Fr29* __restrict__ rc, const Fr29* __restrict__ mds) {
+BZK_HD void full_round(Fr29* st, const Fr29* __restrict__ rc, const Fr29* __restrict__ mds_in) {
+    const Fr29* mds = mds_in;
+#if BZK_POSEIDON_MDS_RELOAD && defined(__HIP_DEVICE_COMPILE__)
+    __asm__ volatile("" : "+s"(mds));  // the address is opaque per round: no loop-invariant hoisting of the loads
+#endif
 #pragma unroll
     for (int k = 0; k < T; ++k) st[k] = fr29::sbox5(fr29::norm(fr29::add(st[k], rc[k])));
     Fr29 nw[T];
@@ -98,15 +117,15 @@ BZK_HD Fr poseidon29_hash(const Fr* __restrict__ in, const Fr29* __restrict__ co
 #pragma unroll 1
     for (int i = 0; i < rp; ++i) {
         const Fr29* c = part + (size_t)i * 2 * T;  // s_i, row0[T], what[T-1]
-        st[0] = fr29::norm(fr29::add(fr29::sbox5(st[0]), c[0]));  // k 3
+        st[0] = fr29::norm(fr29::add(p29::PartialOps<T>::sbox5(st[0]), c[0]));  // k 3
         const Fr29 n0 = p29::row_dot<T>(c + 1, st);
 #pragma unroll
-        for (int j = 1; j < T; ++j) st[j] = fr29::norm(fr29::add(st[j], fr29::mul(c[T + j], st[0])));
+        for (int j = 1; j < T; ++j) st[j] = fr29::norm(fr29::add(st[j], p29::PartialOps<T>::mul(c[T + j], st[0])));
         st[0] = n0;
         if (++since == p29::Renorm<T>::PERIOD) {
             since = 0;
 #pragma unroll
-            for (int j = 1; j < T; ++j) st[j] = fr29::mul(st[j], one);  // same value, k 2
+            for (int j = 1; j < T; ++j) st[j] = p29::PartialOps<T>::mul(st[j], one);  // same value, k 2
         }
     }
     {

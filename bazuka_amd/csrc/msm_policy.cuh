@@ -9,6 +9,9 @@
 
 namespace bzk {
 
+#ifndef BZK_G1_ACC_INLINE
+#define BZK_G1_ACC_INLINE 1  // 1: the accumulate kernel's mixed addition with its eight products inlined (no call ABI moves)
+#endif
 #ifndef BZK_G2_ACC_OCC
 #define BZK_G2_ACC_OCC 1
 #endif
@@ -48,7 +51,13 @@ struct G1Fast {
     __device__ static __forceinline__ Pt identity() { return g1x28::identity(); }
     __device__ static __forceinline__ void add_mixed(Pt& acc, const DevAff& p, bool neg) { g1x28::add_mixed(acc, p, neg); }
     template <class Pre>
-    __device__ static __forceinline__ void add_mixed_pre(Pt& acc, const DevAff& p, bool neg, Pre&& pre) { g1x28::add_mixed(acc, p, neg, pre); }
+    __device__ static __forceinline__ void add_mixed_pre(Pt& acc, const DevAff& p, bool neg, Pre&& pre) {
+#if BZK_G1_ACC_INLINE
+        g1x28::add_mixed(acc, p, neg, pre, g1x28::MulInline());
+#else
+        g1x28::add_mixed(acc, p, neg, pre);
+#endif
+    }
     __device__ static __forceinline__ void add(Pt& acc, const Pt& q) { g1x28::add_full(acc, q); }
     __device__ static __forceinline__ Pt mul_u32(const Pt& p, uint32_t k) { return g1x28::mul_u32(p, k); }
     __device__ static __forceinline__ Pt dbl(const Pt& p) { return g1x28::dbl(p); }

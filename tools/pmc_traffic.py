@@ -9,7 +9,9 @@ taken from the run whose array is Infinity-Cache resident like the MSM's bases (
 Without a calibration database the guide's x2 is applied and the output says so.
 
 usage: python tools/pmc_traffic.py <fetch.db> <write.db> <kernel substring> <out.json> [--calib calib_fetch.db requested_bytes]
-                                   [--stamp SOURCE_STAMP] [--command "..."]"""
+                                   [--stamp SOURCE_STAMP] [--command "..."] [--calib-from earlier_pmc_traffic.json]
+--calib-from: re-use the calibration of an earlier stamped file (the factor is a property of the counter on this access pattern,
+not of the library build) when GPU minutes do not allow a fresh calibration pass; the output says where the factor came from."""
 import json
 import sqlite3
 import sys
@@ -34,10 +36,12 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     fetch_db, write_db, kernel, out = args[:4]
     opt = args[4:]
-    calib = stamp = command = None
+    calib = stamp = command = calib_from = None
     while opt:
         if opt[0] == "--calib":
             calib, opt = (opt[1], int(opt[2])), opt[3:]
+        elif opt[0] == "--calib-from":
+            calib_from, opt = opt[1], opt[2:]
         elif opt[0] == "--stamp":
             stamp, opt = opt[1], opt[2:]
         elif opt[0] == "--command":
@@ -60,6 +64,12 @@ if __name__ == "__main__":
                    "factor_1p9GB_array": round(calib[1] / big, 4)}
         how = (f"FETCH_SIZE x{factor:.3f}: calibrated on k_gather_only (tools/ubench_batched_affine calib): 112-byte records gathered with "
                "16-byte loads from an Infinity-Cache-resident array, requested bytes / reported bytes; WRITE_SIZE as reported")
+    elif calib_from:
+        prev = json.load(open(calib_from))
+        cal_doc = dict(prev["calibration"], taken_from=calib_from, taken_from_stamp=prev.get("source_stamp"))
+        factor = float(prev["calibration"]["factor_cache_resident"])
+        how = (f"FETCH_SIZE x{factor:.3f}: calibration re-used from {calib_from} (k_gather_only, tools/ubench_batched_affine calib: 112-byte records "
+               "gathered with 16-byte loads from an Infinity-Cache-resident array); WRITE_SIZE as reported")
     doc = {"kernel": kernel, "fetch_bytes_per_launch_raw": round(f), "fetch_factor": round(factor, 4),
            "fetch_bytes_per_launch": round(factor * f), "write_bytes_per_launch": round(w),
            "traffic_bytes_per_launch": round(factor * f + w), "dispatches": [nf, nw], "correction": how, "calibration": cal_doc,

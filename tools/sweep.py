@@ -136,6 +136,21 @@ if __name__ == "__main__":
             run("tree", 24, env); run("tree", 20, env)
             for ar in ("2", "3", "4", "5", "7"):
                 run("hash", 22, dict(env, ARITY=ar))
+    if what in ("r4inl",):  # round 4, late: products inlined into the G1 accumulation / Poseidon's partial rounds, quotient digit by v_mad_u64_u32: same-box A/B,
+        # alternating twice.  base = all three switches off, inl = inlined forms without the multiply-add digit, "" = the default build, mdsr = default + MDS re-read per round
+        here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bazuka_amd")
+        L = lambda name: {"BZK_LIBBZK": os.path.join(here, "libbzk.so." + name)} if name else {}
+        for rnd in range(2):
+            for name in ("base", "inl", ""):
+                print("## lib", name or "default", flush=True); run("g1res", 20, L(name))
+            for name in ("base", ""):
+                print("## lib", name or "default", flush=True); run("g2res", 20, L(name))
+            for name in ("base", "", "mdsr"):
+                print("## lib", name or "default", flush=True); run("tree", 24, L(name)); run("hash", 22, dict(L(name), ARITY="4"))
+        for name in ("base", "", "mdsr"):
+            print("## lib", name or "default", flush=True); run("hash", 22, dict(L(name), ARITY="2")); run("hash", 21, dict(L(name), ARITY="7"))
+        for name in ("base", ""):
+            print("## lib", name or "default", flush=True); run("g1res", 22, L(name)); run("g1tab", 20, L(name))
     if what in ("r4ntt",):  # round 4: 32-byte inter-pass elements (BZK_NTT_IP32) vs the 48-byte padded limb form
         for ip in ("0", "1"):
             for lg in (20, 22, 24):
