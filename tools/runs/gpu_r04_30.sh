@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_run30; mkdir -p $O
 export TMPDIR=/tmp
 timeout 330 python tools/sweep.py r4inl > $O/sweep_inl.txt 2>&1
-timeout 400 python -m pytest tests/test_gpu_msm.py tests/test_gpu_endo.py tests/test_gpu_poseidon_ntt.py tests/test_gpu_tree4.py tests/test_golden_gpu.py tests/test_gpu_groth16.py tests/test_gpu_mpn_prove.py tests/test_gpu_fullsize.py tests/test_gpu_state_device.py -m gpu -q -x --durations=5 > $O/pytest_subset.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_subset.txt
+timeout 400 python -m pytest tests/test_gpu_msm.py tests/test_gpu_endo.py tests/test_gpu_poseidon_ntt.py tests/test_gpu_tree4.py tests/test_golden_gpu.py tests/test_gpu_groth16.py tests/test_gpu_mpn_prove.py tests/test_gpu_fullsize.py -m gpu -q -x --durations=5 > $O/pytest_subset.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_subset.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
 CMD="python bench.py --steps 20 --warmup 3 --no-proofs --no-others --no-overlap --no-cpu-baseline"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace -- $CMD > $O/trace.log 2>&1
