@@ -85,10 +85,13 @@ BZK_HD bool limbs_all_zero(const Fp28& a) {
 }
 
 // ---- the quotient digit of one Montgomery step: (lo * PINV) mod 2^28.  v_mul_lo_u32 issues at 18.3 Top/s on gfx950, v_mad_u64_u32 at
-// 31.2 (profiles/r04_ubench_int.txt): the low half of a multiply-add with a zero addend is the same number, 3.6 cycles sooner.  The
-// compiler narrows any C++ spelling of that back to v_mul_lo_u32, hence the asm (BZK_MONT_M_MAD = 0: plain C++, A/B builds).
+// 31.2 (profiles/r04_ubench_int.txt), and the low half of a multiply-add with a zero addend is the same number - but the compiler narrows
+// every C++ spelling of that back to v_mul_lo_u32, and as inline asm the instruction is opaque to the scheduler: the dependent mask lands
+// right behind it and costs an s_nop, the 64-bit temporary costs registers.  MEASURED (profiles/r04_run30_inlined_products_ab.txt, same
+// box, alternating): G1 accumulation 2.55 / 2.54 ms without, 2.58 / 2.52 ms with - nothing; G2 accumulation 9.08 -> 9.29 ms, G2 reduce
+// 1.95 -> 1.99 ms with it (one wave per SIMD, 14 more spilled registers).  Default 0; BZK_MONT_M_MAD = 1 keeps the form for A/B builds.
 #ifndef BZK_MONT_M_MAD
-#define BZK_MONT_M_MAD 1
+#define BZK_MONT_M_MAD 0
 #endif
 BZK_HD uint32_t mont_m(uint32_t lo) {
 #if defined(__HIP_DEVICE_COMPILE__) && BZK_MONT_M_MAD
@@ -757,14 +760,15 @@ BZK_HD G1X28 dbl(const G1X28& p) {  // dbl-2008-s-1
 }
 
 // acc += q  (q affine, never the identity); neg_q: add -q instead.
-// `pre` is called exactly once, after the last CALL of the formula and before its inlined tail (the fused Y): the accumulation issues
-// the NEXT base's loads there.  A call is a wait-for-all-loads point for the compiler, so loads issued any earlier would be waited for
-// at the next product; issued here they fly during the ~3 us of the inlined body and are complete when the next addition starts.
+// `pre` is called exactly once, after the last product of the formula and before its tail (the fused Y): the accumulation issues
+// the NEXT base's loads there.  With products as CALLS a call is a wait-for-all-loads point for the compiler, so loads issued any earlier
+// would be waited for at the next product; issued here they fly during the ~3 us of the tail and are complete when the next addition
+// starts.  With inlined products (MulInline) the position is no longer forced; it is kept - the loads' 28 registers stay free until there.
 struct NoPre {
     BZK_HD void operator()() const {}
 };
-// how the formula's products are issued: as calls to the resident product functions (default), or inlined into the caller
-// (BZK_G1_ACC_INLINE: the accumulation's hot loop without the call ABI's argument moves - A/B builds)
+// how the formula's products are issued: as calls to the resident product functions (every tail kernel), or inlined into the caller
+// (the accumulation's hot loop, msm_policy.cuh BZK_G1_ACC_INLINE: no argument / result moves, and the compiler schedules across products)
 struct MulCalls {
     BZK_HD static Fp28 mul(const Fp28& a, const Fp28& b) { return fp28::mul(a, b); }
     BZK_HD static Fp28 sqr(const Fp28& a) { return fp28::sqr(a); }

@@ -1,7 +1,10 @@
 // K4: G1 instantiation of the Pippenger pipeline (see msm_impl.cuh).  The Fp product is a real
-// function (BZK_FP_NOINLINE): one inlined product is ~11 KB of code, an XYZZ mixed add ten of them -
-// more than the 64 KB instruction cache - and the first GPU measurements showed the fully inlined
-// kernels fetch-bound (200 us per mixed add at low occupancy).  As a call the hot loop stays resident.
+// function (BZK_FP_NOINLINE) for every kernel but one: with the round-1 product (~11 KB of code) an inlined
+// XYZZ addition overflowed the 64 KB instruction cache and the kernels were fetch-bound.  Since the
+// reduced-radix product (bzk_fp28.cuh, ~3.4 KB) the accumulation's mixed addition fits: its hot loop is
+// 42 KB with all eight products inlined (g1x28::MulInline, BZK_G1_ACC_INLINE) and runs without the call
+// ABI's ~500 argument / result moves per addition; the general additions of the tail kernels (14 products,
+// two of them per step) stay calls.
 #define BZK_FP_NOINLINE 1
 #include "msm_impl.cuh"
 using namespace bzk;

@@ -10,7 +10,9 @@
 namespace bzk {
 
 #ifndef BZK_G1_ACC_INLINE
-#define BZK_G1_ACC_INLINE 1  // 1: the accumulate kernel's mixed addition with its eight products inlined (no call ABI moves)
+#define BZK_G1_ACC_INLINE 1  // 1: the accumulate kernel's mixed addition with its eight products inlined: 4 750 instead of 5 245 instructions per addition (no
+                             //    call-ABI moves; the multiply-adds are the same 3 545), 170 registers, 42 KB loop.  Same box, alternating: msm_accumulate 2.67 ->
+                             //    2.55 ms at 2^20, 3.33 -> 3.03 ms over a static table (profiles/r04_run30_inlined_products_ab.txt).  0: calls (A/B builds)
 #endif
 #ifndef BZK_G2_ACC_OCC
 #define BZK_G2_ACC_OCC 1
