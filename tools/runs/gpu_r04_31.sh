@@ -24,6 +24,13 @@ print({k:d[k] for k in ("value","ms_per_step","proofs_per_sec")}, d["roofline"][
 print({k:(v.get("prove_s"),v.get("verified")) if isinstance(v,dict) else v for k,v in pb.items() if k!="what"})
 print({k:(o[k].get("ms")) for k in ("tree_2p24","ntt_2p24","h_stage_2p20","msm_g2_2p20") if k in o})
 PY
+timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_ops_fetch -- python tools/pmc_ops.py > $O/pmc_ops_fetch.log 2>&1
+timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_ops_write -- python tools/pmc_ops.py > $O/pmc_ops_write.log 2>&1
+OF=$(find $O/pmc_ops_fetch -name "*.db" | head -1); OW=$(find $O/pmc_ops_write -name "*.db" | head -1)
+OSTAMP=$(python -c "import bench; print(bench.other_source_stamp())")
+python tools/pmc_kernels.py $OF $OW $O/pmc_other_kernels.json --stamp $OSTAMP --command "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python tools/pmc_ops.py" "ntt_2p24=ntt_pass_kernel:stream:3" "tree_2p24=poseidon29:stream:2" "msm_accumulate_g2=msm_accumulate_kernel<bzk::G2Fast:gather" > $O/pmc_other.log 2>&1
+find $O -name "*.db" -delete; find $O -name "*.csv" -size +200k -delete
+cut -c1-900 $O/pmc_other.log
 timeout 230 python -m pytest tests/test_gpu_production.py tests/test_gpu_mpn_tree.py tests/test_gpu_mpn_devtree.py tests/test_gpu_state_compress.py tests/test_gpu_state_device.py tests/test_gpu_worker.py tests/test_gpu_mg.py -m gpu -q -x -k "not update_15_3_4" --durations=4 > $O/pytest_rest.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_rest.txt
 tail -8 $O/pytest_rest.txt
 echo finished
