@@ -12,36 +12,76 @@ def demangle(names):
     return dict(zip(names, out))
 
 
-def main():
+def extract_device_objects(tmp):
+    """{object name: path of its gfx950 code object} for every built bazuka_amd/csrc/_obj/*.o"""
+    out = {}
+    for o in sorted(f for f in os.listdir(OBJ) if f.endswith(".o")):
+        src = os.path.join(tmp, o)
+        shutil.copy(os.path.join(OBJ, o), src)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", src], capture_output=True)
+        hs = [f for f in os.listdir(tmp) if f.startswith(o + ".") and "gfx950" in f]
+        if hs:
+            out[o[:-2]] = os.path.join(tmp, hs[0])
+    return out
+
+
+def short_name(demangled):
+    return re.sub(r"\(.*", "", demangled).replace("bzk::", "").replace("void ", "")
+
+
+def resources():
+    """one dict per kernel of libbzk's own code objects: object, kernel (short demangled name), symbol, vgpr, agpr, sgpr, spill, scratch, lds, wg, waves"""
     tmp = tempfile.mkdtemp()
     rows = []
     try:
-        for o in sorted(f for f in os.listdir(OBJ) if f.endswith(".o")):
-            src = os.path.join(tmp, o)
-            shutil.copy(os.path.join(OBJ, o), src)
-            subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", src], capture_output=True)
-            hs = [f for f in os.listdir(tmp) if f.startswith(o + ".") and "gfx950" in f]
-            if not hs:
-                continue
-            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, hs[0])], capture_output=True, text=True).stdout
+        for o, path in extract_device_objects(tmp).items():
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", path], capture_output=True, text=True).stdout
             for blk in notes.split("  - .agpr_count:")[1:]:
                 g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]
                 name = g("name")
                 if "rocprim" in name or "at::native" in name:
                     continue
-                rows.append((o[:-2], name, blk.split()[0], g("vgpr_count"), g("sgpr_count"), g("vgpr_spill_count"),
-                             g("private_segment_fixed_size"), g("group_segment_fixed_size"), g("max_flat_workgroup_size")))
+                rows.append({"object": o, "symbol": name, "agpr": int(blk.split()[0]), "vgpr": int(g("vgpr_count")), "sgpr": int(g("sgpr_count")),
+                             "spill": int(g("vgpr_spill_count")), "scratch": int(g("private_segment_fixed_size")),
+                             "lds": int(g("group_segment_fixed_size")), "wg": int(g("max_flat_workgroup_size"))})
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    dm = demangle([r[1] for r in rows])
+    dm = demangle([r["symbol"] for r in rows])
+    for r in rows:
+        r["kernel"] = short_name(dm.get(r["symbol"], r["symbol"]))
+        r["waves"] = min(8, 512 // max(1, ((r["vgpr"] + 7) // 8) * 8))  # on gfx90a+ the unified count already includes the accumulation registers
+    return rows
+
+
+def instruction_counts(obj, symbol_substring):
+    """{mnemonic: count} over the body of the first function of code object `obj` (e.g. "msm_g1") whose mangled name contains the substring"""
+    tmp = tempfile.mkdtemp()
+    try:
+        path = extract_device_objects(tmp)[obj]
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    counts, inside = {}, False
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            if inside:
+                break
+            inside = symbol_substring in m.group(1)
+            continue
+        if inside:
+            t = line.split()
+            if t and not t[0].startswith("//"):
+                counts[t[0]] = counts.get(t[0], 0) + 1
+    return counts
+
+
+def main():
     print("# kernel resources of the gfx950 code objects in bazuka_amd/csrc/_obj (tools/kernel_resources.py)")
     print("# vgpr = unified register count (arch VGPRs + AGPRs, `agpr` of them accumulation registers); waves/SIMD = floor(512 / vgpr) capped at 8; scratch = private segment bytes per lane; LDS = static bytes per workgroup")
     print(f"{'object':9s} {'kernel':78s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'spill':>6s} {'scratch':>8s} {'LDS':>7s} {'wg max':>7s} {'waves/SIMD':>10s}")
-    for o, name, agpr, vgpr, sgpr, spill, scratch, lds, wg in rows:
-        short = re.sub(r"\(.*", "", dm.get(name, name)).replace("bzk::", "").replace("void ", "")[:78]
-        tot = int(vgpr)  # on gfx90a+ the unified count already includes the accumulation registers
-        occ = min(8, 512 // max(1, ((tot + 7) // 8) * 8))
-        print(f"{o:9s} {short:78s} {vgpr:>5s} {agpr:>5s} {sgpr:>5s} {spill:>6s} {scratch:>8s} {lds:>7s} {wg:>7s} {occ:>10d}")
+    for r in resources():
+        print(f"{r['object']:9s} {r['kernel'][:78]:78s} {r['vgpr']:>5d} {r['agpr']:>5d} {r['sgpr']:>5d} {r['spill']:>6d} {r['scratch']:>8d} {r['lds']:>7d} {r['wg']:>7d} {r['waves']:>10d}")
 
 
 if __name__ == "__main__":
