@@ -1,0 +1,69 @@
+"""What the compiler made of the hot kernels, read from the gfx950 code objects of the built library (no GPU needed).
+
+The measured numbers in DESIGN.md rest on properties of the code objects that a compiler update, a flag or an innocent-looking edit can
+silently take away: occupancy steps (a few registers too many halve the waves per SIMD), scratch (the rolled MDS loops of round 4 cost
+2.2 GB of HBM writes per tree), and - since run 30 - the inlined products of the G1 accumulation.  This pins them; the values asserted are
+the ones of profiles/r04_kernel_resources.txt with a little slack where slack is harmless."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources as kr  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(kr.OBJ) or not os.path.exists(os.path.join(kr.OBJ, "msm_g1.o")),
+                                reason="bazuka_amd/csrc/_obj not built (build() compiles it)")
+
+
+@pytest.fixture(scope="module")
+def table():
+    return {(r["object"], r["kernel"]): r for r in kr.resources()}
+
+
+def row(table, obj, kernel):
+    assert (obj, kernel) in table, f"{kernel} not found in {obj}: {[k for o, k in table if o == obj]}"
+    return table[(obj, kernel)]
+
+
+def test_g1_accumulate_keeps_two_waves_and_no_scratch(table):
+    r = row(table, "msm_g1", "msm_accumulate_kernel<G1Fast, 2>")
+    assert r["vgpr"] <= 256 and r["waves"] >= 2
+    assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0
+
+
+def test_g1_accumulate_has_its_products_inlined():
+    c = kr.instruction_counts("msm_g1", "msm_accumulate_kernel")
+    mads, calls = c.get("v_mad_u64_u32", 0), c.get("s_swappc_b64", 0)
+    # 6 products x 392 + 2 squares x 301 + the fused Y 589 = 3 543 multiply-adds in the loop body itself; with the products as calls the
+    # kernel body holds ~600.  The calls that remain belong to the rare doubling / cancellation path (dbl_affine).
+    assert mads >= 3500, c
+    assert calls <= 10, c
+    # the call ABI's argument / result moves are what the inlining removed (741 v_mov in the kernel before, ~450 outside the loop now)
+    assert c.get("v_mov_b32", 0) + c.get("v_mov_b32_e32", 0) <= 520, c
+
+
+def test_g2_accumulate_does_not_spill(table):
+    r = row(table, "msm_g2", "msm_accumulate_kernel<G2Fast, 1>")
+    assert r["spill"] == 0 and r["scratch"] == 0
+
+
+@pytest.mark.parametrize("kernel,max_vgpr", [("tree4_rehash_kernel", 168), ("poseidon29_kernel<5>", 168), ("poseidon29_kernel<4>", 168),
+                                             ("poseidon29_kernel<2>", 96), ("poseidon29_kernel<8>", 256)])
+def test_poseidon_occupancy_steps(table, kernel, max_vgpr):
+    r = row(table, "poseidon", kernel)
+    assert r["vgpr"] <= max_vgpr, r
+    assert r["scratch"] == 0, r  # the MDS rows stay in registers (BZK_POSEIDON_ROWS_STRAIGHT)
+
+
+def test_poseidon_partial_rounds_are_inlined_for_the_tree_width():
+    c = kr.instruction_counts("poseidon", "tree4_rehash_kernel")
+    # full rounds keep their 15 S-box calls (two loops) + conversions; the 7 products of a partial round and the periodic renormalisation are inline
+    assert c.get("s_swappc_b64", 0) <= 45, c
+    assert c.get("v_mad_u64_u32", 0) >= 8000, c
+
+
+def test_ntt_pass_keeps_four_waves(table):
+    r = row(table, "ntt", "ntt_pass_kernel<4, 1, 1>")
+    assert r["vgpr"] <= 128 and r["waves"] >= 4
