@@ -89,6 +89,10 @@ void send_all(int fd, const void* p, size_t n) {
         n -= (size_t)k;
     }
 }
+// A response is bounded: a node (or whatever answers on its port) cannot make the worker buffer without limit.  The largest legitimate body is a
+// round's works - a production Update work is ~0.6 MB of bincode - so 1 GiB is generous; the header block of any sane server fits 64 KiB.
+constexpr size_t MAX_RESPONSE = (size_t)1 << 30, MAX_HEADER = (size_t)1 << 16;
+
 Bytes http(const Url& u, const char* method, const char* path, const Bytes& body, double timeout_s) {
     const int fd = dial(u, timeout_s);
     struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
@@ -109,17 +113,23 @@ Bytes http(const Url& u, const char* method, const char* path, const Bytes& body
         ssize_t k = recv(fd, buf, sizeof buf, 0);
         if (k < 0) throw Fail(std::string(method) + " " + path + ": receive failed (timeout?)");
         if (k == 0) break;
+        if (in.size() + (size_t)k > MAX_RESPONSE) throw Fail(std::string(method) + " " + path + ": response larger than 1 GiB");
+        const size_t scanned = in.size() < 3 ? 0 : in.size() - 3;  // a separator may straddle two reads
         in.insert(in.end(), buf, buf + k);
         if (head_end == std::string::npos) {
             static const char sep[4] = {'\r', '\n', '\r', '\n'};
-            for (size_t i = 0; i + 4 <= in.size(); ++i)
+            for (size_t i = scanned; i + 4 <= in.size(); ++i)
                 if (!memcmp(&in[i], sep, 4)) { head_end = i + 4; break; }
+            if (head_end == std::string::npos && in.size() > MAX_HEADER) throw Fail(std::string(method) + " " + path + ": no end of the HTTP header in 64 KiB");
             if (head_end != std::string::npos) {
                 std::string h((const char*)in.data(), head_end);
                 if (sscanf(h.c_str(), "HTTP/%*d.%*d %d", &status) != 1) throw Fail("malformed HTTP status line");
                 for (char& ch : h) ch = (char)tolower((unsigned char)ch);
-                const size_t p = h.find("content-length:");
-                if (p != std::string::npos) want = atol(h.c_str() + p + 15);
+                const size_t p = h.find("\ncontent-length:");
+                if (p != std::string::npos) {
+                    want = atol(h.c_str() + p + 16);
+                    if (want < 0 || (size_t)want > MAX_RESPONSE) throw Fail(std::string(method) + " " + path + ": implausible Content-Length");
+                }
                 chunked = h.find("transfer-encoding: chunked") != std::string::npos;
             }
         }
@@ -140,7 +150,7 @@ Bytes http(const Url& u, const char* method, const char* path, const Bytes& body
             const unsigned long n = strtoul(std::string((const char*)&payload[pos], e - pos).c_str(), nullptr, 16);
             pos = e + 2;
             if (n == 0) break;
-            if (pos + n + 2 > payload.size()) throw Fail("truncated chunked body");
+            if (n > payload.size() || pos + n + 2 > payload.size()) throw Fail("truncated chunked body");  // n first: pos + n must not wrap
             out.insert(out.end(), payload.begin() + (long)pos, payload.begin() + (long)(pos + n));
             pos += n + 2;
         }
@@ -415,7 +425,7 @@ uint64_t run_once(const Options& o, std::vector<Slot>& slots, Stats& st) {
                 }
                 Slot& s = slots[si];
                 const auto t1 = clk::now();
-                bzk_params* ph = s.params_for(*it.work, work_vk[it.work->id]);
+                bzk_params* ph = s.params_for(*it.work, work_vk.at(it.work->id));  // at(): a lookup only - the map is shared by the slot threads
                 bzk_assignment a{};
                 uint64_t zb = 0;
                 a.z = view<uint8_t>(it.r1cs.get(), 0, &zb);

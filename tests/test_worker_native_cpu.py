@@ -88,3 +88,51 @@ def test_a_node_that_is_away_or_talks_nonsense_does_not_kill_the_loop():
         assert rc == 0 and st["rounds"] == 2 and st["errors"] == 2 and "work response" in st["last_error"]
     finally:
         node.close()
+
+
+def _hostile_server(reply: bytes, repeat: int = 1):
+    """a one-connection-at-a-time TCP server that reads a request head and answers with `reply` x repeat, whatever was asked"""
+    import socket
+    import threading
+    srv = socket.socket()
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(4)
+    srv.settimeout(20)
+
+    def serve():
+        try:
+            while True:
+                c, _ = srv.accept()
+                try:
+                    c.settimeout(5)
+                    c.recv(65536)
+                    for _ in range(repeat):
+                        c.sendall(reply)
+                except OSError:
+                    pass
+                finally:
+                    c.close()
+        except OSError:
+            return
+    threading.Thread(target=serve, daemon=True).start()
+    return srv, srv.getsockname()[1]
+
+
+@pytest.mark.parametrize("reply,repeat,phrase", [
+    (b"HTTP/1.1 200 OK\r\nTransfer-Encoding: chunked\r\n\r\nffffffffffffffff\r\nabc\r\n0\r\n\r\n", 1, "chunked"),   # pos + n would wrap
+    (b"HTTP/1.1 200 OK\r\nContent-Length: 99999999999999\r\n\r\nxx", 1, "implausible Content-Length"),
+    (b"HTTP/1.1 200 OK\r\nContent-Length: -7\r\n\r\nxx", 1, "implausible Content-Length"),
+    (b"a" * 4096, 20, "no end of the HTTP header"),                                                                   # 80 KiB and no header end
+    (b"HTTP/1.1 200 OK\r\nX-Content-Length: 1\r\n\r\n", 1, "registered"),                                            # not the length header: body until close
+])
+def test_a_hostile_http_peer_is_refused_not_obeyed(reply, repeat, phrase):
+    srv, port = _hostile_server(reply, repeat)
+    try:
+        rc, out, err = _run(["--node", f"127.0.0.1:{port}", "--address", ALICE.hex(), "--dry-run", "--rounds", "1", "--timeout", "5"], timeout=60)
+        st = json.loads(out.strip().splitlines()[-1])          # one line of statistics whatever happened: the process ended on its own terms
+        if phrase == "registered":
+            assert "registered: refused" in err and rc == 0 and st["errors"] == 1   # the (empty) work response is then "truncated"
+        else:
+            assert rc == 1 and phrase in st["last_error"], (rc, st, err)
+    finally:
+        srv.close()
