@@ -1,0 +1,345 @@
+// The optimal ate pairing of BLS12-381 on the host, for `groth16_verify` (row a8, host_pairing.hip) and for the CPU harness that checks
+// it piece by piece (tests/host/hostcheck.hip).  Plain C++ over the 64-bit-limb host field (host_fp64.h): nothing here runs on the GPU.
+//
+//   tower    Fp2 = Fp[u] / (u^2 + 1),  Fp6 = Fp2[v] / (v^3 - xi),  xi = 1 + u,  Fp12 = Fp6[w] / (w^2 - v)        (w^6 = xi)
+//   Miller   optimal ate over |x| = 0xd201000000010000 (x < 0: conjugate at the end), M-type twist; all pairs share one accumulator (one
+//            squaring per step); running points in Jacobian coordinates, lines scaled by their slope's denominator (no inversion at all);
+//            a line has three non-zero Fp2 coefficients and is multiplied in as such.  `multi_miller_affine` (slopes of a step inverted
+//            together) is the previous form, kept as the yardstick: both loops give the same pairing
+//   final    f^((p^12 - 1) / r) up to the cube: easy part (p^6 - 1)(p^2 + 1) by conjugate / inverse / Frobenius, hard part through
+//                3 (p^4 - p^2 + 1) / r = (x - 1)^2 (x + p)(x^2 + p^2 - 1) + 3            (integer identity, checked in the tests)
+//            i.e. five exponentiations by |x| (63 Granger-Scott squarings + 5 products each, valid in the cyclotomic subgroup the easy part
+//            lands in) and two Frobenius maps.  The cube does not matter to a verifier: the target group has prime order r, 3 does not
+//            divide r, so g^3 = 1 iff g = 1.  `final_exp_plain` is the 2030-bit square-and-multiply of the first version (round 2): the
+//            yardstick of the tests, which check fast == plain^3 on Miller outputs.
+// Cost (one core, EPYC 9575F): multi-Miller of four pairs ~0.9 ms, final exponentiation ~0.5 ms (the first version: 6.8 + 11 ms).
+#pragma once
+#include "host_fp64.h"
+
+namespace bzk {
+namespace hp {
+
+typedef HFpOps F1;
+typedef HFp2Ops F2;
+typedef HFp2 E2;
+struct E6 { E2 c0, c1, c2; };
+struct E12 { E6 a0, a1; };
+
+inline HFp to_h(const Fp& a) { HFp r; memcpy(r.l, a.l, 48); return r; }          // same Montgomery value, same little-endian bytes
+inline E2 to_h(const Fp2& a) { return {to_h(a.c0), to_h(a.c1)}; }
+
+inline E2 e2_mul_xi(const E2& a) { return {F1::sub(a.c0, a.c1), F1::add(a.c0, a.c1)}; }  // * (1 + u)
+inline E2 e2_scale(const E2& a, const HFp& k) { return {F1::mul(a.c0, k), F1::mul(a.c1, k)}; }
+inline E2 e2_conj(const E2& a) { return {a.c0, F1::neg(a.c1)}; }
+inline E6 e6_zero() { return {F2::zero(), F2::zero(), F2::zero()}; }
+inline E6 e6_one() { return {F2::one(), F2::zero(), F2::zero()}; }
+inline E6 e6_add(const E6& a, const E6& b) { return {F2::add(a.c0, b.c0), F2::add(a.c1, b.c1), F2::add(a.c2, b.c2)}; }
+inline E6 e6_sub(const E6& a, const E6& b) { return {F2::sub(a.c0, b.c0), F2::sub(a.c1, b.c1), F2::sub(a.c2, b.c2)}; }
+inline E6 e6_neg(const E6& a) { return {F2::neg(a.c0), F2::neg(a.c1), F2::neg(a.c2)}; }
+inline E6 e6_mul(const E6& a, const E6& b) {  // Karatsuba: 6 Fp2 products
+    const E2 t0 = F2::mul(a.c0, b.c0), t1 = F2::mul(a.c1, b.c1), t2 = F2::mul(a.c2, b.c2);
+    E6 r;
+    r.c0 = F2::add(t0, e2_mul_xi(F2::sub(F2::sub(F2::mul(F2::add(a.c1, a.c2), F2::add(b.c1, b.c2)), t1), t2)));
+    r.c1 = F2::add(F2::sub(F2::sub(F2::mul(F2::add(a.c0, a.c1), F2::add(b.c0, b.c1)), t0), t1), e2_mul_xi(t2));
+    r.c2 = F2::add(F2::sub(F2::sub(F2::mul(F2::add(a.c0, a.c2), F2::add(b.c0, b.c2)), t0), t2), t1);
+    return r;
+}
+inline E6 e6_mul_v(const E6& a) { return {e2_mul_xi(a.c2), a.c0, a.c1}; }
+// a * (b0 + b1 v)
+inline E6 e6_mul_by_01(const E6& a, const E2& b0, const E2& b1) {
+    return {F2::add(F2::mul(a.c0, b0), e2_mul_xi(F2::mul(a.c2, b1))), F2::add(F2::mul(a.c0, b1), F2::mul(a.c1, b0)),
+            F2::add(F2::mul(a.c1, b1), F2::mul(a.c2, b0))};
+}
+// a * (k v) with k in Fp
+inline E6 e6_mul_by_1_fp(const E6& a, const HFp& k) { return {e2_mul_xi(e2_scale(a.c2, k)), e2_scale(a.c0, k), e2_scale(a.c1, k)}; }
+inline E6 e6_inv(const E6& a) {
+    const E2 c0 = F2::sub(F2::sqr(a.c0), e2_mul_xi(F2::mul(a.c1, a.c2)));
+    const E2 c1 = F2::sub(e2_mul_xi(F2::sqr(a.c2)), F2::mul(a.c0, a.c1));
+    const E2 c2 = F2::sub(F2::sqr(a.c1), F2::mul(a.c0, a.c2));
+    const E2 t = F2::add(F2::mul(a.c0, c0), e2_mul_xi(F2::add(F2::mul(a.c2, c1), F2::mul(a.c1, c2))));
+    const E2 ti = F2::inv(t);
+    return {F2::mul(c0, ti), F2::mul(c1, ti), F2::mul(c2, ti)};
+}
+inline E12 e12_one() { return {e6_one(), e6_zero()}; }
+inline E12 e12_mul(const E12& a, const E12& b) {
+    const E6 t0 = e6_mul(a.a0, b.a0), t1 = e6_mul(a.a1, b.a1);
+    E12 r;
+    r.a0 = e6_add(t0, e6_mul_v(t1));
+    r.a1 = e6_sub(e6_sub(e6_mul(e6_add(a.a0, a.a1), e6_add(b.a0, b.a1)), t0), t1);
+    return r;
+}
+inline E12 e12_sqr(const E12& a) {  // (a0 + a1 w)^2 = (a0 + a1)(a0 + v a1) - ab - v ab + 2 ab w,  ab = a0 a1
+    const E6 ab = e6_mul(a.a0, a.a1);
+    E12 r;
+    r.a0 = e6_sub(e6_sub(e6_mul(e6_add(a.a0, a.a1), e6_add(a.a0, e6_mul_v(a.a1))), ab), e6_mul_v(ab));
+    r.a1 = e6_add(ab, ab);
+    return r;
+}
+inline E12 e12_conj(const E12& a) { return {a.a0, e6_neg(a.a1)}; }
+inline E12 e12_inv(const E12& a) {
+    const E6 t = e6_inv(e6_sub(e6_mul(a.a0, a.a0), e6_mul_v(e6_mul(a.a1, a.a1))));
+    return {e6_mul(a.a0, t), e6_neg(e6_mul(a.a1, t))};
+}
+inline bool e6_eq(const E6& a, const E6& b) { return F2::eq(a.c0, b.c0) && F2::eq(a.c1, b.c1) && F2::eq(a.c2, b.c2); }
+inline bool e12_eq(const E12& a, const E12& b) { return e6_eq(a.a0, b.a0) && e6_eq(a.a1, b.a1); }
+inline bool e12_is_one(const E12& a) { return e12_eq(a, e12_one()); }
+
+// f * l for a line l = l00 + l01 v + (l11 v) w with l11 in Fp (what `line` below produces): 6 + 6 + 3 Fp2-size products instead of 18
+inline E12 e12_mul_by_line(const E12& f, const E2& l00, const E2& l01, const HFp& l11) {
+    const E6 t0 = e6_mul_by_01(f.a0, l00, l01);
+    const E6 t1 = e6_mul_by_1_fp(f.a1, l11);
+    E12 r;
+    r.a0 = e6_add(t0, e6_mul_v(t1));
+    const E2 s01 = {F1::add(l01.c0, l11), l01.c1};
+    r.a1 = e6_sub(e6_sub(e6_mul_by_01(e6_add(f.a0, f.a1), l00, s01), t0), t1);
+    return r;
+}
+
+// the same with l11 in Fp2 (the projective lines): positions 0, 1 and 4 of the tower - 6 + 3 + 6 Fp2 products
+inline E6 e6_mul_by_1(const E6& a, const E2& b1) { return {e2_mul_xi(F2::mul(a.c2, b1)), F2::mul(a.c0, b1), F2::mul(a.c1, b1)}; }
+inline E12 e12_mul_by_014(const E12& f, const E2& c0, const E2& c1, const E2& c4) {
+    const E6 t0 = e6_mul_by_01(f.a0, c0, c1);
+    const E6 t1 = e6_mul_by_1(f.a1, c4);
+    E12 r;
+    r.a0 = e6_add(t0, e6_mul_v(t1));
+    r.a1 = e6_sub(e6_sub(e6_mul_by_01(e6_add(f.a0, f.a1), c0, F2::add(c1, c4)), t0), t1);
+    return r;
+}
+
+// ---- Frobenius: (sum_i c_i w^i)^p = sum_i conj(c_i) gamma_i w^i,  gamma_i = xi^(i (p - 1) / 6)
+struct FrobConsts { E2 g[6]; };
+inline E2 e2_pow(const E2& a, const uint64_t* e, int limbs) {
+    E2 r = F2::one();
+    for (int i = 64 * limbs - 1; i >= 0; --i) {
+        r = F2::sqr(r);
+        if ((e[i >> 6] >> (i & 63)) & 1) r = F2::mul(r, a);
+    }
+    return r;
+}
+inline const FrobConsts& frob_consts() {
+    static const FrobConsts c = [] {
+        uint64_t e[6];
+        memcpy(e, hfp::consts().p, 48);
+        e[0] -= 1;  // p - 1 (p is odd)
+        unsigned __int128 rem = 0;  // (p - 1) / 6, exact
+        for (int i = 5; i >= 0; --i) {
+            const unsigned __int128 cur = (rem << 64) | e[i];
+            e[i] = (uint64_t)(cur / 6);
+            rem = cur % 6;
+        }
+        FrobConsts k;
+        const E2 xi = {F1::one(), F1::one()};
+        k.g[0] = F2::one();
+        k.g[1] = e2_pow(xi, e, 6);
+        for (int i = 2; i < 6; ++i) k.g[i] = F2::mul(k.g[i - 1], k.g[1]);
+        return k;
+    }();
+    return c;
+}
+inline E12 e12_frob(const E12& f) {
+    const FrobConsts& k = frob_consts();
+    E12 r;
+    r.a0.c0 = e2_conj(f.a0.c0);                       // w^0
+    r.a1.c0 = F2::mul(e2_conj(f.a1.c0), k.g[1]);      // w^1
+    r.a0.c1 = F2::mul(e2_conj(f.a0.c1), k.g[2]);      // w^2 = v
+    r.a1.c1 = F2::mul(e2_conj(f.a1.c1), k.g[3]);      // w^3
+    r.a0.c2 = F2::mul(e2_conj(f.a0.c2), k.g[4]);      // w^4 = v^2
+    r.a1.c2 = F2::mul(e2_conj(f.a1.c2), k.g[5]);      // w^5
+    return r;
+}
+
+// ---- squaring in the cyclotomic subgroup (Granger - Scott): three squarings in Fp4 = Fp2[t] / (t^2 - xi) over the pairs
+// (c0, c3), (c1, c4), (c2, c5) of  f = sum c_i w^i  regrouped as  (c0 + c3 w^3) + (c1 + c4 w^3) w + (c2 + c5 w^3) w^2,  (w^3)^2 = xi
+inline void fp4_sqr(const E2& a, const E2& b, E2& o0, E2& o1) {  // (a + b t)^2 = a^2 + xi b^2 + ((a + b)^2 - a^2 - b^2) t
+    const E2 t0 = F2::sqr(a), t1 = F2::sqr(b);
+    o0 = F2::add(e2_mul_xi(t1), t0);
+    o1 = F2::sub(F2::sub(F2::sqr(F2::add(a, b)), t0), t1);
+}
+inline E12 e12_cyc_sqr(const E12& f) {
+    // coefficients by power of w: w^0 = a0.c0, w^1 = a1.c0, w^2 = a0.c1, w^3 = a1.c1, w^4 = a0.c2, w^5 = a1.c2
+    const E2 &c0 = f.a0.c0, &c1 = f.a1.c0, &c2 = f.a0.c1, &c3 = f.a1.c1, &c4 = f.a0.c2, &c5 = f.a1.c2;
+    E2 A0, A1, B0, B1, C0, C1;
+    fp4_sqr(c0, c3, A0, A1);  // (c0 + c3 t)^2
+    fp4_sqr(c1, c4, B0, B1);  // (c1 + c4 t)^2
+    fp4_sqr(c2, c5, C0, C1);  // (c2 + c5 t)^2
+    // g = x + y s + z s^2 over Fp4 (s = w, s^3 = t), unitary:  g^2 = (3 x^2 - 2 conj x) + (3 t z^2 + 2 conj y) s + (3 y^2 - 2 conj z) s^2,
+    // conj (a + b t) = a - b t
+    auto three_minus_two = [](const E2& sq, const E2& v) { const E2 d = F2::sub(sq, v); return F2::add(F2::add(d, d), sq); };   // 3 sq - 2 v
+    auto three_plus_two = [](const E2& sq, const E2& v) { const E2 d = F2::add(sq, v); return F2::add(F2::add(d, d), sq); };     // 3 sq + 2 v
+    E12 r;
+    r.a0.c0 = three_minus_two(A0, c0);            // w^0: 3 A0 - 2 c0
+    r.a1.c1 = three_plus_two(A1, c3);             // w^3: 3 A1 + 2 c3
+    const E2 tz0 = e2_mul_xi(C1);                 // t (C0 + C1 t) = xi C1 + C0 t
+    r.a1.c0 = three_plus_two(tz0, c1);            // w^1: 3 xi C1 + 2 c1
+    r.a0.c2 = three_minus_two(C0, c4);            // w^4: 3 C0 - 2 c4
+    r.a0.c1 = three_minus_two(B0, c2);            // w^2: 3 B0 - 2 c2
+    r.a1.c2 = three_plus_two(B1, c5);             // w^5: 3 B1 + 2 c5
+    return r;
+}
+static constexpr uint64_t X_ABS = 0xd201000000010000ull;
+// g^x for g in the cyclotomic subgroup (x = -|x|: the inverse there is the conjugate)
+inline E12 e12_cyc_exp_x(const E12& g) {
+    E12 r = g;  // bit 63 of |x| is the leading one
+    for (int i = 62; i >= 0; --i) {
+        r = e12_cyc_sqr(r);
+        if ((X_ABS >> i) & 1) r = e12_mul(r, g);
+    }
+    return e12_conj(r);
+}
+inline E12 final_exp_easy(const E12& f) {
+    const E12 g = e12_mul(e12_conj(f), e12_inv(f));   // f^(p^6 - 1)
+    return e12_mul(e12_frob(e12_frob(g)), g);        // ^(p^2 + 1)
+}
+// (easy part)^( (x - 1)^2 (x + p)(x^2 + p^2 - 1) + 3 ) = f^(3 (p^12 - 1) / r)
+inline E12 final_exp(const E12& f) {
+    const E12 m = final_exp_easy(f);
+    const E12 t = e12_mul(e12_cyc_exp_x(m), e12_conj(m));                               // m^(x - 1)
+    const E12 a = e12_mul(e12_cyc_exp_x(t), e12_conj(t));                               // m^((x - 1)^2)
+    const E12 b = e12_mul(e12_cyc_exp_x(a), e12_frob(a));                               // a^(x + p)
+    const E12 c = e12_mul(e12_mul(e12_cyc_exp_x(e12_cyc_exp_x(b)), e12_frob(e12_frob(b))), e12_conj(b));   // b^(x^2 + p^2 - 1)
+    return e12_mul(c, e12_mul(e12_cyc_sqr(m), m));                                      // * m^3
+}
+
+// the first version's final exponentiation: easy half by conjugate / inverse, everything else as one exponentiation by (p^6 + 1) / r
+inline E12 final_exp_plain(const E12& f) {
+    static const uint32_t E[64] = {  // (p^6 + 1) / r, little-endian 32-bit words
+        0xc0705d6au, 0x8739e1cdu, 0xe0381a16u, 0x09a5256du, 0x61c791e2u, 0x9cf0f70au, 0x7903f76eu, 0x3a09c449u, 0x3890f133u, 0x2d727156u,
+        0x6fec7760u, 0x224741b3u, 0x2a12bd40u, 0x338259c2u, 0x778e0de7u, 0x38ee1cd4u, 0x188a20b0u, 0xc3b5ef4bu, 0xe2764d7bu, 0x1d615d49u,
+        0xd076117du, 0x816101ddu, 0x7ebe3afcu, 0xf007c01eu, 0x935021c3u, 0x27d7bd90u, 0x57c0b15fu, 0xc3b5e2f5u, 0xc4f82384u, 0x5e886c94u,
+        0x11e63f56u, 0xee6a95dbu, 0x4a9c4f6fu, 0x2b822f51u, 0xd21b73dau, 0x12d6a874u, 0xf499dffbu, 0x1304275eu, 0xbcb95d1fu, 0x967878feu,
+        0x8b2f2922u, 0x4744497fu, 0xf0841855u, 0x85a2e707u, 0x6c802eecu, 0x9f0c5012u, 0xbd2fa489u, 0xfb46e197u, 0x9bc5f61au, 0x548ce080u,
+        0x73beaa8cu, 0xcf56fb15u, 0x763bdf7cu, 0xad7375a3u, 0x179bdeccu, 0xe0ec9031u, 0x3c48c1dau, 0x6579aea8u, 0x64cf5bb3u, 0xdbf85ae6u,
+        0x55ca7566u, 0x7b6f235cu, 0x14877503u, 0x000028b3u};
+    const E12 g = e12_mul(e12_conj(f), e12_inv(f));
+    E12 r = e12_one();
+    for (int i = 2029; i >= 0; --i) {
+        r = e12_sqr(r);
+        if ((E[i >> 5] >> (i & 31)) & 1) r = e12_mul(r, g);
+    }
+    return r;
+}
+
+// ---- Miller loop
+struct G1A { HFp x, y; bool inf; };
+struct G2A { E2 x, y; bool inf; };
+
+// f *= the line through T (twist coordinates, slope lam) evaluated at P, up to a factor the final exponentiation kills:
+// (lam xT - yT) + (-lam xP) w^2 + yP w^3
+inline E12 mul_line(const E12& f, const E2& lam, const G2A& t, const G1A& p) {
+    return e12_mul_by_line(f, F2::sub(F2::mul(lam, t.x), t.y), e2_scale(F2::neg(lam), p.x), p.y);
+}
+// out[k] = 1 / d[k] for the n <= 4 live denominators; false when one of them is zero
+inline bool batch_inv(const E2* d, int n, E2* out) {
+    E2 pre[4];
+    E2 acc = F2::one();
+    for (int k = 0; k < n; ++k) {
+        if (F2::is_zero(d[k])) return false;
+        pre[k] = acc;
+        acc = F2::mul(acc, d[k]);
+    }
+    E2 inv = F2::inv(acc);
+    for (int k = n - 1; k >= 0; --k) {
+        out[k] = F2::mul(inv, pre[k]);
+        inv = F2::mul(inv, d[k]);
+    }
+    return true;
+}
+// product of the Miller functions of n <= 4 pairs (pairs with an identity member contribute 1).  *degenerate is set when a line's slope
+// has a zero denominator (T of order 2, or T = +-Q): impossible for points of the prime-order subgroup, reachable only with low-order G2
+// points, which the callers only check to be on the curve (as the reference does - it transmutes unchecked points into bellman's
+// projective Miller loop).  Such a proof cannot satisfy the pairing equation; the verdict is then "does not verify" instead of a value
+// computed from 1 / 0.
+// Running points in JACOBIAN coordinates (x = X / Z^2, y = Y / Z^3): no inversion anywhere.  The affine line
+//     (lam xT - yT) - lam xP w^2 + yP w^3
+// is used multiplied by its slope's denominator (an Fp2 factor the final exponentiation removes):
+//   doubling  lam = 3 X^2 / (2 Y Z),          x 2 Y Z^3:   (3 X^3 - 2 Y^2)  -  3 X^2 Z^2 xP w^2  +  2 Y Z^3 yP w^3
+//   addition  lam = (yQ Z^3 - Y) / (Z H),     x Z H:       (R xQ - yQ Z H)  -  R xP w^2          +  Z H yP w^3       H = xQ Z^2 - X, R = yQ Z^3 - Y
+struct G2J { E2 X, Y, Z; };
+inline E12 multi_miller(const G1A* p, const G2A* q, int n, bool* degenerate) {
+    G2J t[4];
+    int live[4], nl = 0;
+    for (int k = 0; k < n && k < 4; ++k)
+        if (!p[k].inf && !q[k].inf) { t[nl] = {q[k].x, q[k].y, F2::one()}; live[nl++] = k; }
+    E12 f = e12_one();
+    for (int i = 62; i >= 0; --i) {  // bit 63 is the leading one
+        f = e12_sqr(f);
+        for (int j = 0; j < nl; ++j) {
+            G2J& T = t[j];
+            const G1A& P = p[live[j]];
+            if (F2::is_zero(T.Y)) { *degenerate = true; return e12_one(); }   // vertical tangent (Z is never zero before this happens)
+            const E2 A = F2::sqr(T.X), B = F2::sqr(T.Y), C = F2::sqr(B), ZZ = F2::sqr(T.Z);
+            const E2 E = F2::add(F2::add(A, A), A);                                          // 3 X^2
+            E2 D = F2::sub(F2::sub(F2::sqr(F2::add(T.X, B)), A), C);
+            D = F2::add(D, D);                                                               // 4 X Y^2
+            const E2 Z3 = F2::sub(F2::sub(F2::sqr(F2::add(T.Y, T.Z)), B), ZZ);               // 2 Y Z
+            // line (before the point moves)
+            const E2 l00 = F2::sub(F2::mul(E, T.X), F2::add(B, B));                          // 3 X^3 - 2 Y^2
+            const E2 l01 = e2_scale(F2::neg(F2::mul(E, ZZ)), P.x);                           // - 3 X^2 Z^2 xP
+            const E2 l11 = e2_scale(F2::mul(Z3, ZZ), P.y);                                   // 2 Y Z^3 yP  (an Fp2 value here, not Fp)
+            f = e12_mul_by_014(f, l00, l01, l11);
+            const E2 X3 = F2::sub(F2::sqr(E), F2::add(D, D));
+            E2 C8 = F2::add(C, C);
+            C8 = F2::add(C8, C8);
+            C8 = F2::add(C8, C8);
+            T = {X3, F2::sub(F2::mul(E, F2::sub(D, X3)), C8), Z3};
+        }
+        if ((X_ABS >> i) & 1) {
+            for (int j = 0; j < nl; ++j) {
+                G2J& T = t[j];
+                const G1A& P = p[live[j]];
+                const G2A& Q = q[live[j]];
+                const E2 ZZ = F2::sqr(T.Z);
+                const E2 H = F2::sub(F2::mul(Q.x, ZZ), T.X);
+                const E2 Rr = F2::sub(F2::mul(Q.y, F2::mul(ZZ, T.Z)), T.Y);
+                if (F2::is_zero(H)) { *degenerate = true; return e12_one(); }                // T = +-Q
+                const E2 Z3 = F2::mul(T.Z, H);
+                const E2 l00 = F2::sub(F2::mul(Rr, Q.x), F2::mul(Q.y, Z3));
+                const E2 l01 = e2_scale(F2::neg(Rr), P.x);
+                const E2 l11 = e2_scale(Z3, P.y);
+                f = e12_mul_by_014(f, l00, l01, l11);
+                const E2 HH = F2::sqr(H), HHH = F2::mul(HH, H), V = F2::mul(T.X, HH);
+                const E2 X3 = F2::sub(F2::sub(F2::sqr(Rr), HHH), F2::add(V, V));
+                T = {X3, F2::sub(F2::mul(Rr, F2::sub(V, X3)), F2::mul(T.Y, HHH)), Z3};
+            }
+        }
+    }
+    return e12_conj(f);  // the curve parameter is -|x|
+}
+
+// the same product with AFFINE running points (slopes inverted together, one Fp2 inversion per step): the second version, kept as the
+// yardstick of the projective loop - the two differ by Fp2 factors per line, which the final exponentiation removes: equal pairings
+inline E12 multi_miller_affine(const G1A* p, const G2A* q, int n, bool* degenerate) {
+    G2A t[4];
+    int live[4], nl = 0;
+    for (int k = 0; k < n && k < 4; ++k)
+        if (!p[k].inf && !q[k].inf) { t[nl] = q[k]; live[nl++] = k; }
+    E12 f = e12_one();
+    E2 den[4], inv[4];
+    for (int i = 62; i >= 0; --i) {  // bit 63 is the leading one
+        f = e12_sqr(f);
+        for (int j = 0; j < nl; ++j) den[j] = F2::add(t[j].y, t[j].y);
+        if (!batch_inv(den, nl, inv)) { *degenerate = true; return e12_one(); }
+        for (int j = 0; j < nl; ++j) {
+            const E2 xx = F2::sqr(t[j].x);
+            const E2 lam = F2::mul(F2::add(F2::add(xx, xx), xx), inv[j]);
+            f = mul_line(f, lam, t[j], p[live[j]]);
+            const E2 x3 = F2::sub(F2::sqr(lam), F2::add(t[j].x, t[j].x));
+            t[j] = {x3, F2::sub(F2::mul(lam, F2::sub(t[j].x, x3)), t[j].y), false};
+        }
+        if ((X_ABS >> i) & 1) {
+            for (int j = 0; j < nl; ++j) den[j] = F2::sub(q[live[j]].x, t[j].x);
+            if (!batch_inv(den, nl, inv)) { *degenerate = true; return e12_one(); }
+            for (int j = 0; j < nl; ++j) {
+                const G2A& qq = q[live[j]];
+                const E2 lam = F2::mul(F2::sub(qq.y, t[j].y), inv[j]);
+                f = mul_line(f, lam, t[j], p[live[j]]);
+                const E2 x3 = F2::sub(F2::sub(F2::sqr(lam), t[j].x), qq.x);
+                t[j] = {x3, F2::sub(F2::mul(lam, F2::sub(t[j].x, x3)), t[j].y), false};
+            }
+        }
+    }
+    return e12_conj(f);  // the curve parameter is -|x|
+}
+
+}  // namespace hp
+}  // namespace bzk

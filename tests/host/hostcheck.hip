@@ -8,6 +8,7 @@
 #include "../../bazuka_amd/csrc/host_fp64.h"
 #include "../../bazuka_amd/csrc/host_fr64.h"
 #include "../../bazuka_amd/csrc/host_fr_ifma.h"
+#include "../../bazuka_amd/csrc/host_pairing.h"
 #include <string.h>
 #include <vector>
 using namespace bzk;
@@ -458,5 +459,106 @@ int hc_mds_mul(int t, const uint8_t* m, const uint8_t* s, int mode, uint8_t* out
     }
     for (int j = 0; j < t; ++j) st<FrParams>(out + 32 * j, y[j]);
     return used;
+}
+
+// ---- the host pairing (host_pairing.h), piece by piece against slower forms of the same thing.  Random elements come from a seed.
+static uint64_t hc_rng(uint64_t& st) { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+static HFp hc_rand_fp(uint64_t& st) {
+    HFp a;
+    for (int i = 0; i < 6; ++i) a.l[i] = hc_rng(st);
+    a.l[5] &= 0x0fffffffffffffffull;  // < 2^380 < p
+    return a;
+}
+static hp::E12 hc_rand_e12(uint64_t& st) {
+    hp::E12 f;
+    HFp* v = (HFp*)&f;
+    for (int i = 0; i < 12; ++i) v[i] = hc_rand_fp(st);
+    return f;
+}
+static hp::E12 hc_e12_pow(const hp::E12& a, const uint64_t* e, int limbs) {
+    hp::E12 r = hp::e12_one();
+    for (int i = 64 * limbs - 1; i >= 0; --i) {
+        r = hp::e12_sqr(r);
+        if ((e[i >> 6] >> (i & 63)) & 1) r = hp::e12_mul(r, a);
+    }
+    return r;
+}
+static hp::E6 hc_e6_mul_schoolbook(const hp::E6& a, const hp::E6& b) {
+    using namespace hp;
+    const E2 t0 = F2::mul(a.c0, b.c0), t1 = F2::mul(a.c1, b.c1), t2 = F2::mul(a.c2, b.c2);
+    E6 r;
+    r.c0 = F2::add(t0, e2_mul_xi(F2::add(F2::mul(a.c1, b.c2), F2::mul(a.c2, b.c1))));
+    r.c1 = F2::add(F2::add(F2::mul(a.c0, b.c1), F2::mul(a.c1, b.c0)), e2_mul_xi(t2));
+    r.c2 = F2::add(F2::add(F2::mul(a.c0, b.c2), F2::mul(a.c2, b.c0)), t1);
+    return r;
+}
+// bit i of the result set = check i failed:
+//  0 Karatsuba Fp6 product == schoolbook          1 Fp12 squaring == product with itself        2 f * f^-1 == 1
+//  3 Frobenius == f^p by square-and-multiply      4 sparse line product == full product          5 easy part lands in the cyclotomic subgroup (g conj(g) == 1)
+//  6 Granger-Scott squaring == plain squaring there   7 cyclotomic exponentiation by x == plain exponentiation by |x|, conjugated
+//  8 fast final exponentiation == (plain final exponentiation)^3                                 9 Frobenius^12 == identity
+// 10 sparse product at tower positions 0, 1, 4 == full product
+int hc_pairing_pieces(uint64_t seed) {
+    using namespace hp;
+    uint64_t st = seed;
+    int bad = 0;
+    const E12 f = hc_rand_e12(st), g = hc_rand_e12(st);
+    if (!e6_eq(e6_mul(f.a0, g.a1), hc_e6_mul_schoolbook(f.a0, g.a1))) bad |= 1 << 0;
+    if (!e12_eq(e12_sqr(f), e12_mul(f, f))) bad |= 1 << 1;
+    if (!e12_is_one(e12_mul(f, e12_inv(f)))) bad |= 1 << 2;
+    if (!e12_eq(e12_frob(f), hc_e12_pow(f, hfp::consts().p, 6))) bad |= 1 << 3;
+    {
+        const E2 l00 = {hc_rand_fp(st), hc_rand_fp(st)}, l01 = {hc_rand_fp(st), hc_rand_fp(st)};
+        const HFp l11 = hc_rand_fp(st);
+        E12 l;
+        l.a0 = {l00, l01, F2::zero()};
+        l.a1 = {F2::zero(), {l11, F1::zero()}, F2::zero()};
+        if (!e12_eq(e12_mul_by_line(f, l00, l01, l11), e12_mul(f, l))) bad |= 1 << 4;
+    }
+    const E12 m = final_exp_easy(f);
+    if (!e12_is_one(e12_mul(m, e12_conj(m)))) bad |= 1 << 5;
+    if (!e12_eq(e12_cyc_sqr(m), e12_sqr(m))) bad |= 1 << 6;
+    {
+        const uint64_t x[1] = {X_ABS};
+        if (!e12_eq(e12_cyc_exp_x(m), e12_conj(hc_e12_pow(m, x, 1)))) bad |= 1 << 7;
+    }
+    {
+        const E12 slow = final_exp_plain(f);
+        if (!e12_eq(final_exp(f), e12_mul(e12_sqr(slow), slow))) bad |= 1 << 8;
+    }
+    {
+        E12 t = g;
+        for (int i = 0; i < 12; ++i) t = e12_frob(t);
+        if (!e12_eq(t, g)) bad |= 1 << 9;
+    }
+    {
+        const E2 c0 = {hc_rand_fp(st), hc_rand_fp(st)}, c1 = {hc_rand_fp(st), hc_rand_fp(st)}, c4 = {hc_rand_fp(st), hc_rand_fp(st)};
+        if (!e12_eq(e12_mul_by_014(f, c0, c1, c4), e12_mul(f, E12{{c0, c1, F2::zero()}, {F2::zero(), c4, F2::zero()}}))) bad |= 1 << 10;
+    }
+    return bad;
+}
+// prod_k e(P_k, Q_k) == 1 ?  (n <= 4 pairs, packed 96-byte G1 / 192-byte G2 affine points in the library's Montgomery form, all finite and on
+// their curves; mode 0: the shipped Miller loop + final exponentiation, 1: the same Miller loop + the plain final exponentiation, 2: the affine Miller loop; mode 3 asks something else: is the
+// pairing value of the projective loop EQUAL to that of the affine loop).  1 yes, 0 no, -1 degenerate
+int hc_pairing_product_is_one(const uint8_t* g1s, const uint8_t* g2s, int n, int mode) {
+    using namespace hp;
+    if (n < 1 || n > 4) return -2;
+    G1A p[4];
+    G2A q[4];
+    for (int k = 0; k < n; ++k) {
+        memcpy(p[k].x.l, g1s + 96 * k, 48); memcpy(p[k].y.l, g1s + 96 * k + 48, 48); p[k].inf = false;
+        memcpy(q[k].x.c0.l, g2s + 192 * k, 48); memcpy(q[k].x.c1.l, g2s + 192 * k + 48, 48);
+        memcpy(q[k].y.c0.l, g2s + 192 * k + 96, 48); memcpy(q[k].y.c1.l, g2s + 192 * k + 144, 48); q[k].inf = false;
+    }
+    bool degenerate = false;
+    const E12 f = mode == 2 ? multi_miller_affine(p, q, n, &degenerate) : multi_miller(p, q, n, &degenerate);
+    if (degenerate) return -1;
+    if (mode == 3) {  // the projective and the affine loop give the SAME pairing value (their lines differ by Fp2 factors only)
+        bool d2 = false;
+        const E12 g = multi_miller_affine(p, q, n, &d2);
+        if (d2) return -1;
+        return e12_eq(final_exp(f), final_exp(g)) ? 1 : 0;
+    }
+    return e12_is_one(mode == 1 ? final_exp_plain(f) : final_exp(f)) ? 1 : 0;
 }
 }

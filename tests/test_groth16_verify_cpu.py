@@ -105,3 +105,36 @@ def test_mpn_work_verify_binds_the_prover(co):
     w.push_deposit(0, ZIESHA, 11)
     other = L.MpnWork.decode(w.make_work(0, [vkb, vkb, vkb], 77).encode())
     assert other.verify(alice, proof) is False                        # another state transition
+
+
+def test_edge_scalars_in_the_public_input_combination(co):
+    """X = IC_0 + sum x_i IC_i runs through shared 4-bit windows in the product: edge scalars (0, 1, r - 1, single bits, all-ones nibbles)
+    must give the point the oracle's arithmetic gives.  For a valid (vk, x, proof) and any other input vector x', the key whose IC_0 is moved
+    by sum (x_i - x'_i) IC_i has the same X under x' - so it must still verify, and must not with one scalar changed."""
+    r1 = synth_r1cs(60, n_in=6, seed=900)
+    A, B, Cm = r1cs_to_csr(co, r1)
+    params = co.groth16_setup(A, B, Cm, r1["n_in"], r1["n_aux"], log2_ceil(len(r1["rows"])), fr_bytes(fr_list(5, 78)))
+    zb = fr_bytes(r1["z"])
+    az, bz, cz = co.r1cs_eval(A, B, Cm, zb)
+    rs = fr_bytes(fr_list(2, 11))
+    proof = co.groth16_prove(params, zb, az, bz, cz, rs[:32], rs[32:])
+    vkb = _vk_bytes(params)
+    x = r1["z"][1:6]
+    assert L.groth16_verify(vkb, fr_bytes(x), proof)
+    ic = [pr.g1_from_bytes(vkb[878 + 97 * i:878 + 97 * (i + 1)]) for i in range(6)]
+    R = pr.R_MOD
+    for xp in ([0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [R - 1, R - 1, 0, 1, R - 1], [1 << 252, (1 << 254) % R, 15, 0xF0F0F0F0, (1 << 128) - 1],
+               [int("f" * 63, 16) % R, int("8" * 63, 16) % R, 16, 1 << 4, R - 16]):
+        moved = ic[0]
+        for i in range(5):
+            moved = pr.g1_add(moved, pr.g1_mul(ic[i + 1], (x[i] - xp[i]) % R))
+        vk2 = vkb[:878] + pr.g1_to_bytes(moved) + vkb[878 + 97:]
+        assert L.groth16_verify(vk2, fr_bytes(xp), proof) is True, xp
+        bumped = list(xp)
+        bumped[3] = (bumped[3] + 1) % R
+        assert L.groth16_verify(vk2, fr_bytes(bumped), proof) is False, xp
+    # an IC point at infinity contributes nothing whatever its scalar
+    inf = pr.g1_to_bytes(None)
+    moved = pr.g1_add(ic[0], pr.g1_mul(ic[2], x[1]))                       # fold input 2 into IC_0, blank its IC
+    vk3 = vkb[:878] + pr.g1_to_bytes(moved) + vkb[975:1072] + inf + vkb[1169:]
+    assert L.groth16_verify(vk3, fr_bytes([x[0], 12345] + x[2:]), proof) is True

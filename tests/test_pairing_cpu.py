@@ -1,0 +1,99 @@
+"""The host pairing behind `bzk_groth16_verify` (bazuka_amd/csrc/host_pairing.h), checked piece by piece on the CPU through the harness
+(tests/host/_hostcheck.so includes the very header): every fast form against a slower form of the same thing - Karatsuba against
+schoolbook, Frobenius against f^p by square-and-multiply, the Granger-Scott squaring against the plain one inside the cyclotomic subgroup,
+the sparse line product against the full one, the five-exponentiation final exponentiation against the cube of the 2030-bit plain one - and
+the whole pairing on bilinearity with points made by the oracle's Python arithmetic.  The verdicts of the verifier proper against the
+oracle's verifier: tests/test_groth16_verify_cpu.py."""
+import ctypes as C
+import os
+import random
+
+import pytest
+
+from oracle import pyref as pr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, R, X = pr.P_MOD, pr.R_MOD, -pr.BLS_X   # the curve parameter is negative; the oracle keeps |x|
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(ROOT, "tests", "host", "_hostcheck.so")
+    if not os.path.exists(so):
+        pytest.skip("tests/host/_hostcheck.so not built (build() compiles it)")
+    h = C.CDLL(so)
+    if not hasattr(h, "hc_pairing_pieces"):
+        pytest.skip("tests/host/_hostcheck.so predates the pairing hooks (build() recompiles it)")
+    h.hc_pairing_pieces.argtypes = [C.c_uint64]
+    h.hc_pairing_pieces.restype = C.c_int
+    h.hc_pairing_product_is_one.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    h.hc_pairing_product_is_one.restype = C.c_int
+    return h
+
+
+def test_the_integer_identities_the_final_exponentiation_rests_on():
+    assert X == -0xd201000000010000 and (P ** 4 - P ** 2 + 1) % R == 0
+    lam = (P ** 4 - P ** 2 + 1) // R
+    assert 3 * lam == (X - 1) ** 2 * (X + P) * (X * X + P * P - 1) + 3         # the chain of hp::final_exp, cubed
+    assert P ** 12 - 1 == (P ** 6 - 1) * (P ** 2 + 1) * (P ** 4 - P ** 2 + 1)   # easy part x hard part
+    assert R % 3 != 0 and (P - 1) % 6 == 0                                      # g^3 = 1 iff g = 1 in the target group; Frobenius constants exist
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 0xDEADBEEF, 2 ** 63 + 5])
+def test_every_fast_form_equals_its_slow_form(hc, seed):
+    names = ["Karatsuba Fp6 product", "Fp12 squaring", "Fp12 inverse", "Frobenius vs f^p", "sparse line product", "easy part is cyclotomic",
+             "Granger-Scott squaring", "cyclotomic exponentiation by x", "final exponentiation vs plain^3", "Frobenius^12", "sparse product 0-1-4"]
+    bad = hc.hc_pairing_pieces(seed)
+    assert bad == 0, [n for i, n in enumerate(names) if (bad >> i) & 1]
+
+
+def _g1(p):
+    return pr.g1_to_bytes(p)[:96]
+
+
+def _g2(p):
+    return pr.g2_to_bytes(p)[:192]
+
+
+def _neg1(p):
+    return (p[0], (-p[1]) % P)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_bilinearity_and_refusal(hc, mode):
+    rnd = random.Random(20 + mode)
+    g1, g2 = pr.G1_GEN, pr.G2_GEN
+    for _ in range(3):
+        a, b = rnd.randrange(1, R), rnd.randrange(1, R)
+        aP, bQ, abP = pr.g1_mul(g1, a), pr.g2_mul(g2, b), pr.g1_mul(g1, a * b % R)
+        # e(aP, bQ) e(-abP, Q) = 1
+        assert hc.hc_pairing_product_is_one(_g1(aP) + _g1(_neg1(abP)), _g2(bQ) + _g2(g2), 2, mode) == 1
+        # the scalars on different sides, three pairs: e(aP, Q) e(P, bQ) e(-(a + b) P, Q) = 1 ; a fourth pair e(P, Q) on top: not one
+        s = pr.g1_mul(g1, (a + b) % R)
+        assert hc.hc_pairing_product_is_one(_g1(aP) + _g1(g1) + _g1(_neg1(s)), _g2(g2) + _g2(bQ) + _g2(g2), 3, mode) == 1
+        assert hc.hc_pairing_product_is_one(_g1(aP) + _g1(g1) + _g1(_neg1(s)) + _g1(g1), _g2(g2) + _g2(bQ) + _g2(g2) + _g2(g2), 4, mode) == 0
+        bP = pr.g1_mul(g1, b)
+        assert hc.hc_pairing_product_is_one(_g1(aP) + _g1(bP) + _g1(_neg1(s)), _g2(g2) + _g2(g2) + _g2(g2), 3, mode) == 1
+        # one scalar off: refused
+        off = pr.g1_mul(g1, (a * b + 1) % R)
+        assert hc.hc_pairing_product_is_one(_g1(aP) + _g1(_neg1(off)), _g2(bQ) + _g2(g2), 2, mode) == 0
+    # a single non-trivial pairing is not one
+    assert hc.hc_pairing_product_is_one(_g1(g1), _g2(g2), 1, mode) == 0
+
+
+def test_a_doubling_with_a_vertical_tangent_is_reported_not_computed(hc):
+    # a G2 point with y = 0 does not exist on y^2 = x^3 + 4 (1 + u) in the prime-order subgroup; the Miller loop must refuse the zero
+    # denominator 2 y instead of inverting it: hand it a made-up point with y = 0 (the harness does not check the curve equation)
+    q = bytes(_g2(pr.G2_GEN)[:96]) + bytes(96)
+    assert hc.hc_pairing_product_is_one(_g1(pr.G1_GEN), q, 1, 0) == -1
+
+
+def test_projective_and_affine_miller_loops_give_the_same_pairing_value(hc):
+    rnd = random.Random(77)
+    g1, g2 = pr.G1_GEN, pr.G2_GEN
+    ps = b"".join(_g1(pr.g1_mul(g1, rnd.randrange(1, R))) for _ in range(4))
+    qs = b"".join(_g2(pr.g2_mul(g2, rnd.randrange(1, R))) for _ in range(4))
+    for n in (1, 2, 4):
+        assert hc.hc_pairing_product_is_one(ps, qs, n, 3) == 1      # mode 3: equality of the two values, not "is one"
+    q0 = bytes(_g2(g2)[:96]) + bytes(96)                            # y = 0: both loops refuse
+    assert hc.hc_pairing_product_is_one(_g1(g1), q0, 1, 2) == -1
