@@ -279,7 +279,7 @@ void sha3_256(const uint8_t* data, size_t len, uint8_t out[32]) {
         off += rate;
     }
     memset(block, 0, rate);
-    memcpy(block, data + off, len - off);
+    if (len - off) memcpy(block, data + off, len - off);  // data may be null for the empty message
     block[len - off] ^= 0x06;
     block[rate - 1] ^= 0x80;
     absorb(block);

@@ -14,7 +14,7 @@ from mock_node import MockNode
 from oracle import pyref as pr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "bazuka_amd", "bzk-worker")
+BIN = os.environ.get("BZK_WORKER_BIN") or os.path.join(ROOT, "bazuka_amd", "bzk-worker")
 Z = pr.fr_to_mont_bytes(1)
 ALICE = bytes(range(1, 33))
 
