@@ -1,5 +1,6 @@
 // Internal plumbing of libbzk: context, error handling, workspace, per-kernel event timing.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -113,6 +114,11 @@ int msm_window_bits(uint64_t n);
 int32_t g1_horner_packed(const void* S, int count, int c, int w0, uint8_t* out);
 int32_t g2_horner_packed(const void* S, int count, int c, int w0, uint8_t* out);
 static inline size_t ws_pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+// an environment switch: set and not "0" (one getenv: the value is read from the pointer it was tested on)
+static inline bool env_on(const char* name) {
+    const char* e = getenv(name);
+    return e && atoi(e) != 0;
+}
 
 // A schedule of Poseidon hashes over one value array (state.hip): values [0, n_up) are uploaded 32-byte scalars, group g's outputs
 // follow in group order.  Groups run one batched launch each, in order, so a group may consume anything uploaded or produced by an

@@ -86,7 +86,7 @@ int32_t groth16_h(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m) {
     if (log_m > 28) return BZK_E_ARG;
     // env BZK_H_UNFUSED=1: the round-1/2 form - seven stand-alone transforms and a pointwise kernel (A/B runs, and the parity
     // reference of the fused chain inside the GPU tests)
-    static const bool unfused = getenv("BZK_H_UNFUSED") && atoi(getenv("BZK_H_UNFUSED")) != 0;
+    static const bool unfused = env_on("BZK_H_UNFUSED");
     if (!unfused && log_m >= 1) return ntt_h_chain(ctx, a, b, c, log_m);
     const uint64_t m = (uint64_t)1 << log_m;
     void* v[3] = {a, b, c};
@@ -541,9 +541,9 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     // (msm_impl.cuh section 8); env BZK_PROVE_NODEDUP=1 switches that off for A/B measurements
     // BZK_F_THROUGHPUT: the five MSMs overlap each other and the neighbouring proofs of a pipelined prover, so the forms with
     // less arithmetic beat those with the shortest chain (env BZK_PROVE_LATENCY=1 switches the hint off for A/B measurements)
-    static const uint32_t tflag = (getenv("BZK_PROVE_LATENCY") && atoi(getenv("BZK_PROVE_LATENCY")) != 0) ? 0u : BZK_F_THROUGHPUT;
-    static const uint32_t wflags = ((getenv("BZK_PROVE_NODEDUP") && atoi(getenv("BZK_PROVE_NODEDUP")) != 0) ? 0u : BZK_F_DEDUP) | tflag;
-    static const bool serial = getenv("BZK_PROVE_SERIAL") && atoi(getenv("BZK_PROVE_SERIAL")) != 0;
+    static const uint32_t tflag = (env_on("BZK_PROVE_LATENCY")) ? 0u : BZK_F_THROUGHPUT;
+    static const uint32_t wflags = ((env_on("BZK_PROVE_NODEDUP")) ? 0u : BZK_F_DEDUP) | tflag;
+    static const bool serial = env_on("BZK_PROVE_SERIAL");
     const void* z_aux = (const char*)slot->d_z + (size_t)p->n_in * 32;
     // every query through its resident set where one was built (crs_prepare), through the raw bases otherwise
     auto g1 = [&](bzk_ctx* c, const bzk_msm_bases* res, const void* raw, const void* sc, uint64_t n, uint32_t fl, uint8_t* out) {

@@ -167,7 +167,7 @@ struct PinnedPool {
             have_device = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0;
             (void)hipGetLastError();
         }
-        static const bool dbg = getenv("BZK_POOL_DEBUG") && atoi(getenv("BZK_POOL_DEBUG")) != 0;
+        static const bool dbg = env_on("BZK_POOL_DEBUG");
         void* p = nullptr;
         if (have_device && hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p) {
             if (dbg) fprintf(stderr, "[bzk] pool: hipHostMalloc %zu MB (pooled %zu MB in %zu blocks)\n", bytes >> 20, pooled >> 20, free_blocks.size());
