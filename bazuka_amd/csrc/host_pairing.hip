@@ -81,6 +81,11 @@ int32_t bzk_groth16_verify(const uint8_t* vk, uint64_t vk_len, const uint8_t* in
         }
         Fr x;
         memcpy(x.l, inputs + 32 * (i - 1), 32);
+        {   // as for Fp above: Montgomery limbs at or above r are not a value a ZkScalar can hold - refused, not computed with
+            Fr t = x;
+            fe_reduce_once<FrParams>(t);
+            if (!t.equals(x)) return 0;
+        }
         scalars[i - 1] = fe_from_mont<FrParams>(x);
         Pt* t = &table[15 * (i - 1)];
         t[0] = ic.inf ? xyzz_identity<HFpOps>() : xyzz_from_affine<HFpOps>({ic.x, ic.y});

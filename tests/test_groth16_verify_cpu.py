@@ -133,6 +133,9 @@ def test_edge_scalars_in_the_public_input_combination(co):
         bumped = list(xp)
         bumped[3] = (bumped[3] + 1) % R
         assert L.groth16_verify(vk2, fr_bytes(bumped), proof) is False, xp
+    # an input whose Montgomery limbs are not below r is not a ZkScalar: refused even where its residue would verify
+    over = (int.from_bytes(fr_bytes(x[:1]), "little") + pr.R_MOD).to_bytes(32, "little") + fr_bytes(x[1:])
+    assert L.groth16_verify(vkb, over, proof) is False
     # an IC point at infinity contributes nothing whatever its scalar
     inf = pr.g1_to_bytes(None)
     moved = pr.g1_add(ic[0], pr.g1_mul(ic[2], x[1]))                       # fold input 2 into IC_0, blank its IC
