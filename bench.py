@@ -756,7 +756,7 @@ def production_block_section(ctx, with_1024tx: bool = False):
         sec["gpu_crs_setup_s"] = round(time.perf_counter() - t0, 2)
         del csr
         r.free()
-        tm, tw, tp, ok = [], [], [], True
+        tm, tw, tp, tv, ok = [], [], [], [], True
         for k in range(3):
             push()
             t0 = time.perf_counter()
@@ -770,10 +770,12 @@ def production_block_section(ctx, with_1024tx: bool = False):
             proof = ctx.groth16_prove(ph, z, rk.raw("az"), rk.raw("bz"), rk.raw("cz"), _fr_blind(5000 + 2 * k), _fr_blind(5001 + 2 * k))
             t3 = time.perf_counter()
             ok = ok and L.groth16_verify(vkb, bytes(z[32:32 * 6]), proof) and not L.groth16_verify(vkb, bytes(z[32:32 * 5]) + _fr(12345), proof)
-            tm.append(t1 - t0); tw.append(t2 - t1); tp.append(t3 - t2)
+            t4 = time.perf_counter()
+            tm.append(t1 - t0); tw.append(t2 - t1); tp.append(t3 - t2); tv.append((t4 - t3) / 2)   # two verifications (accept, refuse)
             rk.free()
         sec.update(make_work_s=round(min(tm), 4), wire_bytes=len(blob), decode_and_witness_s=round(min(tw), 4), prove_s=round(min(tp), 4),
-                   prove_s_all=[round(x, 4) for x in tp], verified=bool(ok), tx_per_s_prove_only=round(n_slots / min(tp), 1))
+                   prove_s_all=[round(x, 4) for x in tp], verified=bool(ok), verify_ms_host=round(min(tv) * 1e3, 2),
+                   tx_per_s_prove_only=round(n_slots / min(tp), 1))
         if b4 <= 4:
             total += min(tp)
         ctx.params_free(ph)
