@@ -54,3 +54,41 @@ def test_the_checker_sees_a_misspelt_name(tmp_path):
     f = tmp_path / "m.py"
     f.write_text("import os\nX = 1\ndef f(a):\n    def g():\n        return a + X + os.sep + len('x') + mispelt\n    return g\n")
     assert [n for _, _, n in undefined_globals(str(f))] == ["mispelt"]
+
+
+def _instance_attributes(cls_name, path):
+    import ast
+    out = set()
+    for node in ast.walk(ast.parse(open(path).read())):
+        if isinstance(node, ast.ClassDef) and node.name == cls_name:
+            for n in ast.walk(node):
+                if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id == "self" and isinstance(n.ctx, ast.Store):
+                    out.add(n.attr)
+    return out
+
+
+GPU_ONLY = sorted(set([os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py"), os.path.join(ROOT, "bazuka_amd", "worker.py")]
+                      + glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tests", "tools", "*.py"))
+                      + glob.glob(os.path.join(ROOT, "tests", "test_gpu_*.py")) + [os.path.join(ROOT, "tests", "test_golden_gpu.py")]))
+
+
+@pytest.mark.parametrize("path", GPU_ONLY, ids=[os.path.relpath(f, ROOT) for f in GPU_ONLY])
+def test_calls_into_the_driver_name_things_that_exist(path):
+    """`ctx.msm_g1_dev(..)`, `L.MpnWork.decode(..)`: every attribute read on the conventional names of a library context (`ctx`, `bzk`) or of the
+    ctypes driver module (however the file imported it) exists on `Bzk` / in `bazuka_amd.lib` - a misspelt method would only fail on the GPU box"""
+    import ast
+    from bazuka_amd import lib as L
+    inst = _instance_attributes("Bzk", os.path.join(ROOT, "bazuka_amd", "lib.py"))
+    tree = ast.parse(open(path).read())
+    aliases = set()
+    for n in ast.walk(tree):
+        if isinstance(n, ast.ImportFrom) and n.module in ("bazuka_amd", None) and n.level <= 1:
+            aliases |= {a.asname or a.name for a in n.names if a.name == "lib"}
+    bad = []
+    for n in ast.walk(tree):
+        if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name):
+            if n.value.id in aliases and not hasattr(L, n.attr):
+                bad.append((n.lineno, f"{n.value.id}.{n.attr}"))
+            if n.value.id in ("ctx", "bzk") and not n.attr.startswith("_") and not hasattr(L.Bzk, n.attr) and n.attr not in inst:
+                bad.append((n.lineno, f"{n.value.id}.{n.attr}"))
+    assert bad == []
