@@ -375,3 +375,45 @@ def test_header_is_plain_c99_and_cxx11(tmp_path):
         pytest.skip("no gcc")
     for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror"], ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-x", "c++"]):
         subprocess.check_call(cmd + ["-I", os.path.join(root, "include"), "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+
+
+def test_ctypes_signatures_agree_with_the_header_prototypes():
+    """argument COUNT and argument CLASS (pointer / 64-bit / 32-bit / double) of every entry of bazuka_amd.lib.SIGNATURES against the prototype in
+    include/bzk.h (parsed by the generator of the Rust raw layer): ctypes would silently pass a 32-bit value where the C side reads 64 bits, or
+    drop / invent an argument, and only a GPU-side call would notice."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_sys as g
+    from bazuka_amd import lib as L
+    _, opaque, structs, funcs, _ = g.parse(open(os.path.join(ROOT, "include", "bzk.h")).read())
+    protos = {name: (ret, params) for name, ret, params in funcs}
+    assert set(protos) == set(L.SIGNATURES), set(protos) ^ set(L.SIGNATURES)
+
+    def c_class(ty):
+        ty = ty.strip()
+        if "*" in ty:
+            return "ptr"
+        base = ty.replace("const", "").strip()
+        return {"uint64_t": "i64", "int64_t": "i64", "size_t": "i64", "uint32_t": "i32", "int32_t": "i32", "int": "i32", "unsigned": "i32",
+                "double": "f64", "void": "void", "uint8_t": "i8"}[base]
+
+    def py_class(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "_type_") and issubclass(t, (C._Pointer, C.Array)):
+            return "ptr"
+        if isinstance(t, type) and issubclass(t, C._Pointer):
+            return "ptr"
+        return {8: "i64", 4: "i32", 1: "i8"}[C.sizeof(t)] if t is not C.c_double else "f64"
+
+    bad = []
+    for name, (res, args) in L.SIGNATURES.items():
+        ret, params = protos[name]
+        want = [c_class(ty) for _, ty in params]
+        got = [py_class(a) for a in args]
+        if want != got:
+            bad.append((name, want, got))
+        rc, rp = c_class(ret), py_class(res)
+        if rc != rp and not (rc == "ptr" and rp == "ptr"):
+            bad.append((name, "returns " + rc, rp))
+    assert bad == []
