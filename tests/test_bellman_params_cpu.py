@@ -59,3 +59,40 @@ def test_infinity_and_malformed_points():
         with pytest.raises(L.BzkError):
             L.bellman_params_decode(mutate(good))
     assert L.bellman_params_decode(good)["n_h"] == len(p["h"])
+
+
+def test_reader_survives_mutated_files():
+    """random byte flips, truncations, splices and length-field edits of a valid file: decoded (and then re-encodable) or refused with an error -
+    never a crash, never a read beyond the input (the CPU suite also runs against an ASAN build: tools/sanitize_cpu.sh)"""
+    import random
+    rnd = random.Random(4242)
+    p = _params()
+    vk = {k: p[k] for k in ("alpha_g1", "beta_g1", "beta_g2", "gamma_g2", "delta_g1", "delta_g2", "ic")}
+    good = pr.bellman_params_bytes(vk, p["h"], p["l"], p["a"], p["b_g1"], p["b_g2"])
+    decoded = refused = 0
+    for it in range(400):
+        b = bytearray(good)
+        mode = it % 5
+        if mode == 0:
+            for _ in range(rnd.randint(1, 4)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:
+            b = b[:rnd.randrange(len(b))]
+        elif mode == 2:
+            i, j = sorted(rnd.randrange(len(b)) for _ in range(2))
+            b = b[:i] + b[j:]
+        elif mode == 3:
+            i = rnd.randrange(len(b) - 4)
+            b[i:i + 4] = rnd.choice([0, 1, 2 ** 31, 2 ** 32 - 1, rnd.randrange(2 ** 32)]).to_bytes(4, "big")
+        else:
+            i = rnd.randrange(len(b))
+            b = b[:i] + bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 200))) + b[i:]
+        try:
+            d = L.bellman_params_decode(bytes(b))
+        except L.BzkError:
+            refused += 1
+            continue
+        decoded += 1
+        assert d["consumed"] <= len(b)
+        assert L.bellman_params_encode(d["vk"], d["ic"], d["h"], d["l"], d["a"], d["b_g1"], d["b_g2"]) == bytes(b[:d["consumed"]])
+    assert refused > 200 and decoded + refused == 400
