@@ -97,3 +97,28 @@ def test_projective_and_affine_miller_loops_give_the_same_pairing_value(hc):
         assert hc.hc_pairing_product_is_one(ps, qs, n, 3) == 1      # mode 3: equality of the two values, not "is one"
     q0 = bytes(_g2(g2)[:96]) + bytes(96)                            # y = 0: both loops refuse
     assert hc.hc_pairing_product_is_one(_g1(g1), q0, 1, 2) == -1
+
+
+def test_relations_inside_the_references_own_verifying_keys(hc):
+    """bytes the reference holds (src/config/blockchain.rs:32-37, copied into tests/golden/reference_vectors.json): a Groth16 key carries beta and
+    delta in both groups over the setup's own generators, so e(beta_g1, delta_g2) = e(delta_g1, beta_g2) - within each key, and across the three
+    keys (they share their toxic waste) - while unrelated pairs do not cancel.  The product's pairing, on points nobody here generated."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")) as f:
+        vks = [bytes.fromhex(v) for v in json.load(f)["verifying_keys_bincode_hex"]]
+    assert len(vks) == 3 and all(len(v) == 1460 for v in vks)
+
+    def fields(v):   # alpha_g1 | beta_g1 | beta_g2 | gamma_g2 | delta_g1 | delta_g2, packed with a trailing infinity flag each
+        return {"alpha_g1": v[0:96], "beta_g1": v[97:193], "beta_g2": v[194:386], "gamma_g2": v[387:579], "delta_g1": v[580:676], "delta_g2": v[677:869]}
+
+    def neg_g1(b):
+        p = pr.g1_from_bytes(b + b"\0")
+        return pr.g1_to_bytes((p[0], (-p[1]) % P))[:96]
+
+    ks = [fields(v) for v in vks]
+    for a in ks:
+        for b in ks:
+            assert hc.hc_pairing_product_is_one(a["beta_g1"] + neg_g1(b["delta_g1"]), b["delta_g2"] + a["beta_g2"], 2, 0) == 1
+    k = ks[0]
+    assert hc.hc_pairing_product_is_one(k["beta_g1"] + neg_g1(k["delta_g1"]), k["gamma_g2"] + k["beta_g2"], 2, 0) == 0     # gamma is not delta
+    assert hc.hc_pairing_product_is_one(k["alpha_g1"] + neg_g1(k["delta_g1"]), k["delta_g2"] + k["beta_g2"], 2, 0) == 0    # alpha is not beta
