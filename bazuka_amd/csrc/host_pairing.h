@@ -12,7 +12,7 @@
 //            lands in) and two Frobenius maps.  The cube does not matter to a verifier: the target group has prime order r, 3 does not
 //            divide r, so g^3 = 1 iff g = 1.  `final_exp_plain` is the 2030-bit square-and-multiply of the first version (round 2): the
 //            yardstick of the tests, which check fast == plain^3 on Miller outputs.
-// Cost on one core of the build container (EPYC-class, -O3): the four-pair check of a Groth16 verification ~2.2 ms (Miller loop ~1.5, final
+// Cost on one core of the build container (Xeon @ 2.1 GHz, -O3): the four-pair check of a Groth16 verification ~2.2 ms (Miller loop ~1.5, final
 // exponentiation ~0.6) of the verifier's 2.8 ms; the first version spent 6.8 ms on line inversions and 11 ms on the plain exponentiation.
 #pragma once
 #include "host_fp64.h"
