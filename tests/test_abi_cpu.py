@@ -417,3 +417,44 @@ def test_ctypes_signatures_agree_with_the_header_prototypes():
         if rc != rp and not (rc == "ptr" and rp == "ptr"):
             bad.append((name, "returns " + rc, rp))
     assert bad == []
+
+
+def test_a_plain_c_program_links_against_the_library_and_uses_it(tmp_path, co):
+    """tests/host/abi_consumer.c: compiled as C99 -pedantic against include/bzk.h, linked against bazuka_amd/libbzk.so, run without a GPU - status
+    strings, SHA3, the work decoder and the verifier called the way a cgo / Rust-FFI binding would call them (plain pointers and lengths, files in,
+    verdicts out).  The proof and key are made by the CPU oracle, the work by the host builder."""
+    import shutil
+    import subprocess
+    from bazuka_amd import lib as L
+    from util import fr_bytes, fr_list, log2_ceil, r1cs_to_csr, synth_r1cs
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    exe = tmp_path / "abi_consumer"
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "abi_consumer.c"), "-o", str(exe), "-L", libdir, "-lbzk",
+                           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    r1 = synth_r1cs(30, n_in=4, seed=4711)
+    A, B, Cm = r1cs_to_csr(co, r1)
+    params = co.groth16_setup(A, B, Cm, r1["n_in"], r1["n_aux"], log2_ceil(len(r1["rows"])), fr_bytes(fr_list(5, 79)))
+    zb = fr_bytes(r1["z"])
+    az, bz, cz = co.r1cs_eval(A, B, Cm, zb)
+    rs = fr_bytes(fr_list(2, 12))
+    proof = co.groth16_prove(params, zb, az, bz, cz, rs[:32], rs[32:])
+    vkb = params["vk"] + (len(params["ic"]) // 97).to_bytes(8, "little") + params["ic"]
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")) as f:
+        vks = [bytes.fromhex(v) for v in json.load(f)["verifying_keys_bincode_hex"]]
+    Z = bytes.fromhex("01" + "00" * 31)
+    w = L.MpnWorld(3, 3)
+    for i in range(2):
+        w.add_account(i, b"acct%d" % i, Z, 10 ** 9)
+    w.set_height(5)
+    w.push_deposit(0, Z, 1000)
+    work = w.make_work(0, vks, 100).encode()
+    files = {"vk.bin": vkb, "inputs.bin": fr_bytes(r1["z"][1:4]), "proof.bin": proof, "work.bin": work, "prover.bin": bytes(range(1, 33))}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    p = subprocess.run([str(exe)] + [str(tmp_path / n) for n in files], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "all checks hold" in p.stdout and "groth16_verify(valid) = 1" in p.stdout and "kind 0" in p.stdout
