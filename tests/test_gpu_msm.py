@@ -1,4 +1,6 @@
 """GPU parity: libbzk Pippenger (K4/K5) vs the CPU oracle, through the C ABI.  Bit-exact (integer)."""
+import os
+
 import pytest
 import torch
 
@@ -325,21 +327,69 @@ def test_msm_g1_2p22_vs_oracle(bzk, co):
     assert bzk.msm_g1_dev(bases, sc, n, dedup=True) == got
 
 
-def test_msm_g1_2p24_partition_property(bzk):
-    """the production circuit's size: MSM over 2^24 points == fold of the MSMs over its two halves"""
-    n = 1 << 24
-    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
-    bzk.g1_synth_bases_dev(10, 0, n, bases)
-    g = torch.Generator(device="cuda").manual_seed(24)
+def _host_mem_budget_gb():
+    """what this process may allocate on the host: the cgroup limit if there is one, else MemAvailable"""
+    try:
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v != "max":
+            return int(v) / 2 ** 30
+    except OSError:
+        pass
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            return int(line.split()[1]) / 2 ** 20
+    return 0.0
+
+
+def _uniform_scalars_dev(n, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
     sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
     sc[:, 31] &= 0x3F
     sc = sc.contiguous().view(-1)
     torch.cuda.synchronize()  # the scalars were produced on torch's stream; libbzk works on its own
+    return sc
+
+
+def _large_g1_msm_vs_oracle(bzk, co, log_n, seed, parts):
+    """one MSM over 2^log_n points: the per-call pipeline, the resident-set form and the `parts`-way window-sharded fold
+    (what `parts` ranks of a device group compute) all equal the oracle's bytes"""
+    n = 1 << log_n
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(seed, 0, n, bases)
+    sc = _uniform_scalars_dev(n, seed + log_n)
     whole = bzk.msm_g1_dev(bases, sc, n)
-    h = n // 2
-    lo = bzk.msm_g1_dev(bases[:h * 96], sc[:h * 32], h)
-    hi = bzk.msm_g1_dev(bases[h * 96:], sc[h * 32:], h)
-    assert bzk.g1_sum(lo + hi) == whole
+    hb, hs = bases.cpu().numpy(), sc.cpu().numpy()
+    want = co.msm_g1_np(hb, hs, nthreads=co.ncpu())
+    del hb, hs
+    assert whole == want
+    h = bzk.msm_bases_load_dev(bases, n)
+    try:
+        del bases
+        assert bzk.msm_bases_run_dev(h, sc, n) == want
+        W = bzk.msm_window_count(n)
+        cuts = [W * i // parts for i in range(parts + 1)]
+        shards = b"".join(bzk.msm_bases_windows_dev(h, sc, n, cuts[i], cuts[i + 1]) for i in range(parts))
+        assert bzk.g1_sum(shards) == want
+    finally:
+        bzk.msm_bases_free(h)
+
+
+def test_msm_g1_2p24_vs_oracle(bzk, co):
+    """the production circuit's size: the 2^24-point G1 MSM with uniform scalars - the bulk regime of the
+    fold (`MSM_FOLD_BULK_FROM`) that only large n reaches and the bench times as `msm_g1_2p24` - bit-exact against the oracle,
+    as are the resident-set form and the 8-way window-sharded fold (~25 s of the box's host cores)"""
+    _large_g1_msm_vs_oracle(bzk, co, 24, 10, 8)
+
+
+@pytest.mark.skipif(os.environ.get("BZK_TEST_2P26", "1") == "0", reason="BZK_TEST_2P26=0")
+def test_msm_g1_2p26_vs_oracle_and_8way_window_shards(bzk, co):
+    """BASELINE configs[3] (65536 tx = one 2^26-point G1 MSM, window-sharded across 8 ranks): whole MSM == oracle,
+    and the fold of the eight window-range shares == the same bytes.  ~90 s of host cores, ~16 GB of host memory."""
+    need = 24.0
+    have = _host_mem_budget_gb()
+    if have < need:
+        pytest.skip(f"host memory budget {have:.0f} GB < {need:.0f} GB needed by the CPU oracle at 2^26 points")
+    _large_g1_msm_vs_oracle(bzk, co, 26, 11, 8)
 
 
 # ---- every window size, not only the ones the size-based pick happens to choose for the test sizes

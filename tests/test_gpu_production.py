@@ -58,3 +58,47 @@ def test_production_shape_proof_equals_oracle_and_verifies(name, bzk, co):
         assert proof == want
     bzk.params_free(ph)
     r.free()
+
+
+@pytest.mark.skipif(os.environ.get("BZK_TEST_1024TX", "1") == "0", reason="BZK_TEST_1024TX=0")
+def test_single_1024tx_update_circuit_proves_and_verifies(bzk):
+    """BASELINE configs[2] at face value: ONE UpdateCircuit with 1024 transitions (L = 15, T = 3, log4 batch 5: 57.8 M constraints,
+    2^26 domain; /root/reference/src/mpn/circuits/update_circuit.rs:81-469) through make_work -> wire bytes -> decode -> synthesis ->
+    CRS on the GPU -> proof on the GPU, judged by the product's host verifier AND the oracle's independent Python pairing
+    (src/zk/groth16/mod.rs:67-121).  No byte comparison with the oracle prover at this size (it would take ~7 min and ~100 GB of
+    host memory): the bytes of this code path are pinned at 2^21 / 2^22 / 2^24 above.  ~70 s, dominated by synthesis with matrices
+    (31 s) and the CRS (26 s)."""
+    from bazuka_amd import lib as L
+    vks = [bytes.fromhex(h) for h in json.load(open(os.path.join(S.G, "reference_vectors.json")))["verifying_keys_bincode_hex"]]
+    Z = pr.fr_to_mont_bytes(1)
+    n_slots, size = 4 ** 5, 4 ** 15
+    w = L.MpnWorld(15, 3)
+    w.set_device(bzk)
+    try:
+        idx = [(i * 22369621 + 5) % size for i in range(2 * n_slots)]
+        for i, a in enumerate(idx):
+            w.add_account(a, b"k1024-%d" % i, Z, 10 ** 12)
+        w.set_height(7)
+        for i in range(n_slots):
+            w.push_tx(idx[i], idx[n_slots + i], Z, 100 + i, Z, i % 7)
+        dec = L.MpnWork.decode(w.make_work(2, vks, 1, log4_batches=(1, 1, 5)).encode())
+        r = dec.synthesize(S.PROVER, record_matrices=True)
+        assert r.satisfied and r.accepted == n_slots and (r.n_constraints - 1).bit_length() == 26
+        csr = [(r.n_constraints, r.raw("rp" + x), r.raw("col" + x), r.raw("val" + x)) for x in "ABC"]
+        ph, vkb = bzk.groth16_setup(csr, r.n_in, r.n_aux, fr_bytes(fr_list(5, 4026)))
+        del csr
+        rs = fr_bytes(fr_list(2, 4027))
+        z = r.raw("z")
+        proof = bzk.groth16_prove(ph, z, r.raw("az"), r.raw("bz"), r.raw("cz"), rs[:32], rs[32:])
+        inputs = bytes(z[32:32 * 6])
+        pub = [U(inputs[32 * i:32 * i + 32]) for i in range(5)]
+        assert pub[0] == U(dec.commitment(S.PROVER)) and pub[2] == U(dec.state) and pub[4] == U(dec.next_state)
+        assert L.groth16_verify(vkb, inputs, proof)
+        assert not L.groth16_verify(vkb, inputs[:128] + pr.fr_to_mont_bytes(pub[4] + 1), proof)
+        vk = pr.vk_from_bytes(vkb)
+        assert pr.groth16_verify(vk, pub, pr.proof_from_bytes(proof))
+        assert not pr.groth16_verify(vk, [pub[0] + 1] + pub[1:], pr.proof_from_bytes(proof))
+        bzk.params_free(ph)
+        r.free()
+    finally:
+        w.close()

@@ -137,6 +137,8 @@ def test_msm_pippenger_vs_naive_4096(co):
     bases = co.g1_bases(3, 0, n, nthreads=co.ncpu())
     sc = rand_scalars_bytes(n, 9)
     assert co.msm_g1(bases, sc, nthreads=co.ncpu()) == co.msm_g1(bases, sc, naive=True)
+    import numpy as np  # the zero-copy entry the 2^24 / 2^26 GPU checks use
+    assert co.msm_g1_np(np.frombuffer(bases, dtype=np.uint8), np.frombuffer(sc, dtype=np.uint8), nthreads=2) == co.msm_g1(bases, sc)
 
 
 def test_msm_linearity(co, pr):
