@@ -242,6 +242,13 @@ if __name__ == "__main__":
         run("g1tab", 20, {"TAB_LEVELS": "2", "BZK_MSM_TABLE_C": "17"})
         run("g1tab", 20, {"TAB_LEVELS": "4", "BZK_MSM_TABLE_C": "17"})
         run("g1", 22); run("g1tab", 22, {"TAB_LEVELS": "2"}); run("g1tab", 22, {"TAB_LEVELS": "4"})
+    if what in ("r5knobs",):  # round 5, run 1: what the existing switches give a stand-alone 2^20 MSM over a resident set - endomorphism form x reduce chunk x one / two-level reduction
+        for mode in ("g1res", "g2res"):
+            e = "BZK_MSM_ENDO_G1" if mode == "g1res" else "BZK_MSM_ENDO_G2"
+            for endo in ("0", "1"):
+                for ch in ("8", "4", "2"):
+                    for r2 in ("-1", "1"):
+                        run(mode, 20, {e: endo, "BZK_MSM_CHUNK": ch, "BZK_MSM_REDUCE2": r2})
     if what in ("all", "tab"):
         for c in (15, 16, 17, 18, 19):
             run("g1tab", 20, {"BZK_MSM_TABLE_C": str(c)})
