@@ -22,6 +22,7 @@ struct bzk_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string last_error;
+    int32_t last_refusal = 0;  // BZK_REFUSE_*: what the last BZK_E_ARG of a bzk_state_* call stands for (bzk_last_refusal)
     bool prof = false;
     std::string prof_only;  // non-empty: only launches whose label contains it get event pairs (bzk_prof_filter)
     std::vector<bzk_prof_rec> recs;

@@ -33,6 +33,19 @@ int32_t ws_reserve(bzk_ctx* ctx, size_t bytes) {
     return BZK_OK;
 }
 
+extern "C" int32_t bzk_ctx_trim(bzk_ctx* ctx, uint64_t* released) {
+    if (!ctx) return BZK_E_ARG;
+    if (released) *released = 0;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->ws) return BZK_OK;
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BZK_HIP(ctx, hipFree(ctx->ws));
+    if (released) *released = ctx->ws_bytes;
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    return BZK_OK;
+}
+
 int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_bytes) return BZK_OK;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -250,6 +263,7 @@ int32_t bzk_sync(bzk_ctx* ctx) {
 }
 
 const char* bzk_last_error(bzk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+int32_t bzk_last_refusal(bzk_ctx* ctx) { return ctx ? ctx->last_refusal : BZK_REFUSE_NONE; }
 
 int32_t bzk_dev_alloc(bzk_ctx* ctx, uint64_t bytes, void** dptr) {
     if (!ctx || !dptr) return BZK_E_ARG;

@@ -40,7 +40,8 @@ struct CrsShared {
     bzk_msm_bases* rlb1 = nullptr;
     // static-base table of the h query: the h bases never change and their scalars are never de-duplicated, so all windows can share one
     // bucket set at a window size of ~log2 m (fewer windows = fewer additions)
-    bzk_msm_table* h_table = nullptr;
+    // published with release / read with acquire: prover slots of this CRS read it without the lock
+    std::atomic<bzk_msm_table*> h_table{nullptr};
     bool prepared = false;
 };
 struct bzk_params {
@@ -208,7 +209,7 @@ extern "C" {
 
 static void crs_release(bzk_ctx* ctx, CrsShared* c) {
     if (!c || c->refs.fetch_sub(1) != 1) return;
-    if (c->h_table) bzk_msm_table_free(ctx, c->h_table);
+    if (bzk_msm_table* t = c->h_table.load(std::memory_order_acquire)) bzk_msm_table_free(ctx, t);
     for (bzk_msm_bases* b : {c->rl, c->ra, c->rb1, c->rb2, c->rh, c->rlb1})
         if (b) bzk_msm_bases_free(ctx, b);
     void* bufs[] = {c->h, c->l, c->a, c->b_g1, c->b_g2, c->a_idx, c->b_idx};
@@ -351,10 +352,12 @@ static void crs_prepare(bzk_ctx* ctx, CrsShared* c) {
     if (want_tab && c->log_m >= 16 && c->log_m <= max_log && m > 1) {
         const uint32_t cw = c->log_m > 20 ? 20u : c->log_m;
         const size_t need = (size_t)((256 + cw - 1) / cw) * 112 * (m - 1);
-        if (!crs_fits(need, reserve) || bzk_msm_g1_table_build_c(ctx, c->h, m - 1, cw, &c->h_table) != BZK_OK) {
-            c->h_table = nullptr;
+        bzk_msm_table* t = nullptr;
+        if (!crs_fits(need, reserve) || bzk_msm_g1_table_build_c(ctx, c->h, m - 1, cw, &t) != BZK_OK) {
+            t = nullptr;
             (void)hipGetLastError();
         }
+        c->h_table.store(t, std::memory_order_release);
     }
     if (!want_res) return;
     // l and b_g1 as one set (prove_merge_lb1): [l | b_g1] concatenated in a temporary raw buffer, converted once
@@ -373,7 +376,7 @@ static void crs_prepare(bzk_ctx* ctx, CrsShared* c) {
     }
     struct Q { const void* raw; uint64_t n; bzk_msm_bases** dst; bool g2; };
     Q qs[] = {{c->b_g2, c->n_b, &c->rb2, true}, {c->rlb1 ? nullptr : c->l, c->n_aux, &c->rl, false}, {c->a, c->n_a, &c->ra, false},
-              {c->rlb1 ? nullptr : c->b_g1, c->n_b, &c->rb1, false}, {c->h_table ? nullptr : c->h, m - 1, &c->rh, false}};
+              {c->rlb1 ? nullptr : c->b_g1, c->n_b, &c->rb1, false}, {c->h_table.load(std::memory_order_acquire) ? nullptr : c->h, m - 1, &c->rh, false}};
     for (auto& q : qs) {
         if (!q.raw || !q.n) continue;
         if (!crs_fits((size_t)q.n * (q.g2 ? 224 : 112), reserve)) continue;
@@ -445,9 +448,10 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
         bool dropped = false;
         {
             std::lock_guard<std::mutex> lk(c->m);
-            if (c->h_table && c->refs.load() == 1) {
-                bzk_msm_table_free(ctx, c->h_table);
-                c->h_table = nullptr;
+            bzk_msm_table* t = c->h_table.load(std::memory_order_acquire);
+            if (t && c->refs.load() == 1) {
+                c->h_table.store(nullptr, std::memory_order_release);
+                bzk_msm_table_free(ctx, t);
                 dropped = true;
             }
         }
@@ -465,7 +469,7 @@ int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* p, int32_t on) {
     if (on) {
         crs_prepare(ctx, c);
         std::lock_guard<std::mutex> lk(c->m);
-        if (c->h_table) return BZK_OK;
+        if (c->h_table.load(std::memory_order_acquire)) return BZK_OK;  // (the build below is serialised by c->m: one table per CRS)
         const uint64_t m = (uint64_t)1 << c->log_m;
         if (c->log_m < 16 || m <= 1) return BZK_E_ARG;
         const uint32_t cw = c->log_m > 20 ? 20u : c->log_m;
@@ -473,20 +477,18 @@ int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* p, int32_t on) {
         //  - they see either no table or a finished one
         bzk_msm_table* t = nullptr;
         const int32_t st = bzk_msm_g1_table_build_c(ctx, c->h, m - 1, cw, &t);
-        if (st == BZK_OK) {
-            std::atomic_thread_fence(std::memory_order_release);
-            c->h_table = t;
-        }
+        if (st == BZK_OK) c->h_table.store(t, std::memory_order_release);
         return st;
     }
     std::lock_guard<std::mutex> lk(c->m);
     c->prepared = true;  // an explicit "off" also keeps the first proof from building it
-    if (!c->h_table) return BZK_OK;
+    bzk_msm_table* t = c->h_table.load(std::memory_order_acquire);
+    if (!t) return BZK_OK;
     if (c->refs.load() != 1) return BZK_E_ARG;
     (void)hipStreamSynchronize(ctx->stream);
     for (bzk_ctx* l : ctx->lanes) (void)hipStreamSynchronize(l->stream);
-    bzk_msm_table_free(ctx, c->h_table);
-    c->h_table = nullptr;
+    c->h_table.store(nullptr, std::memory_order_release);
+    bzk_msm_table_free(ctx, t);
     return BZK_OK;
 }
 
@@ -688,7 +690,7 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
         if (side) BZK_HIP(ctx, hipEventRecord(ctx->ev_h, ctx->stream));
         }
         if (side) BZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h, 0));
-        if (p->h_table) return bzk_msm_g1_table_run_dev(ctx, p->h_table, slot->d_a, m - 1, tflag, pH);
+        if (bzk_msm_table* ht = p->h_table.load(std::memory_order_acquire)) return bzk_msm_g1_table_run_dev(ctx, ht, slot->d_a, m - 1, tflag, pH);
         return g1(ctx, p->rh, p->h, slot->d_a, m - 1, tflag, pH);
     };
     const auto t2 = clk::now();

@@ -370,13 +370,16 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
         window_range(W, rank, mg->world, &lo, &hi);
         // local stage; its status travels with the exchange (RCCL, shared memory: the peers cannot see it otherwise)
         const int32_t lst = [&]() -> int32_t {
-            // test hook (tests/test_gpu_mg.py): "rank:call" makes that rank's local stage of that call of the group fail
+#ifdef BZK_TEST_HOOKS
+            // fault injection, compiled into bazuka_amd/libbzk_testhooks.so only (a stray environment variable must not be able
+            // to fail a production call): "rank:call" makes that rank's local stage of that call of the group fail (tests/test_gpu_mg.py)
             static const char* fault = getenv("BZK_MG_TEST_FAULT");
             if (fault) {
                 int fr = -1;
                 unsigned long long fs = 0;
                 if (sscanf(fault, "%d:%llu", &fr, &fs) == 2 && fr == rank && fs == seq) { c->last_error = "bzk_mg: injected fault"; return BZK_E_ALLOC; }
             }
+#endif
             const void* sc = scalars_dev ? scalars_dev[i] : nullptr;
             if (!scalars_dev && n) BZK_TRY(stage_scalars(mg, i, scalars_host, n, &sc));
             int32_t info[4] = {0, 0, 0, 0};

@@ -466,11 +466,17 @@ struct DevBatch {
             if (it != init_cache.end()) return it->second;
             return init_cache[k] = P.upload(w.accounts->get(lv, i));
         });
-        // test hook (tests/test_gpu_mpn_devtree.py): read per call, so a test can fail one batch and run the next
+#ifdef BZK_TEST_HOOKS
+        // fault injection, compiled into bazuka_amd/libbzk_testhooks.so only; read per call, so that a test can fail one
+        // batch and run the next (tests/test_gpu_mpn_devtree.py)
         const char* fault = getenv("BZK_MPN_TEST_FAULT");
-        const int32_t st = fault && fault[0] == '1' ? BZK_E_DEVICE : P.run(w.dev);
+        const bool injected = fault && fault[0] == '1';
+#else
+        const bool injected = false;
+#endif
+        const int32_t st = injected ? BZK_E_DEVICE : P.run(w.dev);
         if (st != BZK_OK) {
-            w.dev_error = fault && fault[0] == '1' ? "injected fault" : bzk_last_error(w.dev);
+            w.dev_error = injected ? "injected fault" : bzk_last_error(w.dev);
             return st;
         }
         // bring the host-side sparse account tree up to date: every event's leaf and ancestors, in time order (the last write wins)

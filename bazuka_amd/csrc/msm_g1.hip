@@ -92,6 +92,14 @@ int32_t bzk_msm_g1_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, c
 }
 void bzk_msm_bases_free(bzk_ctx* ctx, bzk_msm_bases* bases) { msm_bases_free(ctx, (MsmBases*)bases); }
 uint64_t bzk_msm_bases_size(const bzk_msm_bases* bases) { return bases ? ((const MsmBases*)bases)->n : 0; }
+int32_t bzk_msm_bases_info(const bzk_msm_bases* bases, uint64_t* n, int32_t* forms, uint64_t* device_bytes) {
+    const MsmBases* b = (const MsmBases*)bases;
+    if (!b) return BZK_E_ARG;
+    if (n) *n = b->n;
+    if (forms) *forms = b->endo;
+    if (device_bytes) *device_bytes = b->bytes;
+    return BZK_OK;
+}
 
 }  // extern "C"
 

@@ -1193,11 +1193,19 @@ struct MsmTable {
 // A resident base set in the policy's internal form (G1: 112 B, G2: 224 B per point): converted ONCE when a static point set - a
 // Groth16 CRS query - is loaded, shared read-only by every later call (and by every rank of a window-sharded MSM: no rank converts
 // anything per call).  bzk_msm_g*_bases_*.
+// endomorphism policy of a curve (msm_policy.cuh ENDO_DEFAULT; env BZK_MSM_ENDO_G1 / _G2): 0 never, 1 every whole-MSM call over a set
+// with images, 2 only calls flagged BZK_F_THROUGHPUT.  ONE predicate for load time (are the images worth their memory?) and run time
+template <class C>
+static int msm_endo_mode() {
+    static const int mode = [] { const char* e = getenv(C::ENDO_ENV); return e ? atoi(e) : C::ENDO_DEFAULT; }();
+    return mode;
+}
 struct MsmBases {
     void* data = nullptr;  // DevAff[endo][n]: the set itself, then (endo > 1) its images X^m P, m = 1 .. endo - 1 (bzk_endo.cuh)
     uint64_t n = 0;
     int device = 0;
     int endo = 1;
+    size_t bytes = 0;  // device memory of `data` (bzk_msm_bases_info)
 };
 // Where a call that must not finish on this host thread leaves its window sums: `d_win` receives, in DEVICE memory and in stream
 // order, the (w_end - w_begin) window sums S_w as standard-limb XYZZ points; no read-back, no Horner, no synchronisation.  The
@@ -1248,7 +1256,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     // resp. 1 / 4 of the buckets to reduce.  Calls that name a window range or leave their window sums on the device (the
     // multi-GPU entry points) keep the plain form: their partition is defined over the plain windows.
     int E = 1, ibits = 31;
-    static const int endo_mode = [] { const char* e = getenv(C::ENDO_ENV); return e ? atoi(e) : C::ENDO_DEFAULT; }();
+    const int endo_mode = msm_endo_mode<C>();
     const bool endo_wanted = endo_mode == 1 || (endo_mode == 2 && (flags & BZK_F_THROUGHPUT));
     if (endo_wanted && prep && prep->endo > 1 && !table && !wout && w_begin == 0 && w_end < 0 && !ctx->msm_no_endo && !wiv_off) {
         const int e = prep->endo, ib = 27 - (e == 4 ? 2 : 1), ws = (C::ENDO_BITS + c - 1) / c;
@@ -1675,8 +1683,9 @@ static int32_t msm_bases_load(bzk_ctx* ctx, const void* bases_raw, uint64_t n, M
     if (!b) return BZK_E_ALLOC;
     b->n = n;
     b->device = ctx->device;
-    // with its endomorphism images (E x the memory) unless the context opts out or the device has no room for them beside a reserve
-    b->endo = ctx->msm_no_endo ? 1 : C::ENDO;
+    // with its endomorphism images (E x the memory) unless no call could ever use them - the curve's policy is 0, or the context opts
+    // out (BZK_MSM_NO_ENDO, device groups) - or the device has no room for them beside a reserve.  bzk_msm_bases_info reports the outcome
+    b->endo = (ctx->msm_no_endo || msm_endo_mode<C>() == 0) ? 1 : C::ENDO;
     if (b->endo > 1) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
@@ -1708,6 +1717,7 @@ static int32_t msm_bases_load(bzk_ctx* ctx, const void* bases_raw, uint64_t n, M
         delete b;
         return st;
     }
+    b->bytes = (size_t)b->endo * n * sizeof(typename C::DevAff);
     *out = b;
     return BZK_OK;
 }

@@ -133,6 +133,7 @@ struct Plan {
     std::vector<uint32_t> inputs;  // their input ids, back to back (node ids are offset by `hash_base` once all leaves are known)
     uint64_t n_pairs = 0;
     std::string err;
+    int32_t code = 0;  // BZK_REFUSE_* of `err`
 };
 constexpr uint32_t HASHED = 0x80000000u;  // input id tag: index into Plan::nodes (resolved after levelling)
 
@@ -157,7 +158,7 @@ struct Builder {
     uint32_t hashed(const std::vector<uint32_t>& in) {
         uint32_t lv = 0;
         for (uint32_t x : in) lv = std::max(lv, level_of(x));
-        if (P.nodes.size() >= 0x7ffffff0u) { P.err = "too many nodes"; return 0; }
+        if (P.nodes.size() >= 0x7ffffff0u) { P.err = "too many nodes"; P.code = BZK_REFUSE_OTHER; return 0; }
         P.nodes.push_back({(uint32_t)P.inputs.size(), (uint32_t)in.size(), lv + 1});
         P.inputs.insert(P.inputs.end(), in.begin(), in.end());
         return HASHED | (uint32_t)(P.nodes.size() - 1);
@@ -168,12 +169,12 @@ struct Builder {
         if (!P.err.empty()) return 0;
         if (n.kind == 0) {
             // `set_data`: the locator must end exactly here (NonScalarLocatorError / LocatorError otherwise); a HashMap holds a key once
-            if (hi - lo != 1) { P.err = "duplicate locator"; return 0; }
-            if (len(lo) != d) { P.err = "locator points below a scalar (ZkLocatorError::InvalidLocator)"; return 0; }
+            if (hi - lo != 1) { P.err = "duplicate locator"; P.code = BZK_REFUSE_DUPLICATE_LOCATOR; return 0; }
+            if (len(lo) != d) { P.err = "locator points below a scalar (ZkLocatorError::InvalidLocator)"; P.code = BZK_REFUSE_INVALID_LOCATOR; return 0; }
             return 0x40000000u | (uint32_t)order[lo];  // pair value, resolved to consts.size() + pair index
         }
         for (uint64_t i = lo; i < hi; ++i)
-            if (len(i) <= d) { P.err = "locator does not reach a scalar (StateManagerError::NonScalarLocatorError)"; return 0; }
+            if (len(i) <= d) { P.err = "locator does not reach a scalar (StateManagerError::NonScalarLocatorError)"; P.code = BZK_REFUSE_NON_SCALAR_LOCATOR; return 0; }
         if (n.kind == 1) {
             std::vector<uint32_t> in(n.fields.size());
             uint64_t i = lo;
@@ -183,7 +184,7 @@ struct Builder {
                 in[f] = j > i ? build(n.fields[f], d + 1, i, j) : cst(n.fields[f], -1, M.nodes[n.fields[f]].dflt);
                 i = j;
             }
-            if (i != hi) { P.err = "struct field index out of range (the reference indexes field_types out of bounds)"; return 0; }
+            if (i != hi) { P.err = "struct field index out of range (the reference indexes field_types out of bounds)"; P.code = BZK_REFUSE_INVALID_LOCATOR; return 0; }
             return hashed(in);
         }
         // List: items first, then the sparse 4-ary tree over them, level by level
@@ -191,7 +192,7 @@ struct Builder {
         std::vector<std::pair<uint64_t, uint32_t>> cur;  // (index at the current depth, value id), ascending
         for (uint64_t i = lo; i < hi;) {
             const uint64_t idx = at(i, d);
-            if (idx >= size) { P.err = "list index out of range (ZkLocatorError::InvalidLocator)"; return 0; }
+            if (idx >= size) { P.err = "list index out of range (ZkLocatorError::InvalidLocator)"; P.code = BZK_REFUSE_INVALID_LOCATOR; return 0; }
             uint64_t j = i;
             while (j < hi && at(j, d) == idx) ++j;
             cur.push_back({idx, build(n.item, d + 1, i, j)});
@@ -236,7 +237,7 @@ int32_t compress_core(bzk_ctx* ctx, const Model& M, const uint64_t* loc_off, con
         memcpy(f.l, v, 32);
         Fr g = f;
         fe_reduce_once<FrParams>(g);
-        if (!g.equals(f)) { ctx->last_error = "state_compress: a value is not a canonical field element"; return BZK_E_ARG; }
+        if (!g.equals(f)) { ctx->last_error = "state_compress: a value is not a canonical field element"; ctx->last_refusal = BZK_REFUSE_NON_CANONICAL_VALUE; return BZK_E_ARG; }
     }
     if (state_size) *state_size = nz;
     if (n == 0) {
@@ -258,6 +259,7 @@ int32_t compress_core(bzk_ctx* ctx, const Model& M, const uint64_t* loc_off, con
     const uint32_t top = B.build(M.root, 0, 0, n);
     if (!P.err.empty()) {
         ctx->last_error = "state_compress: " + P.err;
+        ctx->last_refusal = P.code;
         return BZK_E_ARG;
     }
     const uint32_t n_const = (uint32_t)P.consts.size();
@@ -460,6 +462,7 @@ struct UpPlan {
     std::vector<uint32_t> scalar_dst;                // per pair: its slot
     uint32_t next_slot = 0;
     std::string err;
+    int32_t code = 0;  // BZK_REFUSE_* of `err`
 };
 struct Updater {
     bzk_state& S;
@@ -474,7 +477,7 @@ struct Updater {
     uint32_t slot_for(const Key& k) {  // the slot of a key that is being written: its own, or a fresh one
         auto it = S.slot_of.find(k);
         if (it != S.slot_of.end()) return it->second;
-        if (P.next_slot >= 0x7ffffff0u) { P.err = "too many nodes"; return 0; }
+        if (P.next_slot >= 0x7ffffff0u) { P.err = "too many nodes"; P.code = BZK_REFUSE_OTHER; return 0; }
         P.new_keys.push_back({k, P.next_slot});
         return P.next_slot++;
     }
@@ -493,14 +496,14 @@ struct Updater {
         const ModelNode& n = S.M.nodes[m];
         if (!P.err.empty()) return {0, 0};
         if (n.kind == 0) {
-            if (hi - lo != 1) { P.err = "duplicate locator"; return {0, 0}; }
-            if (len(lo) != d) { P.err = "locator points below a scalar (ZkLocatorError::InvalidLocator)"; return {0, 0}; }
+            if (hi - lo != 1) { P.err = "duplicate locator"; P.code = BZK_REFUSE_DUPLICATE_LOCATOR; return {0, 0}; }
+            if (len(lo) != d) { P.err = "locator points below a scalar (ZkLocatorError::InvalidLocator)"; P.code = BZK_REFUSE_INVALID_LOCATOR; return {0, 0}; }
             const uint32_t s = slot_for(prefix);
             P.scalar_dst[order[lo]] = s;
             return {s, 0};
         }
         for (uint64_t i = lo; i < hi; ++i)
-            if (len(i) <= d) { P.err = "locator does not reach a scalar (StateManagerError::NonScalarLocatorError)"; return {0, 0}; }
+            if (len(i) <= d) { P.err = "locator does not reach a scalar (StateManagerError::NonScalarLocatorError)"; P.code = BZK_REFUSE_NON_SCALAR_LOCATOR; return {0, 0}; }
         if (n.kind == 1) {
             std::vector<uint32_t> in(n.fields.size());
             uint32_t lv = 0;
@@ -519,7 +522,7 @@ struct Updater {
                 prefix.pop_back();
                 i = j;
             }
-            if (i != hi) { P.err = "struct field index out of range (the reference indexes field_types out of bounds)"; return {0, 0}; }
+            if (i != hi) { P.err = "struct field index out of range (the reference indexes field_types out of bounds)"; P.code = BZK_REFUSE_INVALID_LOCATOR; return {0, 0}; }
             if (!P.err.empty()) return {0, 0};
             return hashed(prefix, in, lv + 1);
         }
@@ -528,7 +531,7 @@ struct Updater {
         std::vector<Cur> cur;
         for (uint64_t i = lo; i < hi;) {
             const uint64_t idx = at(i, d);
-            if (idx >= size) { P.err = "list index out of range (ZkLocatorError::InvalidLocator)"; return {0, 0}; }
+            if (idx >= size) { P.err = "list index out of range (ZkLocatorError::InvalidLocator)"; P.code = BZK_REFUSE_INVALID_LOCATOR; return {0, 0}; }
             uint64_t j = i;
             while (j < hi && at(j, d) == idx) ++j;
             prefix.push_back(idx);
@@ -592,7 +595,7 @@ int32_t state_update_impl(bzk_state* S, const uint64_t* loc_off, const uint64_t*
         memcpy(f.l, values + 32 * i, 32);
         Fr g = f;
         fe_reduce_once<FrParams>(g);
-        if (!g.equals(f)) { ctx->last_error = "state_update: a value is not a canonical field element"; return BZK_E_ARG; }
+        if (!g.equals(f)) { ctx->last_error = "state_update: a value is not a canonical field element"; ctx->last_refusal = BZK_REFUSE_NON_CANONICAL_VALUE; return BZK_E_ARG; }
     }
     if (n == 0) {
         S->height = target_height;
@@ -610,6 +613,7 @@ int32_t state_update_impl(bzk_state* S, const uint64_t* loc_off, const uint64_t*
     const Updater::Val top = U.build(S->M.root, 0, 0, n);
     if (!P.err.empty()) {
         ctx->last_error = "state_update: " + P.err;
+        ctx->last_refusal = P.code;
         return BZK_E_ARG;
     }
     (void)hipSetDevice(ctx->device);
@@ -665,10 +669,19 @@ int32_t state_update_impl(bzk_state* S, const uint64_t* loc_off, const uint64_t*
     uint32_t* d_dst = cur.take<uint32_t>(gdst.size());
     Fr* d_in = cur.take<Fr>(widest);
     Fr* d_out = cur.take<Fr>(widest);
-    BZK_HIP(ctx, hipMemcpyAsync(d_new, values, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
-    BZK_HIP(ctx, hipMemcpyAsync(d_sdst, P.scalar_dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (!gidx.empty()) BZK_HIP(ctx, hipMemcpyAsync(d_idx, gidx.data(), gidx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (!gdst.empty()) BZK_HIP(ctx, hipMemcpyAsync(d_dst, gdst.data(), gdst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the sources of these copies are pageable vectors of this frame and the caller's `values`: no early return may leave one of
+    // them in flight - a failed upload waits for the stream before it reports
+    auto upload = [&]() -> int32_t {
+        BZK_HIP(ctx, hipMemcpyAsync(d_new, values, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(d_sdst, P.scalar_dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!gidx.empty()) BZK_HIP(ctx, hipMemcpyAsync(d_idx, gidx.data(), gidx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!gdst.empty()) BZK_HIP(ctx, hipMemcpyAsync(d_dst, gdst.data(), gdst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        return BZK_OK;
+    };
+    if (const int32_t up = upload(); up != BZK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return up;  // no slot was written yet: the state is still the old one
+    }
     // from here on the slots change: a failure leaves them half-written
     auto run = [&]() -> int32_t {
         BZK_LAUNCH(ctx, "state_scatter", state_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Fr*)d_new, (const uint32_t*)d_sdst,
@@ -688,6 +701,7 @@ int32_t state_update_impl(bzk_state* S, const uint64_t* loc_off, const uint64_t*
     };
     const int32_t st = run();
     if (st != BZK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);  // whatever was queued reads this frame's vectors: let it finish (or fail) first
         S->poisoned = true;
         return st;
     }
@@ -751,6 +765,18 @@ int32_t hash_plan_run(bzk_ctx* ctx, const uint8_t* uploaded, uint64_t n_up, cons
 }
 }  // namespace bzk
 
+// bzk_last_refusal (include/bzk.h): every public state call starts with "not refused"; a BZK_E_ARG that no site classified is OTHER
+template <class Fn>
+static int32_t refusal_scope(bzk_ctx* ctx, Fn&& fn) {
+    if (ctx) ctx->last_refusal = BZK_REFUSE_NONE;
+    const int32_t st = fn();
+    if (ctx) {
+        if (st != BZK_E_ARG) ctx->last_refusal = BZK_REFUSE_NONE;
+        else if (ctx->last_refusal == BZK_REFUSE_NONE) ctx->last_refusal = BZK_REFUSE_OTHER;
+    }
+    return st;
+}
+
 extern "C" {
 
 int32_t bzk_state_model_default(const uint8_t* model, uint64_t model_len, uint8_t out[32]) {
@@ -761,7 +787,7 @@ int32_t bzk_state_model_default(const uint8_t* model, uint64_t model_len, uint8_
     return BZK_OK;
 }
 
-int32_t bzk_state_compress(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint64_t* loc_off, const uint64_t* loc,
+static int32_t state_entry_compress(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint64_t* loc_off, const uint64_t* loc,
                            const uint8_t* values, uint64_t n, uint8_t state_hash[32], uint64_t* state_size) {
     if (!ctx || !state_hash || (n && (!loc_off || !values))) return BZK_E_ARG;
     if (n && loc_off[n] && !loc) return BZK_E_ARG;
@@ -776,7 +802,7 @@ int32_t bzk_state_compress(bzk_ctx* ctx, const uint8_t* model, uint64_t model_le
 
 // pairs = bincode(ZkDataPairs) = HashMap<ZkDataLocator, ZkScalar>: u64 count, then per entry Vec<u64> (u64 length + items) and the
 // scalar's four Montgomery limbs (src/zk/mod.rs:202-206, 425-426, 469-470).  out = bincode(ZkCompressedState) = state_hash | u64 state_size
-int32_t bzk_state_compress_bincode(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint8_t* pairs, uint64_t pairs_len,
+static int32_t state_entry_compress_bincode(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint8_t* pairs, uint64_t pairs_len,
                                    uint8_t compressed_out[40]) {
     if (!ctx || !pairs || !compressed_out) return BZK_E_ARG;
     Rd r{pairs, pairs_len};
@@ -796,7 +822,7 @@ int32_t bzk_state_compress_bincode(bzk_ctx* ctx, const uint8_t* model, uint64_t 
     }
     if (!r.ok || r.off != pairs_len) return BZK_E_ARG;
     uint64_t size = 0;
-    BZK_TRY(bzk_state_compress(ctx, model, model_len, off.data(), loc.data(), vals.data(), n, compressed_out, &size));
+    BZK_TRY(state_entry_compress(ctx, model, model_len, off.data(), loc.data(), vals.data(), n, compressed_out, &size));
     memcpy(compressed_out + 32, &size, 8);
     return BZK_OK;
 }
@@ -844,7 +870,7 @@ void bzk_state_free(bzk_state* st) {
     delete st;  // frees the value store (see ~bzk_state)
 }
 
-int32_t bzk_state_update(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, const uint8_t* values, uint64_t n, uint64_t target_height,
+static int32_t state_entry_update(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, const uint8_t* values, uint64_t n, uint64_t target_height,
                          uint8_t state_hash[32], uint64_t* state_size, uint8_t* prev_values_out) {
     if (!st || (n && (!loc_off || !values))) return BZK_E_ARG;
     if (n && loc_off[n] && !loc) return BZK_E_ARG;
@@ -858,7 +884,7 @@ int32_t bzk_state_update(bzk_state* st, const uint64_t* loc_off, const uint64_t*
 
 // delta = bincode(ZkDeltaPairs) = HashMap<ZkDataLocator, Option<ZkScalar>> (src/zk/mod.rs:473-474): u64 count; per entry Vec<u64>,
 // the Option's u8 tag, the four Montgomery limbs when Some.  None writes zero, as `update_contract` does (`v.unwrap_or_default()`).
-int32_t bzk_state_update_bincode(bzk_state* st, const uint8_t* delta, uint64_t delta_len, uint64_t target_height, uint8_t compressed_out[40]) {
+static int32_t state_entry_update_bincode(bzk_state* st, const uint8_t* delta, uint64_t delta_len, uint64_t target_height, uint8_t compressed_out[40]) {
     if (!st || !delta || !compressed_out) return BZK_E_ARG;
     Rd r{delta, delta_len};
     const uint64_t n = r.u(8);
@@ -880,7 +906,7 @@ int32_t bzk_state_update_bincode(bzk_state* st, const uint8_t* delta, uint64_t d
     }
     if (!r.ok || r.off != delta_len) return BZK_E_ARG;
     uint64_t size = 0;
-    BZK_TRY(bzk_state_update(st, off.data(), loc.data(), vals.data(), n, target_height, compressed_out, &size, nullptr));
+    BZK_TRY(state_entry_update(st, off.data(), loc.data(), vals.data(), n, target_height, compressed_out, &size, nullptr));
     memcpy(compressed_out + 32, &size, 8);
     return BZK_OK;
 }
@@ -897,7 +923,7 @@ int32_t bzk_state_root(bzk_state* st, uint8_t state_hash[32], uint64_t* state_si
 
 // `get_data` for n locators: the value at each (a scalar, or the hash of the struct / list it names), the type's default where
 // nothing was ever written
-int32_t bzk_state_get(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, uint64_t n, uint8_t* values_out) {
+static int32_t state_entry_get(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, uint64_t n, uint8_t* values_out) {
     if (!st || (n && (!loc_off || !values_out))) return BZK_E_ARG;
     if (n && loc_off[n] && !loc) return BZK_E_ARG;
     std::lock_guard<std::mutex> g(st->m);
@@ -912,6 +938,7 @@ int32_t bzk_state_get(bzk_state* st, const uint64_t* loc_off, const uint64_t* lo
         const int m = state_locate(st->M, l, len);
         if (m < 0) {
             st->ctx->last_error = "state_get: the locator names nothing in this model (ZkLocatorError::InvalidLocator)";
+            st->ctx->last_refusal = BZK_REFUSE_INVALID_LOCATOR;
             return BZK_E_ARG;
         }
         k.assign(l, l + len);
@@ -923,7 +950,7 @@ int32_t bzk_state_get(bzk_state* st, const uint64_t* loc_off, const uint64_t* lo
 
 // `prove` (src/zk/state/mod.rs:218-264) for n indices of the list at `tree_loc`: per index log4_size x 3 scalars, leaf level first,
 // the three siblings of each level in ascending position
-int32_t bzk_state_prove(bzk_state* st, const uint64_t* tree_loc, uint64_t tree_loc_len, const uint64_t* indices, uint64_t n, uint8_t* proof_out,
+static int32_t state_entry_prove(bzk_state* st, const uint64_t* tree_loc, uint64_t tree_loc_len, const uint64_t* indices, uint64_t n, uint8_t* proof_out,
                         uint32_t* log4_size) {
     if (!st || (tree_loc_len && !tree_loc) || (n && (!indices || !proof_out))) return BZK_E_ARG;
     std::lock_guard<std::mutex> g(st->m);
@@ -931,11 +958,13 @@ int32_t bzk_state_prove(bzk_state* st, const uint64_t* tree_loc, uint64_t tree_l
     const int m = state_locate(st->M, tree_loc, tree_loc_len);
     if (m < 0) {
         st->ctx->last_error = "state_prove: the locator names nothing in this model (ZkLocatorError::InvalidLocator)";
+        st->ctx->last_refusal = BZK_REFUSE_INVALID_LOCATOR;
         return BZK_E_ARG;
     }
     const ModelNode& nd = st->M.nodes[m];
     if (nd.kind != 2) {
         st->ctx->last_error = "state_prove: not locating a tree (StateManagerError::NonTreeLocatorError)";
+        st->ctx->last_refusal = BZK_REFUSE_NON_TREE_LOCATOR;
         return BZK_E_ARG;
     }
     if (log4_size) *log4_size = (uint32_t)nd.log4;
@@ -947,6 +976,7 @@ int32_t bzk_state_prove(bzk_state* st, const uint64_t* tree_loc, uint64_t tree_l
         uint64_t cur = indices[i];
         if (nd.log4 < 32 && cur >= ((uint64_t)1 << (2 * nd.log4))) {
             st->ctx->last_error = "state_prove: index beyond the list";
+            st->ctx->last_refusal = BZK_REFUSE_INVALID_LOCATOR;
             return BZK_E_ARG;
         }
         for (int d = nd.log4; d > 0; --d) {  // siblings at depth d
@@ -976,6 +1006,25 @@ int32_t bzk_state_stats(bzk_state* st, uint64_t* slots, uint64_t* device_bytes, 
     if (device_bytes) *device_bytes = st->cap * sizeof(Fr);
     if (keys) *keys = st->slot_of.size();
     return BZK_OK;
+}
+
+int32_t bzk_state_compress(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint64_t* loc_off, const uint64_t* loc, const uint8_t* values, uint64_t n, uint8_t state_hash[32], uint64_t* state_size) {
+    return refusal_scope(ctx, [&] { return state_entry_compress(ctx, model, model_len, loc_off, loc, values, n, state_hash, state_size); });
+}
+int32_t bzk_state_compress_bincode(bzk_ctx* ctx, const uint8_t* model, uint64_t model_len, const uint8_t* pairs, uint64_t pairs_len, uint8_t compressed_out[40]) {
+    return refusal_scope(ctx, [&] { return state_entry_compress_bincode(ctx, model, model_len, pairs, pairs_len, compressed_out); });
+}
+int32_t bzk_state_update(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, const uint8_t* values, uint64_t n, uint64_t target_height, uint8_t state_hash[32], uint64_t* state_size, uint8_t* prev_values_out) {
+    return refusal_scope((st ? st->ctx : nullptr), [&] { return state_entry_update(st, loc_off, loc, values, n, target_height, state_hash, state_size, prev_values_out); });
+}
+int32_t bzk_state_update_bincode(bzk_state* st, const uint8_t* delta, uint64_t delta_len, uint64_t target_height, uint8_t compressed_out[40]) {
+    return refusal_scope((st ? st->ctx : nullptr), [&] { return state_entry_update_bincode(st, delta, delta_len, target_height, compressed_out); });
+}
+int32_t bzk_state_get(bzk_state* st, const uint64_t* loc_off, const uint64_t* loc, uint64_t n, uint8_t* values_out) {
+    return refusal_scope((st ? st->ctx : nullptr), [&] { return state_entry_get(st, loc_off, loc, n, values_out); });
+}
+int32_t bzk_state_prove(bzk_state* st, const uint64_t* tree_loc, uint64_t tree_loc_len, const uint64_t* indices, uint64_t n, uint8_t* proof_out, uint32_t* log4_size) {
+    return refusal_scope((st ? st->ctx : nullptr), [&] { return state_entry_prove(st, tree_loc, tree_loc_len, indices, n, proof_out, log4_size); });
 }
 
 }  // extern "C"

@@ -27,9 +27,11 @@ SIGNATURES = {
     "bzk_sync": (_i32, [_vp]),
     "bzk_strerror": (C.c_char_p, [_i32]),
     "bzk_last_error": (C.c_char_p, [_vp]),
+    "bzk_last_refusal": (_i32, [_vp]),
     "bzk_abi_version": (_u32, []),
     "bzk_dev_alloc": (_i32, [_vp, _u64, C.POINTER(_vp)]),
     "bzk_dev_free": (_i32, [_vp, _vp]),
+    "bzk_ctx_trim": (_i32, [_vp, C.POINTER(_u64)]),
     "bzk_h2d": (_i32, [_vp, _vp, _vp, _u64]),
     "bzk_d2h": (_i32, [_vp, _vp, _vp, _u64]),
     "bzk_prof_enable": (_i32, [_vp, _i32]),
@@ -145,6 +147,7 @@ SIGNATURES = {
     "bzk_msm_g2_bases_load_dev": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
     "bzk_msm_bases_free": (None, [_vp, _vp]),
     "bzk_msm_bases_size": (_u64, [_vp]),
+    "bzk_msm_bases_info": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_i32), C.POINTER(_u64)]),
     "bzk_msm_g1_bases_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "bzk_msm_g2_bases_run_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "bzk_msm_g1_bases_windows_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
@@ -272,6 +275,16 @@ class Bzk:
 
     def sync(self):
         self._ck(self.lib.bzk_sync(self.h), "sync")
+
+    def trim(self) -> int:
+        """hand the grow-only call workspace back to the device (after a one-off large call); returns the bytes released"""
+        n = C.c_uint64(0)
+        self._ck(self.lib.bzk_ctx_trim(self.h, C.byref(n)), "ctx_trim")
+        return n.value
+
+    def last_refusal(self) -> int:
+        """BZK_REFUSE_*: which of the reference's errors the last refused bzk_state_* call stands for"""
+        return self.lib.bzk_last_refusal(self.h)
 
     # ---- profiling
     def prof_filter(self, substr: str | None):
@@ -402,6 +415,11 @@ class Bzk:
         fn = self.lib.bzk_msm_g2_bases_load_dev if g2 else self.lib.bzk_msm_g1_bases_load_dev
         self._ck(fn(self.h, _ptr(bases), n, C.byref(h)), "msm_bases_load_dev")
         return h
+
+    def msm_bases_info(self, handle) -> dict:
+        n, forms, nbytes = C.c_uint64(0), C.c_int32(0), C.c_uint64(0)
+        self._ck(self.lib.bzk_msm_bases_info(handle, C.byref(n), C.byref(forms), C.byref(nbytes)), "msm_bases_info")
+        return {"n": n.value, "forms": forms.value, "device_bytes": nbytes.value}
 
     def msm_bases_free(self, handle):
         self.lib.bzk_msm_bases_free(self.h, handle)

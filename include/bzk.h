@@ -54,11 +54,27 @@ void bzk_ctx_destroy(bzk_ctx* ctx);
 int32_t bzk_sync(bzk_ctx* ctx); /* wait for the ctx stream */
 const char* bzk_strerror(int32_t status);
 const char* bzk_last_error(bzk_ctx* ctx); /* detail of the last BZK_E_DEVICE on this ctx */
+/* Which of the reference's errors the last BZK_E_ARG of a bzk_state_* call on this ctx stands for, so that a Rust host can return
+ * `StateManagerError::{LocatorError(InvalidLocator), NonScalarLocatorError, NonTreeLocatorError}` (src/zk/state/mod.rs:12-27,
+ * src/zk/mod.rs:348-351) instead of parsing bzk_last_error; 0 after a state call that was not refused.  OTHER = malformed input the
+ * reference cannot express (bad bincode, locator offsets out of order, counts beyond the ABI's limits). */
+#define BZK_REFUSE_NONE 0
+#define BZK_REFUSE_INVALID_LOCATOR 1     /* names nothing in the model, index beyond a list / struct, points below a scalar */
+#define BZK_REFUSE_NON_SCALAR_LOCATOR 2  /* ends above a scalar where a scalar is written */
+#define BZK_REFUSE_NON_TREE_LOCATOR 3    /* `prove` on something that is not a list */
+#define BZK_REFUSE_DUPLICATE_LOCATOR 4   /* the same locator twice in one delta (a HashMap cannot hold that) */
+#define BZK_REFUSE_NON_CANONICAL_VALUE 5 /* 32 bytes that are not the Montgomery limbs of a residue (a ZkScalar cannot hold that) */
+#define BZK_REFUSE_OTHER 6
+int32_t bzk_last_refusal(bzk_ctx* ctx);
 uint32_t bzk_abi_version(void);
 
 /* device-memory plumbing for hosts that want to keep inputs resident without a tensor library */
 int32_t bzk_dev_alloc(bzk_ctx* ctx, uint64_t bytes, void** dptr);
 int32_t bzk_dev_free(bzk_ctx* ctx, void* dptr);
+/* The call workspace of a ctx is grow-only (one slab, re-used by every call: no allocation on the hot path).  After a one-off large
+ * call - a 2^26-point MSM leaves ~24 GB behind - bzk_ctx_trim waits for the stream and hands the slab back to the device; the next
+ * call allocates what it needs.  *released (may be NULL) = bytes freed. */
+int32_t bzk_ctx_trim(bzk_ctx* ctx, uint64_t* released);
 int32_t bzk_h2d(bzk_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int32_t bzk_d2h(bzk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 
@@ -459,6 +475,11 @@ int32_t bzk_msm_g1_bases_load_dev(bzk_ctx* ctx, const void* bases_dev, uint64_t 
 int32_t bzk_msm_g2_bases_load_dev(bzk_ctx* ctx, const void* bases_dev, uint64_t n, bzk_msm_bases** out);
 void bzk_msm_bases_free(bzk_ctx* ctx, bzk_msm_bases* bases);
 uint64_t bzk_msm_bases_size(const bzk_msm_bases* bases);
+/* What a load decided: *forms = 1 (the set alone) or the number of arrays held - the set plus its endomorphism images X^m P (G1: 2,
+ * G2: 4), which whole-MSM calls flagged BZK_F_THROUGHPUT use (fewer bucket sets, same additions, same result).  The images are built
+ * at load unless no call could use them (BZK_MSM_ENDO_G1 / _G2 = 0, BZK_MSM_NO_ENDO = 1, device groups) or they do not fit beside an
+ * 8 GiB reserve; *device_bytes = HBM held by the set. */
+int32_t bzk_msm_bases_info(const bzk_msm_bases* bases, uint64_t* n, int32_t* forms, uint64_t* device_bytes);
 int32_t bzk_msm_g1_bases_run_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[97]);
 int32_t bzk_msm_g2_bases_run_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags, uint8_t out[193]);
 int32_t bzk_msm_g1_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* scalars_dev, uint64_t n, uint32_t flags,

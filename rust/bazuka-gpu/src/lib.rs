@@ -81,16 +81,15 @@ impl Gpu {
     }
 
     /// `ZkStateModel::compress::<PoseidonHasher>(&data)` (src/zk/mod.rs:392-399) for any model over sparse pairs
-    pub fn compress(&self, model: &ZkStateModel, data: &ZkDataPairs) -> Result<ZkCompressedState, StateManagerError> {
-        let m = bincode::serialize(model).expect("ZkStateModel serialises");
-        let d = bincode::serialize(data).expect("ZkDataPairs serialises");
+    pub fn compress(&self, model: &ZkStateModel, data: &ZkDataPairs) -> Result<ZkCompressedState, DeviceStateError> {
+        let m = bincode::serialize(model).map_err(GpuError::from)?;
+        let d = bincode::serialize(data).map_err(GpuError::from)?;
         let mut out = [0u8; 40];
         let st = unsafe { sys::bzk_state_compress_bincode(self.0, m.as_ptr(), m.len() as u64, d.as_ptr(), d.len() as u64, out.as_mut_ptr()) };
         match st {
-            sys::BZK_OK => Ok(bincode::deserialize(&out).expect("40-byte ZkCompressedState")),
-            // the library refuses exactly what the reference reports as a locator error (or panics on)
-            sys::BZK_E_ARG => Err(StateManagerError::LocatorError(ZkLocatorError::InvalidLocator)),
-            e => panic!("libbzk state_compress: status {}", e),
+            sys::BZK_OK => Ok(bincode::deserialize(&out).map_err(GpuError::from)?),
+            // refused exactly where the reference reports LocatorError / NonScalarLocatorError (or panics); device failures as GpuError
+            e => Err(state_error(self.0, e)),
         }
     }
 }
@@ -112,12 +111,32 @@ pub struct DeviceStateManager<'g> {
 }
 unsafe impl Send for DeviceStateManager<'_> {}
 
-fn locator_error(st: i32) -> StateManagerError {
-    match st {
-        // refused exactly where the reference returns LocatorError / NonScalarLocatorError / NonTreeLocatorError
-        sys::BZK_E_ARG => StateManagerError::LocatorError(ZkLocatorError::InvalidLocator),
-        e => panic!("libbzk device state: status {}", e),
+/// What a `DeviceStateManager` call can fail with: the reference's own `StateManagerError` where the library REFUSED the request
+/// (nothing changed), or a device-side failure the reference has no variant for (out of HBM while the value store grows; a device
+/// error in the middle of an update, after which the handle answers `BZK_E_DEVICE` to everything).  Never a panic.
+#[derive(thiserror::Error, Debug)]
+pub enum DeviceStateError {
+    #[error(transparent)]
+    State(#[from] StateManagerError),
+    #[error(transparent)]
+    Gpu(#[from] GpuError),
+}
+
+/// Maps a non-OK status of a `bzk_state_*` call.  `BZK_E_ARG` = refused: `bzk_last_refusal` says which of the reference's errors it
+/// stands for (src/zk/state/mod.rs:12-27, src/zk/mod.rs:348-351); anything else is a device / allocation failure and travels as
+/// `GpuError::Status` with `bzk_last_error`'s text.
+fn state_error(ctx: *mut sys::bzk_ctx, st: i32) -> DeviceStateError {
+    if st == sys::BZK_E_ARG {
+        return DeviceStateError::State(match unsafe { sys::bzk_last_refusal(ctx) } {
+            sys::BZK_REFUSE_NON_SCALAR_LOCATOR => StateManagerError::NonScalarLocatorError,
+            sys::BZK_REFUSE_NON_TREE_LOCATOR => StateManagerError::NonTreeLocatorError,
+            // InvalidLocator proper; a duplicate locator / a non-canonical value cannot be expressed by the Rust types that produced
+            // the bincode (a HashMap key occurs once, a ZkScalar is a residue) and malformed bincode cannot come out of `serialize`:
+            // all of them mean "this request names something the state does not have"
+            _ => StateManagerError::LocatorError(ZkLocatorError::InvalidLocator),
+        });
     }
+    DeviceStateError::Gpu(check(ctx, st).unwrap_err())
 }
 
 impl<'g> DeviceStateManager<'g> {
@@ -130,25 +149,26 @@ impl<'g> DeviceStateManager<'g> {
     }
 
     /// `update_contract(db, id, patch, target_height)` (src/zk/state/mod.rs:286-308): all or nothing
-    pub fn update_contract(&mut self, patch: &ZkDeltaPairs, target_height: u64) -> Result<ZkCompressedState, StateManagerError> {
-        let d = bincode::serialize(patch).expect("ZkDeltaPairs serialises");
+    pub fn update_contract(&mut self, patch: &ZkDeltaPairs, target_height: u64) -> Result<ZkCompressedState, DeviceStateError> {
+        let d = bincode::serialize(patch).map_err(GpuError::from)?;
         let mut out = [0u8; 40];
         match unsafe { sys::bzk_state_update_bincode(self.st, d.as_ptr(), d.len() as u64, target_height, out.as_mut_ptr()) } {
-            sys::BZK_OK => Ok(bincode::deserialize(&out).expect("40-byte ZkCompressedState")),
-            e => Err(locator_error(e)),
+            sys::BZK_OK => Ok(bincode::deserialize(&out).map_err(GpuError::from)?),
+            e => Err(state_error(self.gpu.0, e)),
         }
     }
 
     /// `root` (:274-284) and `height_of` (:210-216)
-    pub fn root(&self) -> (ZkCompressedState, u64) {
+    pub fn root(&self) -> Result<(ZkCompressedState, u64), DeviceStateError> {
         let (mut hash, mut size, mut height) = (ZkScalar::default(), 0u64, 0u64);
-        let st = unsafe { sys::bzk_state_root(self.st, &mut hash as *mut _ as *mut u8, &mut size, &mut height) };
-        assert_eq!(st, sys::BZK_OK);
-        (ZkCompressedState::new(hash, size), height)
+        match unsafe { sys::bzk_state_root(self.st, &mut hash as *mut _ as *mut u8, &mut size, &mut height) } {
+            sys::BZK_OK => Ok((ZkCompressedState::new(hash, size), height)),
+            e => Err(state_error(self.gpu.0, e)),  // BZK_E_DEVICE: an earlier update failed on the device
+        }
     }
 
     /// `get_data` (:422-438) for many locators in one device read
-    pub fn get_data(&self, locators: &[ZkDataLocator]) -> Result<Vec<ZkScalar>, StateManagerError> {
+    pub fn get_data(&self, locators: &[ZkDataLocator]) -> Result<Vec<ZkScalar>, DeviceStateError> {
         let mut off = vec![0u64];
         let mut flat = Vec::new();
         for l in locators {
@@ -158,23 +178,23 @@ impl<'g> DeviceStateManager<'g> {
         let mut out = vec![ZkScalar::default(); locators.len()];
         match unsafe { sys::bzk_state_get(self.st, off.as_ptr(), flat.as_ptr(), locators.len() as u64, out.as_mut_ptr() as *mut u8) } {
             sys::BZK_OK => Ok(out),
-            e => Err(locator_error(e)),
+            e => Err(state_error(self.gpu.0, e)),
         }
     }
 
     /// `prove(db, id, tree_loc, index)` (:218-264): `Vec<[ZkScalar; 3]>`, leaf level first
-    pub fn prove(&self, tree_loc: &ZkDataLocator, index: u64) -> Result<Vec<[ZkScalar; 3]>, StateManagerError> {
+    pub fn prove(&self, tree_loc: &ZkDataLocator, index: u64) -> Result<Vec<[ZkScalar; 3]>, DeviceStateError> {
         let mut log4 = 0u32;
         let st = unsafe { sys::bzk_state_prove(self.st, tree_loc.0.as_ptr(), tree_loc.0.len() as u64, ptr::null(), 0, ptr::null_mut(), &mut log4) };
         if st != sys::BZK_OK {
-            return Err(if st == sys::BZK_E_ARG { StateManagerError::NonTreeLocatorError } else { locator_error(st) });
+            return Err(state_error(self.gpu.0, st));  // InvalidLocator vs NonTreeLocatorError: told apart by bzk_last_refusal
         }
         let mut out = vec![[ZkScalar::default(); 3]; log4 as usize];
         match unsafe {
             sys::bzk_state_prove(self.st, tree_loc.0.as_ptr(), tree_loc.0.len() as u64, &index, 1, out.as_mut_ptr() as *mut u8, &mut log4)
         } {
             sys::BZK_OK => Ok(out),
-            e => Err(locator_error(e)),
+            e => Err(state_error(self.gpu.0, e)),  // an index beyond the list: InvalidLocator
         }
     }
 

@@ -178,7 +178,10 @@ def test_mg_local_failure_reaches_every_rank_and_the_group_survives(bzk, co):
     from bazuka_amd import mg_unique_id
     n, seed, world = 20000, 78, 2
     uid = mg_unique_id().hex()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BZK_MG_TEST_FAULT="1:3", BZK_MG_TIMEOUT_S="60")
+    # the fault hook is compiled into the -DBZK_TEST_HOOKS build only: the ranks load that library
+    hooks = os.path.join(ROOT, "bazuka_amd", "libbzk_testhooks.so")
+    assert os.path.exists(hooks), "build() makes bazuka_amd/libbzk_testhooks.so"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BZK_MG_TEST_FAULT="1:3", BZK_MG_TIMEOUT_S="60", BZK_LIBBZK=hooks)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "mg_rank.py"), str(r), str(world), uid, str(n), str(seed),
                                "0", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     d = torch.empty(n * 96, dtype=torch.uint8, device="cuda")

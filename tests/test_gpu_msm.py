@@ -372,6 +372,9 @@ def _large_g1_msm_vs_oracle(bzk, co, log_n, seed, parts):
         assert bzk.g1_sum(shards) == want
     finally:
         bzk.msm_bases_free(h)
+        del sc
+        bzk.trim()                 # the grow-only call workspace (24 GB after 2^26 points) goes back to the device for the tests that follow
+        torch.cuda.empty_cache()
 
 
 def test_msm_g1_2p24_vs_oracle(bzk, co):

@@ -68,7 +68,12 @@ def test_single_1024tx_update_circuit_proves_and_verifies(bzk):
     (src/zk/groth16/mod.rs:67-121).  No byte comparison with the oracle prover at this size (it would take ~7 min and ~100 GB of
     host memory): the bytes of this code path are pinned at 2^21 / 2^22 / 2^24 above.  ~70 s, dominated by synthesis with matrices
     (31 s) and the CRS (26 s)."""
+    import torch
     from bazuka_amd import lib as L
+    # this circuit's CRS with its resident forms takes ~220 of the 288 GB: hand back what earlier tests of the session left behind
+    # (run 1 of round 5 failed here with "lane 2: hipMalloc workspace: out of memory" after the 2^26-point MSM test)
+    bzk.trim()
+    torch.cuda.empty_cache()
     vks = [bytes.fromhex(h) for h in json.load(open(os.path.join(S.G, "reference_vectors.json")))["verifying_keys_bincode_hex"]]
     Z = pr.fr_to_mont_bytes(1)
     n_slots, size = 4 ** 5, 4 ** 15
@@ -102,3 +107,4 @@ def test_single_1024tx_update_circuit_proves_and_verifies(bzk):
         r.free()
     finally:
         w.close()
+        bzk.trim()

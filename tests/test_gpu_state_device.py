@@ -189,17 +189,29 @@ def test_errors_change_nothing(bzk):
     one = F(1)
     bad = [[((16, 0), one)], [((3,), one)], [((3, 2), one)], [((3, 0, 0), one)], [((3, 0), one), ((3, 0), one)], [((3, 0), b"\xff" * 32)],
            [((2, 0), one), ((3, 1, 9), one)]]      # the second pair is the bad one: the first must not land either
-    for pairs in bad:
+    # bzk_last_refusal: which of the reference's errors each refusal stands for (src/zk/state/mod.rs:12-27) - what the Rust shim maps
+    # to StateManagerError::{LocatorError(InvalidLocator), NonScalarLocatorError, NonTreeLocatorError} instead of one catch-all
+    INVALID, NON_SCALAR, NON_TREE, DUPLICATE, NON_CANONICAL = 1, 2, 3, 4, 5
+    want = [INVALID, NON_SCALAR, INVALID, INVALID, DUPLICATE, NON_CANONICAL, INVALID]
+    for pairs, code in zip(bad, want):
         with pytest.raises(BzkError):
             b.dev.update(pairs, 99)
+        assert bzk.last_refusal() == code, (pairs, bzk.last_refusal())
         b.check_root()
     b.check_get([(2, 0), (3, 0), (3, 1, 2)])
+    assert bzk.last_refusal() == 0            # a call that was not refused clears it
     with pytest.raises(BzkError):
         b.dev.get([(3, 0, 0)])
+    assert bzk.last_refusal() == INVALID
     with pytest.raises(BzkError):
         b.dev.prove((3,), [0])                # a struct is not a tree: NonTreeLocatorError
+    assert bzk.last_refusal() == NON_TREE
+    with pytest.raises(BzkError):
+        b.dev.prove((9, 9, 9), [0])           # names nothing in the model: InvalidLocator, not NonTreeLocatorError
+    assert bzk.last_refusal() == INVALID
     with pytest.raises(BzkError):
         b.dev.prove((3, 1), [4])              # beyond the list
+    assert bzk.last_refusal() == INVALID
     with pytest.raises(BzkError):
         DeviceState(bzk, ps.model_bincode(m) + b"\0")
     b.update({(2, 0): 1})                     # still usable
