@@ -451,6 +451,93 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
     else partial[t] = acc;
 }
 
+// ---- 5b. (round 5) the G2 accumulation on PAIRS of lanes (bzk_g2pair.cuh): lanes 2 k and 2 k + 1 share task k, each holds one Fp2 component
+// of the accumulator (56 registers) and of the bases it gathers (2 x 56 bytes of the 224).  Same task table, same buckets / partial sums in
+// memory (the one-lane tail kernels consume them unchanged: X is brought below 3 p once per task).  No product is a call, so nothing between
+// the request of the next base - at the top of an addition - and its first use forces a wait: the gather has a whole addition to land.
+#ifndef BZK_G2_PAIR_OCC
+#define BZK_G2_PAIR_OCC 2
+#endif
+struct alignas(8) U128a8 {
+    uint32_t x, y, z, w;
+};
+struct alignas(8) U64a8 {
+    uint32_t x, y;
+};
+__device__ __forceinline__ Fp28 g2p_load56(const char* p) {  // 14 limbs at an 8-byte aligned address: 3 x 16 B + 8 B
+    const U128a8 a = *(const U128a8*)p, b = *(const U128a8*)(p + 16), c = *(const U128a8*)(p + 32);
+    const U64a8 d = *(const U64a8*)(p + 48);
+    Fp28 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+    r.l[12] = d.x; r.l[13] = d.y;
+    return r;
+}
+__device__ __forceinline__ void g2p_store56(char* p, const Fp28& v) {
+    *(U128a8*)p = U128a8{v.l[0], v.l[1], v.l[2], v.l[3]};
+    *(U128a8*)(p + 16) = U128a8{v.l[4], v.l[5], v.l[6], v.l[7]};
+    *(U128a8*)(p + 32) = U128a8{v.l[8], v.l[9], v.l[10], v.l[11]};
+    *(U64a8*)(p + 48) = U64a8{v.l[12], v.l[13]};
+}
+template <int OCC>  // a template so that only the G2 translation unit instantiates it
+__global__ void __launch_bounds__(128, OCC) msm_accumulate_g2pair_kernel(const void* __restrict__ bases, const uint32_t* __restrict__ vals,
+                                                                                     const uint32_t* __restrict__ start,
+                                                                                     const uint32_t* __restrict__ count_sorted,
+                                                                                     const uint32_t* __restrict__ order,
+                                                                                     const uint32_t* __restrict__ tbase, uint32_t nb, uint32_t t_max,
+                                                                                     uint32_t seg, G2X28* __restrict__ buckets, G2X28* __restrict__ partial,
+                                                                                     uint32_t vmask, const void* __restrict__ bases2, uint32_t n_split,
+                                                                                     uint32_t ibits, uint32_t stride1, uint32_t stride2) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gt >> 1;
+    const uint32_t comp = (gt & 1u) * 56u;  // byte offset of this lane's component inside an Fp2 value (c0 | c1)
+    if (t >= t_max) return;                // pairs leave together
+    const uint32_t imask = (1u << ibits) - 1u;
+    auto ld = [&](uint32_t idx) {
+        const uint32_t m = idx >> ibits, b = idx & imask;
+        const char* p = b >= n_split ? (const char*)bases2 + (size_t)(m * stride2 + (b - n_split)) * sizeof(G2A28)
+                                     : (const char*)bases + (size_t)(m * stride1 + b) * sizeof(G2A28);
+        g2p::Aff a;
+        a.x = g2p_load56(p + comp);
+        a.y = g2p_load56(p + 112 + comp);
+        return a;
+    };
+    uint32_t lo = 0, hi = nb;
+    while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tbase[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t i = lo;
+    const uint32_t cnt = count_sorted[i];
+    const uint32_t k = t - tbase[i];
+    const uint32_t nt = cnt <= seg ? 1u : (cnt + seg - 1) / seg;
+    const uint32_t q = (cnt + nt - 1) / nt;
+    if (k >= nt) return;
+    const uint32_t g = order[i];
+    const uint32_t s = start[g] + k * q;
+    const uint32_t len = k * q >= cnt ? 0u : (cnt - k * q < q ? cnt - k * q : q);
+    g2p::Pt acc = g2p::identity();
+    if (len) {
+        uint32_t v = vals[s];
+        g2p::Aff p = ld(v & vmask);
+        for (uint32_t j = 0; j < len; ++j) {
+            const uint32_t vn = vals[s + (j + 1 < len ? j + 1 : j)];
+            const g2p::Aff pn = ld(vn & vmask);  // requested now, first read by the next iteration
+            g2p::add_mixed(acc, p, (v >> 31) != 0);
+            p = pn;
+            v = vn;
+        }
+        acc.X = fp28::reduce(acc.X);  // < 3 p: the discipline of the one-lane consumers (folds, bucket reduction)
+    }
+    char* dst = (char*)(cnt <= seg ? &buckets[g] : &partial[t]) + comp;
+    g2p_store56(dst, acc.X);
+    g2p_store56(dst + 112, acc.Y);
+    g2p_store56(dst + 224, acc.ZZ);
+    g2p_store56(dst + 336, acc.ZZZ);
+}
+
 // acc += *q.  G2 (PARK_REDUCE): q stays in memory and is read where the formula uses it - two resident 112-register points
 // plus an addition's temporaries do not survive the calls to the field product, and the tail kernels spilled to scratch
 // memory (fold 368, fold_small 352, reduce 1744, window sums 304 / 352 bytes per lane; now 16 - 80).  G1: by value, as before.
@@ -1119,7 +1206,23 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     auto k_acc = msm_accumulate_kernel<C, C::ACC_OCC>;
     auto k_fold = msm_fold_kernel<C>;
     auto k_fold_small = msm_fold_small_kernel<C>;
-    if (group_sums) {
+    static const bool g2_pair = [] { const char* e = getenv("BZK_G2_PAIR"); return !(e && atoi(e) == 0); }();
+    bool launched = false;
+    if constexpr (C::PAIR_ACC) {
+        if (g2_pair) {
+            const uint64_t lanes = 2ull * t_max;
+            if (group_sums) {
+                BZK_LAUNCH(ctx, "dedup_accumulate", (msm_accumulate_g2pair_kernel<BZK_G2_PAIR_OCC>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, bases,
+                           vals_s, A.start, A.count_s, A.order, A.tbase, nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split, ibits, stride1, stride2);
+            } else {
+                BZK_LAUNCH(ctx, "msm_accumulate", (msm_accumulate_g2pair_kernel<BZK_G2_PAIR_OCC>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, bases,
+                           vals_s, A.start, A.count_s, A.order, A.tbase, nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split, ibits, stride1, stride2);
+            }
+            launched = true;
+        }
+    }
+    if (launched) {
+    } else if (group_sums) {
         BZK_LAUNCH(ctx, "dedup_accumulate", k_acc, dim3((t_max + 127) / 128), dim3(128), 0, bases, vals_s, A.start, A.count_s, A.order, A.tbase,
                    nb, t_max, seg, buckets, A.partial, vmask, bases2, n_split, ibits, stride1, stride2);
     } else {

@@ -6,6 +6,7 @@
 #pragma once
 #include "bzk_endo.cuh"
 #include "bzk_fp28.cuh"
+#include "bzk_g2pair.cuh"
 
 namespace bzk {
 
@@ -22,6 +23,7 @@ struct alignas(16) U128 {
 };
 
 struct G1Fast {
+    static constexpr bool PAIR_ACC = false;  // one lane per task
     typedef FpOps HostF;
     typedef G1X28 Pt;
     typedef G1A28 DevAff;
@@ -111,6 +113,9 @@ static_assert(sizeof(G1A28) == 112 && sizeof(G1X28) == 224, "internal G1 layouts
 
 // G2 over Fp2x28: generic XYZZ code on the reduced-radix field; bases converted per call (224 B each)
 struct G2Fast {
+    // the accumulation on PAIRS of lanes (bzk_g2pair.cuh): half a point per lane, two waves per SIMD, every product inlined.
+    // env BZK_G2_PAIR=0 keeps the one-lane kernel (same-box A/B; both are compiled in)
+    static constexpr bool PAIR_ACC = true;
     typedef Fp2Ops HostF;
     typedef G2X28 Pt;
     typedef G2A28 DevAff;

@@ -2,6 +2,8 @@
 // so that limb-level logic is checked against the oracle in this GPU-less container.
 #define BZK_FP28_CHECK 1
 #include "../../bazuka_amd/csrc/bzk_fp28.cuh"
+#define BZK_G2P_HOST_EMU 1  // the pair-lane G2 arithmetic as host functions: two threads per pair, the DPP exchange a rendezvous (below)
+#include "../../bazuka_amd/csrc/bzk_g2pair.cuh"
 #include "../../bazuka_amd/csrc/bzk_endo.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon29.cuh"
 #include "../../bazuka_amd/csrc/bzk_poseidon_opt.h"
@@ -10,6 +12,10 @@
 #include "../../bazuka_amd/csrc/host_fr_ifma.h"
 #include "../../bazuka_amd/csrc/host_pairing.h"
 #include <string.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 using namespace bzk;
 
@@ -44,6 +50,66 @@ static void st_g2(uint8_t* o, const G2Xyzz& p) {
     G2Affine a; bool ok = xyzz_to_affine<Fp2Ops>(p, a);
     st<FpParams>(o, a.x.c0); st<FpParams>(o + 48, a.x.c1); st<FpParams>(o + 96, a.y.c0); st<FpParams>(o + 144, a.y.c1);
     o[192] = ok ? 0 : 1;
+}
+
+
+// ---- bzk_g2pair.cuh on the CPU: lanes 2 k / 2 k + 1 are two threads, swp32 (the DPP quad_perm move on the device) a rendezvous
+namespace {
+struct PairEmu {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t slot[2] = {0, 0}, res[2] = {0, 0};
+    int arrived = 0, gen = 0;
+};
+thread_local PairEmu* g_emu = nullptr;
+thread_local int g_lane = 0;
+void run_pair(const std::function<void(int)>& body) {
+    PairEmu emu;
+    auto th = [&](int lane) {
+        g_emu = &emu;
+        g_lane = lane;
+        body(lane);
+    };
+    std::thread a(th, 0), b(th, 1);
+    a.join();
+    b.join();
+}
+}  // namespace
+namespace bzk { namespace g2p {
+uint32_t bzk_g2p_host_swp32(uint32_t v) {
+    PairEmu& e = *g_emu;
+    std::unique_lock<std::mutex> lk(e.m);
+    const int my_gen = e.gen;
+    e.slot[g_lane] = v;
+    if (++e.arrived == 2) {
+        e.res[0] = e.slot[1];
+        e.res[1] = e.slot[0];
+        e.arrived = 0;
+        ++e.gen;
+        e.cv.notify_all();
+    } else {
+        e.cv.wait(lk, [&] { return e.gen != my_gen; });
+    }
+    return e.res[g_lane];
+}
+bool bzk_g2p_host_lane_odd() { return g_lane != 0; }
+} }  // namespace bzk::g2p
+static g2p::Aff pair_aff(const G2A28& a, int lane) { return lane ? g2p::Aff{a.x.c1, a.y.c1} : g2p::Aff{a.x.c0, a.y.c0}; }
+static void pair_store(G2X28& dst, const g2p::Pt& p, int lane) {
+    (lane ? dst.X.c1 : dst.X.c0) = p.X;
+    (lane ? dst.Y.c1 : dst.Y.c0) = p.Y;
+    (lane ? dst.ZZ.c1 : dst.ZZ.c0) = p.ZZ;
+    (lane ? dst.ZZZ.c1 : dst.ZZZ.c0) = p.ZZZ;
+}
+static g2p::Pt pair_load(const G2X28& src, int lane) {
+    return lane ? g2p::Pt{src.X.c1, src.Y.c1, src.ZZ.c1, src.ZZZ.c1} : g2p::Pt{src.X.c0, src.Y.c0, src.ZZ.c0, src.ZZZ.c0};
+}
+// stored-point discipline of bzk_g2pair.cuh: X normalised and < 12 p, Y normalised and < 3 p, ZZ / ZZZ product outputs
+static int pair_invariants(const g2p::Pt& p) {
+    for (int i = 0; i < 13; ++i)
+        if ((p.X.l[i] >> 28) || (p.Y.l[i] >> 28) || (p.ZZ.l[i] >> 28) || (p.ZZZ.l[i] >> 28)) return -2;
+    if (p.X.l[13] >= 12 * 0x1a012u || p.Y.l[13] >= 3 * 0x1a012u || p.ZZ.l[13] >= 2 * 0x1a012u || p.ZZZ.l[13] >= 2 * 0x1a012u) return -1;
+    return 0;
 }
 
 extern "C" {
@@ -234,6 +300,77 @@ int hc_g2x28_lincomb_mem(const uint8_t* pts, const uint32_t* k, const uint8_t* n
         }
     }
     st_g2(out193, g2x28::to_std(acc));
+    return 0;
+}
+// what msm_accumulate_g2pair_kernel runs (g2p::add_mixed on a pair of lanes): a chain of (+/-) points; mode 2: bases that are Fp2 product
+// outputs of the one-lane code (c0 < 5p, c1 < 8p: group sums, table entries); mode 1: the pair's sum is stored the way the kernel stores it
+// (X brought below 3 p) and handed to the one-lane GENERIC general addition (the tail kernels' consumer discipline)
+int hc_g2p_sum_mixed(const uint8_t* pts, const uint8_t* neg, int n, int mode, uint8_t* out193) {
+    G2X28 sum;
+    int bad[2] = {0, 0};
+    run_pair([&](int lane) {
+        g2p::Pt acc = g2p::identity();
+        for (int i = 0; i < n; ++i) {
+            G2A28 a = g2x28::affine_to28(ld_g2(pts + 192 * i));
+            if (mode == 2) {
+                const Fp2x28 one = Fp2x28Ops::one();
+                a.x = Fp2x28Ops::mul(a.x, one);
+                a.y = Fp2x28Ops::mul(a.y, one);
+            }
+            g2p::add_mixed(acc, pair_aff(a, lane), neg[i] != 0);
+            if (!g2p::is_identity(acc) && pair_invariants(acc)) bad[lane] = pair_invariants(acc);
+        }
+        if (!g2p::is_identity(acc)) acc.X = fp28::reduce(acc.X);
+        pair_store(sum, acc, lane);
+    });
+    if (bad[0] || bad[1]) return bad[0] ? bad[0] : bad[1];
+    if (mode == 1) {
+        G2X28 twice = sum;
+        xyzz_add<Fp2x28Ops>(twice, sum);
+        sum = twice;
+    }
+    st_g2(out193, g2x28::to_std(sum));
+    return 0;
+}
+// sum_i (+/-) k_i * P_i with every general addition / doubling done by g2p::add / g2p::dbl on a pair of lanes (terms enter through
+// g2p::add_mixed); mode 1 adds each term twice more through a copy (P + P = the doubling branch of add), mode 2 adds a term and its
+// negation (cancellation -> identity, then the identity as an operand); the one-lane generic addition consumes the result once
+int hc_g2p_lincomb(const uint8_t* pts, const uint32_t* k, const uint8_t* neg, int n, int mode, uint8_t* out193) {
+    G2X28 sum;
+    int bad[2] = {0, 0};
+    run_pair([&](int lane) {
+        g2p::Pt acc = g2p::identity();
+        for (int i = 0; i < n; ++i) {
+            g2p::Pt t = g2p::identity();
+            const G2A28 a = g2x28::affine_to28(ld_g2(pts + 192 * i));
+            g2p::add_mixed(t, pair_aff(a, lane), neg[i] != 0);
+            g2p::Pt m = g2p::identity();
+            for (int b = 31; b >= 0; --b) {
+                m = g2p::dbl(m);
+                if ((k[i] >> b) & 1) g2p::add(m, t);
+            }
+            g2p::add(acc, m);
+            if (mode == 1) {
+                g2p::Pt d = m;
+                g2p::add(d, m);  // doubling branch
+                g2p::add(acc, d);
+            } else if (mode == 2) {
+                g2p::Pt c = m, minus = m;
+                minus.Y = fp28::norm(fp28::sub<3>(fp28::zero(), m.Y));  // 3 p - Y
+                minus.Y = fp28::reduce(minus.Y);
+                g2p::add(c, minus);  // cancellation branch
+                if (!g2p::is_identity(c)) bad[lane] = 1;
+                g2p::add(acc, c);
+            }
+            if (!g2p::is_identity(acc) && pair_invariants(acc)) bad[lane] = pair_invariants(acc);
+        }
+        if (!g2p::is_identity(acc)) acc.X = fp28::reduce(acc.X);
+        pair_store(sum, acc, lane);
+    });
+    if (bad[0] || bad[1]) return bad[0] ? bad[0] : bad[1];
+    G2X28 z = xyzz_identity<Fp2x28Ops>();
+    xyzz_add<Fp2x28Ops>(z, sum);  // generic consumer
+    st_g2(out193, g2x28::to_std(z));
     return 0;
 }
 // Fr in 9 x 29-bit limbs

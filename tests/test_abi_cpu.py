@@ -229,6 +229,30 @@ def test_reduced_radix_curves_on_host_match_oracle(hc, co, pr):
     assert out2.raw[192] == 1  # cancellation -> identity
     assert hc.hc_g2x28_sum_mixed_fast(Q2 + Q2 + Q2, bytes([0, 1, 0]), 3, 0, out2) == 0
     assert out2.raw == co.msm_g2(Q2, (1).to_bytes(32, "little"), mont=False, naive=True)  # identity accumulator takes a point again
+    # ---- the pair-lane G2 arithmetic of round 5 (bzk_g2pair.cuh: what msm_accumulate_g2pair_kernel runs): the SAME source on two host
+    # threads per pair (the DPP exchange a rendezvous), bound assertions on, the stored-point discipline checked after every addition
+    assert hc.hc_g2p_sum_mixed(b4, negs2, m2, 0, out2) == 0
+    assert out2.raw == co.msm_g2(b4, sc4, mont=False, naive=True)
+    assert hc.hc_g2p_sum_mixed(b4, negs2, m2, 2, out2) == 0   # bases that are one-lane Fp2 product outputs (group sums, table entries)
+    assert out2.raw == co.msm_g2(b4, sc4, mont=False, naive=True)
+    assert hc.hc_g2p_sum_mixed(b4, negs2, m2, 1, out2) == 0   # the pair's sum consumed by the one-lane generic addition
+    assert out2.raw == co.msm_g2(b4, sc4x2, mont=False, naive=True)
+    assert hc.hc_g2p_sum_mixed(Q2 + Q2, bytes([0, 0]), 2, 0, out2) == 0
+    assert out2.raw == co.msm_g2(Q2, (2).to_bytes(32, "little"), mont=False, naive=True)  # doubling through the mixed add (dbl_affine)
+    assert hc.hc_g2p_sum_mixed(Q2 + Q2, bytes([1, 1]), 2, 0, out2) == 0
+    assert out2.raw == co.msm_g2(Q2, (pr.R_MOD - 2).to_bytes(32, "little"), mont=False, naive=True)
+    assert hc.hc_g2p_sum_mixed(Q2 + Q2, bytes([0, 1]), 2, 0, out2) == 0
+    assert out2.raw[192] == 1  # cancellation -> identity
+    assert hc.hc_g2p_sum_mixed(Q2 + Q2 + Q2, bytes([0, 1, 0]), 3, 0, out2) == 0
+    assert out2.raw == co.msm_g2(Q2, (1).to_bytes(32, "little"), mont=False, naive=True)  # identity accumulator takes a point again
+    assert hc.hc_g2p_sum_mixed(b"", b"", 0, 0, out2) == 0 and out2.raw[192] == 1
+    # g2p::add / g2p::dbl (general addition and doubling on a pair): scalar multiples by double-and-add, doubling and cancellation branches
+    assert hc.hc_g2p_lincomb(b2, (C.c_uint32 * n)(*ks), neg, n, 0, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    assert hc.hc_g2p_lincomb(b2, (C.c_uint32 * n)(*ks), neg, n, 2, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc, mont=False, naive=True)
+    assert hc.hc_g2p_lincomb(b2, (C.c_uint32 * n)(*ks), neg, n, 1, out2) == 0
+    assert out2.raw == co.msm_g2(b2, sc3, mont=False, naive=True)
     m = 150  # long chains of mixed adds: the weak-reduction bounds must hold indefinitely
     b3 = co.g1_bases(9, 0, m)
     negs = bytes(rnd.randrange(2) for _ in range(m))

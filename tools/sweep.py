@@ -242,6 +242,14 @@ if __name__ == "__main__":
         run("g1tab", 20, {"TAB_LEVELS": "2", "BZK_MSM_TABLE_C": "17"})
         run("g1tab", 20, {"TAB_LEVELS": "4", "BZK_MSM_TABLE_C": "17"})
         run("g1", 22); run("g1tab", 22, {"TAB_LEVELS": "2"}); run("g1tab", 22, {"TAB_LEVELS": "4"})
+    if what in ("r5pair",):  # round 5, run 2: the G2 accumulation on pairs of lanes (BZK_G2_PAIR=1, the default) against the one-lane kernel, same box, alternating
+        for rep in range(2):
+            for pair in ("0", "1"):
+                run("g2", 20, {"BZK_G2_PAIR": pair})
+                run("g2res", 20, {"BZK_G2_PAIR": pair, "BZK_MSM_ENDO_G2": "0"})
+                run("g2res", 20, {"BZK_G2_PAIR": pair, "BZK_MSM_ENDO_G2": "1"})
+        for pair in ("0", "1"):
+            run("g2", 16, {"BZK_G2_PAIR": pair}); run("g2", 18, {"BZK_G2_PAIR": pair}); run("g2", 22, {"BZK_G2_PAIR": pair})
     if what in ("r5knobs",):  # round 5, run 1: what the existing switches give a stand-alone 2^20 MSM over a resident set - endomorphism form x reduce chunk x one / two-level reduction
         for mode in ("g1res", "g2res"):
             e = "BZK_MSM_ENDO_G1" if mode == "g1res" else "BZK_MSM_ENDO_G2"
