@@ -122,6 +122,12 @@ struct bzk_mg {
     size_t shm_bytes = 0;
     uint64_t seq = 0;
     std::string shm_name;
+    // bzk_mg_stats: where a window-sharded call's time goes on THIS rank (local device 0), cumulative since creation / the last reset
+    struct Stats {
+        uint64_t calls = 0;
+        double local_ms = 0, exchange_ms = 0, peer_wait_ms = 0, combine_ms = 0, create_s = 0, comm_init_s = 0;
+    } stats;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // start of the call / local stage queued / exchange queued, on local device 0's stream
 };
 // proof pool: `slots` prover slots (context + lanes + scratch) per local device over one shared CRS per device; one host thread per
 // slot takes proofs from a common queue - whichever slot is free next, on whichever device (replicas: proofs do not shard)
@@ -266,7 +272,19 @@ int32_t shm_barrier(bzk_mg* mg, uint64_t seq) {
     return BZK_OK;
 }
 
+static int32_t mg_finish_create_impl(bzk_mg* mg, uint32_t exchange, const uint8_t* uid);
 int32_t mg_finish_create(bzk_mg* mg, uint32_t exchange, const uint8_t* uid) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t st = mg_finish_create_impl(mg, exchange, uid);
+    mg->stats.create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st == BZK_OK && !mg->devices.empty()) {  // timing events of bzk_mg_stats; a failure here only leaves the spans at zero
+        (void)hipSetDevice(mg->devices[0]);
+        for (auto& e : mg->ev)
+            if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+    }
+    return st;
+}
+static int32_t mg_finish_create_impl(bzk_mg* mg, uint32_t exchange, const uint8_t* uid) {
     // contexts (own non-blocking stream each)
     for (int i = 0; i < mg->n_local; ++i) {
         bzk_ctx* c = nullptr;
@@ -295,9 +313,13 @@ int32_t mg_finish_create(bzk_mg* mg, uint32_t exchange, const uint8_t* uid) {
             ncclUniqueId id;
             memcpy(id.internal, uid, NCCL_UNIQUE_ID_BYTES);
             (void)hipSetDevice(mg->devices[0]);
+            const auto t0 = std::chrono::steady_clock::now();
             r = R->CommInitRank(&mg->comms[0], mg->world, id, mg->rank0);
+            mg->stats.comm_init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         } else {
+            const auto t0 = std::chrono::steady_clock::now();
             r = R->CommInitAll(mg->comms.data(), mg->n_local, mg->devices.data());
+            mg->stats.comm_init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
         if (r != ncclSuccess) return mg_fail(mg, BZK_E_DEVICE, std::string("RCCL communicator: ") + (R->GetErrorString ? R->GetErrorString(r) : "error"));
     } else if (exchange == BZK_MG_X_PEER) {
@@ -368,6 +390,8 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
         const int rank = mg->rank0 + i;
         int lo, hi;
         window_range(W, rank, mg->world, &lo, &hi);
+        const bool timed = i == 0 && mg->ev[0] && mg->ev[1] && mg->ev[2];
+        if (timed) (void)hipEventRecord(mg->ev[0], c->stream);
         // local stage; its status travels with the exchange (RCCL, shared memory: the peers cannot see it otherwise)
         const int32_t lst = [&]() -> int32_t {
 #ifdef BZK_TEST_HOOKS
@@ -392,6 +416,7 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
             return BZK_OK;
         }();
         hdr[i] = MgHdr{seq, lst, cs[i]};
+        if (timed) (void)hipEventRecord(mg->ev[1], c->stream);
         const size_t mine = lst == BZK_OK ? (size_t)(hi - lo) * sz : 0;
         if (x == BZK_MG_X_RCCL) {
             RcclApi* R = rccl_api();
@@ -412,13 +437,24 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
         } else if (mine) {  // HOST: straight into the shared pinned array (one process) / this rank's staging (shared memory below)
             BZK_HIP(c, hipMemcpyAsync(mg->h_win + (size_t)rank * blk, mg->d_send[i], mine, hipMemcpyDeviceToHost, c->stream));
         }
+        if (timed) (void)hipEventRecord(mg->ev[2], c->stream);
         if (hipStreamSynchronize(c->stream) != hipSuccess) {
             (void)hipGetLastError();
             if (lst == BZK_OK) c->last_error = "bzk_mg: exchange synchronisation";
             return lst != BZK_OK ? lst : BZK_E_DEVICE;
         }
+        if (timed) {  // device-side spans of this call: local windows, then the all-gather / peer copy / read-back behind them
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, mg->ev[0], mg->ev[1]) == hipSuccess && hipEventElapsedTime(&b, mg->ev[1], mg->ev[2]) == hipSuccess) {
+                mg->stats.local_ms += a;
+                mg->stats.exchange_ms += b;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         return lst;
     });
+    ++mg->stats.calls;
     if (st != BZK_OK && !shm) return st;   // (RCCL: the peers read this rank's status from the gathered records below)
     if (x == BZK_MG_X_RCCL) {
         // compact the gathered blocks [sums | record] into the plain per-rank layout the combine below reads
@@ -453,7 +489,9 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
         const MgHdr h0{seq, st, cs[0]};
         memcpy(mine, &h0, MG_HDR);
         if (st == BZK_OK) memcpy(mine + MG_HDR, mg->h_win + (size_t)mg->rank0 * blk, (size_t)(hi - lo) * sz);
+        const auto tw0 = std::chrono::steady_clock::now();
         const int32_t bst = shm_barrier(mg, seq);
+        mg->stats.peer_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
         if (st != BZK_OK) return st;
         BZK_TRY(bst);
         for (int r = 0; r < mg->world; ++r) {
@@ -477,7 +515,10 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
             memcpy(S.data() + (size_t)lo * sz, mg->h_win + (size_t)r * blk, (size_t)(hi - lo) * sz);
         }
     }
-    return horner(S.data(), n ? W : 0, c_bits, 0, out);
+    const auto tc0 = std::chrono::steady_clock::now();
+    const int32_t hst = horner(S.data(), n ? W : 0, c_bits, 0, out);
+    mg->stats.combine_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
+    return hst;
 }
 
 }  // namespace
@@ -580,11 +621,30 @@ void bzk_mg_destroy(bzk_mg* mg) {
         if (i < (int)mg->d_stage.size() && mg->d_stage[i]) (void)hipFree(mg->d_stage[i]);
         bzk_ctx_destroy(mg->ctxs[i]);
     }
+    if (!mg->devices.empty()) (void)hipSetDevice(mg->devices[0]);
+    for (auto& e : mg->ev)
+        if (e) (void)hipEventDestroy(e);
     if (mg->h_win) (void)hipHostFree(mg->h_win);
     if (mg->shm) munmap(mg->shm, mg->shm_bytes);
     delete mg;
 }
 
+int32_t bzk_mg_stats(bzk_mg* mg, int32_t reset, double out[8]) {
+    if (!mg) return BZK_E_ARG;
+    std::lock_guard<std::mutex> call(mg->call_mutex);
+    if (out) {
+        const bzk_mg::Stats& t = mg->stats;
+        const double v[8] = {(double)t.calls, t.local_ms, t.exchange_ms, t.peer_wait_ms, t.combine_ms, t.create_s, t.comm_init_s, 0.0};
+        memcpy(out, v, sizeof v);
+    }
+    if (reset) {
+        const double cs = mg->stats.create_s, ci = mg->stats.comm_init_s;
+        mg->stats = bzk_mg::Stats();
+        mg->stats.create_s = cs;
+        mg->stats.comm_init_s = ci;
+    }
+    return BZK_OK;
+}
 int32_t bzk_mg_world(const bzk_mg* mg) { return mg ? mg->world : 0; }
 int32_t bzk_mg_local(const bzk_mg* mg) { return mg ? mg->n_local : 0; }
 int32_t bzk_mg_rank(const bzk_mg* mg) { return mg ? mg->rank0 : -1; }

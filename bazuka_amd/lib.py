@@ -162,6 +162,7 @@ SIGNATURES = {
     "bzk_mg_rank": (_i32, [_vp]),
     "bzk_mg_exchange": (_u32, [_vp]),
     "bzk_mg_ctx": (_vp, [_vp, _i32]),
+    "bzk_mg_stats": (_i32, [_vp, _i32, C.POINTER(C.c_double)]),
     "bzk_mg_last_error": (C.c_char_p, [_vp]),
     "bzk_mg_bases_g1_load": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
     "bzk_mg_bases_g2_load": (_i32, [_vp, _vp, _u64, C.POINTER(_vp)]),
@@ -709,6 +710,13 @@ class Mg:
     def _ptrs(self, xs):
         assert len(xs) == self.local, "one device pointer per local device"
         return (_vp * self.local)(*[_ptr(x) for x in xs])
+
+    def stats(self, reset: bool = False) -> dict:
+        """where this rank's window-sharded calls spent their time (bzk_mg_stats)"""
+        v = (C.c_double * 8)()
+        self._ck(self.lib.bzk_mg_stats(self.h, int(reset), v), "mg_stats")
+        return {"calls": int(v[0]), "local_ms": v[1], "exchange_ms": v[2], "peer_wait_ms": v[3], "combine_ms": v[4], "create_s": v[5],
+                "comm_init_s": v[6]}
 
     def ctx_handle(self, i: int):
         return self.lib.bzk_mg_ctx(self.h, i)

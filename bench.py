@@ -62,6 +62,36 @@ def _fr(x: int) -> bytes:
     return (x * ((1 << 256) % R_MOD) % R_MOD).to_bytes(32, "little")
 
 
+def _rows_ge_r(rows):
+    """per row of a (k, 32) uint8 tensor (little-endian 256-bit integers): value >= r ?"""
+    import torch
+    q = rows.contiguous().view(torch.int64).view(-1, 4)
+    ge = torch.ones(q.shape[0], dtype=torch.bool, device=rows.device)   # "equal on every limb seen so far" counts as >=
+    for i in range(4):                                                   # least significant limb first: a higher limb overrides
+        a = q[:, i] ^ (-(1 << 63))                                       # x ^ 2^63 read as int64 keeps the unsigned order
+        b = ((R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) ^ (1 << 63)
+        b -= (1 << 64) if b >= (1 << 63) else 0
+        ge = torch.where(a == b, ge, a > b)
+    return ge
+
+
+def uniform_fr_dev(cnt: int, seed: int, dev):
+    """cnt Fr values UNIFORM in [0, r) by rejection, as 32-byte little-endian Montgomery limbs on `dev`: 255-bit candidates
+    (acceptance r / 2^255 = 0.906), rows >= r redrawn until none is left.  Limbs uniform in [0, r) <=> the canonical values are (x -> x R^-1
+    is a bijection of the residues)."""
+    import torch
+    g = torch.Generator(device=dev).manual_seed(seed & 0x7FFFFFFF)
+    t = torch.randint(0, 256, (cnt, 32), dtype=torch.uint8, device=dev, generator=g)
+    t[:, 31] &= 0x7F
+    bad = _rows_ge_r(t).nonzero().flatten()
+    while bad.numel():
+        fresh = torch.randint(0, 256, (bad.numel(), 32), dtype=torch.uint8, device=dev, generator=g)
+        fresh[:, 31] &= 0x7F
+        t[bad] = fresh
+        bad = bad[_rows_ge_r(fresh)]
+    return t.contiguous()
+
+
 def _fr_blind(k: int) -> bytes:
     """A full-size (255-bit) blinding scalar for proof k, seeded: bellman's create_random_proof draws r and s uniformly, and the
     host assembly of a proof (six scalar multiplications in the reference) costs time in proportion to their bit length - a
@@ -580,10 +610,7 @@ def other_configs_section(ctx, dev):
     import torch
 
     def rand_fr(cnt, seed):
-        g = torch.Generator(device=dev).manual_seed(seed)
-        t = torch.randint(0, 256, (cnt, 32), dtype=torch.uint8, device=dev, generator=g)
-        t[:, 31] &= 0x3F
-        return t.contiguous()
+        return uniform_fr_dev(cnt, seed, dev)
 
     def timeit(fn, reps=3):
         fn()
@@ -888,10 +915,7 @@ def main():
     n = (1 << args.log_n_total) if args.scaling == "strong" else (1 << args.log_n) * world
     bases = torch.empty(n * 96, dtype=torch.uint8, device=dev)
     ctx.g1_synth_bases_dev(SEED, 0, n, bases)
-    g = torch.Generator(device=dev).manual_seed(SEED & 0x7FFFFFFF)
-    scalars = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
-    scalars[:, 31] &= 0x3F  # < 2^254 < r: valid Montgomery residues, uniform over that range
-    scalars = scalars.contiguous()
+    scalars = uniform_fr_dev(n, SEED, dev)  # uniform in [0, r) by rejection, as SURVEY 8d prescribes
     torch.cuda.synchronize()
 
     from bazuka_amd.dist import allgather_fold, window_range
@@ -951,6 +975,8 @@ def main():
     pctx.prof_filter("msm_accumulate")
     pctx.prof_enable(True)
     pctx.prof_reset()
+    if mg:
+        mg.stats(reset=True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -969,6 +995,8 @@ def main():
     fence()
     pctx.prof_enable(False)
     prof_all = pctx.prof_dump()
+    elapsed_rank = elapsed
+    acc_n_rank, acc_ms_rank = prof.get("msm_accumulate", (0, 0.0))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1041,6 +1069,7 @@ def main():
                                 f"(bases k_i*G, uniform scalars, resident in HBM)") if args.scaling == "weak" else
                                (f"BASELINE configs[3] reading (i): ONE 2^{args.log_n_total}-point G1 MSM for the whole job, "
                                 f"{'point' if by_points else 'window'}-sharded over the ranks (bases k_i*G, uniform scalars, replicated in HBM)"),
+                   "scalars": "uniform in [0, r) by rejection sampling (255-bit candidates, rows >= r redrawn), 32-byte Montgomery limbs; seed 0x42415A554B41",
                    "points_total": n, "windows": W, "window_range_this_rank": [w0, w1], "point_range_this_rank": [p_lo, p_hi],
                    "bases": "resident set in the internal 112-byte form (converted once at load, outside the timed region)",
                    "parallelism": "single-gpu" if world == 1 else
@@ -1048,7 +1077,24 @@ def main():
         "proofs_per_sec": None,
     }
     if world > 1:  # what the collective layer actually saw
-        out["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+        assert dist.get_world_size() == args.gpus, f"collective world size {dist.get_world_size()} != --gpus {args.gpus}"
+        # every rank's view of the timed steps, so that the first hardware SCALE run diagnoses itself: a slow rank shows as
+        # a long local stage there and as exchange / waiting time on the others; the transport is the one actually in use, not the one asked for
+        st_mg = mg.stats() if mg else None
+        calls = max(1, st_mg["calls"]) if st_mg else 1
+        mine_diag = {"rank": rank, "device": local_rank, "windows": [w0, w1],
+                     "msm_accumulate_ms": round(acc_ms_rank / max(1, acc_n_rank), 4) if acc_n_rank else None,
+                     "step_ms_this_rank": round(elapsed_rank * 1e3 / args.steps, 4),
+                     "transport": ({0: "auto", 1: "host/shm", 2: "peer", 3: "rccl"}.get(mg.exchange, str(mg.exchange)) if mg else "torch.distributed"),
+                     "local_stage_ms": round(st_mg["local_ms"] / calls, 4) if st_mg else None,
+                     "exchange_ms": round(st_mg["exchange_ms"] / calls, 4) if st_mg else None,
+                     "peer_wait_ms": round(st_mg["peer_wait_ms"] / calls, 4) if st_mg else None,
+                     "host_combine_ms": round(st_mg["combine_ms"] / calls, 4) if st_mg else None,
+                     "group_create_s": round(st_mg["create_s"], 3) if st_mg else None,
+                     "comm_init_s": round(st_mg["comm_init_s"], 3) if st_mg else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_diag)
+        out["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "per_rank": per_rank,
                              "launcher_role": "rendezvous, barriers and the 128-byte group id only",
                              "data_path": (f"libbzk bzk_mg_* (C ABI): transport {mg.exchange}, group of {mg.world}; one all-gather of the "
                                            f"{W} window sums (192 B each) per MSM, Horner combine on the host") if mg else

@@ -527,6 +527,12 @@ int32_t bzk_mg_local(const bzk_mg* mg);      /* devices this process drives */
 int32_t bzk_mg_rank(const bzk_mg* mg);       /* rank of local device 0 */
 uint32_t bzk_mg_exchange(const bzk_mg* mg);  /* the transport in use (BZK_MG_X_*) */
 bzk_ctx* bzk_mg_ctx(bzk_mg* mg, int32_t local_index);
+/* Where the window-sharded calls of this rank spent their time (cumulative; reset != 0 clears the per-call sums afterwards):
+ *   out[0] calls   out[1] local stage, ms (this rank's windows, device side, local device 0)   out[2] exchange, ms (device side: the
+ *   all-gather / peer copies and the read-back queued behind the local stage)   out[3] waiting for the other ranks, ms (host side:
+ *   the shared-memory transport's barrier)   out[4] host combine (Horner), ms   out[5] group creation, s   out[6] of which the
+ *   communicator (ncclCommInitRank / ncclCommInitAll), s   out[7] reserved.  A slow rank shows up as exchange / waiting time of the others. */
+int32_t bzk_mg_stats(bzk_mg* mg, int32_t reset, double out[8]);
 const char* bzk_mg_last_error(bzk_mg* mg);
 /* replicate a static base set on every local device (host pointer: uploaded + converted per device; _dev: one device pointer
  * per local device, raw affine) */
