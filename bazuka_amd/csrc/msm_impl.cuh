@@ -33,6 +33,7 @@
 #include "bzk_internal.h"
 #include "host_fp64.h"
 #include "msm_policy.cuh"
+#include "msm_g2pair_tails.cuh"
 
 namespace bzk {
 
@@ -65,6 +66,16 @@ static int msm_pick_c(uint64_t n) {
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return c;
+}
+// G2 on pairs of lanes (bzk_g2pair.cuh: accumulation; msm_g2pair_tails.cuh: folds, bucket reduction, window sums).  BZK_G2_PAIR=0: the
+// one-lane kernels everywhere (same-box A/B; both are compiled in); BZK_G2_PAIR_TAILS=0: pair accumulation with the one-lane tails
+static bool msm_g2_pair_on() {
+    static const bool on = [] { const char* e = getenv("BZK_G2_PAIR"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+static bool msm_g2_pair_tails_on() {
+    static const bool on = [] { const char* e = getenv("BZK_G2_PAIR_TAILS"); return !(e && atoi(e) == 0); }();
+    return on && msm_g2_pair_on();
 }
 static int msm_windows_for(int c) { return (256 + c - 1) / c; }  // signed digits need one spare bit
 // Window size of a proof's witness MSMs (flag BZK_F_DEDUP: l, a, b_g1, b_g2) - A/B knob.  By WORK, in units of one mixed
@@ -1206,7 +1217,7 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     auto k_acc = msm_accumulate_kernel<C, C::ACC_OCC>;
     auto k_fold = msm_fold_kernel<C>;
     auto k_fold_small = msm_fold_small_kernel<C>;
-    static const bool g2_pair = [] { const char* e = getenv("BZK_G2_PAIR"); return !(e && atoi(e) == 0); }();
+    const bool g2_pair = msm_g2_pair_on();
     bool launched = false;
     if constexpr (C::PAIR_ACC) {
         if (g2_pair) {
@@ -1239,6 +1250,15 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     // 2^24-point regime: 524 288 launches that exit at once otherwise) and the kernel re-checks per bucket either way
     const bool surely_bulk = len / seg >= 4ull * MSM_FOLD_BULK_FROM && len / seg >= 2ull * nb;
     const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * (surely_bulk ? MSM_FOLD_SMALL_BULK : MSM_FOLD_SMALL)) + 1);
+    if constexpr (C::PAIR_ACC) {
+        if (msm_g2_pair_tails_on()) {
+            BZK_LAUNCH(ctx, "msm_fold", msm_fold_g2pair_kernel<0>, dim3(n_big), dim3(128), 0, A.count_s, A.order, A.tbase, A.ntask, nb, seg, MSM_FOLD_BULK_FROM,
+                       MSM_FOLD_SMALL, MSM_FOLD_SMALL_BULK, A.partial, buckets);
+            BZK_LAUNCH(ctx, "msm_fold_small", msm_fold_small_g2pair_kernel<0>, dim3((unsigned)((2ull * n_pos + 63) / 64)), dim3(64), 0, A.count_s, A.order, A.tbase,
+                       A.ntask, nb, n_pos, seg, MSM_FOLD_BULK_FROM, MSM_FOLD_SMALL, MSM_FOLD_SMALL_BULK, A.partial, buckets);
+            return BZK_OK;
+        }
+    }
     BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, seg, A.partial, buckets);
     BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_pos, seg,
                A.partial, buckets);
@@ -1629,7 +1649,34 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                                      (uint32_t)ibits, E > 1 ? (uint32_t)prep->n : 0u, E > 1 ? m_max : 0u));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
-        if (two_level) {
+        bool tails_done = false;
+        if constexpr (C::PAIR_ACC) {
+            if (msm_g2_pair_tails_on()) {
+                auto grid2 = [](uint32_t chunks) { return dim3((unsigned)((2ull * chunks + 63) / 64)); };
+                if (two_level) {
+                    int lg = 0;
+                    while ((1u << lg) < ch) ++lg;
+                    const uint32_t n_chunks2 = (uint32_t)n_red_win * (per_win / ch2);
+                    BZK_LAUNCH(ctx, "msm_reduce", msm_reduce_g2pair_kernel<0>, grid2(n_chunks), dim3(64), 0, (const Pt*)buckets, half, ch, n_chunks, chunk_out,
+                               per_win_out, 0u, chunk_tot, 0u);
+                    BZK_LAUNCH(ctx, "msm_reduce_l2", msm_reduce_g2pair_kernel<0>, grid2(n_chunks2), dim3(64), 0, (const Pt*)chunk_tot, per_win, ch2, n_chunks2,
+                               chunk_out, per_win_out, per_win, (Pt*)nullptr, (uint32_t)lg);
+                } else {
+                    BZK_LAUNCH(ctx, "msm_reduce", msm_reduce_g2pair_kernel<0>, grid2(n_chunks), dim3(64), 0, (const Pt*)buckets, half, ch, n_chunks, chunk_out, per_win,
+                               0u, (Pt*)nullptr, 0u);
+                }
+                constexpr int WTP = C::WSUM_THREADS;
+                const uint32_t groups_p = (per_win_out + WTP - 1) / WTP;
+                StdPt* const win_dst_p = wout ? (StdPt*)wout->d_win + ((table && !folded) ? 0 : wb - w_begin) : win_out;
+                BZK_LAUNCH(ctx, "msm_window_partial", (msm_window_partial_g2pair_kernel<WTP>), dim3((unsigned)n_red_win * groups_p), dim3(WTP), 0,
+                           (const Pt*)chunk_out, per_win_out, groups_p, wpart);
+                BZK_LAUNCH(ctx, "msm_window_sum", (msm_window_sum_g2pair_kernel<WTP>), dim3((unsigned)n_red_win), dim3(WTP), 0, (const Pt*)wpart, groups_p,
+                           win_dst_p);
+                tails_done = true;
+            }
+        }
+        if (tails_done) {
+        } else if (two_level) {
             int lg = 0;
             while ((1u << lg) < ch) ++lg;
             const uint32_t n_chunks2 = (uint32_t)n_red_win * (per_win / ch2);
@@ -1655,9 +1702,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         auto k_wp = msm_window_partial_kernel<C, WT>;
         auto k_ws = msm_window_sum_kernel<C, WT>;
         StdPt* const win_dst = wout ? (StdPt*)wout->d_win + ((table && !folded) ? 0 : wb - w_begin) : win_out;
-        // G1: the two trees on quads of lanes (7b); env BZK_MSM_QUAD_TREE=0: the one-lane-per-point form (A/B runs).  G2 keeps the latter
+        // G1: the two trees on quads of lanes (7b); env BZK_MSM_QUAD_TREE=0: the one-lane-per-point form (A/B runs).  G2: on pairs (above) or one lane
         static const bool quad_tree = [] { const char* e = getenv("BZK_MSM_QUAD_TREE"); return !(e && atoi(e) == 0); }();
-        if constexpr (!C::PARK_REDUCE) {
+        if (tails_done) {  // the pair kernels above produced the window sums already
+        } else if constexpr (!C::PARK_REDUCE) {
             if (quad_tree) {
                 BZK_LAUNCH(ctx, "msm_window_partial", (msm_window_partial_quad_kernel<WT>), dim3((unsigned)n_red_win * groups), dim3(WT), 0,
                            (const G1X28*)chunk_out, per_win_out, groups, (G1X28*)wpart);

@@ -77,8 +77,7 @@ def test_single_1024tx_update_circuit_proves_and_verifies(bzk):
     vks = [bytes.fromhex(h) for h in json.load(open(os.path.join(S.G, "reference_vectors.json")))["verifying_keys_bincode_hex"]]
     Z = pr.fr_to_mont_bytes(1)
     n_slots, size = 4 ** 5, 4 ** 15
-    w = L.MpnWorld(15, 3)
-    w.set_device(bzk)
+    w = L.MpnWorld(15, 3)   # host-side work builder: the device builder's account tree (46 GB at L = 15) is memory this circuit's prover needs
     try:
         idx = [(i * 22369621 + 5) % size for i in range(2 * n_slots)]
         for i, a in enumerate(idx):

@@ -242,6 +242,16 @@ if __name__ == "__main__":
         run("g1tab", 20, {"TAB_LEVELS": "2", "BZK_MSM_TABLE_C": "17"})
         run("g1tab", 20, {"TAB_LEVELS": "4", "BZK_MSM_TABLE_C": "17"})
         run("g1", 22); run("g1tab", 22, {"TAB_LEVELS": "2"}); run("g1tab", 22, {"TAB_LEVELS": "4"})
+    if what in ("r5tails",):  # round 5, run 3: the G2 tails (folds, bucket reduction, window sums) on pairs of lanes against the one-lane kernels, same box, alternating
+        for rep in range(2):
+            for tails in ("0", "1"):
+                run("g2", 20, {"BZK_G2_PAIR_TAILS": tails})
+                run("g2res", 20, {"BZK_G2_PAIR_TAILS": tails, "BZK_MSM_ENDO_G2": "0"})
+                run("g2res", 20, {"BZK_G2_PAIR_TAILS": tails, "BZK_MSM_ENDO_G2": "1", "THROUGHPUT": "1"})
+        for tails in ("0", "1"):
+            run("g2", 16, {"BZK_G2_PAIR_TAILS": tails}); run("g2", 18, {"BZK_G2_PAIR_TAILS": tails})
+        for ch in ("4", "16"):
+            run("g2", 20, {"BZK_MSM_CHUNK": ch})
     if what in ("r5pair",):  # round 5, run 2: the G2 accumulation on pairs of lanes (BZK_G2_PAIR=1, the default) against the one-lane kernel, same box, alternating
         for rep in range(2):
             for pair in ("0", "1"):
