@@ -242,8 +242,17 @@ G2P_FN Pt dbl(const Pt& p) {
     return r;
 }
 
-// acc += q (add-2008-s), both in the stored-point discipline
-G2P_FN void add(Pt& acc, const Pt& q) {
+// acc += q (add-2008-s), both in the stored-point discipline.  `dbl_fn(acc)` doubles acc in place in the (rare) P + P branch: the tail
+// kernels pass a CALL of their no-inline doubling there, which keeps their no-inline addition below the 128 KB reach of a conditional
+// branch (with the doubling inlined the body is 137 KB, and the compiler's long-branch expansion of its early exits took s[30:31] - the
+// live return address - as the scratch pair: a wave whose lanes ALL left early then returned to the function's own epilogue for ever;
+// first GPU run of the pair tails, round 5 run 4; tests/test_code_objects_cpu.py now refuses such a function)
+struct DblInline {
+    template <class P>
+    G2P_FN void operator()(P& p) const;
+};
+template <class DblFn = DblInline>
+G2P_FN void add(Pt& acc, const Pt& q, DblFn&& dbl_fn = DblFn()) {
     if (is_identity(q)) return;
     if (is_identity(acc)) {
         acc = q;
@@ -260,7 +269,7 @@ G2P_FN void add(Pt& acc, const Pt& q) {
     const Fp28 PP = sqr<6>(Pp, Ppo);                           // (10)(5 + 6)
     if (pair_mulout_is_zero(PP)) {
         const Fp28 RR = sqr<6>(R, Ro);
-        if (pair_mulout_is_zero(RR)) acc = dbl(acc);
+        if (pair_mulout_is_zero(RR)) dbl_fn(acc);
         else acc = identity();
         return;
     }
@@ -283,6 +292,9 @@ G2P_FN void add(Pt& acc, const Pt& q) {
     acc.Y = mul4_body(R, sel(odd, T, To), Ro, sel(odd, nTo, T), nS, sel(odd, PPP, PPPo), sel(odd, S1o, nSo), sel(odd, PPPo, PPP));
     acc.X = X3;
 }
+
+template <class P>
+G2P_FN void DblInline::operator()(P& p) const { p = dbl(p); }
 
 #undef G2P_FN
 }  // namespace g2p

@@ -48,13 +48,17 @@ __device__ __forceinline__ void g2p_st_pt(G2X28* p, uint32_t comp, const g2p::Pt
     g2p_st56(b + 224, v.ZZ);
     g2p_st56(b + 336, v.ZZZ);
 }
-// the two bodies (one copy per code object)
+// the two bodies (one copy per code object).  The addition CALLS the doubling in its P + P branch (see g2p::add: with the doubling inlined the
+// body outgrows a conditional branch's reach and the compiler's long-branch expansion destroyed the return address)
+static __device__ __noinline__ void g2p_dbl_ni(g2p::Pt* p) { *p = g2p::dbl(*p); }
+struct G2pDblCall {
+    __device__ __forceinline__ void operator()(g2p::Pt& p) const { g2p_dbl_ni(&p); }
+};
 static __device__ __noinline__ void g2p_add_ni(g2p::Pt* acc, const g2p::Pt* q) {
     g2p::Pt a = *acc;
-    g2p::add(a, *q);
+    g2p::add(a, *q, G2pDblCall());
     *acc = a;
 }
-static __device__ __noinline__ void g2p_dbl_ni(g2p::Pt* p) { *p = g2p::dbl(*p); }
 
 // ---- multi-task buckets with few tasks: one PAIR per bucket (sorted position), serial fold.  thr: see msm_fold_threshold
 template <int UNIT = 0>  // a template so that only the G2 translation unit instantiates it

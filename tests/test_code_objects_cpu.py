@@ -67,3 +67,16 @@ def test_poseidon_partial_rounds_are_inlined_for_the_tree_width():
 def test_ntt_pass_keeps_four_waves(table):
     r = row(table, "ntt", "ntt_pass_kernel<4, 1, 1>")
     assert r["vgpr"] <= 128 and r["waves"] >= 4
+
+
+def test_no_device_function_destroys_its_return_address():
+    # the hang of the first GPU run of the pair-lane G2 tails (round 5, run 4): `s_getpc_b64 s[30:31]` as the scratch pair of a long branch
+    # inside a called function (kernels have no return address; there the pair is free)
+    assert kr.functions_clobbering_return_address() == []
+
+
+def test_g2_pair_tails_do_not_spill(table):
+    # the one-lane tails ran at 512 registers with 94 / 33 / 31 spilled ones
+    for k in ("msm_fold_g2pair_kernel<0>", "msm_fold_small_g2pair_kernel<0>", "msm_reduce_g2pair_kernel<0>", "msm_window_partial_g2pair_kernel<128>",
+              "msm_window_sum_g2pair_kernel<128>"):
+        assert row(table, "msm_g2", k)["spill"] <= 2, k

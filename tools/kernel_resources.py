@@ -76,6 +76,29 @@ def instruction_counts(obj, symbol_substring):
     return counts
 
 
+def functions_clobbering_return_address():
+    """[(object, mangled name)] of every NON-kernel device function that takes s[30:31] - its own return address - as the scratch pair of a
+    long-branch expansion (`s_getpc_b64 s[30:31]`).  Round 5, run 4: the compiler did that in a 137 KB no-inline function whose early exits jump
+    further than a conditional branch reaches; a wave whose lanes all left early then `returned` to the function's epilogue for ever."""
+    tmp = tempfile.mkdtemp()
+    bad = []
+    try:
+        for o, path in extract_device_objects(tmp).items():
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", path], capture_output=True, text=True).stdout
+            kernels = set(re.findall(r"\.name:\s+(\S+)", notes))
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
+            cur = None
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = m.group(1)
+                elif cur and cur not in kernels and "s_getpc_b64 s[30:31]" in line and (o, cur) not in bad:
+                    bad.append((o, cur))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return bad
+
+
 def main():
     print("# kernel resources of the gfx950 code objects in bazuka_amd/csrc/_obj (tools/kernel_resources.py)")
     print("# vgpr = unified register count (arch VGPRs + AGPRs, `agpr` of them accumulation registers); waves/SIMD = floor(512 / vgpr) capped at 8; scratch = private segment bytes per lane; LDS = static bytes per workgroup")

@@ -90,7 +90,8 @@ if __name__ == "__main__":
     def run(mode, log_n, env=None):
         e = dict(os.environ); e.update(env or {})
         try:
-            out = subprocess.run([sys.executable, __file__, "child", mode, str(log_n)], env=e, capture_output=True, text=True, timeout=150)
+            out = subprocess.run([sys.executable, __file__, "child", mode, str(log_n)], env=e, capture_output=True, text=True,
+                                 timeout=int(os.environ.get("SWEEP_CHILD_TIMEOUT", "150")))
             lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
             print(lines[-1] if lines else ("FAILED " + mode + " " + out.stderr[-300:]), flush=True)
         except subprocess.TimeoutExpired:
@@ -242,6 +243,19 @@ if __name__ == "__main__":
         run("g1tab", 20, {"TAB_LEVELS": "2", "BZK_MSM_TABLE_C": "17"})
         run("g1tab", 20, {"TAB_LEVELS": "4", "BZK_MSM_TABLE_C": "17"})
         run("g1", 22); run("g1tab", 22, {"TAB_LEVELS": "2"}); run("g1tab", 22, {"TAB_LEVELS": "4"})
+    if what in ("r5g1tails",):  # round 5, run 5: what the reduction's existing forms give the stand-alone headline MSM (one level / two levels, chunk)
+        for rep in range(2):
+            for r2 in ("-1", "1"):
+                for ch in ("8", "4"):
+                    run("g1res", 20, {"BZK_MSM_ENDO_G1": "0", "BZK_MSM_CHUNK": ch, "BZK_MSM_REDUCE2": r2})
+    if what in ("r5g2",):  # round 5, run 4: one-lane G2 / pair accumulation with one-lane tails / pairs everywhere, same box, alternating (the container of runs 2 - 3 was lost)
+        cfgs = ({"BZK_G2_PAIR": "0"}, {"BZK_G2_PAIR": "1", "BZK_G2_PAIR_TAILS": "0"}, {"BZK_G2_PAIR": "1", "BZK_G2_PAIR_TAILS": "1"})
+        for rep in range(2):
+            for cfg in cfgs:
+                run("g2", 20, cfg)
+                run("g2res", 20, dict(cfg, BZK_MSM_ENDO_G2="1", THROUGHPUT="1"))
+        for cfg in cfgs:
+            run("g2", 18, cfg)
     if what in ("r5tails",):  # round 5, run 3: the G2 tails (folds, bucket reduction, window sums) on pairs of lanes against the one-lane kernels, same box, alternating
         for rep in range(2):
             for tails in ("0", "1"):
