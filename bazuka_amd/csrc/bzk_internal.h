@@ -57,6 +57,7 @@ struct bzk_ctx {
     // (evaluations staged + seven transforms).  Created on first use.
     hipStream_t hprio = nullptr;
     hipEvent_t ev_h = nullptr;
+    void* wf_state = nullptr;  // witfill.hip: device copies of the deferred-witness programs, dense Poseidon constants, scratch (witfill_free)
 };
 
 #define BZK_HIP(ctx, call)                                                                  \
@@ -102,6 +103,7 @@ struct WsCursor {
         return p;
     }
 };
+void witfill_free(bzk_ctx* ctx);  // witfill.hip
 int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int coset);  // ntt.hip
 int32_t ntt_h_chain(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m);              // ntt.hip: the h polynomial's 7 transforms, fused
 // msm_g1.hip / msm_g2.hip: windows [w_begin, w_end) (w_end < 0: all) of an MSM over a resident base set (or raw bases when `bases` is

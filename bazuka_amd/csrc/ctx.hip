@@ -240,6 +240,7 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
     for (auto& p : ctx->poseidon_dev)
         if (p) (void)hipFree(p);
     bzk::ntt_free_tables(ctx);
+    bzk::witfill_free(ctx);
     if (ctx->ev_z) (void)hipEventDestroy(ctx->ev_z);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux);

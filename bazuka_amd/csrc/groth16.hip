@@ -22,6 +22,8 @@
 #include "bzk_curve.cuh"
 #include "bzk_internal.h"
 #include "host_fp64.h"
+#include "host_r1cs.h"  // DeferData / witfill_run_dev: witness values the device fills in (bzk_groth16_prove_r1cs)
+namespace bzk { void r1cs_assignment(const bzk_r1cs* r, bzk_assignment* a, const DeferData** dd); }  // mpn.hip
 
 // The CRS of one circuit on one device, shared (reference-counted, read-only once prepared) by every prover SLOT of that device:
 // a slot = bzk_params = the shared CRS + its own per-proof scratch.  Four slots per GPU (bench.py) used to hold four CRS copies and
@@ -422,16 +424,34 @@ int32_t bzk_groth16_h_dev(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_
     return groth16_h(ctx, a, b, c, log_m);
 }
 
-static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
-                                  uint8_t proof[387]);
+static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32],
+                                  const uint8_t s32[32], uint8_t proof[387]);
+static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32],
+                                   const uint8_t s32[32], uint8_t proof[387]);
 
 int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
                           uint8_t proof[387]) {
+    return groth16_prove_entry(ctx, p, asg, nullptr, r32, s32, proof);
+}
+// The same over an R1CS instance of the host generator (bzk_mpn_*_synthesize), INCLUDING one whose hash-dependent values were deferred
+// (bzk_mpn_set_defer): the arrays are uploaded as they are and the instance's DeferProgram fills the rest in on the device before any
+// MSM or transform reads them.  BZK_E_UNSAT: a deferred constraint does not hold, or a transition's computed state differs from the one
+// the witness builder predicted (the caller may synthesize again without deferral for the exact first unsatisfied row).
+int32_t bzk_groth16_prove_r1cs(bzk_ctx* ctx, bzk_params* p, const bzk_r1cs* r, const uint8_t r32[32], const uint8_t s32[32], uint8_t proof[387]) {
+    if (!r) return BZK_E_ARG;
+    bzk_assignment asg;
+    const bzk::DeferData* dd = nullptr;
+    bzk::r1cs_assignment(r, &asg, &dd);
+    return groth16_prove_entry(ctx, p, &asg, dd, r32, s32, proof);
+}
+
+static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32],
+                                   const uint8_t s32[32], uint8_t proof[387]) {
     if (!ctx || !p || !asg || !r32 || !s32 || !proof || !asg->z || !asg->az || !asg->bz || !asg->cz) return BZK_E_ARG;
     if (p->crs->device != ctx->device) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     crs_prepare(ctx, p->crs);
-    int32_t st = groth16_prove_impl(ctx, p, asg, r32, s32, proof);
+    int32_t st = groth16_prove_impl(ctx, p, asg, dd, r32, s32, proof);
     auto quiesce = [&] {
         // the caller frees (re-uses) the assignment arrays as soon as this returns: no copy out of them may still be in
         // flight, on the main stream or on a lane
@@ -455,7 +475,7 @@ int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg
                 dropped = true;
             }
         }
-        if (dropped) st = groth16_prove_impl(ctx, p, asg, r32, s32, proof);
+        if (dropped) st = groth16_prove_impl(ctx, p, asg, dd, r32, s32, proof);
     }
     if (st != BZK_OK) quiesce();
     return st;
@@ -492,7 +512,7 @@ int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* p, int32_t on) {
     return BZK_OK;
 }
 
-static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
+static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32], const uint8_t s32[32],
                                   uint8_t proof[387]) {
     const CrsShared* p = slot->crs;
     const uint64_t m = (uint64_t)1 << p->log_m, nv = (uint64_t)p->n_in + p->n_aux;
@@ -514,6 +534,17 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     for (int i = 0; i < n_lanes; ++i)
         if (!(lane[i] = bzk::ctx_lane(ctx, (size_t)i))) return BZK_E_DEVICE;
     BZK_HIP(ctx, hipMemcpyAsync(slot->d_z, asg->z, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (dd) {
+        // deferred witness values: z is not complete until the instance's program has run, and the program also writes into the three
+        // evaluation arrays - so those are staged now (main_part skips them) and every consumer below is behind the fill in stream order
+        void* ev[3] = {slot->d_a, slot->d_b, slot->d_c};
+        const uint8_t* hv[3] = {asg->az, asg->bz, asg->cz};
+        for (int k = 0; k < 3; ++k) {
+            BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+            if (m > asg->n_rows) BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
+        }
+        BZK_TRY(bzk::witfill_run_dev(ctx, *dd, bzk::wf::Arrays{(Fr*)slot->d_z + p->n_in, (Fr*)slot->d_a, (Fr*)slot->d_b, (Fr*)slot->d_c}));
+    }
     // density-filtered scalar vectors
     if (p->n_a)
         BZK_LAUNCH(ctx, "g16_gather", g16_gather_kernel, dim3((p->n_a + 255) / 256), dim3(256), 0, (const Fr*)slot->d_z, p->a_idx, p->n_a, (Fr*)slot->d_sa);
@@ -675,11 +706,11 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
             StreamSwap(bzk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { if (s) c->stream = s; }
             ~StreamSwap() { c->stream = saved; }
         };
-        const bool side = h_prio && ctx->hprio;
+        const bool side = h_prio && ctx->hprio && !dd;
         {
         StreamSwap swap(ctx, side ? ctx->hprio : nullptr);
         if (tm[0]) (void)hipEventRecord(tm[0], ctx->stream);
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 3 && !dd; ++k) {
             BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
             if (m > asg->n_rows)
                 BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
@@ -705,6 +736,14 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
             ctx->last_error = "lane " + std::to_string(i) + ": " + lane[i]->last_error;
             return st[i];
         }
+    if (dd) {  // (the h MSM's read-back has synchronised the main stream: the program's flags word has landed)
+        const uint32_t f = bzk::witfill_flags(ctx);
+        if (f) {
+            ctx->last_error = std::string("groth16_prove: deferred witness values -") + ((f & bzk::wf::FLAG_UNSATISFIED) ? " a deferred constraint does not hold" : "") +
+                              ((f & bzk::wf::FLAG_CHAIN) ? " a transition's computed state differs from the witness builder's prediction" : "");
+            return BZK_E_UNSAT;
+        }
+    }
     // assembly (host): g_a = (alpha + r delta) + a;  g_b = (beta + s delta) + b;  g_c = gc_pre + s a + r b_g1 + h + l
     // (= bellman's h + l + s g_a + r g_b1 - r s delta with g_b1 = beta_g1 + b_g1 + s delta)
     HG1 ga = ga_pre;

@@ -19,10 +19,15 @@
 #include <utility>
 #include <vector>
 
+#include <algorithm>
+#include <tuple>
+
+#include "bzk_witfill.cuh"
 #include "host_fr64.h"
 #include "host_fr_ifma.h"
 #include "host_zk.h"
 
+struct bzk_ctx;
 namespace bzk {
 
 typedef uint32_t Var;  // bit 31 set => aux variable, else input variable (0 = ONE)
@@ -111,6 +116,99 @@ struct CsrBuilder {
     std::vector<Fr> val;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Deferred witness values (bzk_witfill.cuh): what the gadgets emit instead of values when a transition is synthesized with
+// `cs.defer` set.  The PROGRAM is a property of the circuit shape (every transition runs the same gadget calls): it is recorded
+// once, on a plan pass over a null transition; a normal pass only appends the host-known operand values to the transition's
+// input record - in the same order - and skips the slots.
+// ------------------------------------------------------------------------------------------------
+struct DeferGroup {  // a run of ops of one kind and width (pass 1: inside one level): one launch
+    uint8_t kind, t;
+    uint16_t level;
+    uint32_t start, count;
+};
+struct DeferProgram {
+    std::vector<wf::Op> ops;            // emission order (plan pass)
+    uint32_t n_regs = 0, n_inputs = 0;
+    size_t n_aux = 0, n_con = 0;        // the transition's window
+    // finalize(): the V ops by (level, kind, t), the F ops by (kind, t), each list cut into launches; the constraint slots the device
+    // fills, as sorted disjoint ranges (the host's a b = c scan skips them)
+    std::vector<wf::Op> v_ops, f_ops;
+    std::vector<DeferGroup> v_groups, f_groups;
+    std::vector<std::pair<uint32_t, uint32_t>> con_holes;
+    uint32_t n_levels = 0;
+    size_t hole_aux = 0, hole_con = 0;  // slots per transition left to the device
+    void finalize() {
+        v_ops.clear(); f_ops.clear();
+        for (const wf::Op& o : ops) (o.kind == wf::V_HASH || o.kind == wf::V_SEL ? v_ops : f_ops).push_back(o);
+        std::stable_sort(v_ops.begin(), v_ops.end(), [](const wf::Op& a, const wf::Op& b) {
+            return std::make_tuple(a.level, a.kind, a.t) < std::make_tuple(b.level, b.kind, b.t);
+        });
+        std::stable_sort(f_ops.begin(), f_ops.end(), [](const wf::Op& a, const wf::Op& b) { return std::make_tuple(a.kind, a.t) < std::make_tuple(b.kind, b.t); });
+        auto cut = [](const std::vector<wf::Op>& v, std::vector<DeferGroup>& g, bool by_level) {
+            g.clear();
+            for (uint32_t i = 0; i < v.size(); ++i) {
+                if (!g.empty() && g.back().kind == v[i].kind && g.back().t == v[i].t && (!by_level || g.back().level == v[i].level)) ++g.back().count;
+                else g.push_back({v[i].kind, v[i].t, v[i].level, i, 1u});
+            }
+        };
+        cut(v_ops, v_groups, true);
+        cut(f_ops, f_groups, false);
+        n_levels = v_ops.empty() ? 0 : v_ops.back().level;
+        con_holes.clear();
+        hole_aux = hole_con = 0;
+        for (const wf::Op& o : f_ops) {
+            uint32_t na = 0, nc = 0;
+            if (o.kind == wf::F_POSEIDON) {
+                const PoseidonHostParams P = poseidon_host_params_cached(o.t);
+                na = nc = wf::poseidon_slots(o.t, P.rf, P.rp);
+            } else if (o.kind == wf::F_MUX) { na = 1; nc = 1; }
+            else if (o.kind == wf::F_ASSERT_EQ_IF) { na = 1; nc = 2; }
+            else if (o.kind == wf::F_ENFORCE_EQ) { nc = 1; }
+            hole_aux += na; hole_con += nc;
+            if (nc) con_holes.push_back({o.con_off, nc});
+        }
+        std::sort(con_holes.begin(), con_holes.end());
+    }
+};
+struct Defer {
+    DeferProgram* prog;  // written on the plan pass only
+    bool plan;
+    Fr* inputs;          // this transition's input record
+    uint32_t cap_inputs;
+    uint32_t n_in = 0;
+    int32_t n_regs = 0;
+    bool overflow = false;
+    std::vector<uint16_t> reg_level;  // plan pass: level of the op producing each register
+    int32_t in_val(const Fr& v) {
+        if (n_in < cap_inputs) inputs[n_in] = v;
+        else overflow = true;
+        return ~(int32_t)(n_in++);
+    }
+    int32_t new_reg(uint16_t level) {
+        if (plan) reg_level.push_back(level);
+        return n_regs++;
+    }
+    uint16_t level_of(int32_t operand) const { return plan && operand >= 0 ? reg_level[(size_t)operand] : (uint16_t)0; }
+    void emit(const wf::Op& op) {
+        if (plan) prog->ops.push_back(op);
+    }
+};
+// what an R1CS instance with deferred values carries besides its (incomplete) arrays
+struct DeferData {
+    const DeferProgram* prog = nullptr;
+    FrVec inputs;                       // n_tx records of prog->n_inputs scalars (pinned: uploaded by DMA)
+    size_t n_tx = 0;
+    size_t base_aux = 0, base_con = 0;  // aux / constraint index of transition 0's window; transition t at base + t * stride
+    size_t stride_aux = 0, stride_con = 0;
+    bool filled = false;                // the host arrays are complete (bzk_r1cs_fill_host ran)
+    uint32_t flags = 0;                 // wf::FLAG_* of that fill
+};
+// witfill.hip: the program over all transitions on the device (arrays = device views) / on the host
+int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A);  // enqueues on ctx->stream; the flags word follows in stream order
+uint32_t witfill_flags(bzk_ctx* ctx);                                                // ... and is read here once that stream has been synchronised
+uint32_t witfill_run_host(const DeferData& dd, const wf::Arrays& A);
+
 class ConstraintSystem {
    public:
     bool record_matrices;
@@ -129,6 +227,12 @@ class ConstraintSystem {
     Fr *win_aux = nullptr, *win_az = nullptr, *win_bz = nullptr, *win_cz = nullptr;
     size_t win_n_aux = 0, win_n_con = 0, win_cap_aux = 0, win_cap_con = 0;
     bool win_overflow = false;
+    Defer* defer = nullptr;  // window mode only: hash-dependent values are left to the device (DeferProgram above)
+    void skip(size_t n_aux_slots, size_t n_con_slots) {
+        win_n_aux += n_aux_slots;
+        win_n_con += n_con_slots;
+        if (win_n_aux > win_cap_aux || win_n_con > win_cap_con) win_overflow = true;
+    }
     void set_window(Fr* a, size_t cap_a, Fr* x, Fr* y, Fr* z, size_t cap_c) {
         win_aux = a; win_az = x; win_bz = y; win_cz = z;
         win_cap_aux = cap_a; win_cap_con = cap_c;
@@ -234,6 +338,7 @@ class ConstraintSystem {
 struct Num {  // AllocatedNum
     Var var;
     Fr val;
+    int32_t ref = -1;  // >= 0: the value is deferred (register of the transition's DeferProgram), `val` is not meaningful
 };
 struct Bit {  // AllocatedBit
     Var var;
@@ -363,45 +468,59 @@ static inline std::vector<Bit> num_to_bits_le_strict(ConstraintSystem& cs, const
 struct Number {
     LC lc;
     Fr val;
+    int32_t ref = -1;  // as Num::ref.  Arithmetic on a deferred Number is refused: only the gadgets with a device form may consume one
+    void known() const {
+        if (ref >= 0) throw std::logic_error("arithmetic on a deferred witness value");
+    }
     static Number zero() { return {LC(), Fr::zero()}; }
     static Number one() { return {LC::one(), Fr::one()}; }
     static Number constant(const Fr& v) { return {LC().add(VAR_ONE, v), v}; }
-    static Number from(const Num& n) { return {LC::of(n.var), n.val}; }
-    static Number from_scaled(const Fr& k, const Num& n) { return {LC().add(n.var, k), hfr::mul(n.val, k)}; }
+    static Number from(const Num& n) { return {LC::of(n.var), n.val, n.ref}; }
+    static Number from_scaled(const Fr& k, const Num& n) {
+        if (n.ref >= 0) throw std::logic_error("arithmetic on a deferred witness value");
+        return {LC().add(n.var, k), hfr::mul(n.val, k)};
+    }
     static Number from(const Bit& b) { return {LC::of(b.var), fr_from_bool(b.val)}; }
     void add_constant(const Fr& c) {
         lc.add(VAR_ONE, c);
         val = fe_add<FrParams>(val, c);
     }
     void add_num(const Fr& coeff, const Num& n) {
+        known();
+        if (n.ref >= 0) throw std::logic_error("arithmetic on a deferred witness value");
         lc.add(n.var, coeff);
         val = fe_add<FrParams>(val, hfr::mul(n.val, coeff));
     }
     Number plus(const Number& o) const {
+        known(); o.known();
         Number r = *this;
         r.lc.add_lc(o.lc);
         r.val = fe_add<FrParams>(val, o.val);
         return r;
     }
     Number plus_scaled(const Fr& k, const Number& o) const {
+        known(); o.known();
         Number r = *this;
         r.lc.add_scaled(o.lc, k);
         r.val = fe_add<FrParams>(val, hfr::mul(k, o.val));
         return r;
     }
     Number minus(const Number& o) const {
+        known(); o.known();
         Number r = *this;
         r.lc.sub_lc(o.lc);
         r.val = fe_sub<FrParams>(val, o.val);
         return r;
     }
     Num mul(ConstraintSystem& cs, const Number& o) const {  // number.rs:48-65
+        known(); o.known();
         Num r = num_alloc(cs, hfr::mul(val, o.val));
         cs.enforce(lc, val, o.lc, o.val, LC::of(r.var), r.val);
         return r;
     }
     Num compress(ConstraintSystem& cs) const { return mul(cs, one()); }  // :66-72
     Bool is_zero(ConstraintSystem& cs) const {                            // :75-111
+        known();
         const bool z = val.is_zero();
         Bit isz = bit_alloc(cs, z);
         Num inv = num_alloc(cs, z ? Fr::zero() : hfr::inv(val));
@@ -411,8 +530,32 @@ struct Number {
         return Bool::is(isz);
     }
     Bool is_equal(ConstraintSystem& cs, const Number& o) const { return minus(o).is_zero(cs); }  // :113-119
-    void assert_equal(ConstraintSystem& cs, const Number& o) const { cs.enforce(lc, val, LC::one(), Fr::one(), o.lc, o.val); }  // :121-128
+    void assert_equal(ConstraintSystem& cs, const Number& o) const {  // :121-128
+        if (cs.defer && (ref >= 0 || o.ref >= 0)) {  // this * 1 = other, on the device
+            Defer& D = *cs.defer;
+            wf::Op f{};
+            f.kind = wf::F_ENFORCE_EQ; f.out = -1; f.aux_off = (uint32_t)cs.win_n_aux; f.con_off = (uint32_t)cs.win_n_con;
+            f.in[0] = ref >= 0 ? ref : D.in_val(val);
+            f.in[1] = o.ref >= 0 ? o.ref : D.in_val(o.val);
+            D.emit(f);
+            cs.skip(0, 1);
+            return;
+        }
+        cs.enforce(lc, val, LC::one(), Fr::one(), o.lc, o.val);
+    }
     void assert_equal_if_enabled(ConstraintSystem& cs, const Bool& enabled, const Number& o) const {  // :130-177
+        if (cs.defer && (ref >= 0 || o.ref >= 0) && enabled.kind == Bool::IS) {
+            Defer& D = *cs.defer;
+            wf::Op f{};
+            f.kind = wf::F_ASSERT_EQ_IF; f.out = -1; f.aux_off = (uint32_t)cs.win_n_aux; f.con_off = (uint32_t)cs.win_n_con;
+            f.in[0] = D.in_val(fr_from_bool(enabled.bit.val));
+            f.in[1] = ref >= 0 ? ref : D.in_val(val);
+            f.in[2] = o.ref >= 0 ? o.ref : D.in_val(o.val);
+            D.emit(f);
+            cs.skip(1, 2);
+            return;
+        }
+        known(); o.known();
         if (enabled.kind == Bool::IS) {
             const Fr ev = enabled.bit.val ? val : Fr::zero(), en = fr_from_bool(enabled.bit.val);
             Var eis = cs.alloc(ev);
@@ -440,6 +583,27 @@ static inline Bool boolean_or(ConstraintSystem& cs, const Bool& a, const Bool& b
 }
 // select ? b : a      (mux.rs:7-47)
 static inline Num mux(ConstraintSystem& cs, const Bool& select, const Number& a, const Number& b) {
+    if (cs.defer && (a.ref >= 0 || b.ref >= 0) && select.kind != Bool::CONST) {
+        // one variable, one constraint, filled in by the device (F_MUX); the selected VALUE is a register of pass 1 (V_SEL)
+        Defer& D = *cs.defer;
+        wf::Op f{};
+        f.kind = wf::F_MUX; f.t = select.kind == Bool::NOT ? 1 : 0; f.out = -1;
+        f.aux_off = (uint32_t)cs.win_n_aux; f.con_off = (uint32_t)cs.win_n_con;
+        f.in[0] = D.in_val(fr_from_bool(select.bit.val));
+        f.in[1] = a.ref >= 0 ? a.ref : D.in_val(a.val);
+        f.in[2] = b.ref >= 0 ? b.ref : D.in_val(b.val);
+        wf::Op v = f;
+        v.kind = wf::V_SEL; v.aux_off = v.con_off = 0;
+        v.level = (uint16_t)(std::max(D.level_of(f.in[1]), D.level_of(f.in[2])) + 1);
+        v.out = D.new_reg(v.level);
+        D.emit(v);
+        D.emit(f);
+        cs.skip(1, 1);
+        Num ret{VAR_AUX | (Var)(cs.win_n_aux - 1), Fr::zero()};
+        ret.ref = v.out;
+        return ret;
+    }
+    a.known(); b.known();
     if (select.kind == Bool::IS) {
         Num ret = num_alloc(cs, select.bit.val ? b.val : a.val);
         cs.enforce(LC().add_lc(a.lc).sub_lc(b.lc), fe_sub<FrParams>(a.val, b.val), LC::of(select.bit.var), fr_from_bool(select.bit.val),
@@ -524,10 +688,45 @@ static inline std::vector<Number> g_product_mds(const std::vector<Number>& vals,
 // same order as the LC form below - per S-box  x2 = x x, x4 = x2 x2, x5 = x x4  (three variables, three constraints), per idle lane of a
 // partial round  v = v * 1  - on plain field values, the MDS rows as dot products with one reduction each (host_fr64.h).  The Poseidon
 // gadget is ~2/3 of a transaction's witness time; this form needs no vector<Number> traffic and ~0.6 of the word multiplications.
-static inline Number g_poseidon_values(ConstraintSystem& cs, const std::vector<Number>& vals) {
+static inline bool defer_width_ok(int t) { return t == 3 || t == 5 || t == 6 || t == 8; }  // the widths the device fill is instantiated for (witfill.hip)
+static inline Number g_poseidon_values(ConstraintSystem& cs, const std::vector<Number>& vals, bool need_value) {
     static const LC none;
     const int t = (int)vals.size() + 1;
     const PoseidonHostParams P = poseidon_host_params_cached(t);
+    if (cs.defer && defer_width_ok(t)) {
+        // the gadget's variables and constraints are written by the device (F_POSEIDON); the OUTPUT is a register of pass 1 (V_HASH: the
+        // sparse-round hash) unless the caller needs it here (EdDSA's bit decomposition): then all inputs must be known and the host hashes
+        Defer& D = *cs.defer;
+        wf::Op f{};
+        f.kind = wf::F_POSEIDON; f.t = (uint8_t)t; f.out = -1;
+        f.aux_off = (uint32_t)cs.win_n_aux; f.con_off = (uint32_t)cs.win_n_con;
+        bool any_ref = false;
+        uint16_t lvl = 0;
+        for (int i = 0; i < t - 1; ++i) {
+            f.in[i] = vals[i].ref >= 0 ? vals[i].ref : D.in_val(vals[i].val);
+            any_ref |= vals[i].ref >= 0;
+            lvl = std::max(lvl, D.level_of(f.in[i]));
+        }
+        D.emit(f);
+        const uint32_t slots = wf::poseidon_slots(t, P.rf, P.rp);
+        cs.skip(slots, slots);
+        Number out{LC(), Fr::zero()};
+        if (need_value) {
+            if (any_ref) throw std::logic_error("a Poseidon output is needed on the host but depends on deferred values");
+            ZkScalar in[8];
+            for (int i = 0; i < t - 1; ++i) in[i].v = vals[i].val;
+            out.val = poseidon_hash(in, t - 1).v;
+        } else {
+            wf::Op v = f;
+            v.kind = wf::V_HASH; v.aux_off = v.con_off = 0;
+            v.level = (uint16_t)(lvl + 1);
+            v.out = D.new_reg(v.level);
+            D.emit(v);
+            out.ref = v.out;
+        }
+        return out;
+    }
+    for (auto& x : vals) x.known();
     const hfr::MdsTable& mds_tab = poseidon_mds_table(t);
     Fr e[17], nw[17];
     e[0] = Fr::zero();
@@ -564,8 +763,9 @@ static inline Number g_poseidon_values(ConstraintSystem& cs, const std::vector<N
     }
     return {LC(), e[1]};
 }
-static inline Number g_poseidon(ConstraintSystem& cs, const std::vector<Number>& vals) {
-    if (!lc_tracking()) return g_poseidon_values(cs, vals);
+// need_value: the caller uses the output's VALUE on the host (only matters while values are deferred, see g_poseidon_values)
+static inline Number g_poseidon(ConstraintSystem& cs, const std::vector<Number>& vals, bool need_value = false) {
+    if (!lc_tracking()) return g_poseidon_values(cs, vals, need_value);
     std::vector<Number> e;
     e.push_back(Number::zero());
     for (auto& v : vals) e.push_back(v);
@@ -741,7 +941,7 @@ static inline APoint g_mul_cofactor(ConstraintSystem& cs, const APoint& p) {  //
 
 static inline void g_verify_eddsa(ConstraintSystem& cs, const Bool& enabled, const APoint& pk, const Number& msg,
                                   const APoint& sig_r, const Num& sig_s) {  // :249-280
-    Num h = g_poseidon(cs, {Number::from(sig_r.x), Number::from(sig_r.y), Number::from(pk.x), Number::from(pk.y), msg}).compress(cs);
+    Num h = g_poseidon(cs, {Number::from(sig_r.x), Number::from(sig_r.y), Number::from(pk.x), Number::from(pk.y), msg}, true).compress(cs);
     APoint sb = g_base_mul(cs, jubjub_base_cofactor(), sig_s);
     APoint rpha = pk.mul(cs, h);
     rpha = rpha.add(cs, sig_r);

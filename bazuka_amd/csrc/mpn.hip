@@ -93,6 +93,7 @@ struct bzk_mpn {
     ZkScalar contract_id = ZkScalar::from_u64(0x4D504E);  // ContractId::Custom of the MPN contract (payments of synthetic txs)
     int threads = (int)std::max(1u, std::thread::hardware_concurrency());
     bzk_ctx* dev = nullptr;  // bzk_mpn_set_device: the witness builders hash their Merkle updates in batches on this context
+    bool defer = false;      // bzk_mpn_set_defer: witness-only Update instances leave the hash-dependent values to the device (host_r1cs.h DeferProgram)
     std::string dev_error;
 
     bzk_mpn(int l, int t) : L(l), T(t) {
@@ -133,6 +134,7 @@ struct bzk_r1cs {
     std::vector<uint8_t> a_density, b_density;
     std::vector<uint32_t> colA, colB, colC;  // flat variable indices (after finalize)
     uint64_t accepted = 0, rejected = 0;
+    std::unique_ptr<bzk::DeferData> defer;  // set: the arrays have holes a DeferProgram fills (device: bzk_groth16_prove_r1cs, host: bzk_r1cs_fill_host)
     explicit bzk_r1cs(bool rec) : cs(rec) {}
 };
 
@@ -716,7 +718,8 @@ static TxOut synth_tx(ConstraintSystem& cs, int L, int T, const Num& accepted_fe
     Number::from(tx_nonce).assert_equal_if_enabled(cs, enabled, Number::from(src_tx_nonce).plus(Number::constant(Fr::one())));  // 24
     Num final_fee = mux(cs, enabled, Number::zero(), tx_fee.num);
     Number tx_hash = g_poseidon(cs, {Number::from(tx_nonce), Number::from(tx_dst_addr.x), Number::from(tx_dst_addr.y),
-                                     Number::from(tx_amount_token_id), tx_amount.num, Number::from(tx_fee_token_id), tx_fee.num});  // 25
+                                     Number::from(tx_amount_token_id), tx_amount.num, Number::from(tx_fee_token_id), tx_fee.num},
+                                true);  // 25 (its VALUE feeds the signature gadget's bit decomposition: hashed on the host even when values are deferred)
     APoint sig_r = APoint::alloc(cs, tr.tx.sig.r);
     sig_r.assert_on_curve(cs, enabled);
     Num sig_s = num_alloc(cs, tr.tx.sig.s.v);
@@ -727,7 +730,7 @@ static TxOut synth_tx(ConstraintSystem& cs, int L, int T, const Num& accepted_fe
 // impl Circuit for UpdateCircuit (src/mpn/circuits/update_circuit.rs:49-494)
 static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
                               const ZkScalar& aux_data, const ZkScalar& next_state, const ZkScalar& fee_token,
-                              const std::vector<UpdateTransition>& transitions, int nthreads) {
+                              const std::vector<UpdateTransition>& transitions, int nthreads, DeferData* dd = nullptr) {
     Num commitment_wit = num_alloc(cs, commitment.v);
     num_inputize(cs, commitment_wit);
     Num height_wit = num_alloc(cs, fr_from_u64(height));
@@ -742,7 +745,8 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
     Number fee_sum = Number::zero();
 
     bool done = false;
-    if (!lc_tracking() && nthreads > 1 && transitions.size() > 1) {
+    if (lc_tracking()) dd = nullptr;  // deferral is a witness-only form
+    if (!lc_tracking() && ((nthreads > 1 && transitions.size() > 1) || (dd && !transitions.empty()))) {
         // Witness-only mode, parallel over transitions.  Variable identities do not matter here (no LCs), only the
         // ORDER of the emitted values, so each worker fills a private system and the pieces are concatenated.
         // The state entering transition t is predicted from the witness builder (`state_after` chain) and checked
@@ -766,6 +770,47 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
             }
             size_hint_aux = it->second.first;
             size_hint_cons = it->second.second;
+        }
+        // deferred values: the program of one transition, recorded once per (L, T) on a null transition (every transition runs the same
+        // gadget calls); the chain check against the builder's predicted state is its last op
+        const DeferProgram* prog = nullptr;
+        auto chain_check = [](ConstraintSystem& part, Defer& D, const Num& state_out, const Fr& predicted) {
+            wf::Op f{};
+            f.kind = wf::F_CHECK_EQ; f.out = -1;
+            f.aux_off = (uint32_t)part.win_n_aux; f.con_off = (uint32_t)part.win_n_con;
+            f.in[0] = state_out.ref >= 0 ? state_out.ref : D.in_val(state_out.val);
+            f.in[1] = D.in_val(predicted);
+            D.emit(f);
+        };
+        if (dd) {
+            static std::mutex mu;
+            static std::map<std::pair<int, int>, std::unique_ptr<DeferProgram>> progs;
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = progs.find({L, T});
+            if (it == progs.end()) {
+                std::unique_ptr<DeferProgram> P(new DeferProgram());
+                std::vector<Fr> sa(size_hint_aux), sx(size_hint_cons), sy(size_hint_cons), sz(size_hint_cons), sin(1 << 14);
+                ConstraintSystem plan(false);
+                plan.set_window(sa.data(), size_hint_aux, sx.data(), sy.data(), sz.data(), size_hint_cons);
+                Defer D{P.get(), true, sin.data(), (uint32_t)sin.size()};
+                plan.defer = &D;
+                LcModeGuard g(false);
+                Num st0 = {VAR_ONE, state.v};
+                TxOut o = synth_tx(plan, L, T, accepted_fee_token, st0, UpdateTransition::null(L, T));
+                chain_check(plan, D, o.state_out, state.v);
+                if (D.overflow || plan.win_overflow || plan.win_n_aux != size_hint_aux || plan.win_n_con != size_hint_cons)
+                    throw std::logic_error("deferred synthesis changed the shape of a transition");
+                P->n_regs = (uint32_t)D.n_regs;
+                P->n_inputs = D.n_in;
+                P->n_aux = size_hint_aux;
+                P->n_con = size_hint_cons;
+                P->finalize();
+                it = progs.emplace(std::make_pair(L, T), std::move(P)).first;
+            }
+            prog = it->second.get();
+            dd->prog = prog;
+            dd->n_tx = n;
+            dd->inputs.resize(n * (size_t)prog->n_inputs);
         }
         // workers write straight into their slice of the final (pinned) arrays: no per-transition buffers, no merge copy
         const auto ta0 = std::chrono::steady_clock::now();
@@ -796,8 +841,12 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
                                 cs.bz.data() + base_con + t * size_hint_cons, cs.cz.data() + base_con + t * size_hint_cons, size_hint_cons);
                 Num st_in = {VAR_ONE, state_in[t]};
                 const auto q0 = std::chrono::steady_clock::now();
+                Defer D{nullptr, false, dd ? dd->inputs.data() + t * (size_t)prog->n_inputs : nullptr, dd ? prog->n_inputs : 0u};
+                if (dd) part.defer = &D;
                 outs[t] = synth_tx(part, L, T, accepted_fee_token, st_in, transitions[t]);
-                shape_ok[t] = !part.win_overflow && part.win_n_aux == size_hint_aux && part.win_n_con == size_hint_cons;
+                if (dd) chain_check(part, D, outs[t].state_out, state_in[t + 1]);
+                shape_ok[t] = !part.win_overflow && part.win_n_aux == size_hint_aux && part.win_n_con == size_hint_cons &&
+                              (!dd || (!D.overflow && D.n_in == prog->n_inputs && (uint32_t)D.n_regs == prog->n_regs));
                 if (getenv("BZK_DEBUG") && t < 3)
                     fprintf(stderr, "[bzk]   tx %zu: %.3f s\n", t, std::chrono::duration<double>(std::chrono::steady_clock::now() - q0).count());
             }
@@ -812,7 +861,8 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
             fprintf(stderr, "[bzk] %d workers: %.3f s\n", nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
         bool chain_ok = true;
         for (size_t t = 0; t < n; ++t) {
-            if (!shape_ok[t] || !outs[t].state_out.val.equals(state_in[t + 1])) {
+            // (deferred: the computed state only exists on the device, which raises wf::FLAG_CHAIN where it differs from the prediction)
+            if (!shape_ok[t] || (!dd && !outs[t].state_out.val.equals(state_in[t + 1]))) {
                 if (getenv("BZK_DEBUG")) fprintf(stderr, "[bzk] state chain / shape mismatch at transition %zu (enabled %d)\n", t, (int)transitions[t].enabled);
                 chain_ok = false;
             }
@@ -821,12 +871,22 @@ static void synthesize_update(ConstraintSystem& cs, int L, int T, const ZkScalar
             for (size_t t = 0; t < n; ++t) fee_sum.add_num(Fr::one(), outs[t].final_fee);
             state_wit = {VAR_ONE, state_in[n]};
             done = true;
+            if (dd) {
+                dd->base_aux = base_aux;
+                dd->base_con = base_con;
+                dd->stride_aux = size_hint_aux;
+                dd->stride_con = size_hint_cons;
+            }
         } else {  // back to the state before the workers ran; the sequential walk below redoes everything
             cs.aux.resize(base_aux);
             cs.az.resize(base_con);
             cs.bz.resize(base_con);
             cs.cz.resize(base_con);
         }
+    }
+    if (!done && dd) {  // nothing was deferred after all (the sequential walk below computes every value)
+        dd->prog = nullptr;
+        dd->n_tx = 0;
     }
     if (!done) {
         for (const UpdateTransition& tr : transitions) {
@@ -1398,6 +1458,18 @@ static void finish_r1cs(bzk_r1cs* r) {
     }
 }
 
+// groth16.hip (bzk_groth16_prove_r1cs): the instance's arrays as an assignment, and what is deferred in them (nullptr: nothing, or already filled in)
+void r1cs_assignment(const bzk_r1cs* r, bzk_assignment* a, const DeferData** dd) {
+    const ConstraintSystem& cs = r->cs;
+    a->z = r->z_bytes.data();
+    a->az = (const uint8_t*)cs.az.data();
+    a->bz = (const uint8_t*)cs.bz.data();
+    a->cz = (const uint8_t*)cs.cz.data();
+    a->n_rows = cs.az.size();
+    a->n_vars = cs.inputs.size() + cs.aux.size();
+    *dd = (r->defer && !r->defer->filled) ? r->defer.get() : nullptr;
+}
+
 }  // namespace bzk
 
 extern "C" {
@@ -1507,7 +1579,9 @@ int32_t bzk_mpn_update_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_t
         // or pure ProvingAssignment role (values only: no linear-combination bookkeeping at all)
         LcModeGuard guard(record_matrices != 0);
         r->cs.self_check = record_matrices != 0;
-        synthesize_update(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, next_state, ft, trs, w->threads);
+        if (w->defer && !record_matrices) r->defer.reset(new DeferData());
+        synthesize_update(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, next_state, ft, trs, w->threads, r->defer.get());
+        if (r->defer && !r->defer->prog) r->defer.reset();
         if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;  // a gadget supplied a value that is not <LC, z>
         double t2 = now();
         r->accepted = accepted;
@@ -1697,10 +1771,34 @@ int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]) {
         const size_t nrows = cs.num_constraints();
         const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(8, nrows / 65536));
         std::vector<long> first((size_t)nt, -1);
+        // rows a DeferProgram fills on the device are not the host's to judge (they hold stale bytes until then): the scan covers the gaps
+        // between them; the device reports its own rows through wf::FLAG_UNSATISFIED
+        std::vector<std::pair<size_t, size_t>> ranges;
+        if (r->defer && !r->defer->filled) {
+            const DeferData& dd = *r->defer;
+            size_t pos = 0;
+            for (size_t t = 0; t < dd.n_tx; ++t) {
+                const size_t base = dd.base_con + t * dd.stride_con;
+                for (auto& h : dd.prog->con_holes) {
+                    if (base + h.first > pos) ranges.push_back({pos, base + h.first});
+                    pos = base + h.first + h.second;
+                }
+            }
+            if (pos < nrows) ranges.push_back({pos, nrows});
+        } else {
+            ranges.push_back({0, nrows});
+        }
         auto scan = [&](unsigned t) {
             const size_t lo = nrows * t / nt, hi = nrows * (t + 1) / nt;
-            // eight rows per step on AVX-512 IFMA where the CPU has it, the 64-bit-limb product otherwise (host_fr_ifma.h)
-            first[t] = hfr::products_first_mismatch(cs.az.data(), cs.bz.data(), cs.cz.data(), lo, hi);
+            long bad = -1;
+            for (auto& rg : ranges) {
+                const size_t a = std::max(lo, rg.first), b = std::min(hi, rg.second);
+                if (a >= b) continue;
+                // eight rows per step on AVX-512 IFMA where the CPU has it, the 64-bit-limb product otherwise (host_fr_ifma.h)
+                bad = hfr::products_first_mismatch(cs.az.data(), cs.bz.data(), cs.cz.data(), a, b);
+                if (bad >= 0) break;
+            }
+            first[t] = bad;
         };
         std::vector<std::thread> th;
         for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
@@ -1738,6 +1836,39 @@ const void* bzk_r1cs_data(const bzk_r1cs* r, int32_t which, uint64_t* bytes) {
         case 13: return ret(cs.B.row_ptr.data(), cs.B.row_ptr.size() * 4);
         case 14: return ret(cs.C.row_ptr.data(), cs.C.row_ptr.size() * 4);
         default: *bytes = 0; return nullptr;
+    }
+}
+
+// ---- deferred witness values (host_r1cs.h DeferProgram, bzk_witfill.cuh)
+int32_t bzk_mpn_set_defer(bzk_mpn* w, int32_t on) {
+    if (!w) return BZK_E_ARG;
+    w->defer = on != 0;
+    return BZK_OK;
+}
+// info: 0 deferred (1 / 0), 1 transitions, 2 ops, 3 registers, 4 inputs per transition, 5 levels of pass 1, 6 / 7 variable / constraint
+// slots per transition left to the device, 8 filled on the host (1 / 0), 9 wf::FLAG_* of that fill
+int32_t bzk_r1cs_defer_info(const bzk_r1cs* r, uint64_t info[10]) {
+    if (!r || !info) return BZK_E_ARG;
+    for (int i = 0; i < 10; ++i) info[i] = 0;
+    if (!r->defer) return BZK_OK;
+    const DeferData& dd = *r->defer;
+    info[0] = 1; info[1] = dd.n_tx; info[2] = dd.prog->ops.size(); info[3] = dd.prog->n_regs; info[4] = dd.prog->n_inputs;
+    info[5] = dd.prog->n_levels; info[6] = dd.prog->hole_aux; info[7] = dd.prog->hole_con; info[8] = dd.filled ? 1 : 0; info[9] = dd.flags;
+    return BZK_OK;
+}
+// completes the host arrays with the same ops the device runs (CPU consumers of bzk_r1cs_data; the CPU suite)
+int32_t bzk_r1cs_fill_host(bzk_r1cs* r) {
+    if (!r) return BZK_E_ARG;
+    if (!r->defer || r->defer->filled) return BZK_OK;
+    try {
+        ConstraintSystem& cs = r->cs;
+        wf::Arrays A{(Fr*)(r->z_bytes.data() + 32 * cs.inputs.size()), cs.az.data(), cs.bz.data(), cs.cz.data()};
+        r->defer->flags = witfill_run_host(*r->defer, A);
+        memcpy((void*)cs.aux.data(), A.z_aux, cs.aux.size() * 32);  // the generator's own copy of the aux part
+        r->defer->filled = true;
+        return BZK_OK;
+    } catch (const std::exception&) {
+        return BZK_E_INTERNAL;
     }
 }
 
@@ -1953,14 +2084,17 @@ int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* h, const uint8_t prover_pub[
         const size_t cap = (size_t)1 << (2 * B);
         const int nt = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
         const ZkScalar commitment = mpn_work_commitment(prover_pub, w.reward);
-        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
-        LcModeGuard guard(record_matrices != 0);
-        r->cs.self_check = record_matrices != 0;
+        const bool rec = record_matrices == 1, defer = record_matrices == BZK_SYNTH_DEFER;  // 0: witness only
+        std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(rec));
+        LcModeGuard guard(rec);
+        r->cs.self_check = rec;
         if (w.kind == 2) {
             std::vector<UpdateTransition> trs = w.updates;
             while (trs.size() < cap) trs.push_back(UpdateTransition::null(L, T));
             const ZkScalar ft = fee_token ? ZkScalar::from_bytes(fee_token) : ZkScalar::one();
-            synthesize_update(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, ft, trs, nt);
+            if (defer) r->defer.reset(new DeferData());
+            synthesize_update(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, ft, trs, nt, r->defer.get());
+            if (r->defer && !r->defer->prog) r->defer.reset();
         } else if (w.kind == 0) {
             std::vector<DepositTransition> trs = w.deposits;
             while (trs.size() < cap) trs.push_back(DepositTransition::null(L, T));

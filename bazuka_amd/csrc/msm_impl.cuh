@@ -1411,8 +1411,19 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         return (uint32_t)((v == 2 || v == 4 || v == 8 || v == 16) ? v : 4);
     }();
     const bool quad_l2 = quad_l2_on && !C::PARK_REDUCE;
-    const uint32_t ch2 = std::min<uint32_t>(quad_l2 ? quad_l2_ch : 8u, per_win);
-    const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && (flags & BZK_F_THROUGHPUT)));
+    // G2 on pairs of lanes (msm_g2pair_tails.cuh): the reduction is two-level for EVERY call, with level-2 chunks of 4.  Measured (round 5, run 5,
+    // 2^20 points, same box): one level 2.17 - 2.21 ms (65 536 pairs x 41 links: two rounds of waves at one wave per SIMD; the one-lane kernel
+    // 1.89) against 0.41 + 0.77 ms in two levels with chunks of 8, where level 2 is 64 - 256 waves walking 41 links: shorter chunks put
+    // more pairs on a shorter chain (8 + ~17 links).  env BZK_MSM_PAIR_L2_CH = 2 | 4 | 8 | 16, BZK_MSM_REDUCE2=-1 for the one-level form (A/B)
+    static const uint32_t pair_l2_ch = [] {
+        const char* e = getenv("BZK_MSM_PAIR_L2_CH");
+        const int v = e ? atoi(e) : 4;
+        return (uint32_t)((v == 2 || v == 4 || v == 8 || v == 16) ? v : 4);
+    }();
+    bool pair_tails = false;
+    if constexpr (C::PAIR_ACC) pair_tails = msm_g2_pair_tails_on();
+    const uint32_t ch2 = std::min<uint32_t>(pair_tails ? pair_l2_ch : quad_l2 ? quad_l2_ch : 8u, per_win);
+    const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && ((flags & BZK_F_THROUGHPUT) || pair_tails)));
     const uint32_t per_win_out = two_level ? per_win + per_win / ch2 : per_win;  // chunk results per window handed to the window sums
     if (wout) { wout->c = c; wout->w_total = w_total; wout->w_begin = w_begin; wout->w_end = w_end; wout->single = table && !folded; }
 

@@ -368,6 +368,8 @@ static int32_t poseidon_consts_dev(bzk_ctx* ctx, int t, const void** out, int* r
     *out = ctx->poseidon_dev[t];
     return BZK_OK;
 }
+// the same table for witfill.hip (pass 1 of the deferred witness values hashes with poseidon29_hash too)
+int32_t poseidon_consts_dev_shared(bzk_ctx* ctx, int t, const void** out, int* rf, int* rp) { return poseidon_consts_dev(ctx, t, out, rf, rp); }
 
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,294 @@
+// Witness value traces on the device: the executor of a DeferProgram (host_r1cs.h) over all transitions of one R1CS instance.
+// The ops and what they restate of the reference's gadgets: bzk_witfill.cuh.  One lane per (op, transition); pass 1 level by level
+// (a level's ops only read registers of lower levels), pass 2 in one sweep per op kind.  The same ops run on the host in
+// witfill_run_host (bzk_r1cs_fill_host: CPU consumers of the complete arrays, and the CPU suite's comparison with the host generator).
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <thread>
+
+#include "bzk_internal.h"
+#include "bzk_poseidon_opt.h"
+#include "bzk_witfill.cuh"
+#include "host_r1cs.h"
+
+namespace bzk {
+
+int32_t poseidon_consts_dev_shared(bzk_ctx* ctx, int t, const void** out, int* rf, int* rp);  // poseidon.hip
+
+namespace {
+
+// dense constants of width t in the 29-bit form: rc[(rf + rp) t] | mds[t t] (the sparse form of the hash kernels has no per-round state)
+std::vector<Fr29> dense_consts_host(int t) {
+    const PoseidonHostParams P = poseidon_host_params_cached(t);
+    std::vector<Fr29> out;
+    const size_t n_rc = (size_t)t * (P.rf + P.rp), n_mds = (size_t)t * t;
+    out.reserve(n_rc + n_mds);
+    for (size_t i = 0; i < n_rc; ++i) out.push_back(fr29::norm(fr29::to29(P.rc[i])));
+    for (size_t i = 0; i < n_mds; ++i) out.push_back(fr29::norm(fr29::to29(P.mds[i])));
+    return out;
+}
+
+struct DevTables {
+    const Fr29* dense[9] = {};
+    const Fr29* sparse[9] = {};
+    int rf[9] = {}, rp[9] = {};
+};
+
+template <int T>
+__global__ void __launch_bounds__(64) wf_hash_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
+                                                     uint32_t n_inputs, Fr* __restrict__ regs, const Fr29* __restrict__ consts, int rf, int rp) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count * n_tx) return;
+    const uint32_t tx = g % n_tx;
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, 0, 0};
+    wf::v_hash<T>(ops[g / n_tx], v, consts, rf, rp);
+}
+__global__ void __launch_bounds__(256) wf_sel_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
+                                                     uint32_t n_inputs, Fr* __restrict__ regs) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count * n_tx) return;
+    const uint32_t tx = g % n_tx;
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, 0, 0};
+    wf::v_sel(ops[g / n_tx], v);
+}
+template <int T>
+__global__ void __launch_bounds__(64) wf_poseidon_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
+                                                         uint32_t n_inputs, Fr* __restrict__ regs, wf::Arrays A, size_t base_aux, size_t stride_aux,
+                                                         size_t base_con, size_t stride_con, const Fr29* __restrict__ dense, int rf, int rp) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count * n_tx) return;
+    const uint32_t tx = g % n_tx;
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con};
+    wf::f_poseidon<T>(ops[g / n_tx], v, A, dense, rf, rp);
+}
+__global__ void __launch_bounds__(256) wf_small_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
+                                                       uint32_t n_inputs, Fr* __restrict__ regs, wf::Arrays A, size_t base_aux, size_t stride_aux,
+                                                       size_t base_con, size_t stride_con, uint32_t* __restrict__ flags) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count * n_tx) return;
+    const uint32_t tx = g % n_tx;
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con};
+    const wf::Op op = ops[g / n_tx];
+    uint32_t f = 0;
+    switch (op.kind) {
+        case wf::F_MUX: wf::f_mux(op, v, A); break;
+        case wf::F_ASSERT_EQ_IF: f = wf::f_assert_eq_if(op, v, A); break;
+        case wf::F_ENFORCE_EQ: f = wf::f_enforce_eq(op, v, A); break;
+        case wf::F_CHECK_EQ: f = wf::f_check_eq(op, v); break;
+        default: break;
+    }
+    if (f) atomicOr(flags, f);
+}
+
+// per (context, program): the ops in device memory; per context: the constant tables and the grow-only scratch (registers + inputs)
+struct CtxState {
+    std::map<const DeferProgram*, std::pair<wf::Op*, wf::Op*>> progs;  // v_ops, f_ops
+    DevTables tab;
+    void* dense_dev[9] = {};
+    void* scratch = nullptr;   // [flags word, padded to 256 B][input records][registers]
+    size_t scratch_bytes = 0;
+    uint32_t* flags_host = nullptr;  // pinned: where the flags word of the last run lands (stream order)
+};
+
+int32_t tables(bzk_ctx* ctx, CtxState& S, int t) {
+    if (S.tab.dense[t]) return BZK_OK;
+    const void* sp;
+    int rf, rp;
+    BZK_TRY(poseidon_consts_dev_shared(ctx, t, &sp, &rf, &rp));
+    const std::vector<Fr29> d = dense_consts_host(t);
+    void* dev = nullptr;
+    BZK_HIP(ctx, hipMalloc(&dev, d.size() * sizeof(Fr29)));
+    BZK_HIP(ctx, hipMemcpyAsync(dev, d.data(), d.size() * sizeof(Fr29), hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    S.dense_dev[t] = dev;
+    S.tab.dense[t] = (const Fr29*)dev;
+    S.tab.sparse[t] = (const Fr29*)sp;
+    S.tab.rf[t] = rf;
+    S.tab.rp[t] = rp;
+    return BZK_OK;
+}
+
+}  // namespace
+
+uint32_t witfill_flags(bzk_ctx* ctx) {  // after the stream of the last witfill_run_dev has been synchronised
+    CtxState* S = (CtxState*)ctx->wf_state;
+    return S && S->flags_host ? *S->flags_host : 0u;
+}
+
+int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) {
+    const DeferProgram& P = *dd.prog;
+    if (!dd.n_tx || P.ops.empty()) return BZK_OK;
+    // (a context is driven by one host thread at a time - the library's rule for every entry point - so its state needs no lock)
+    if (!ctx->wf_state) ctx->wf_state = new CtxState();
+    CtxState* S = (CtxState*)ctx->wf_state;
+    if (!S->flags_host) BZK_HIP(ctx, hipHostMalloc((void**)&S->flags_host, 64));
+    *S->flags_host = 0;
+    for (const DeferGroup& g : P.v_groups)
+        if (g.kind == wf::V_HASH) BZK_TRY(tables(ctx, *S, g.t));
+    for (const DeferGroup& g : P.f_groups)
+        if (g.kind == wf::F_POSEIDON) BZK_TRY(tables(ctx, *S, g.t));
+    auto it = S->progs.find(&P);
+    if (it == S->progs.end()) {
+        wf::Op *dv = nullptr, *df = nullptr;
+        BZK_HIP(ctx, hipMalloc((void**)&dv, std::max<size_t>(1, P.v_ops.size()) * sizeof(wf::Op)));
+        BZK_HIP(ctx, hipMalloc((void**)&df, std::max<size_t>(1, P.f_ops.size()) * sizeof(wf::Op)));
+        BZK_HIP(ctx, hipMemcpyAsync(dv, P.v_ops.data(), P.v_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(df, P.f_ops.data(), P.f_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the vectors above belong to the (immutable, process-lifetime) program, but be strict
+        it = S->progs.emplace(&P, std::make_pair(dv, df)).first;
+    }
+    const size_t n_tx = dd.n_tx;
+    const size_t in_bytes = ws_pad(n_tx * (size_t)P.n_inputs * 32), reg_bytes = ws_pad(n_tx * (size_t)P.n_regs * 32);
+    if (S->scratch_bytes < 256 + in_bytes + reg_bytes) {
+        // the previous buffer may still be read by launches of an earlier call on this stream
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (S->scratch) (void)hipFree(S->scratch);
+        S->scratch = nullptr;
+        S->scratch_bytes = 0;
+        BZK_HIP(ctx, hipMalloc(&S->scratch, 256 + in_bytes + reg_bytes));
+        S->scratch_bytes = 256 + in_bytes + reg_bytes;
+    }
+    uint32_t* flags_dev = (uint32_t*)S->scratch;
+    Fr* d_in = (Fr*)((char*)S->scratch + 256);
+    Fr* d_regs = (Fr*)((char*)S->scratch + 256 + in_bytes);
+    BZK_HIP(ctx, hipMemsetAsync(flags_dev, 0, 4, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(d_in, dd.inputs.data(), n_tx * (size_t)P.n_inputs * 32, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t ntx = (uint32_t)n_tx;
+    auto blocks = [&](uint32_t count, uint32_t bs) { return dim3((unsigned)(((uint64_t)count * ntx + bs - 1) / bs)); };
+    // pass 1
+    for (const DeferGroup& g : P.v_groups) {
+        const wf::Op* o = it->second.first + g.start;
+        if (g.kind == wf::V_SEL) {
+            BZK_LAUNCH(ctx, "wf_sel", wf_sel_kernel, blocks(g.count, 256), dim3(256), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs);
+            continue;
+        }
+        const Fr29* c = S->tab.sparse[g.t];
+        const int rf = S->tab.rf[g.t], rp = S->tab.rp[g.t];
+        switch (g.t) {
+            case 3: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<3>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
+            case 5: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<5>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
+            case 6: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<6>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
+            case 8: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<8>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
+            default: ctx->last_error = "witfill: no device form for Poseidon width " + std::to_string(g.t); return BZK_E_INTERNAL;
+        }
+    }
+    // pass 2
+    for (const DeferGroup& g : P.f_groups) {
+        const wf::Op* o = it->second.second + g.start;
+        if (g.kind != wf::F_POSEIDON) {
+            BZK_LAUNCH(ctx, "wf_small", wf_small_kernel, blocks(g.count, 256), dim3(256), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux,
+                       dd.stride_aux, dd.base_con, dd.stride_con, flags_dev);
+            continue;
+        }
+        const Fr29* c = S->tab.dense[g.t];
+        const int rf = S->tab.rf[g.t], rp = S->tab.rp[g.t];
+        switch (g.t) {
+            case 3: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<3>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            case 5: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<5>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            case 6: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<6>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            case 8: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<8>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            default: ctx->last_error = "witfill: no device form for Poseidon width " + std::to_string(g.t); return BZK_E_INTERNAL;
+        }
+    }
+    BZK_HIP(ctx, hipMemcpyAsync(S->flags_host, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return BZK_OK;
+}
+
+void witfill_free(bzk_ctx* ctx) {  // bzk_ctx_destroy
+    CtxState* S = (CtxState*)ctx->wf_state;
+    if (!S) return;
+    for (auto& kv : S->progs) {
+        (void)hipFree(kv.second.first);
+        (void)hipFree(kv.second.second);
+    }
+    for (void* p : S->dense_dev)
+        if (p) (void)hipFree(p);
+    if (S->scratch) (void)hipFree(S->scratch);
+    if (S->flags_host) (void)hipHostFree(S->flags_host);
+    delete S;
+    ctx->wf_state = nullptr;
+}
+
+// the same program on the host, one transition after the other (a few host threads): CPU consumers and the CPU suite
+uint32_t witfill_run_host(const DeferData& dd, const wf::Arrays& A) {
+    const DeferProgram& P = *dd.prog;
+    if (!dd.n_tx || P.ops.empty()) return 0;
+    struct Tab {
+        std::vector<Fr29> dense, sparse;
+        int rf = 0, rp = 0;
+    };
+    static std::mutex mu;
+    static Tab tabs[9];
+    auto tab = [&](int t) -> const Tab& {
+        std::lock_guard<std::mutex> lk(mu);
+        Tab& T = tabs[t];
+        if (T.dense.empty()) {
+            const PoseidonHostParams Pp = poseidon_host_params_cached(t);
+            T.rf = Pp.rf;
+            T.rp = Pp.rp;
+            T.dense = dense_consts_host(t);
+            std::vector<Fr> flat;
+            const std::vector<Fr> rc(Pp.rc, Pp.rc + (size_t)t * (Pp.rf + Pp.rp)), mds(Pp.mds, Pp.mds + (size_t)t * t);
+            if (!poseidon_optimize(t, Pp.rf, Pp.rp, rc, mds, flat)) throw std::logic_error("witfill: no sparse form");
+            T.sparse.resize(flat.size());
+            for (size_t i = 0; i < flat.size(); ++i) T.sparse[i] = fr29::norm(fr29::to29(flat[i]));
+        }
+        return T;
+    };
+    for (const DeferGroup& g : P.v_groups)
+        if (g.kind == wf::V_HASH) (void)tab(g.t);
+    for (const DeferGroup& g : P.f_groups)
+        if (g.kind == wf::F_POSEIDON) (void)tab(g.t);
+    std::atomic<size_t> next(0);
+    std::atomic<uint32_t> flags(0);
+    auto worker = [&] {
+        std::vector<Fr> regs(P.n_regs);
+        for (;;) {
+            const size_t tx = next.fetch_add(1);
+            if (tx >= dd.n_tx) break;
+            wf::TxView v{dd.inputs.data() + tx * P.n_inputs, regs.data(), 1, dd.base_aux + tx * dd.stride_aux, dd.base_con + tx * dd.stride_con};
+            uint32_t f = 0;
+            for (const wf::Op& op : P.v_ops) {
+                if (op.kind == wf::V_SEL) { wf::v_sel(op, v); continue; }
+                const Tab& T = tabs[op.t];
+                switch (op.t) {
+                    case 3: wf::v_hash<3>(op, v, T.sparse.data(), T.rf, T.rp); break;
+                    case 5: wf::v_hash<5>(op, v, T.sparse.data(), T.rf, T.rp); break;
+                    case 6: wf::v_hash<6>(op, v, T.sparse.data(), T.rf, T.rp); break;
+                    case 8: wf::v_hash<8>(op, v, T.sparse.data(), T.rf, T.rp); break;
+                    default: throw std::logic_error("witfill: width");
+                }
+            }
+            for (const wf::Op& op : P.f_ops) {
+                switch (op.kind) {
+                    case wf::F_MUX: wf::f_mux(op, v, A); break;
+                    case wf::F_ASSERT_EQ_IF: f |= wf::f_assert_eq_if(op, v, A); break;
+                    case wf::F_ENFORCE_EQ: f |= wf::f_enforce_eq(op, v, A); break;
+                    case wf::F_CHECK_EQ: f |= wf::f_check_eq(op, v); break;
+                    case wf::F_POSEIDON: {
+                        const Tab& T = tabs[op.t];
+                        switch (op.t) {
+                            case 3: wf::f_poseidon<3>(op, v, A, T.dense.data(), T.rf, T.rp); break;
+                            case 5: wf::f_poseidon<5>(op, v, A, T.dense.data(), T.rf, T.rp); break;
+                            case 6: wf::f_poseidon<6>(op, v, A, T.dense.data(), T.rf, T.rp); break;
+                            case 8: wf::f_poseidon<8>(op, v, A, T.dense.data(), T.rf, T.rp); break;
+                            default: throw std::logic_error("witfill: width");
+                        }
+                        break;
+                    }
+                    default: break;
+                }
+            }
+            if (f) flags.fetch_or(f);
+        }
+    };
+    const size_t nt = std::min<size_t>(dd.n_tx, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nt; ++i) th.emplace_back(worker);
+    worker();
+    for (auto& x : th) x.join();
+    return flags.load();
+}
+
+}  // namespace bzk

@@ -70,6 +70,7 @@ SIGNATURES = {
     "bzk_params_slot": (_i32, [_vp, _vp, C.POINTER(_vp)]),
     "bzk_params_h_table": (_i32, [_vp, _vp, _i32]),
     "bzk_groth16_prove": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "bzk_groth16_prove_r1cs": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "bzk_bellman_params_info": (_i32, [_vp, _u64, C.POINTER(_u64)]),
     "bzk_bellman_params_decode": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "bzk_bellman_params_encode": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64)]),
@@ -110,6 +111,9 @@ SIGNATURES = {
     "bzk_mpn_update_synthesize": (_i32, [_vp, _u32, _vp, _vp, _i32, C.POINTER(_vp)]),
     "bzk_mpn_update_empty": (_i32, [_u32, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
     "bzk_r1cs_info": (_i32, [_vp, C.POINTER(_u64)]),
+    "bzk_r1cs_defer_info": (_i32, [_vp, C.POINTER(_u64)]),
+    "bzk_r1cs_fill_host": (_i32, [_vp]),
+    "bzk_mpn_set_defer": (_i32, [_vp, _i32]),
     "bzk_r1cs_data": (_vp, [_vp, _i32, C.POINTER(_u64)]),
     "bzk_r1cs_free": (None, [_vp]),
     "bzk_host_poseidon": (_i32, [_vp, _u32, _vp]),
@@ -612,6 +616,12 @@ class Bzk:
         self._ck(self.lib.bzk_groth16_prove(self.h, ph, C.byref(asg), _ptr(r), _ptr(s), out), "groth16_prove")
         return out.raw
 
+    def groth16_prove_r1cs(self, ph, r1cs, r: bytes, s: bytes) -> bytes:
+        """the same over an R1cs of the host generator; an instance synthesized with MpnWorld.set_defer(True) is completed on the device first"""
+        out = C.create_string_buffer(387)
+        self._ck(self.lib.bzk_groth16_prove_r1cs(self.h, ph, r1cs.h, _ptr(r), _ptr(s), out), "groth16_prove_r1cs")
+        return out.raw
+
     def params_read(self, ph, which: int) -> bytes:
         n = _u64()
         self._ck(self.lib.bzk_params_read(self.h, ph, which, None, 0, C.byref(n)), "params_read")
@@ -800,6 +810,19 @@ class R1cs:
         self.first_unsatisfied = first_bad - 1
         self.satisfied = first_bad == 0
 
+    DEFER_FIELDS = ("deferred", "n_tx", "n_ops", "n_regs", "n_inputs", "n_levels", "hole_aux", "hole_con", "filled", "flags")
+
+    def defer_info(self) -> dict:
+        """what a synthesis with MpnWorld.set_defer(True) left to the device (bzk_r1cs_defer_info)"""
+        info = (_u64 * 10)()
+        _st(self.lib.bzk_r1cs_defer_info(self.h, info), "r1cs_defer_info")
+        return dict(zip(self.DEFER_FIELDS, [int(x) for x in info]))
+
+    def fill_host(self) -> dict:
+        """runs the instance's deferred-value program on the CPU (same ops as the device): the views are complete afterwards"""
+        _st(self.lib.bzk_r1cs_fill_host(self.h), "r1cs_fill_host")
+        return self.defer_info()
+
     def view(self, name: str) -> bytes:
         """a COPY of the array as bytes (tests); the prover path uses raw()"""
         n = _u64()
@@ -849,6 +872,10 @@ class MpnWorld:
 
     def set_threads(self, n: int):
         _st(self.lib.bzk_mpn_set_threads(self.h, n), "set_threads")
+
+    def set_defer(self, on: bool = True):
+        """witness-only update instances leave the hash-dependent values to the device (Bzk.groth16_prove_r1cs) or to R1cs.fill_host"""
+        _st(self.lib.bzk_mpn_set_defer(self.h, 1 if on else 0), "set_defer")
 
     def set_device(self, ctx):
         """ctx: a Bzk context (kept alive by this object) whose GPU batches the builders' Merkle hashing; None: host path"""
@@ -974,9 +1001,10 @@ class MpnWork:
         _st(self.lib.bzk_mpn_work_encode(self.h, buf, n.value, None), "work_encode")
         return buf.raw[: n.value]
 
-    def synthesize(self, prover_pub: bytes, fee_token: bytes | None = None, threads: int = 0, record_matrices=False) -> R1cs:
+    def synthesize(self, prover_pub: bytes, fee_token: bytes | None = None, threads: int = 0, record_matrices=False, defer=False) -> R1cs:
+        """defer: BZK_SYNTH_DEFER - an Update work's hash-dependent values are left to the device (Bzk.groth16_prove_r1cs) / R1cs.fill_host"""
         h = C.c_void_p()
-        _st(self.lib.bzk_mpn_work_synthesize(self.h, _ptr(prover_pub), _ptr(fee_token), threads, int(record_matrices), C.byref(h)),
+        _st(self.lib.bzk_mpn_work_synthesize(self.h, _ptr(prover_pub), _ptr(fee_token), threads, 2 if defer else int(record_matrices), C.byref(h)),
             "work_synthesize")
         return R1cs(h)
 

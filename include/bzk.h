@@ -388,6 +388,25 @@ int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]);
  * variable index, 12-14 row_ptr(A/B/C) u32 */
 const void* bzk_r1cs_data(const bzk_r1cs* r, int32_t which, uint64_t* bytes);
 void bzk_r1cs_free(bzk_r1cs* r);
+/* Witness value traces on the device.  With bzk_mpn_set_defer(w, 1) a witness-only bzk_mpn_update_synthesize does NOT
+ * evaluate what hangs off Poseidon outputs - the Poseidon gadget's S-box / idle-lane variables (src/zk/groth16/gadgets/poseidon/mod.rs:8-95: two
+ * thirds of a transition's constraints), the Merkle gadget's muxes (gadgets/merkle/mod.rs:21-78, common/mux.rs:7-47), the equality checks against
+ * computed roots (common/number.rs:121-177) - but records a small program per circuit shape and, per transition, the values the host does know;
+ * those slots of z / A.z / B.z / C.z are left untouched.  bzk_groth16_prove_r1cs (below, beside bzk_groth16_prove) uploads the arrays as they are
+ * and runs the program on the device before anything reads them; bzk_r1cs_fill_host runs the SAME ops on the CPU for consumers of the complete
+ * arrays (bzk_r1cs_data) - the result is byte-identical to a synthesis without deferral.  bzk_r1cs_info's satisfied-check covers the rows the host
+ * wrote; the deferred rows are judged where they are computed (BZK_E_UNSAT from the prove call, info[9] after a host fill).
+ *   defer_info: 0 deferred (1 / 0), 1 transitions, 2 ops of the program, 3 registers, 4 host-known values per transition, 5 dependency levels
+ *               (a Merkle path is a chain of hashes), 6 / 7 variable / constraint slots per transition left to the device, 8 filled on the
+ *               host (1 / 0), 9 flags of that fill (1 a deferred constraint does not hold, 2 a computed state differs from the builder's) */
+int32_t bzk_mpn_set_defer(bzk_mpn* w, int32_t on);
+int32_t bzk_r1cs_defer_info(const bzk_r1cs* r, uint64_t info[10]);
+int32_t bzk_r1cs_fill_host(bzk_r1cs* r);
+/* bzk_groth16_prove over an instance of the host generator (z / A.z / B.z / C.z are the instance's own pinned arrays), completing deferred
+ * witness values on the device first.  BZK_E_UNSAT: a deferred constraint does not hold or a transition's computed state differs from the
+ * witness builder's prediction (synthesize again without deferral for the exact first unsatisfied row). */
+int32_t bzk_groth16_prove_r1cs(bzk_ctx* ctx, bzk_params* params, const bzk_r1cs* r, const uint8_t r_blind[32], const uint8_t s_blind[32],
+                               uint8_t proof_out[387]);
 /* CPU mirrors of `ZkHasher::hash`, `hash_to_scalar`'s SHA3 and `JubJub::{generate_keys, sign, verify}` */
 /* ---- f-2: the proving worker's wire format ---------------------------------------------------------------------------
  * `MpnWork` (src/mpn/mod.rs:263-270) as `GET /bincode/mpn/work` delivers it (src/node/mod.rs:393-398,
@@ -412,7 +431,10 @@ int32_t bzk_mpn_work_vk(const bzk_mpn_work* work, int32_t which, uint8_t* out, u
 int32_t bzk_mpn_work_commitment(const bzk_mpn_work* work, const uint8_t prover_pub[32], uint8_t out[32]);
 /* `MpnWork::verify(prover, proof)` (src/mpn/mod.rs:281-295) on the host: 1 accepted / 0 refused / negative bad arguments */
 int32_t bzk_mpn_work_verify(const bzk_mpn_work* work, const uint8_t prover_pub[32], const uint8_t proof[387]);
-/* the circuit instance to prove: transitions padded with null ones to 4^batch; fee_token NULL = Ziesha; threads 0 = all */
+/* the circuit instance to prove: transitions padded with null ones to 4^batch; fee_token NULL = Ziesha; threads 0 = all;
+ * record_matrices: 0 witness only, 1 with the CSR matrices (setup), BZK_SYNTH_DEFER witness only with the hash-dependent values of an
+ * Update work left to the device (see bzk_mpn_set_defer; deposit / withdraw works are synthesized in full) */
+#define BZK_SYNTH_DEFER 2
 int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* work, const uint8_t prover_pub[32], const uint8_t fee_token[32],
                                 int32_t threads, int32_t record_matrices, bzk_r1cs** out);
 int32_t bzk_mpn_work_encode(const bzk_mpn_work* work, uint8_t* out, uint64_t cap, uint64_t* len); /* out NULL: size query */

@@ -1,0 +1,95 @@
+"""Deferred witness values ON THE DEVICE: bzk_groth16_prove_r1cs over an instance whose hash-dependent values were left
+out by the host generator (bzk_witfill.cuh / witfill.hip run the instance's program before any MSM or transform reads the arrays) must give the
+SAME 387 proof bytes as bzk_groth16_prove over the complete arrays of a plain synthesis - which tests/test_gpu_fullsize.py and
+tests/test_gpu_mpn_prove.py pin on the oracle prover.  The CPU side of the same program (instance + host fill == the independent restatement's
+fixtures): tests/test_defer_cpu.py."""
+import pytest
+
+import r1cs_scenarios as S
+from bazuka_amd import lib as L
+from util import fr_bytes, fr_list
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(bzk, dec):
+    r = dec.synthesize(S.PROVER, record_matrices=True)
+    assert r.satisfied
+    csr = [(r.n_constraints, r.view("rp" + w), r.view("col" + w), r.view("val" + w)) for w in "ABC"]
+    ph, vkb = bzk.groth16_setup(csr, r.n_in, r.n_aux, fr_bytes(fr_list(5, 515)))
+    return r, ph, vkb
+
+
+@pytest.mark.parametrize("name", ["update_3_3_1", "update_15_3_2"])
+def test_device_fill_gives_the_same_proof_bytes(bzk, name):
+    dec = L.MpnWork.decode(S.make_work(name))
+    r, ph, vkb = _setup(bzk, dec)
+    rs = fr_bytes(fr_list(2, 516))
+    want = bzk.groth16_prove(ph, *(r.view(k) for k in ("z", "az", "bz", "cz")), rs[:32], rs[32:])
+    assert bzk.groth16_prove_r1cs(ph, r, rs[:32], rs[32:]) == want          # a complete instance through the new entry
+    d = dec.synthesize(S.PROVER, threads=4, defer=True)
+    assert d.defer_info()["deferred"] == 1
+    for rep in range(3):                                                    # the program, its tables and scratch are cached per context
+        assert bzk.groth16_prove_r1cs(ph, d, rs[:32], rs[32:]) == want, rep
+    assert d.defer_info()["filled"] == 0                                    # the host arrays still have their holes: nothing was filled in on the CPU
+    d.fill_host()
+    assert bzk.groth16_prove_r1cs(ph, d, rs[:32], rs[32:]) == want          # ... and a host-filled instance is a complete one
+    assert L.groth16_verify(vkb, d.view("z")[32:32 * d.n_in], want)
+    bzk.params_free(ph)
+
+
+def test_world_side_deferral_and_slots(bzk):
+    """bzk_mpn_set_defer on the validator-side world + a second prover slot over the same CRS (the pipelined prover's arrangement)"""
+    Z = S.ZIESHA
+
+    def world(defer):
+        w = L.MpnWorld(3, 3)
+        w.set_defer(defer)
+        for i in range(8):
+            w.add_account(i, b"a%d" % i, Z, 10 ** 9)
+        for i in range(4):
+            w.push_tx(i, (i + 1) % 8, Z, 50 + i, Z, i)
+        return w
+
+    wa, wb = world(False), world(True)
+    a = wa.update_synthesize(1, S.F(3), Z, record_matrices=True)
+    csr = [(a.n_constraints, a.view("rp" + w), a.view("col" + w), a.view("val" + w)) for w in "ABC"]
+    ph, _ = bzk.groth16_setup(csr, a.n_in, a.n_aux, fr_bytes(fr_list(5, 616)))
+    slot = bzk.params_slot(ph)
+    rs = fr_bytes(fr_list(2, 617))
+    b = wb.update_synthesize(1, S.F(3), Z)
+    assert b.defer_info()["deferred"] == 1
+    want = bzk.groth16_prove(ph, *(a.view(k) for k in ("z", "az", "bz", "cz")), rs[:32], rs[32:])
+    assert bzk.groth16_prove_r1cs(slot, b, rs[:32], rs[32:]) == want
+    assert bzk.groth16_prove_r1cs(ph, b, rs[:32], rs[32:]) == want
+    bzk.params_free(slot)
+    bzk.params_free(ph)
+
+
+def test_a_deferred_violation_is_refused_by_the_prove_call(bzk):
+    blob = bytearray(S.make_work("update_3_3_1"))
+    dec0 = L.MpnWork.decode(bytes(blob))
+    r, ph, _ = _setup(bzk, dec0)
+    rs = fr_bytes(fr_list(2, 716))
+    found = False
+    for off in range(len(blob) // 2, len(blob) // 2 + 4000, 97):
+        mut = bytearray(blob)
+        mut[off] ^= 1
+        try:
+            dec = L.MpnWork.decode(bytes(mut))
+            if dec.synthesize(S.PROVER, threads=1).satisfied:
+                continue
+            d = dec.synthesize(S.PROVER, threads=2, defer=True)
+        except Exception:
+            continue
+        if not d.defer_info()["deferred"] or not d.satisfied:
+            continue
+        with pytest.raises(L.BzkError):
+            bzk.groth16_prove_r1cs(ph, d, rs[:32], rs[32:])
+        found = True
+        break
+    assert found, "no sampled mutation produced a violation that only the deferred rows see"
+    # the context is usable afterwards
+    want = bzk.groth16_prove(ph, *(r.view(k) for k in ("z", "az", "bz", "cz")), rs[:32], rs[32:])
+    assert bzk.groth16_prove_r1cs(ph, dec0.synthesize(S.PROVER, defer=True), rs[:32], rs[32:]) == want
+    bzk.params_free(ph)

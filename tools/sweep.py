@@ -248,6 +248,14 @@ if __name__ == "__main__":
             for r2 in ("-1", "1"):
                 for ch in ("8", "4"):
                     run("g1res", 20, {"BZK_MSM_ENDO_G1": "0", "BZK_MSM_CHUNK": ch, "BZK_MSM_REDUCE2": r2})
+    if what in ("r5g2b",):  # round 5, run 6: pair tails with the two-level reduction for every call (level-2 chunk 2 / 4 / 8) against one level
+        for rep in range(2):
+            run("g2", 20, {"BZK_MSM_REDUCE2": "-1"})
+            for ch in ("2", "4", "8"):
+                run("g2", 20, {"BZK_MSM_PAIR_L2_CH": ch})
+        for ch in ("2", "4", "8"):
+            run("g2res", 20, {"BZK_MSM_PAIR_L2_CH": ch, "BZK_MSM_ENDO_G2": "1", "THROUGHPUT": "1"})
+        run("g2", 18); run("g2", 16); run("g2", 22)
     if what in ("r5g2",):  # round 5, run 4: one-lane G2 / pair accumulation with one-lane tails / pairs everywhere, same box, alternating (the container of runs 2 - 3 was lost)
         cfgs = ({"BZK_G2_PAIR": "0"}, {"BZK_G2_PAIR": "1", "BZK_G2_PAIR_TAILS": "0"}, {"BZK_G2_PAIR": "1", "BZK_G2_PAIR_TAILS": "1"})
         for rep in range(2):
