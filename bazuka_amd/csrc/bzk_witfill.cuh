@@ -27,7 +27,7 @@ enum : uint32_t { FLAG_UNSATISFIED = 1u, FLAG_CHAIN = 2u };  // a deferred const
 struct Op {
     uint8_t kind;
     uint8_t t;        // V_HASH / F_POSEIDON: state width (arity + 1); V_SEL / F_MUX: 0 = Boolean::Is, 1 = Boolean::Not
-    uint16_t level;   // V ops: 1 + the highest level among the producers of its register operands
+    uint16_t level;   // V_HASH: 1 + the highest level among the producers of its register operands; V_SEL: that highest level itself
     int32_t out;      // V ops: the register written; F ops: unused (-1)
     uint32_t aux_off, con_off;  // F ops: first variable / constraint slot inside the transition's window
     int32_t in[7];
@@ -47,9 +47,23 @@ struct TxView {       // where transition `tx` lives
     Fr* regs;         // regs[r * reg_stride]
     size_t reg_stride;
     size_t aux_base, con_base;
+    // device: per register {select input, a, b, Is / Not} of the V_SEL that defines it, or {.., .., .., -1}: selections are then never
+    // materialised - an operand that names one is resolved here, through at most a few links (a Merkle level is two deep), which
+    // takes the ~35 one-select launches out of pass 1.  nullptr (host executor): every V_SEL has been executed into its register
+    const int32_t* sel;
 };
 
-BZK_HD Fr operand(const TxView& v, int32_t o) { return o >= 0 ? v.regs[(size_t)o * v.reg_stride] : v.inputs[~o]; }
+BZK_HD Fr operand(const TxView& v, int32_t o) {
+    if (v.sel) {
+        for (int it = 0; it < 8 && o >= 0; ++it) {
+            const int32_t* s = v.sel + 4 * (size_t)o;
+            if (s[3] < 0) break;
+            const bool bit = !v.inputs[~s[0]].is_zero();
+            o = (s[3] == 0 ? bit : !bit) ? s[2] : s[1];
+        }
+    }
+    return o >= 0 ? v.regs[(size_t)o * v.reg_stride] : v.inputs[~o];
+}
 BZK_HD Fr fr_one_mont() { return Fr::one(); }
 
 // ---- pass 1 -------------------------------------------------------------------------------------------------------------------

@@ -456,6 +456,7 @@ static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assign
         // the caller frees (re-uses) the assignment arrays as soon as this returns: no copy out of them may still be in
         // flight, on the main stream or on a lane
         (void)hipStreamSynchronize(ctx->stream);
+        bzk::witfill_quiesce(ctx);
         if (ctx->hprio) (void)hipStreamSynchronize(ctx->hprio);
         for (bzk_ctx* c : ctx->lanes) (void)hipStreamSynchronize(c->stream);
         (void)hipGetLastError();

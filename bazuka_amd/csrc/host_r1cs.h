@@ -208,6 +208,7 @@ struct DeferData {
 int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A);  // enqueues on ctx->stream; the flags word follows in stream order
 uint32_t witfill_flags(bzk_ctx* ctx);                                                // ... and is read here once that stream has been synchronised
 uint32_t witfill_run_host(const DeferData& dd, const wf::Arrays& A);
+void witfill_quiesce(bzk_ctx* ctx);
 
 class ConstraintSystem {
    public:
@@ -594,7 +595,7 @@ static inline Num mux(ConstraintSystem& cs, const Bool& select, const Number& a,
         f.in[2] = b.ref >= 0 ? b.ref : D.in_val(b.val);
         wf::Op v = f;
         v.kind = wf::V_SEL; v.aux_off = v.con_off = 0;
-        v.level = (uint16_t)(std::max(D.level_of(f.in[1]), D.level_of(f.in[2])) + 1);
+        v.level = std::max(D.level_of(f.in[1]), D.level_of(f.in[2]));  // a selection costs no level: the device resolves it where it is read
         v.out = D.new_reg(v.level);
         D.emit(v);
         D.emit(f);

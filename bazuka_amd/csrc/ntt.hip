@@ -510,7 +510,9 @@ static int32_t ntt_run_ex(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inve
     // tiles above 64 KiB of dynamic LDS need the opt-in; the attribute is per DEVICE, so remember it per device id (a process
     // may hold contexts on several GPUs, and prover slots call this from concurrent threads)
     typedef void (*pass_fn)(NttPass);
-    static const pass_fn variants[6] = {ntt_pass_kernel<3, 2, 0>, ntt_pass_kernel<4, 2, 0>, ntt_pass_kernel<4, 1, 0>, ntt_pass_kernel<4, 0, 0>,
+    // (variants 1 and 2 - <4, 2, 0> and <4, 1, 0>, the forms of round 3 that spilled 19 / 3 registers at four waves per SIMD and lost their A/B to
+    // variant 4 - are no longer instantiated: the indices select the default, so every NTT kernel in the code object is spill-free)
+    static const pass_fn variants[6] = {ntt_pass_kernel<3, 2, 0>, ntt_pass_kernel<4, 1, 1>, ntt_pass_kernel<4, 1, 1>, ntt_pass_kernel<4, 0, 0>,
                                         ntt_pass_kernel<4, 1, 1>, ntt_pass_kernel<3, 2, 1>};
     static const int variant = [] {
         const char* e = getenv("BZK_NTT_VARIANT");

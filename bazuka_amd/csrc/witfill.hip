@@ -37,38 +37,31 @@ struct DevTables {
 
 template <int T>
 __global__ void __launch_bounds__(64) wf_hash_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
-                                                     uint32_t n_inputs, Fr* __restrict__ regs, const Fr29* __restrict__ consts, int rf, int rp) {
+                                                     uint32_t n_inputs, Fr* __restrict__ regs, const int32_t* __restrict__ sel, const Fr29* __restrict__ consts,
+                                                     int rf, int rp) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= count * n_tx) return;
     const uint32_t tx = g % n_tx;
-    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, 0, 0};
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, 0, 0, sel};
     wf::v_hash<T>(ops[g / n_tx], v, consts, rf, rp);
-}
-__global__ void __launch_bounds__(256) wf_sel_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
-                                                     uint32_t n_inputs, Fr* __restrict__ regs) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= count * n_tx) return;
-    const uint32_t tx = g % n_tx;
-    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, 0, 0};
-    wf::v_sel(ops[g / n_tx], v);
 }
 template <int T>
 __global__ void __launch_bounds__(64) wf_poseidon_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
-                                                         uint32_t n_inputs, Fr* __restrict__ regs, wf::Arrays A, size_t base_aux, size_t stride_aux,
-                                                         size_t base_con, size_t stride_con, const Fr29* __restrict__ dense, int rf, int rp) {
+                                                         uint32_t n_inputs, Fr* __restrict__ regs, const int32_t* __restrict__ sel, wf::Arrays A, size_t base_aux,
+                                                         size_t stride_aux, size_t base_con, size_t stride_con, const Fr29* __restrict__ dense, int rf, int rp) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= count * n_tx) return;
     const uint32_t tx = g % n_tx;
-    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con};
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con, sel};
     wf::f_poseidon<T>(ops[g / n_tx], v, A, dense, rf, rp);
 }
 __global__ void __launch_bounds__(256) wf_small_kernel(const wf::Op* __restrict__ ops, uint32_t count, uint32_t n_tx, const Fr* __restrict__ inputs,
-                                                       uint32_t n_inputs, Fr* __restrict__ regs, wf::Arrays A, size_t base_aux, size_t stride_aux,
-                                                       size_t base_con, size_t stride_con, uint32_t* __restrict__ flags) {
+                                                       uint32_t n_inputs, Fr* __restrict__ regs, const int32_t* __restrict__ sel, wf::Arrays A, size_t base_aux,
+                                                       size_t stride_aux, size_t base_con, size_t stride_con, uint32_t* __restrict__ flags) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= count * n_tx) return;
     const uint32_t tx = g % n_tx;
-    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con};
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con, sel};
     const wf::Op op = ops[g / n_tx];
     uint32_t f = 0;
     switch (op.kind) {
@@ -83,12 +76,22 @@ __global__ void __launch_bounds__(256) wf_small_kernel(const wf::Op* __restrict_
 
 // per (context, program): the ops in device memory; per context: the constant tables and the grow-only scratch (registers + inputs)
 struct CtxState {
-    std::map<const DeferProgram*, std::pair<wf::Op*, wf::Op*>> progs;  // v_ops, f_ops
+    struct DevProg {
+        wf::Op *v = nullptr, *f = nullptr;  // v_ops, f_ops
+        int32_t* sel = nullptr;             // per register: the V_SEL that defines it (bzk_witfill.cuh TxView::sel)
+    };
+    std::map<const DeferProgram*, DevProg> progs;
     DevTables tab;
     void* dense_dev[9] = {};
     void* scratch = nullptr;   // [flags word, padded to 256 B][input records][registers]
     size_t scratch_bytes = 0;
     uint32_t* flags_host = nullptr;  // pinned: where the flags word of the last run lands (stream order)
+    // the program is ~150 small DEPENDENT launches (a Merkle path is a chain): beside the big grids of other prover slots each of them would wait
+    // for a free slot on the device.  They run on a highest-priority side stream, forked from / joined to the context's stream by events
+    // (env BZK_WF_PRIO=0: on the context's own stream, A/B)
+    hipStream_t prio = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    bool prio_tried = false;
 };
 
 int32_t tables(bzk_ctx* ctx, CtxState& S, int t) {
@@ -111,6 +114,10 @@ int32_t tables(bzk_ctx* ctx, CtxState& S, int t) {
 
 }  // namespace
 
+void witfill_quiesce(bzk_ctx* ctx) {  // a failed prove call: nothing of the program may still be reading the instance's input records
+    CtxState* S = (CtxState*)ctx->wf_state;
+    if (S && S->prio) (void)hipStreamSynchronize(S->prio);
+}
 uint32_t witfill_flags(bzk_ctx* ctx) {  // after the stream of the last witfill_run_dev has been synchronised
     CtxState* S = (CtxState*)ctx->wf_state;
     return S && S->flags_host ? *S->flags_host : 0u;
@@ -130,19 +137,28 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) 
         if (g.kind == wf::F_POSEIDON) BZK_TRY(tables(ctx, *S, g.t));
     auto it = S->progs.find(&P);
     if (it == S->progs.end()) {
-        wf::Op *dv = nullptr, *df = nullptr;
-        BZK_HIP(ctx, hipMalloc((void**)&dv, std::max<size_t>(1, P.v_ops.size()) * sizeof(wf::Op)));
-        BZK_HIP(ctx, hipMalloc((void**)&df, std::max<size_t>(1, P.f_ops.size()) * sizeof(wf::Op)));
-        BZK_HIP(ctx, hipMemcpyAsync(dv, P.v_ops.data(), P.v_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipMemcpyAsync(df, P.f_ops.data(), P.f_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the vectors above belong to the (immutable, process-lifetime) program, but be strict
-        it = S->progs.emplace(&P, std::make_pair(dv, df)).first;
+        CtxState::DevProg dp;
+        std::vector<int32_t> sel((size_t)std::max<uint32_t>(1, P.n_regs) * 4, -1);
+        for (const wf::Op& o : P.v_ops)
+            if (o.kind == wf::V_SEL) {
+                int32_t* s = &sel[(size_t)o.out * 4];
+                s[0] = o.in[0]; s[1] = o.in[1]; s[2] = o.in[2]; s[3] = o.t;
+            }
+        BZK_HIP(ctx, hipMalloc((void**)&dp.v, std::max<size_t>(1, P.v_ops.size()) * sizeof(wf::Op)));
+        BZK_HIP(ctx, hipMalloc((void**)&dp.f, std::max<size_t>(1, P.f_ops.size()) * sizeof(wf::Op)));
+        BZK_HIP(ctx, hipMalloc((void**)&dp.sel, sel.size() * sizeof(int32_t)));
+        BZK_HIP(ctx, hipMemcpyAsync(dp.v, P.v_ops.data(), P.v_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(dp.f, P.f_ops.data(), P.f_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(dp.sel, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `sel` is a local
+        it = S->progs.emplace(&P, dp).first;
     }
     const size_t n_tx = dd.n_tx;
     const size_t in_bytes = ws_pad(n_tx * (size_t)P.n_inputs * 32), reg_bytes = ws_pad(n_tx * (size_t)P.n_regs * 32);
     if (S->scratch_bytes < 256 + in_bytes + reg_bytes) {
         // the previous buffer may still be read by launches of an earlier call on this stream
         BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (S->prio) BZK_HIP(ctx, hipStreamSynchronize(S->prio));
         if (S->scratch) (void)hipFree(S->scratch);
         S->scratch = nullptr;
         S->scratch_bytes = 0;
@@ -154,44 +170,69 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) 
     Fr* d_regs = (Fr*)((char*)S->scratch + 256 + in_bytes);
     BZK_HIP(ctx, hipMemsetAsync(flags_dev, 0, 4, ctx->stream));
     BZK_HIP(ctx, hipMemcpyAsync(d_in, dd.inputs.data(), n_tx * (size_t)P.n_inputs * 32, hipMemcpyHostToDevice, ctx->stream));
+    static const bool want_prio = [] { const char* e = getenv("BZK_WF_PRIO"); return !(e && atoi(e) == 0); }();
+    if (want_prio && !S->prio_tried) {
+        S->prio_tried = true;
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&S->prio, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&S->ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S->ev_out, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (S->prio) (void)hipStreamDestroy(S->prio);
+            S->prio = nullptr;  // no side stream: everything on the context's stream
+        }
+    }
+    struct StreamSwap {  // BZK_LAUNCH works on ctx->stream: it points at the side stream while the program is enqueued
+        bzk_ctx* c;
+        hipStream_t saved;
+        StreamSwap(bzk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { if (s) c->stream = s; }
+        ~StreamSwap() { c->stream = saved; }
+    };
+    const hipStream_t home = ctx->stream;
+    if (S->prio) {
+        BZK_HIP(ctx, hipEventRecord(S->ev_in, home));
+        BZK_HIP(ctx, hipStreamWaitEvent(S->prio, S->ev_in, 0));
+    }
+    StreamSwap swap(ctx, S->prio);
     const uint32_t ntx = (uint32_t)n_tx;
+    const int32_t* dsel = it->second.sel;
     auto blocks = [&](uint32_t count, uint32_t bs) { return dim3((unsigned)(((uint64_t)count * ntx + bs - 1) / bs)); };
     // pass 1
     for (const DeferGroup& g : P.v_groups) {
-        const wf::Op* o = it->second.first + g.start;
-        if (g.kind == wf::V_SEL) {
-            BZK_LAUNCH(ctx, "wf_sel", wf_sel_kernel, blocks(g.count, 256), dim3(256), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs);
-            continue;
-        }
+        const wf::Op* o = it->second.v + g.start;
+        if (g.kind == wf::V_SEL) continue;  // resolved where they are read
         const Fr29* c = S->tab.sparse[g.t];
         const int rf = S->tab.rf[g.t], rp = S->tab.rp[g.t];
         switch (g.t) {
-            case 3: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<3>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
-            case 5: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<5>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
-            case 6: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<6>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
-            case 8: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<8>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, c, rf, rp); break;
+            case 3: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<3>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, c, rf, rp); break;
+            case 5: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<5>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, c, rf, rp); break;
+            case 6: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<6>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, c, rf, rp); break;
+            case 8: BZK_LAUNCH(ctx, "wf_hash", wf_hash_kernel<8>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, c, rf, rp); break;
             default: ctx->last_error = "witfill: no device form for Poseidon width " + std::to_string(g.t); return BZK_E_INTERNAL;
         }
     }
     // pass 2
     for (const DeferGroup& g : P.f_groups) {
-        const wf::Op* o = it->second.second + g.start;
+        const wf::Op* o = it->second.f + g.start;
         if (g.kind != wf::F_POSEIDON) {
-            BZK_LAUNCH(ctx, "wf_small", wf_small_kernel, blocks(g.count, 256), dim3(256), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux,
+            BZK_LAUNCH(ctx, "wf_small", wf_small_kernel, blocks(g.count, 256), dim3(256), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux,
                        dd.stride_aux, dd.base_con, dd.stride_con, flags_dev);
             continue;
         }
         const Fr29* c = S->tab.dense[g.t];
         const int rf = S->tab.rf[g.t], rp = S->tab.rp[g.t];
         switch (g.t) {
-            case 3: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<3>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
-            case 5: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<5>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
-            case 6: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<6>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
-            case 8: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<8>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            case 3: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<3>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            case 5: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<5>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            case 6: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<6>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
+            case 8: BZK_LAUNCH(ctx, "wf_poseidon", wf_poseidon_kernel<8>, blocks(g.count, 64), dim3(64), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con, c, rf, rp); break;
             default: ctx->last_error = "witfill: no device form for Poseidon width " + std::to_string(g.t); return BZK_E_INTERNAL;
         }
     }
     BZK_HIP(ctx, hipMemcpyAsync(S->flags_host, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (S->prio) {  // join: everything the caller enqueues on its stream from here on is behind the program and its flags word
+        BZK_HIP(ctx, hipEventRecord(S->ev_out, S->prio));
+        BZK_HIP(ctx, hipStreamWaitEvent(home, S->ev_out, 0));
+    }
     return BZK_OK;
 }
 
@@ -199,13 +240,20 @@ void witfill_free(bzk_ctx* ctx) {  // bzk_ctx_destroy
     CtxState* S = (CtxState*)ctx->wf_state;
     if (!S) return;
     for (auto& kv : S->progs) {
-        (void)hipFree(kv.second.first);
-        (void)hipFree(kv.second.second);
+        (void)hipFree(kv.second.v);
+        (void)hipFree(kv.second.f);
+        (void)hipFree(kv.second.sel);
     }
     for (void* p : S->dense_dev)
         if (p) (void)hipFree(p);
     if (S->scratch) (void)hipFree(S->scratch);
     if (S->flags_host) (void)hipHostFree(S->flags_host);
+    if (S->prio) {
+        (void)hipStreamSynchronize(S->prio);
+        (void)hipStreamDestroy(S->prio);
+    }
+    if (S->ev_in) (void)hipEventDestroy(S->ev_in);
+    if (S->ev_out) (void)hipEventDestroy(S->ev_out);
     delete S;
     ctx->wf_state = nullptr;
 }
@@ -247,7 +295,7 @@ uint32_t witfill_run_host(const DeferData& dd, const wf::Arrays& A) {
         for (;;) {
             const size_t tx = next.fetch_add(1);
             if (tx >= dd.n_tx) break;
-            wf::TxView v{dd.inputs.data() + tx * P.n_inputs, regs.data(), 1, dd.base_aux + tx * dd.stride_aux, dd.base_con + tx * dd.stride_con};
+            wf::TxView v{dd.inputs.data() + tx * P.n_inputs, regs.data(), 1, dd.base_aux + tx * dd.stride_aux, dd.base_con + tx * dd.stride_con, nullptr};
             uint32_t f = 0;
             for (const wf::Op& op : P.v_ops) {
                 if (op.kind == wf::V_SEL) { wf::v_sel(op, v); continue; }

@@ -4,6 +4,9 @@ per-kernel table of ONE proof (what the rocPRIM sorts, the de-duplication and ev
 
     BZK_PROVE_SERIAL=1 rocprofv3 --kernel-trace --stats -d out -- python tools/prove_serial.py 6
 
+PROVE_DEFER=1: the witness generator leaves the hash-dependent values to the device (bzk_mpn_set_defer) and the proofs go through
+bzk_groth16_prove_r1cs - the trace then also shows the witness-fill kernels (wf_hash / wf_poseidon / wf_small).
+
 usage: python tools/prove_serial.py [n_proofs=6]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,14 +31,19 @@ def main(n_proofs=6):
     csr = [(r.n_constraints, r.raw("rp" + x), r.raw("col" + x), r.raw("val" + x)) for x in "ABC"]
     ph, _ = ctx.groth16_setup(csr, r.n_in, r.n_aux, b"".join(_fr(x) for x in (1234567, 2345678, 3456789, 4567891, 5678912)))
     ts = []
+    defer = os.environ.get("PROVE_DEFER", "0") != "0"
+    w.set_defer(defer)
     for k in range(n_proofs):
         batch(k + 1)
         rk = w.update_synthesize(2, _fr(99), Z)
         t0 = time.perf_counter()
-        ctx.groth16_prove(ph, rk.raw("z"), rk.raw("az"), rk.raw("bz"), rk.raw("cz"), _fr_blind(2 * k), _fr_blind(2 * k + 1))
+        if defer:
+            ctx.groth16_prove_r1cs(ph, rk, _fr_blind(2 * k), _fr_blind(2 * k + 1))
+        else:
+            ctx.groth16_prove(ph, rk.raw("z"), rk.raw("az"), rk.raw("bz"), rk.raw("cz"), _fr_blind(2 * k), _fr_blind(2 * k + 1))
         ts.append(time.perf_counter() - t0)
         rk.free()
-    print(json.dumps({"n_proofs": n_proofs, "serial_msms": os.environ.get("BZK_PROVE_SERIAL", "0"), "prove_s": [round(t, 4) for t in ts]}))
+    print(json.dumps({"n_proofs": n_proofs, "serial_msms": os.environ.get("BZK_PROVE_SERIAL", "0"), "deferred": defer, "prove_s": [round(t, 4) for t in ts]}))
     ctx.params_free(ph)
     ctx.close()
 
