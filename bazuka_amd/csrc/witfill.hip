@@ -2,6 +2,8 @@
 // The ops and what they restate of the reference's gadgets: bzk_witfill.cuh.  One lane per (op, transition); pass 1 level by level
 // (a level's ops only read registers of lower levels), pass 2 in one sweep per op kind.  The same ops run on the host in
 // witfill_run_host (bzk_r1cs_fill_host: CPU consumers of the complete arrays, and the CPU suite's comparison with the host generator).
+#include <string.h>
+
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -74,11 +76,125 @@ __global__ void __launch_bounds__(256) wf_small_kernel(const wf::Op* __restrict_
     if (f) atomicOr(flags, f);
 }
 
+// ---- the whole program of one transition in ONE launch (round 5, run 8): a workgroup of four waves per transition walks the dependency levels
+// with a barrier between them; inside a level (and in the final stage, pass 2) every wave runs its own segments - runs of <= 64 ops of one kind and
+// width, so a wave never diverges - assigned by cost on the host (Schedule below).  Why: as ~45 dependent launches the program waited for the device
+// behind other prover slots' MSM grids at every step (the process's streams share a handful of hardware queues): with live producers on the deferred
+// generator the pipelined rate fell from 62 - 64 to 35 - 50 proofs/s (profiles/r05_run7...).  One launch queues once.
+struct Seg {
+    uint32_t start;   // first op (index into v_ops / f_ops)
+    uint16_t count;   // <= 64
+    uint8_t kind, t;
+};
+constexpr int WF_WAVES = 4;
+// the eight heavy bodies as CALLS: inlined into one kernel the compiler allocated registers for all of them at once (512 + 930 spilled, 1.7 KB of scratch per
+// lane); as functions each keeps the allocation it has as a kernel of its own and the kernel proper is a dispatcher
+template <int T>
+static __device__ __noinline__ void tx_hash(const wf::Op* op, const wf::TxView* v, const Fr29* consts, int rf, int rp) { wf::v_hash<T>(*op, *v, consts, rf, rp); }
+template <int T>
+static __device__ __noinline__ void tx_trace(const wf::Op* op, const wf::TxView* v, const wf::Arrays* A, const Fr29* dense, int rf, int rp) {
+    wf::f_poseidon<T>(*op, *v, *A, dense, rf, rp);
+}
+__global__ void __launch_bounds__(64 * WF_WAVES) wf_tx_kernel(const wf::Op* __restrict__ v_ops, const wf::Op* __restrict__ f_ops, const Seg* __restrict__ segs,
+                                                              const uint32_t* __restrict__ idx, uint32_t n_stages, uint32_t n_tx, const Fr* __restrict__ inputs,
+                                                              uint32_t n_inputs, Fr* __restrict__ regs, const int32_t* __restrict__ sel, wf::Arrays A, size_t base_aux,
+                                                              size_t stride_aux, size_t base_con, size_t stride_con, DevTables tab, uint32_t* __restrict__ flags) {
+    const uint32_t tx = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con, sel};
+    uint32_t f = 0;
+    for (uint32_t stage = 0; stage < n_stages; ++stage) {
+        for (uint32_t s = idx[stage * WF_WAVES + wave]; s < idx[stage * WF_WAVES + wave + 1]; ++s) {
+            const Seg sg = segs[s];
+            if (lane >= sg.count) continue;
+            const int t = sg.t;
+            if (sg.kind == wf::V_HASH) {
+                const wf::Op op = v_ops[sg.start + lane];
+                switch (t) {
+                    case 3: tx_hash<3>(&op, &v, tab.sparse[3], tab.rf[3], tab.rp[3]); break;
+                    case 5: tx_hash<5>(&op, &v, tab.sparse[5], tab.rf[5], tab.rp[5]); break;
+                    case 6: tx_hash<6>(&op, &v, tab.sparse[6], tab.rf[6], tab.rp[6]); break;
+                    default: tx_hash<8>(&op, &v, tab.sparse[8], tab.rf[8], tab.rp[8]); break;
+                }
+            } else {
+                const wf::Op op = f_ops[sg.start + lane];
+                switch (sg.kind) {
+                    case wf::F_POSEIDON:
+                        switch (t) {
+                            case 3: tx_trace<3>(&op, &v, &A, tab.dense[3], tab.rf[3], tab.rp[3]); break;
+                            case 5: tx_trace<5>(&op, &v, &A, tab.dense[5], tab.rf[5], tab.rp[5]); break;
+                            case 6: tx_trace<6>(&op, &v, &A, tab.dense[6], tab.rf[6], tab.rp[6]); break;
+                            default: tx_trace<8>(&op, &v, &A, tab.dense[8], tab.rf[8], tab.rp[8]); break;
+                        }
+                        break;
+                    case wf::F_MUX: wf::f_mux(op, v, A); break;
+                    case wf::F_ASSERT_EQ_IF: f |= wf::f_assert_eq_if(op, v, A); break;
+                    case wf::F_ENFORCE_EQ: f |= wf::f_enforce_eq(op, v, A); break;
+                    case wf::F_CHECK_EQ: f |= wf::f_check_eq(op, v); break;
+                    default: break;
+                }
+            }
+        }
+        __threadfence_block();  // a level's registers (global memory, written by one wave) are read by the other waves of this workgroup next
+        __syncthreads();
+    }
+    if (f) atomicOr(flags, f);
+}
+// stages = the hash levels 1 .. n_levels, then pass 2; per (stage, wave) a run of segments.  Greedy by cost: the most expensive segment first, to the
+// least loaded wave (relative costs from the run-7 trace: a sparse hash of width 3 / 5 / 6 / 8 ~ 0.25 / 0.41 / 0.56 / 0.8 ms per lone wave, the dense trace
+// ~ 0.5 / 1.14 / 1.54 / 2.07 ms)
+struct Schedule {
+    std::vector<Seg> segs;
+    std::vector<uint32_t> idx;
+    uint32_t n_stages = 0;
+};
+Schedule make_schedule(const DeferProgram& P) {
+    auto cost = [](uint8_t kind, uint8_t t) {
+        if (kind == wf::V_HASH) return t <= 3 ? 0.25 : t <= 5 ? 0.41 : t <= 6 ? 0.56 : 0.8;
+        if (kind == wf::F_POSEIDON) return t <= 3 ? 0.5 : t <= 5 ? 1.14 : t <= 6 ? 1.54 : 2.07;
+        return 0.01;
+    };
+    Schedule S;
+    S.n_stages = P.n_levels + 1;
+    S.idx.push_back(0);
+    auto stage = [&](std::vector<Seg> chunks) {
+        std::stable_sort(chunks.begin(), chunks.end(), [&](const Seg& a, const Seg& b) { return cost(a.kind, a.t) > cost(b.kind, b.t); });
+        std::vector<Seg> per_wave[WF_WAVES];
+        double load[WF_WAVES] = {0, 0, 0, 0};
+        for (const Seg& c : chunks) {
+            int w = 0;
+            for (int i = 1; i < WF_WAVES; ++i)
+                if (load[i] < load[w]) w = i;
+            per_wave[w].push_back(c);
+            load[w] += cost(c.kind, c.t);
+        }
+        for (int w = 0; w < WF_WAVES; ++w) {
+            S.segs.insert(S.segs.end(), per_wave[w].begin(), per_wave[w].end());
+            S.idx.push_back((uint32_t)S.segs.size());
+        }
+    };
+    auto chunks_of = [](const DeferGroup& g, std::vector<Seg>& out) {
+        for (uint32_t o = 0; o < g.count; o += 64) out.push_back({g.start + o, (uint16_t)std::min<uint32_t>(64, g.count - o), g.kind, g.t});
+    };
+    for (uint32_t lvl = 1; lvl <= P.n_levels; ++lvl) {
+        std::vector<Seg> c;
+        for (const DeferGroup& g : P.v_groups)
+            if (g.kind == wf::V_HASH && g.level == lvl) chunks_of(g, c);
+        stage(c);
+    }
+    std::vector<Seg> c;
+    for (const DeferGroup& g : P.f_groups) chunks_of(g, c);
+    stage(c);
+    return S;
+}
+
 // per (context, program): the ops in device memory; per context: the constant tables and the grow-only scratch (registers + inputs)
 struct CtxState {
     struct DevProg {
         wf::Op *v = nullptr, *f = nullptr;  // v_ops, f_ops
         int32_t* sel = nullptr;             // per register: the V_SEL that defines it (bzk_witfill.cuh TxView::sel)
+        Seg* segs = nullptr;                // the one-launch schedule (make_schedule)
+        uint32_t* idx = nullptr;
+        uint32_t n_stages = 0;
     };
     std::map<const DeferProgram*, DevProg> progs;
     DevTables tab;
@@ -150,7 +266,13 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) 
         BZK_HIP(ctx, hipMemcpyAsync(dp.v, P.v_ops.data(), P.v_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
         BZK_HIP(ctx, hipMemcpyAsync(dp.f, P.f_ops.data(), P.f_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
         BZK_HIP(ctx, hipMemcpyAsync(dp.sel, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `sel` is a local
+        const Schedule sch = make_schedule(P);
+        dp.n_stages = sch.n_stages;
+        BZK_HIP(ctx, hipMalloc((void**)&dp.segs, std::max<size_t>(1, sch.segs.size()) * sizeof(Seg)));
+        BZK_HIP(ctx, hipMalloc((void**)&dp.idx, sch.idx.size() * sizeof(uint32_t)));
+        BZK_HIP(ctx, hipMemcpyAsync(dp.segs, sch.segs.data(), sch.segs.size() * sizeof(Seg), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(dp.idx, sch.idx.data(), sch.idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `sel` and `sch` are locals
         it = S->progs.emplace(&P, dp).first;
     }
     const size_t n_tx = dd.n_tx;
@@ -170,7 +292,10 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) 
     Fr* d_regs = (Fr*)((char*)S->scratch + 256 + in_bytes);
     BZK_HIP(ctx, hipMemsetAsync(flags_dev, 0, 4, ctx->stream));
     BZK_HIP(ctx, hipMemcpyAsync(d_in, dd.inputs.data(), n_tx * (size_t)P.n_inputs * 32, hipMemcpyHostToDevice, ctx->stream));
-    static const bool want_prio = [] { const char* e = getenv("BZK_WF_PRIO"); return !(e && atoi(e) == 0); }();
+    // BZK_WF_MODE=levels: one launch per (level, width) group instead of the one-launch form (A/B); BZK_WF_PRIO=1: on a highest-priority side stream
+    // (measured worse under load with the launch-per-level form: 35 vs 50 proofs/s at 8 slots, profiles/r05_run7...; default off)
+    static const bool one_launch = [] { const char* e = getenv("BZK_WF_MODE"); return !(e && strcmp(e, "levels") == 0); }();
+    static const bool want_prio = [] { const char* e = getenv("BZK_WF_PRIO"); return e && atoi(e) != 0; }();
     if (want_prio && !S->prio_tried) {
         S->prio_tried = true;
         int lo = 0, hi = 0;
@@ -195,6 +320,19 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) 
     StreamSwap swap(ctx, S->prio);
     const uint32_t ntx = (uint32_t)n_tx;
     const int32_t* dsel = it->second.sel;
+    if (one_launch) {
+        for (int t = 0; t < 9; ++t)
+            if (t != 3 && t != 5 && t != 6 && t != 8 && S->tab.dense[t]) { ctx->last_error = "witfill: no device form for Poseidon width " + std::to_string(t); return BZK_E_INTERNAL; }
+        BZK_LAUNCH(ctx, "wf_tx", wf_tx_kernel, dim3(ntx), dim3(64 * WF_WAVES), 0, (const wf::Op*)it->second.v, (const wf::Op*)it->second.f, (const Seg*)it->second.segs,
+                   (const uint32_t*)it->second.idx, it->second.n_stages, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux, dd.stride_aux, dd.base_con,
+                   dd.stride_con, S->tab, flags_dev);
+        BZK_HIP(ctx, hipMemcpyAsync(S->flags_host, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (S->prio) {
+            BZK_HIP(ctx, hipEventRecord(S->ev_out, S->prio));
+            BZK_HIP(ctx, hipStreamWaitEvent(home, S->ev_out, 0));
+        }
+        return BZK_OK;
+    }
     auto blocks = [&](uint32_t count, uint32_t bs) { return dim3((unsigned)(((uint64_t)count * ntx + bs - 1) / bs)); };
     // pass 1
     for (const DeferGroup& g : P.v_groups) {
@@ -243,6 +381,8 @@ void witfill_free(bzk_ctx* ctx) {  // bzk_ctx_destroy
         (void)hipFree(kv.second.v);
         (void)hipFree(kv.second.f);
         (void)hipFree(kv.second.sel);
+        (void)hipFree(kv.second.segs);
+        (void)hipFree(kv.second.idx);
     }
     for (void* p : S->dense_dev)
         if (p) (void)hipFree(p);
