@@ -7,6 +7,7 @@
 
 #include <string.h>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -15,6 +16,19 @@
 struct bzk_prof_rec {
     const char* name;
     hipEvent_t a, b;
+};
+
+// An instance's assignment resident in HBM (bzk_r1cs_stage, groth16.hip): z | A.z | B.z | C.z as the prover reads them, complete - the deferred-value
+// program, if the instance had one, has run behind the uploads on the staging context's stream; `ready` marks the end of that work
+struct bzk_staged {
+    bzk_ctx* owner = nullptr;
+    void* buf = nullptr;          // one allocation: z (n_vars) | az | bz | cz (n_rows each), 32-byte scalars
+    size_t cap = 0;               // bytes behind buf
+    uint64_t n_vars = 0, n_rows = 0;
+    hipEvent_t ready = nullptr;
+    uint32_t* flags_host = nullptr;  // pinned: wf::FLAG_* of the program (0 without one), valid once `ready` has completed
+    void* z() const { return buf; }
+    void* ev(int k) const { return (char*)buf + (n_vars + (uint64_t)k * n_rows) * 32; }
 };
 
 struct bzk_ctx {
@@ -58,6 +72,9 @@ struct bzk_ctx {
     hipStream_t hprio = nullptr;
     hipEvent_t ev_h = nullptr;
     void* wf_state = nullptr;  // witfill.hip: device copies of the deferred-witness programs, dense Poseidon constants, scratch (witfill_free)
+    // bzk_r1cs_stage: staged assignments handed back by bzk_staged_free (possibly from another thread: the prover's), kept for the next call
+    std::mutex staged_mu;
+    std::vector<bzk_staged*> staged_pool;
 };
 
 #define BZK_HIP(ctx, call)                                                                  \

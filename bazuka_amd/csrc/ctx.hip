@@ -241,6 +241,12 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
         if (p) (void)hipFree(p);
     bzk::ntt_free_tables(ctx);
     bzk::witfill_free(ctx);
+    for (bzk_staged* st : ctx->staged_pool) {  // (handles still out at this point are the caller's leak: bzk_staged_free before bzk_ctx_destroy)
+        (void)hipFree(st->buf);
+        (void)hipEventDestroy(st->ready);
+        (void)hipHostFree(st->flags_host);
+        delete st;
+    }
     if (ctx->ev_z) (void)hipEventDestroy(ctx->ev_z);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux);

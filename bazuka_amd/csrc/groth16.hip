@@ -23,7 +23,7 @@
 #include "bzk_internal.h"
 #include "host_fp64.h"
 #include "host_r1cs.h"  // DeferData / witfill_run_dev: witness values the device fills in (bzk_groth16_prove_r1cs)
-namespace bzk { void r1cs_assignment(const bzk_r1cs* r, bzk_assignment* a, const DeferData** dd); }  // mpn.hip
+namespace bzk { void r1cs_assignment(const bzk_r1cs* r, bzk_assignment* a, const DeferData** dd, uint64_t* n_in); }  // mpn.hip
 
 // The CRS of one circuit on one device, shared (reference-counted, read-only once prepared) by every prover SLOT of that device:
 // a slot = bzk_params = the shared CRS + its own per-proof scratch.  Four slots per GPU (bench.py) used to hold four CRS copies and
@@ -424,14 +424,14 @@ int32_t bzk_groth16_h_dev(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_
     return groth16_h(ctx, a, b, c, log_m);
 }
 
-static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32],
+static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const bzk_staged* st, const uint8_t r32[32],
                                   const uint8_t s32[32], uint8_t proof[387]);
-static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32],
+static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const bzk_staged* st, const uint8_t r32[32],
                                    const uint8_t s32[32], uint8_t proof[387]);
 
 int32_t bzk_groth16_prove(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const uint8_t r32[32], const uint8_t s32[32],
                           uint8_t proof[387]) {
-    return groth16_prove_entry(ctx, p, asg, nullptr, r32, s32, proof);
+    return groth16_prove_entry(ctx, p, asg, nullptr, nullptr, r32, s32, proof);
 }
 // The same over an R1CS instance of the host generator (bzk_mpn_*_synthesize), INCLUDING one whose hash-dependent values were deferred
 // (bzk_mpn_set_defer): the arrays are uploaded as they are and the instance's DeferProgram fills the rest in on the device before any
@@ -441,17 +441,105 @@ int32_t bzk_groth16_prove_r1cs(bzk_ctx* ctx, bzk_params* p, const bzk_r1cs* r, c
     if (!r) return BZK_E_ARG;
     bzk_assignment asg;
     const bzk::DeferData* dd = nullptr;
-    bzk::r1cs_assignment(r, &asg, &dd);
-    return groth16_prove_entry(ctx, p, &asg, dd, r32, s32, proof);
+    bzk::r1cs_assignment(r, &asg, &dd, nullptr);
+    return groth16_prove_entry(ctx, p, &asg, dd, nullptr, r32, s32, proof);
 }
 
-static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32],
-                                   const uint8_t s32[32], uint8_t proof[387]) {
+// ---- staged assignments: the uploads and the deferred-value program in the PRODUCER's pipeline ------------------------------------------------
+// bzk_r1cs_stage puts an instance's z | A.z | B.z | C.z into HBM on `ctx`'s stream - a context of the witness producer's, not a prover slot's - runs the
+// instance's deferred-value program behind the uploads and returns at once; bzk_groth16_prove_staged (any context of the same device) waits for that work in
+// stream order and copies device to device (128 MB at HBM rate) instead of uploading.  Why (profiles/r05_run8...): inside bzk_groth16_prove_r1cs the program is
+// 15 ms during which its slot feeds the device no MSM work - 50 proofs/s with live producers on the deferred generator against 62 - 63 on the plain one.
+int32_t bzk_r1cs_stage(bzk_ctx* ctx, const bzk_r1cs* r, bzk_staged** out) {
+    if (!ctx || !r || !out) return BZK_E_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    bzk_assignment asg;
+    const bzk::DeferData* dd = nullptr;
+    uint64_t n_in = 0;
+    bzk::r1cs_assignment(r, &asg, &dd, &n_in);
+    const size_t bytes = (size_t)(asg.n_vars + 3 * asg.n_rows) * 32;
+    bzk_staged* st = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->staged_mu);
+        for (size_t i = 0; i < ctx->staged_pool.size(); ++i)
+            if (ctx->staged_pool[i]->cap >= bytes) {
+                st = ctx->staged_pool[i];
+                ctx->staged_pool.erase(ctx->staged_pool.begin() + (long)i);
+                break;
+            }
+    }
+    auto give_back = [&] {
+        std::lock_guard<std::mutex> lk(ctx->staged_mu);
+        ctx->staged_pool.push_back(st);
+    };
+    if (!st) {
+        st = new bzk_staged();
+        st->owner = ctx;
+        if (hipMalloc(&st->buf, bytes) != hipSuccess || hipEventCreateWithFlags(&st->ready, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void**)&st->flags_host, 64) != hipSuccess) {
+            (void)hipGetLastError();
+            if (st->buf) (void)hipFree(st->buf);
+            if (st->ready) (void)hipEventDestroy(st->ready);
+            if (st->flags_host) (void)hipHostFree(st->flags_host);
+            delete st;
+            return BZK_E_ALLOC;
+        }
+        st->cap = bytes;
+    }
+    st->n_vars = asg.n_vars;
+    st->n_rows = asg.n_rows;
+    *st->flags_host = 0;
+    const uint8_t* src[4] = {asg.z, asg.az, asg.bz, asg.cz};
+    void* dst[4] = {st->z(), st->ev(0), st->ev(1), st->ev(2)};
+    const size_t len[4] = {(size_t)asg.n_vars * 32, (size_t)asg.n_rows * 32, (size_t)asg.n_rows * 32, (size_t)asg.n_rows * 32};
+    int32_t rc = BZK_OK;
+    for (int k = 0; k < 4 && rc == BZK_OK; ++k)
+        if (hipMemcpyAsync(dst[k], src[k], len[k], hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = BZK_E_DEVICE;
+    if (rc == BZK_OK && dd)
+        rc = bzk::witfill_run_dev(ctx, *dd, bzk::wf::Arrays{(Fr*)st->z() + n_in, (Fr*)st->ev(0), (Fr*)st->ev(1), (Fr*)st->ev(2)}, st->flags_host);
+    if (rc == BZK_OK && hipEventRecord(st->ready, ctx->stream) != hipSuccess) rc = BZK_E_DEVICE;
+    if (rc != BZK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);  // nothing may still be reading the instance's arrays
+        bzk::witfill_quiesce(ctx);
+        (void)hipGetLastError();
+        give_back();
+        return rc;
+    }
+    *out = st;
+    return BZK_OK;
+}
+// blocks until the staging work has finished (the instance's host arrays may be freed from here on).  BZK_E_UNSAT: see bzk_groth16_prove_r1cs
+int32_t bzk_staged_wait(bzk_staged* st) {
+    if (!st) return BZK_E_ARG;
+    if (hipEventSynchronize(st->ready) != hipSuccess) return BZK_E_DEVICE;
+    return *st->flags_host ? BZK_E_UNSAT : BZK_OK;
+}
+// hands the buffers back to the staging context (callable from any thread, once no prove call is using them)
+void bzk_staged_free(bzk_staged* st) {
+    if (!st) return;
+    std::lock_guard<std::mutex> lk(st->owner->staged_mu);
+    st->owner->staged_pool.push_back(st);
+}
+int32_t bzk_groth16_prove_staged(bzk_ctx* ctx, bzk_params* p, const bzk_staged* st, const uint8_t r32[32], const uint8_t s32[32], uint8_t proof[387]) {
+    if (!st || !ctx || st->owner->device != ctx->device) return BZK_E_ARG;
+    bzk_assignment asg;
+    asg.z = (const uint8_t*)st->z();
+    asg.az = (const uint8_t*)st->ev(0);
+    asg.bz = (const uint8_t*)st->ev(1);
+    asg.cz = (const uint8_t*)st->ev(2);
+    asg.n_rows = st->n_rows;
+    asg.n_vars = st->n_vars;
+    return groth16_prove_entry(ctx, p, &asg, nullptr, st, r32, s32, proof);
+}
+
+static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assignment* asg, const bzk::DeferData* dd, const bzk_staged* st_in,
+                                   const uint8_t r32[32], const uint8_t s32[32], uint8_t proof[387]) {
     if (!ctx || !p || !asg || !r32 || !s32 || !proof || !asg->z || !asg->az || !asg->bz || !asg->cz) return BZK_E_ARG;
     if (p->crs->device != ctx->device) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     crs_prepare(ctx, p->crs);
-    int32_t st = groth16_prove_impl(ctx, p, asg, dd, r32, s32, proof);
+    int32_t st = groth16_prove_impl(ctx, p, asg, dd, st_in, r32, s32, proof);
     auto quiesce = [&] {
         // the caller frees (re-uses) the assignment arrays as soon as this returns: no copy out of them may still be in
         // flight, on the main stream or on a lane
@@ -476,7 +564,7 @@ static int32_t groth16_prove_entry(bzk_ctx* ctx, bzk_params* p, const bzk_assign
                 dropped = true;
             }
         }
-        if (dropped) st = groth16_prove_impl(ctx, p, asg, dd, r32, s32, proof);
+        if (dropped) st = groth16_prove_impl(ctx, p, asg, dd, st_in, r32, s32, proof);
     }
     if (st != BZK_OK) quiesce();
     return st;
@@ -513,8 +601,11 @@ int32_t bzk_params_h_table(bzk_ctx* ctx, bzk_params* p, int32_t on) {
     return BZK_OK;
 }
 
-static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assignment* asg, const bzk::DeferData* dd, const uint8_t r32[32], const uint8_t s32[32],
-                                  uint8_t proof[387]) {
+static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assignment* asg, const bzk::DeferData* dd, const bzk_staged* staged,
+                                  const uint8_t r32[32], const uint8_t s32[32], uint8_t proof[387]) {
+    // a staged assignment is device memory another stream has been filling: this stream waits for that work, and every "upload" below is a device-to-device copy
+    const hipMemcpyKind up = staged ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (staged) BZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, staged->ready, 0));
     const CrsShared* p = slot->crs;
     const uint64_t m = (uint64_t)1 << p->log_m, nv = (uint64_t)p->n_in + p->n_aux;
     if (asg->n_rows > m) return BZK_E_ARG;
@@ -534,7 +625,7 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
     bzk_ctx* lane[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < n_lanes; ++i)
         if (!(lane[i] = bzk::ctx_lane(ctx, (size_t)i))) return BZK_E_DEVICE;
-    BZK_HIP(ctx, hipMemcpyAsync(slot->d_z, asg->z, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(slot->d_z, asg->z, nv * 32, up, ctx->stream));
     if (dd) {
         // deferred witness values: z is not complete until the instance's program has run, and the program also writes into the three
         // evaluation arrays - so those are staged now (main_part skips them) and every consumer below is behind the fill in stream order
@@ -707,12 +798,12 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
             StreamSwap(bzk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { if (s) c->stream = s; }
             ~StreamSwap() { c->stream = saved; }
         };
-        const bool side = h_prio && ctx->hprio && !dd;
+        const bool side = h_prio && ctx->hprio && !dd && !staged;
         {
         StreamSwap swap(ctx, side ? ctx->hprio : nullptr);
         if (tm[0]) (void)hipEventRecord(tm[0], ctx->stream);
         for (int k = 0; k < 3 && !dd; ++k) {
-            BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipMemcpyAsync(ev[k], hv[k], asg->n_rows * 32, up, ctx->stream));
             if (m > asg->n_rows)
                 BZK_HIP(ctx, hipMemsetAsync((char*)ev[k] + asg->n_rows * 32, 0, (m - asg->n_rows) * 32, ctx->stream));
         }
@@ -737,8 +828,8 @@ static int32_t groth16_prove_impl(bzk_ctx* ctx, bzk_params* slot, const bzk_assi
             ctx->last_error = "lane " + std::to_string(i) + ": " + lane[i]->last_error;
             return st[i];
         }
-    if (dd) {  // (the h MSM's read-back has synchronised the main stream: the program's flags word has landed)
-        const uint32_t f = bzk::witfill_flags(ctx);
+    if (dd || staged) {  // (the h MSM's read-back has synchronised the main stream: the program's flags word has landed)
+        const uint32_t f = staged ? *staged->flags_host : bzk::witfill_flags(ctx);
         if (f) {
             ctx->last_error = std::string("groth16_prove: deferred witness values -") + ((f & bzk::wf::FLAG_UNSATISFIED) ? " a deferred constraint does not hold" : "") +
                               ((f & bzk::wf::FLAG_CHAIN) ? " a transition's computed state differs from the witness builder's prediction" : "");

@@ -205,7 +205,8 @@ struct DeferData {
     uint32_t flags = 0;                 // wf::FLAG_* of that fill
 };
 // witfill.hip: the program over all transitions on the device (arrays = device views) / on the host
-int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A);  // enqueues on ctx->stream; the flags word follows in stream order
+// enqueues on ctx->stream; the flags word follows in stream order (into flags_dst, a pinned word, or the context's own: witfill_flags)
+int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, uint32_t* flags_dst = nullptr);
 uint32_t witfill_flags(bzk_ctx* ctx);                                                // ... and is read here once that stream has been synchronised
 uint32_t witfill_run_host(const DeferData& dd, const wf::Arrays& A);
 void witfill_quiesce(bzk_ctx* ctx);

@@ -1459,8 +1459,9 @@ static void finish_r1cs(bzk_r1cs* r) {
 }
 
 // groth16.hip (bzk_groth16_prove_r1cs): the instance's arrays as an assignment, and what is deferred in them (nullptr: nothing, or already filled in)
-void r1cs_assignment(const bzk_r1cs* r, bzk_assignment* a, const DeferData** dd) {
+void r1cs_assignment(const bzk_r1cs* r, bzk_assignment* a, const DeferData** dd, uint64_t* n_in) {
     const ConstraintSystem& cs = r->cs;
+    if (n_in) *n_in = cs.inputs.size();
     a->z = r->z_bytes.data();
     a->az = (const uint8_t*)cs.az.data();
     a->bz = (const uint8_t*)cs.bz.data();

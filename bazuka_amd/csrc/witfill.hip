@@ -239,14 +239,16 @@ uint32_t witfill_flags(bzk_ctx* ctx) {  // after the stream of the last witfill_
     return S && S->flags_host ? *S->flags_host : 0u;
 }
 
-int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) {
+int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, uint32_t* flags_dst) {
     const DeferProgram& P = *dd.prog;
     if (!dd.n_tx || P.ops.empty()) return BZK_OK;
     // (a context is driven by one host thread at a time - the library's rule for every entry point - so its state needs no lock)
     if (!ctx->wf_state) ctx->wf_state = new CtxState();
     CtxState* S = (CtxState*)ctx->wf_state;
     if (!S->flags_host) BZK_HIP(ctx, hipHostMalloc((void**)&S->flags_host, 64));
-    *S->flags_host = 0;
+    // flags_dst: a pinned word of the caller's (staged instances: several runs may be in flight on this stream); default: the context's own
+    uint32_t* const flags_out = flags_dst ? flags_dst : S->flags_host;
+    *flags_out = 0;
     for (const DeferGroup& g : P.v_groups)
         if (g.kind == wf::V_HASH) BZK_TRY(tables(ctx, *S, g.t));
     for (const DeferGroup& g : P.f_groups)
@@ -326,7 +328,7 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) 
         BZK_LAUNCH(ctx, "wf_tx", wf_tx_kernel, dim3(ntx), dim3(64 * WF_WAVES), 0, (const wf::Op*)it->second.v, (const wf::Op*)it->second.f, (const Seg*)it->second.segs,
                    (const uint32_t*)it->second.idx, it->second.n_stages, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux, dd.stride_aux, dd.base_con,
                    dd.stride_con, S->tab, flags_dev);
-        BZK_HIP(ctx, hipMemcpyAsync(S->flags_host, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+        BZK_HIP(ctx, hipMemcpyAsync(flags_out, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
         if (S->prio) {
             BZK_HIP(ctx, hipEventRecord(S->ev_out, S->prio));
             BZK_HIP(ctx, hipStreamWaitEvent(home, S->ev_out, 0));
@@ -366,7 +368,7 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A) 
             default: ctx->last_error = "witfill: no device form for Poseidon width " + std::to_string(g.t); return BZK_E_INTERNAL;
         }
     }
-    BZK_HIP(ctx, hipMemcpyAsync(S->flags_host, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BZK_HIP(ctx, hipMemcpyAsync(flags_out, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (S->prio) {  // join: everything the caller enqueues on its stream from here on is behind the program and its flags word
         BZK_HIP(ctx, hipEventRecord(S->ev_out, S->prio));
         BZK_HIP(ctx, hipStreamWaitEvent(home, S->ev_out, 0));

@@ -71,6 +71,10 @@ SIGNATURES = {
     "bzk_params_h_table": (_i32, [_vp, _vp, _i32]),
     "bzk_groth16_prove": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "bzk_groth16_prove_r1cs": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "bzk_r1cs_stage": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "bzk_staged_wait": (_i32, [_vp]),
+    "bzk_staged_free": (None, [_vp]),
+    "bzk_groth16_prove_staged": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "bzk_bellman_params_info": (_i32, [_vp, _u64, C.POINTER(_u64)]),
     "bzk_bellman_params_decode": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "bzk_bellman_params_encode": (_i32, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _u64, C.POINTER(_u64)]),
@@ -620,6 +624,24 @@ class Bzk:
         """the same over an R1cs of the host generator; an instance synthesized with MpnWorld.set_defer(True) is completed on the device first"""
         out = C.create_string_buffer(387)
         self._ck(self.lib.bzk_groth16_prove_r1cs(self.h, ph, r1cs.h, _ptr(r), _ptr(s), out), "groth16_prove_r1cs")
+        return out.raw
+
+    def r1cs_stage(self, r1cs):
+        """the instance's arrays into HBM on THIS context's stream + its deferred-value program behind them; returns at once (a staged handle).
+        Keep `r1cs` alive until staged_wait / a prove call on the handle has returned."""
+        h = C.c_void_p()
+        self._ck(self.lib.bzk_r1cs_stage(self.h, r1cs.h, C.byref(h)), "r1cs_stage")
+        return h
+
+    def staged_wait(self, staged):
+        self._ck(self.lib.bzk_staged_wait(staged), "staged_wait")
+
+    def staged_free(self, staged):
+        self.lib.bzk_staged_free(staged)
+
+    def groth16_prove_staged(self, ph, staged, r: bytes, s: bytes) -> bytes:
+        out = C.create_string_buffer(387)
+        self._ck(self.lib.bzk_groth16_prove_staged(self.h, ph, staged, _ptr(r), _ptr(s), out), "groth16_prove_staged")
         return out.raw
 
     def params_read(self, ph, which: int) -> bytes:

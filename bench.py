@@ -260,6 +260,9 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     # instance's program on the GPU before anything reads the arrays.  Same proof bytes (tests/test_gpu_defer.py).  BZK_BENCH_DEFER=1: the live producers
     # below use it too (A/B; the default is the plain generator: see DESIGN.md section 3.5 for the measured trade)
     defer = os.environ.get("BZK_BENCH_DEFER", "0") != "0"
+    # BZK_BENCH_STAGE=1 (with or without deferral): each producer owns a context and STAGES its instances - the 116 MB upload and the deferred-value
+    # program run on the producer's stream (bzk_r1cs_stage), the prover slots copy device to device (bzk_groth16_prove_staged)
+    stage = os.environ.get("BZK_BENCH_STAGE", "0") != "0"
     w.set_defer(True)
     twd, tpd, tcd = [], [], []
     for k in range(n_proofs):
@@ -278,7 +281,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
         curd.free()
     w.set_defer(False)
     out["deferred"] = {"witness_s": round(min(twd), 4), "witness_cpu_s": round(min(tcd), 4), "gpu_prove_s": round(min(tpd), 4),
-                       "live_producers_use_it": defer,
+                       "live_producers_use_it": defer, "live_producers_stage": stage,
                        "what": "host generator without the Poseidon / Merkle value traces (bzk_mpn_set_defer), the device fills them in inside bzk_groth16_prove_r1cs"}
     if cpu_baseline:
         # The same proof on the host cores with the CPU oracle (kind "port": bellman's algorithms restated; the Rust
@@ -339,6 +342,7 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
             pw.set_defer(True)
         if prod_dev:  # A/B: the producers' Merkle hashing in batched launches on the GPU (bzk_mpn_set_device) instead of on their host threads
             pw.set_device(Bzk(ctx.device))
+        pctx = Bzk(ctx.device) if stage else None
         for i in range(2 * n_tx):
             pw.add_account(i, b"p%dacct%d" % (seed, i), ZIESHA, 10 ** 12)
         k = 0
@@ -350,9 +354,10 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
             rr = pw.update_synthesize(b, _fr(99), ZIESHA)
             synth_s.append(time.perf_counter() - ts)
             assert rr.satisfied and rr.n_constraints == r.n_constraints  # host-side self check of the witness
+            item = (rr, pctx, pctx.r1cs_stage(rr)) if stage else rr
             while not stop.is_set():
                 try:
-                    q.put(rr, timeout=0.05)
+                    q.put(item, timeout=0.05)
                     break
                 except queue.Full:
                     pass
@@ -388,7 +393,13 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
                     j = done["n"]
                     done["n"] += 1
                 rr = ring[j % len(ring)] if ring is not None else q.get()
-                c.groth16_prove_r1cs(p, rr, _fr_blind(1000 + 2 * j), _fr_blind(1001 + 2 * j))  # completes a deferred instance on the device first
+                if isinstance(rr, tuple):  # staged by its producer: (instance, staging context, handle)
+                    inst, pc, hd = rr
+                    c.groth16_prove_staged(p, hd, _fr_blind(1000 + 2 * j), _fr_blind(1001 + 2 * j))
+                    pc.staged_free(hd)
+                    inst.free()
+                else:
+                    c.groth16_prove_r1cs(p, rr, _fr_blind(1000 + 2 * j), _fr_blind(1001 + 2 * j))  # completes a deferred instance on the device first
                 with lock:
                     finished.append(time.perf_counter())
 

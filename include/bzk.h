@@ -407,6 +407,18 @@ int32_t bzk_r1cs_fill_host(bzk_r1cs* r);
  * witness builder's prediction (synthesize again without deferral for the exact first unsatisfied row). */
 int32_t bzk_groth16_prove_r1cs(bzk_ctx* ctx, bzk_params* params, const bzk_r1cs* r, const uint8_t r_blind[32], const uint8_t s_blind[32],
                                uint8_t proof_out[387]);
+/* Staging - the uploads and the deferred-value program in the witness PRODUCER's pipeline instead of the prover slot's.  bzk_r1cs_stage puts the
+ * instance's z | A.z | B.z | C.z into HBM on `ctx`'s stream (a context of the producer's), runs the deferred-value program behind the uploads if the instance
+ * has one, and returns at once; the instance's host arrays must stay alive until bzk_staged_wait (or a prove call on the handle) has returned.
+ * bzk_groth16_prove_staged (any context of the same device) waits for that work in stream order and copies device to device instead of uploading; same proof
+ * bytes, BZK_E_UNSAT as bzk_groth16_prove_r1cs.  bzk_staged_free hands the buffers back to the staging context (any thread; after the last prove call on the
+ * handle has returned, before that context is destroyed). */
+typedef struct bzk_staged bzk_staged;
+int32_t bzk_r1cs_stage(bzk_ctx* ctx, const bzk_r1cs* r, bzk_staged** out);
+int32_t bzk_staged_wait(bzk_staged* staged);
+void bzk_staged_free(bzk_staged* staged);
+int32_t bzk_groth16_prove_staged(bzk_ctx* ctx, bzk_params* params, const bzk_staged* staged, const uint8_t r_blind[32], const uint8_t s_blind[32],
+                                 uint8_t proof_out[387]);
 /* CPU mirrors of `ZkHasher::hash`, `hash_to_scalar`'s SHA3 and `JubJub::{generate_keys, sign, verify}` */
 /* ---- f-2: the proving worker's wire format ---------------------------------------------------------------------------
  * `MpnWork` (src/mpn/mod.rs:263-270) as `GET /bincode/mpn/work` delivers it (src/node/mod.rs:393-398,

@@ -93,3 +93,51 @@ def test_a_deferred_violation_is_refused_by_the_prove_call(bzk):
     want = bzk.groth16_prove(ph, *(r.view(k) for k in ("z", "az", "bz", "cz")), rs[:32], rs[32:])
     assert bzk.groth16_prove_r1cs(ph, dec0.synthesize(S.PROVER, defer=True), rs[:32], rs[32:]) == want
     bzk.params_free(ph)
+
+
+def test_staged_instances_prove_to_the_same_bytes(bzk):
+    """bzk_r1cs_stage on a PRODUCER's context (uploads + the deferred-value program there), bzk_groth16_prove_staged on the prover's: plain and deferred
+    instances, several staged at once on one staging stream, handles reused from the pool"""
+    from bazuka_amd import Bzk
+    dec = L.MpnWork.decode(S.make_work("update_15_3_1"))
+    r, ph, vkb = _setup(bzk, dec)
+    rs = [fr_bytes(fr_list(2, 800 + i)) for i in range(4)]
+    want = [bzk.groth16_prove(ph, *(r.view(k) for k in ("z", "az", "bz", "cz")), x[:32], x[32:]) for x in rs]
+    stager = Bzk(bzk.device)
+    plain = dec.synthesize(S.PROVER)
+    deferred = [dec.synthesize(S.PROVER, threads=2, defer=True) for _ in range(3)]
+    handles = [stager.r1cs_stage(x) for x in [plain] + deferred]      # four instances in flight on the staging stream
+    for i, h in enumerate(handles):
+        assert bzk.groth16_prove_staged(ph, h, rs[i][:32], rs[i][32:]) == want[i], i
+    stager.staged_wait(handles[0])
+    for h in handles:
+        stager.staged_free(h)
+    h2 = stager.r1cs_stage(deferred[0])                               # a pooled buffer again
+    assert bzk.groth16_prove_staged(ph, h2, rs[0][:32], rs[0][32:]) == want[0]
+    assert deferred[0].defer_info()["filled"] == 0
+    stager.staged_free(h2)
+    # a violated deferred constraint surfaces from the wait and from the prove call
+    blob = bytearray(S.make_work("update_15_3_1"))
+    bad = None
+    for off in range(len(blob) // 2, len(blob) // 2 + 6000, 97):
+        mut = bytearray(blob)
+        mut[off] ^= 1
+        try:
+            d2 = L.MpnWork.decode(bytes(mut))
+            if d2.synthesize(S.PROVER, threads=1).satisfied:
+                continue
+            cand = d2.synthesize(S.PROVER, threads=2, defer=True)
+        except Exception:
+            continue
+        if cand.defer_info()["deferred"] and cand.satisfied:
+            bad = cand
+            break
+    if bad is not None:
+        hb = stager.r1cs_stage(bad)
+        with pytest.raises(L.BzkError):
+            stager.staged_wait(hb)
+        with pytest.raises(L.BzkError):
+            bzk.groth16_prove_staged(ph, hb, rs[0][:32], rs[0][32:])
+        stager.staged_free(hb)
+    bzk.params_free(ph)
+    stager.close()
