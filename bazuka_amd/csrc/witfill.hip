@@ -89,16 +89,16 @@ struct Seg {
 constexpr int WF_WAVES = 4;
 // the eight heavy bodies as CALLS: inlined into one kernel the compiler allocated registers for all of them at once (512 + 930 spilled, 1.7 KB of scratch per
 // lane); as functions each keeps the allocation it has as a kernel of its own and the kernel proper is a dispatcher
-#ifndef BZK_WF_OCC
-#define BZK_WF_OCC 3  // waves per SIMD the one-launch program is allocated for: 168 registers - a wave then fits beside two waves of the G1 accumulation (2 x 176)
-#endif
+// (allocating the kernel for three waves per SIMD - amdgpu_waves_per_eu(3, 3) on the kernel, which the callees inherit: 168 registers, so that a wave fits beside two
+// waves of the G1 accumulation - was built and measured in run 10: the width-6 / 8 bodies then live in 9 KB of scratch per lane, the kernel alone takes 19.5 instead of
+// 15 ms and the pipelined rate with staged deferred producers FALLS from 51.7 - 52.7 to 45.4 - 47.0 proofs/s, profiles/r05_run10...: not taken)
 template <int T>
 static __device__ __noinline__ void tx_hash(const wf::Op* op, const wf::TxView* v, const Fr29* consts, int rf, int rp) { wf::v_hash<T>(*op, *v, consts, rf, rp); }
 template <int T>
 static __device__ __noinline__ void tx_trace(const wf::Op* op, const wf::TxView* v, const wf::Arrays* A, const Fr29* dense, int rf, int rp) {
     wf::f_poseidon<T>(*op, *v, *A, dense, rf, rp);
 }
-__global__ void __launch_bounds__(64 * WF_WAVES) __attribute__((amdgpu_waves_per_eu(BZK_WF_OCC, BZK_WF_OCC))) wf_tx_kernel(const wf::Op* __restrict__ v_ops, const wf::Op* __restrict__ f_ops, const Seg* __restrict__ segs,
+__global__ void __launch_bounds__(64 * WF_WAVES) wf_tx_kernel(const wf::Op* __restrict__ v_ops, const wf::Op* __restrict__ f_ops, const Seg* __restrict__ segs,
                                                               const uint32_t* __restrict__ idx, uint32_t n_stages, uint32_t n_tx, const Fr* __restrict__ inputs,
                                                               uint32_t n_inputs, Fr* __restrict__ regs, const int32_t* __restrict__ sel, wf::Arrays A, size_t base_aux,
                                                               size_t stride_aux, size_t base_con, size_t stride_con, DevTables tab, uint32_t* __restrict__ flags) {
