@@ -847,6 +847,20 @@ def production_block_section(ctx, with_1024tx: bool = False):
         sec.update(make_work_s=round(min(tm), 4), wire_bytes=len(blob), decode_and_witness_s=round(min(tw), 4), prove_s=round(min(tp), 4),
                    prove_s_all=[round(x, 4) for x in tp], verified=bool(ok), verify_ms_host=round(min(tv) * 1e3, 2),
                    tx_per_s_prove_only=round(n_slots / min(tp), 1))
+        if kind == 2:
+            # the same work with the hash-dependent witness values left to the device: at 256 transitions the deferred-value program has 256
+            # workgroups to run, and the host generator is what a production block waits for longest after the proof itself
+            twd, tpd, okd = [], [], True
+            for k in range(2):
+                t1 = time.perf_counter()
+                rd = L.MpnWork.decode(blob).synthesize(prover, defer=True)
+                t2 = time.perf_counter()
+                pd = ctx.groth16_prove_r1cs(ph, rd, _fr_blind(6000 + 2 * k), _fr_blind(6001 + 2 * k))
+                t3 = time.perf_counter()
+                okd = okd and rd.defer_info()["deferred"] == 1 and L.groth16_verify(vkb, bytes(rd.raw("z")[32:32 * 6]), pd)
+                twd.append(t2 - t1); tpd.append(t3 - t2)
+                rd.free()
+            sec["deferred"] = {"decode_and_witness_s": round(min(twd), 4), "prove_s": round(min(tpd), 4), "verified": bool(okd)}
         if b4 <= 4:
             total += min(tp)
         ctx.params_free(ph)
