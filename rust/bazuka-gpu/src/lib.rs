@@ -337,6 +337,32 @@ pub fn groth16_prove(params: &ProvingParams, witness: &Witness, r: ZkScalar, s: 
     Ok(bincode::deserialize(&buf)?) // private fields: through bincode, never a pointer cast
 }
 
+/// `synthesize_work` with the hash-dependent witness values of an Update work LEFT TO THE DEVICE (include/bzk.h: BZK_SYNTH_DEFER): the
+/// Poseidon gadget's variables, the Merkle muxes and the root checks - four fifths of a transition - are not evaluated on the host;
+/// `groth16_prove_witness` completes them on the GPU before proving.  Deposit / withdraw works come back complete.
+pub fn synthesize_work_deferred(work: &MpnWork, prover: &Address) -> Result<Witness, GpuError> {
+    let bytes = bincode::serialize(work)?;
+    let prover_pub = bincode::serialize(prover)?;
+    let mut w = ptr::null_mut();
+    let mut consumed = 0u64;
+    check(ptr::null_mut(), unsafe { sys::bzk_mpn_work_decode(bytes.as_ptr(), bytes.len() as u64, 0, &mut w, &mut consumed) })?;
+    let mut r1cs = ptr::null_mut();
+    let st = unsafe { sys::bzk_mpn_work_synthesize(w, prover_pub.as_ptr(), ptr::null(), 0, sys::BZK_SYNTH_DEFER as i32, &mut r1cs) };
+    unsafe { sys::bzk_mpn_work_free(w) };
+    check(ptr::null_mut(), st)?;
+    Ok(Witness(r1cs))
+}
+
+/// `groth16_prove` over the generator's own instance handle: a deferred instance is completed on the device first.  `BZK_E_UNSAT` (a
+/// deferred constraint does not hold) arrives as `GpuError::Status`, never as a panic.
+pub fn groth16_prove_witness(params: &ProvingParams, witness: &Witness, r: ZkScalar, s: ZkScalar) -> Result<Groth16Proof, GpuError> {
+    let mut buf = [0u8; 387];
+    check(params.gpu.0, unsafe {
+        sys::bzk_groth16_prove_r1cs(params.gpu.0, params.params, witness.0, &r as *const _ as *const u8, &s as *const _ as *const u8, buf.as_mut_ptr())
+    })?;
+    Ok(bincode::deserialize(&buf)?)
+}
+
 /// `GET /bincode/mpn/work` -> this -> `POST /bincode/mpn/solution` (src/client/messages.rs:368-388): the `ZkProof` that
 /// `work.verify(prover, &proof)` accepts
 pub fn prove_work(params: &ProvingParams, work: &MpnWork, prover: &Address, r: ZkScalar, s: ZkScalar) -> Result<ZkProof, GpuError> {
