@@ -935,10 +935,53 @@ static std::vector<Fr> chain_states(const ZkScalar& state, const std::vector<Tr>
     return st;
 }
 
+// the last op of every transition's deferred-value program: the state it computes against the state the witness builder predicted for it
+static void defer_chain_check(ConstraintSystem& part, Defer& D, const Num& state_out, const Fr& predicted) {
+    wf::Op f{};
+    f.kind = wf::F_CHECK_EQ; f.out = -1;
+    f.aux_off = (uint32_t)part.win_n_aux; f.con_off = (uint32_t)part.win_n_con;
+    f.in[0] = state_out.ref >= 0 ? state_out.ref : D.in_val(state_out.val);
+    f.in[1] = D.in_val(predicted);
+    D.emit(f);
+}
+// dd (optional, witness-only mode): the hash-dependent values of every body are deferred (host_r1cs.h DeferProgram); prog_key names the circuit
+// shape (kind, L, T) whose program this is - recorded once, on body 0 run against a scratch window
 template <class Body>
 static Num run_tx_bodies(ConstraintSystem& cs, int nthreads, size_t n, std::pair<size_t, size_t> shape, const Num& state0,
-                         const std::vector<Fr>& state_in, Body body) {
-    if (!lc_tracking() && nthreads > 1 && n > 1 && shape.first && shape.second) {
+                         const std::vector<Fr>& state_in, Body body, DeferData* dd = nullptr, uint64_t prog_key = 0) {
+    if (lc_tracking()) dd = nullptr;
+    if (!lc_tracking() && ((nthreads > 1 && n > 1) || (dd && n >= 1)) && shape.first && shape.second) {
+        const DeferProgram* prog = nullptr;
+        if (dd) {
+            static std::mutex mu;
+            static std::map<uint64_t, std::unique_ptr<DeferProgram>> progs;
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = progs.find(prog_key);
+            if (it == progs.end()) {
+                std::unique_ptr<DeferProgram> P(new DeferProgram());
+                std::vector<Fr> sa(shape.first), sx(shape.second), sy(shape.second), sz(shape.second), sin(1 << 14);
+                ConstraintSystem plan(false);
+                plan.set_window(sa.data(), shape.first, sx.data(), sy.data(), sz.data(), shape.second);
+                Defer D{P.get(), true, sin.data(), (uint32_t)sin.size()};
+                plan.defer = &D;
+                LcModeGuard g(false);
+                const Num st_in = {VAR_ONE, state_in[0]};
+                const Num st_out = body(plan, 0, st_in);
+                defer_chain_check(plan, D, st_out, state_in[1]);
+                if (D.overflow || plan.win_overflow || plan.win_n_aux != shape.first || plan.win_n_con != shape.second)
+                    throw std::logic_error("deferred synthesis changed the shape of a transition");
+                P->n_regs = (uint32_t)D.n_regs;
+                P->n_inputs = D.n_in;
+                P->n_aux = shape.first;
+                P->n_con = shape.second;
+                P->finalize();
+                it = progs.emplace(prog_key, std::move(P)).first;
+            }
+            prog = it->second.get();
+            dd->prog = prog;
+            dd->n_tx = n;
+            dd->inputs.resize(n * (size_t)prog->n_inputs);
+        }
         const size_t base_aux = cs.aux.size(), base_con = cs.az.size();
         cs.aux.resize(base_aux + n * shape.first);
         cs.az.resize(base_con + n * shape.second);
@@ -955,9 +998,13 @@ static Num run_tx_bodies(ConstraintSystem& cs, int nthreads, size_t n, std::pair
                 part.set_window(cs.aux.data() + base_aux + t * shape.first, shape.first, cs.az.data() + base_con + t * shape.second,
                                 cs.bz.data() + base_con + t * shape.second, cs.cz.data() + base_con + t * shape.second, shape.second);
                 const Num st_in = {VAR_ONE, state_in[t]};
+                Defer D{nullptr, false, dd ? dd->inputs.data() + t * (size_t)prog->n_inputs : nullptr, dd ? prog->n_inputs : 0u};
+                if (dd) part.defer = &D;
                 const Num st_out = body(part, t, st_in);
+                if (dd) defer_chain_check(part, D, st_out, state_in[t + 1]);
+                // (deferred: the computed state only exists on the device, which raises wf::FLAG_CHAIN where it differs from the prediction)
                 ok[t] = !part.win_overflow && part.win_n_aux == shape.first && part.win_n_con == shape.second &&
-                        st_out.val.equals(state_in[t + 1]);
+                        (dd ? (!D.overflow && D.n_in == prog->n_inputs && (uint32_t)D.n_regs == prog->n_regs) : st_out.val.equals(state_in[t + 1]));
             }
         };
         std::vector<std::thread> th;
@@ -968,7 +1015,19 @@ static Num run_tx_bodies(ConstraintSystem& cs, int nthreads, size_t n, std::pair
         bool all_ok = true;
         for (size_t t = 0; t < n; ++t) all_ok = all_ok && ok[t];
         if (getenv("BZK_DEBUG")) fprintf(stderr, "[bzk] run_tx_bodies: %zu bodies on %d threads, shape (%zu, %zu): %s\n", n, nt, shape.first, shape.second, all_ok ? "ok" : "MISMATCH -> sequential");
-        if (all_ok) return {VAR_ONE, state_in[n]};
+        if (all_ok) {
+            if (dd) {
+                dd->base_aux = base_aux;
+                dd->base_con = base_con;
+                dd->stride_aux = shape.first;
+                dd->stride_con = shape.second;
+            }
+            return {VAR_ONE, state_in[n]};
+        }
+        if (dd) {  // nothing is deferred after all: the sequential walk below computes every value
+            dd->prog = nullptr;
+            dd->n_tx = 0;
+        }
         cs.aux.resize(base_aux);
         cs.az.resize(base_con);
         cs.bz.resize(base_con);
@@ -1125,7 +1184,7 @@ static ZkScalar deposit_aux(const std::vector<DepositTransition>& trs, int log4_
 
 static void synthesize_deposit(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
                                const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<DepositTransition>& trs,
-                               int nthreads = 1) {
+                               int nthreads = 1, DeferData* dd = nullptr) {
     Num commitment_wit = num_alloc(cs, commitment.v);
     num_inputize(cs, commitment_wit);
     Num height_wit = num_alloc(cs, fr_from_u64(height));
@@ -1190,7 +1249,7 @@ static void synthesize_deposit(ConstraintSystem& cs, int L, int T, const ZkScala
                                   body(pcs, 0, st0);
                                   return std::make_pair(pcs.aux.size() - a0, pcs.az.size() - c0);
                               }),
-                              state_wit, chain_states(state, trs), body);
+                              state_wit, chain_states(state, trs), body, dd, ((uint64_t)0 << 32) | ((uint64_t)L << 16) | (uint64_t)T);
     cs.enforce(LC::of(state_wit.var), state_wit.val, LC::one(), Fr::one(), LC::of(claimed_next.var), claimed_next.val);
     cs.finalize();
 }
@@ -1329,7 +1388,7 @@ static ZkScalar withdraw_aux(const std::vector<WithdrawTransition>& trs, int log
 
 static void synthesize_withdraw(ConstraintSystem& cs, int L, int T, const ZkScalar& commitment, uint64_t height, const ZkScalar& state,
                                 const ZkScalar& aux_data, const ZkScalar& next_state, const std::vector<WithdrawTransition>& trs,
-                                int nthreads = 1) {
+                                int nthreads = 1, DeferData* dd = nullptr) {
     Num commitment_wit = num_alloc(cs, commitment.v);
     num_inputize(cs, commitment_wit);
     Num height_wit = num_alloc(cs, fr_from_u64(height));
@@ -1370,7 +1429,7 @@ static void synthesize_withdraw(ConstraintSystem& cs, int L, int T, const ZkScal
         UInt tx_token_index = UInt::alloc(cs, fr_from_u64(tr.token_index), 2 * T);
         UInt tx_fee_token_index = UInt::alloc(cs, fr_from_u64(tr.fee_token_index), 2 * T);
         tw.pub_key.assert_on_curve(cs, tw.enabled);
-        Number tx_hash = g_poseidon(cs, {Number::from(tw.fingerprint), Number::from(tw.nonce)});
+        Number tx_hash = g_poseidon(cs, {Number::from(tw.fingerprint), Number::from(tw.nonce)}, true);  // its value feeds the signature gadget
         tw.sig_r.assert_on_curve(cs, tw.enabled);
         g_verify_eddsa(cs, tw.enabled, tw.pub_key, tx_hash, tw.sig_r, tw.sig_s);
         Num src_tx_nonce = num_alloc(cs, fr_from_u64(tr.before.tx_nonce));
@@ -1411,7 +1470,7 @@ static void synthesize_withdraw(ConstraintSystem& cs, int L, int T, const ZkScal
                                   body(pcs, 0, st0);
                                   return std::make_pair(pcs.aux.size() - a0, pcs.az.size() - c0);
                               }),
-                              state_wit, chain_states(state, trs), body);
+                              state_wit, chain_states(state, trs), body, dd, ((uint64_t)1 << 32) | ((uint64_t)L << 16) | (uint64_t)T);
     cs.enforce(LC::of(state_wit.var), state_wit.val, LC::one(), Fr::one(), LC::of(claimed_next.var), claimed_next.val);
     cs.finalize();
 }
@@ -1680,7 +1739,9 @@ int32_t bzk_mpn_deposit_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8_
         std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
         LcModeGuard guard(record_matrices != 0);
         r->cs.self_check = record_matrices != 0;
-        synthesize_deposit(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs, w->threads);
+        if (w->defer && !record_matrices) r->defer.reset(new DeferData());
+        synthesize_deposit(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs, w->threads, r->defer.get());
+        if (r->defer && !r->defer->prog) r->defer.reset();
         if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
         r->accepted = accepted;
         r->rejected = rejected;
@@ -1710,7 +1771,9 @@ int32_t bzk_mpn_withdraw_synthesize(bzk_mpn* w, uint32_t log4_batch, const uint8
         std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(record_matrices != 0));
         LcModeGuard guard(record_matrices != 0);
         r->cs.self_check = record_matrices != 0;
-        synthesize_withdraw(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs, w->threads);
+        if (w->defer && !record_matrices) r->defer.reset(new DeferData());
+        synthesize_withdraw(r->cs, w->L, w->T, ZkScalar::from_bytes(commitment), w->height, state, aux, w->accounts->root(), trs, w->threads, r->defer.get());
+        if (r->defer && !r->defer->prog) r->defer.reset();
         if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
         r->accepted = accepted;
         r->rejected = rejected;
@@ -2099,11 +2162,15 @@ int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* h, const uint8_t prover_pub[
         } else if (w.kind == 0) {
             std::vector<DepositTransition> trs = w.deposits;
             while (trs.size() < cap) trs.push_back(DepositTransition::null(L, T));
-            synthesize_deposit(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, trs, nt);
+            if (defer) r->defer.reset(new DeferData());
+            synthesize_deposit(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, trs, nt, r->defer.get());
+            if (r->defer && !r->defer->prog) r->defer.reset();
         } else {
             std::vector<WithdrawTransition> trs = w.withdraws;
             while (trs.size() < cap) trs.push_back(WithdrawTransition::null(L, T));
-            synthesize_withdraw(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, trs, nt);
+            if (defer) r->defer.reset(new DeferData());
+            synthesize_withdraw(r->cs, L, T, commitment, w.height, w.state, w.aux_data, w.next_state, trs, nt, r->defer.get());
+            if (r->defer && !r->defer->prog) r->defer.reset();
         }
         if (r->cs.check_failed_at >= 0) return BZK_E_INTERNAL;
         r->accepted = w.n_transitions();

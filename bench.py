@@ -847,9 +847,9 @@ def production_block_section(ctx, with_1024tx: bool = False):
         sec.update(make_work_s=round(min(tm), 4), wire_bytes=len(blob), decode_and_witness_s=round(min(tw), 4), prove_s=round(min(tp), 4),
                    prove_s_all=[round(x, 4) for x in tp], verified=bool(ok), verify_ms_host=round(min(tv) * 1e3, 2),
                    tx_per_s_prove_only=round(n_slots / min(tp), 1))
-        if kind == 2:
-            # the same work with the hash-dependent witness values left to the device: at 256 transitions the deferred-value program has 256
-            # workgroups to run, and the host generator is what a production block waits for longest after the proof itself
+        if True:
+            # the same work with the hash-dependent witness values left to the device: at 64 / 256 transitions the deferred-value program has that
+            # many workgroups to run, and the host generator is what a production block waits for longest after the proof itself
             twd, tpd, okd = [], [], True
             for k in range(2):
                 t1 = time.perf_counter()

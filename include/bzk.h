@@ -388,7 +388,7 @@ int32_t bzk_r1cs_info(const bzk_r1cs* r, uint64_t info[9]);
  * variable index, 12-14 row_ptr(A/B/C) u32 */
 const void* bzk_r1cs_data(const bzk_r1cs* r, int32_t which, uint64_t* bytes);
 void bzk_r1cs_free(bzk_r1cs* r);
-/* Witness value traces on the device.  With bzk_mpn_set_defer(w, 1) a witness-only bzk_mpn_update_synthesize does NOT
+/* Witness value traces on the device.  With bzk_mpn_set_defer(w, 1) a witness-only bzk_mpn_{update,deposit,withdraw}_synthesize does NOT
  * evaluate what hangs off Poseidon outputs - the Poseidon gadget's S-box / idle-lane variables (src/zk/groth16/gadgets/poseidon/mod.rs:8-95: two
  * thirds of a transition's constraints), the Merkle gadget's muxes (gadgets/merkle/mod.rs:21-78, common/mux.rs:7-47), the equality checks against
  * computed roots (common/number.rs:121-177) - but records a small program per circuit shape and, per transition, the values the host does know;
@@ -444,8 +444,8 @@ int32_t bzk_mpn_work_commitment(const bzk_mpn_work* work, const uint8_t prover_p
 /* `MpnWork::verify(prover, proof)` (src/mpn/mod.rs:281-295) on the host: 1 accepted / 0 refused / negative bad arguments */
 int32_t bzk_mpn_work_verify(const bzk_mpn_work* work, const uint8_t prover_pub[32], const uint8_t proof[387]);
 /* the circuit instance to prove: transitions padded with null ones to 4^batch; fee_token NULL = Ziesha; threads 0 = all;
- * record_matrices: 0 witness only, 1 with the CSR matrices (setup), BZK_SYNTH_DEFER witness only with the hash-dependent values of an
- * Update work left to the device (see bzk_mpn_set_defer; deposit / withdraw works are synthesized in full) */
+ * record_matrices: 0 witness only, 1 with the CSR matrices (setup), BZK_SYNTH_DEFER witness only with the hash-dependent values of the
+ * work's transitions left to the device (see bzk_mpn_set_defer; all three kinds) */
 #define BZK_SYNTH_DEFER 2
 int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* work, const uint8_t prover_pub[32], const uint8_t fee_token[32],
                                 int32_t threads, int32_t record_matrices, bzk_r1cs** out);

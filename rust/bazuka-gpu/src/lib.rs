@@ -337,9 +337,9 @@ pub fn groth16_prove(params: &ProvingParams, witness: &Witness, r: ZkScalar, s: 
     Ok(bincode::deserialize(&buf)?) // private fields: through bincode, never a pointer cast
 }
 
-/// `synthesize_work` with the hash-dependent witness values of an Update work LEFT TO THE DEVICE (include/bzk.h: BZK_SYNTH_DEFER): the
+/// `synthesize_work` with the hash-dependent witness values of the work's transitions LEFT TO THE DEVICE (include/bzk.h: BZK_SYNTH_DEFER): the
 /// Poseidon gadget's variables, the Merkle muxes and the root checks - four fifths of a transition - are not evaluated on the host;
-/// `groth16_prove_witness` completes them on the GPU before proving.  Deposit / withdraw works come back complete.
+/// `groth16_prove_witness` completes them on the GPU before proving.  All three kinds of work (update, deposit, withdraw).
 pub fn synthesize_work_deferred(work: &MpnWork, prover: &Address) -> Result<Witness, GpuError> {
     let bytes = bincode::serialize(work)?;
     let prover_pub = bincode::serialize(prover)?;

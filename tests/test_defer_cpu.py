@@ -18,7 +18,8 @@ FIX = json.load(open(os.path.join(S.G, "r1cs_sha256.json")))
 ARRAYS = ("z", "az", "bz", "cz", "a_density", "b_density")
 
 
-@pytest.mark.parametrize("name,threads", [("update_3_3_1", 1), ("update_15_3_1", 3), ("update_15_3_2", 0)])
+@pytest.mark.parametrize("name,threads", [("update_3_3_1", 1), ("update_15_3_1", 3), ("update_15_3_2", 0), ("deposit_3_3_1", 1), ("withdraw_3_3_1", 2),
+                                          ("deposit_15_3_3", 0), ("withdraw_15_3_3", 0)])
 def test_deferred_instance_plus_host_fill_equals_the_independent_restatement(name, threads):
     dec = L.MpnWork.decode(S.make_work(name))
     r = dec.synthesize(S.PROVER, threads=threads, defer=True)
@@ -27,7 +28,8 @@ def test_deferred_instance_plus_host_fill_equals_the_independent_restatement(nam
     assert d["deferred"] == 1 and d["n_tx"] == 4 ** b4 and d["filled"] == 0
     assert (r.n_in, r.n_aux, r.n_constraints) == (FIX[name]["n_in"], FIX[name]["n_aux"], FIX[name]["n_constraints"])
     # most of a transition is the device's: 3 * (l4 + t4) + ... Merkle levels of ~540 Poseidon constraints each
-    assert d["hole_con"] * d["n_tx"] > (0.7 if l4 >= 15 else 0.5) * r.n_constraints, d
+    # (deposit / withdraw circuits also hash every transaction into the batch root OUTSIDE the per-transition bodies: a smaller share there)
+    assert d["hole_con"] * d["n_tx"] > (0.7 if l4 >= 15 and kind == "update" else 0.2) * r.n_constraints, d
     # the rows the host wrote hold; the others are not the host's to judge yet
     assert r.satisfied
     holes = sum(hashlib.sha256(r.view(k)).hexdigest() != FIX[name]["sha256"][k] for k in ("z", "az", "bz", "cz"))

@@ -20,7 +20,7 @@ def _setup(bzk, dec):
     return r, ph, vkb
 
 
-@pytest.mark.parametrize("name", ["update_3_3_1", "update_15_3_2"])
+@pytest.mark.parametrize("name", ["update_3_3_1", "update_15_3_2", "deposit_3_3_1", "withdraw_3_3_1", "deposit_15_3_3"])
 def test_device_fill_gives_the_same_proof_bytes(bzk, name):
     dec = L.MpnWork.decode(S.make_work(name))
     r, ph, vkb = _setup(bzk, dec)
