@@ -26,7 +26,7 @@ def extract_device_objects(tmp):
 
 
 def short_name(demangled):
-    return re.sub(r"\(.*", "", demangled).replace("bzk::", "").replace("void ", "")
+    return re.sub(r"\(.*", "", demangled.replace("(anonymous namespace)::", "")).replace("bzk::", "").replace("void ", "")
 
 
 def resources():
