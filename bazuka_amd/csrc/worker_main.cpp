@@ -327,6 +327,7 @@ struct Options {
     double poll = 1.0, timeout_s = 30.0;
     long rounds = -1;
     bool self_check = false, dry_run = false;
+    bool defer = false;  // --defer: BZK_SYNTH_DEFER + bzk_groth16_prove_r1cs (the hash-dependent witness values on the device: less host CPU per work)
     uint32_t flags = 0;
 };
 
@@ -384,7 +385,7 @@ uint64_t run_once(const Options& o, std::vector<Slot>& slots, Stats& st) {
         for (auto& w : works) {
             const auto t0 = clk::now();
             bzk_r1cs* r = nullptr;
-            const int32_t s = bzk_mpn_work_synthesize(w.w.get(), o.address, nullptr, o.threads, 0, &r);
+            const int32_t s = bzk_mpn_work_synthesize(w.w.get(), o.address, nullptr, o.threads, o.defer ? BZK_SYNTH_DEFER : 0, &r);
             if (s != BZK_OK) {
                 failed("synthesis", w.id, bzk_strerror(s));
                 continue;
@@ -438,7 +439,10 @@ uint64_t run_once(const Options& o, std::vector<Slot>& slots, Stats& st) {
                 random_scalar(r);
                 random_scalar(sb);
                 Bytes proof(387);
-                ck(bzk_groth16_prove(s.ctx, ph, &a, r, sb, proof.data()), "bzk_groth16_prove", s.ctx);
+                if (o.defer)  // completes a deferred instance on the device first; a complete one goes through unchanged
+                    ck(bzk_groth16_prove_r1cs(s.ctx, ph, it.r1cs.get(), r, sb, proof.data()), "bzk_groth16_prove_r1cs", s.ctx);
+                else
+                    ck(bzk_groth16_prove(s.ctx, ph, &a, r, sb, proof.data()), "bzk_groth16_prove", s.ctx);
                 const bool ok = !o.self_check || bzk_mpn_work_verify(it.work->w.get(), o.address, proof.data()) == 1;
                 std::lock_guard<std::mutex> g(st.m);
                 st.synth_s += it.synth_s;
@@ -503,7 +507,7 @@ int usage(const char* why) {
     fprintf(stderr,
             "%s\nusage: bzk-worker --node HOST:PORT --address <64 hex> (--dev-toxic SEED | --params DEPOSIT WITHDRAW UPDATE)\n"
             "                  [--devices 0,1,..] [--slots-per-device N] [--threads N] [--poll S] [--rounds N] [--timeout S]\n"
-            "                  [--self-check] [--sig-len-prefixed] [--dry-run]\n",
+            "                  [--self-check] [--defer] [--sig-len-prefixed] [--dry-run]\n",
             why);
     return 2;
 }
@@ -547,6 +551,8 @@ int main(int argc, char** argv) {
             o.rounds = atol(next());
         } else if (a == "--timeout") {
             o.timeout_s = atof(next());
+        } else if (a == "--defer") {
+            o.defer = true;
         } else if (a == "--self-check") {
             o.self_check = true;
         } else if (a == "--sig-len-prefixed") {

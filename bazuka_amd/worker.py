@@ -234,7 +234,7 @@ class SlotKeys:
 # ---- the loop ----------------------------------------------------------------------------------------------------------
 class Worker:
     def __init__(self, bzk: L.Bzk, address: bytes, node: tuple[str, int], params_for, flags: int = 0, threads: int = 0,
-                 rng=os.urandom, timeout_s: float = 30.0, self_check: bool = False, extra_slots=()):
+                 rng=os.urandom, timeout_s: float = 30.0, self_check: bool = False, extra_slots=(), defer: bool = False):
         """self_check: verify every proof on the host with the work's own verifying key before posting it (bzk_groth16_verify =
         the check the node will run, src/mpn/mod.rs:281-295; ~20 ms of one core per proof) - a proof that fails is not posted.
         extra_slots: further (Bzk, params_for) prover slots - more slots on the same GPU (params_for = SlotKeys: shared CRS) and / or
@@ -244,6 +244,9 @@ class Worker:
         self.bzk, self.address, self.node, self.params_for = bzk, address, node, params_for
         self.slots = [(bzk, params_for)] + list(extra_slots)
         self.flags, self.threads, self.rng, self.timeout_s, self.self_check = flags, threads, rng, timeout_s, self_check
+        # defer: the host generator leaves the hash-dependent witness values to the device (BZK_SYNTH_DEFER + bzk_groth16_prove_r1cs: DESIGN.md 3.5) -
+        # fewer host CPU seconds per work, ~15 ms more GPU latency per proof; same proof statement, same acceptance test
+        self.defer = defer
         self.stats = {"fetched": 0, "proved": 0, "accepted": 0, "unsat": 0, "self_check_failed": 0, "synth_s": 0.0, "prove_s": 0.0,
                       "proved_by_slot": [0] * len(self.slots)}
         import threading
@@ -274,8 +277,13 @@ class Worker:
         """387 proof bytes for the work, or None when the work's witness does not satisfy its circuit (a proof of it
         could only be rejected by the node).  slot: which prover slot runs it."""
         t0 = time.perf_counter()
-        r1cs = work.synthesize(self.address, threads=self.threads)
+        r1cs = self._synthesize(work)
         return self._prove_synthesized(work, r1cs, time.perf_counter() - t0, slot)
+
+    def _synthesize(self, work: L.MpnWork):
+        if self.defer:
+            return work.synthesize(self.address, threads=self.threads, defer=True)
+        return work.synthesize(self.address, threads=self.threads)
 
     def _prove_synthesized(self, work: L.MpnWork, r1cs, synth_s: float, slot: int = 0) -> bytes | None:
         """the GPU half of `prove`: the witness arrays are already there (run_once synthesizes the next work on a host thread while the
@@ -289,7 +297,10 @@ class Worker:
             return None
         ph = params_for(work)
         r, s = L.host_scalar_new(self.rng(64)), L.host_scalar_new(self.rng(64))  # bellman: `E::Fr::random(rng)` twice
-        proof = bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
+        if self.defer:
+            proof = bzk.groth16_prove_r1cs(ph, r1cs, r, s)   # the deferred instance is completed on the device first
+        else:
+            proof = bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
         ok = (not self.self_check) or work.verify(self.address, proof)   # MpnWork::verify: the node's own acceptance test
         with self._lock:
             self.stats["synth_s"] += synth_s
@@ -342,7 +353,7 @@ class Worker:
             for wid, work in works.items():
                 t0 = time.perf_counter()
                 try:
-                    r1cs = work.synthesize(self.address, threads=self.threads)
+                    r1cs = self._synthesize(work)
                 except Exception as e:  # noqa: BLE001 - counted and reported; the other works go on
                     failed("synthesis", wid, e)
                     continue
@@ -438,6 +449,7 @@ def main(argv=None):
     ap.add_argument("--poll", type=float, default=1.0)
     ap.add_argument("--rounds", type=int, default=None)
     ap.add_argument("--self-check", action="store_true", help="verify every proof on the host (pairing check) before posting it")
+    ap.add_argument("--defer", action="store_true", help="leave the hash-dependent witness values to the GPU (less host CPU per work, ~15 ms more GPU latency per proof)")
     ap.add_argument("--sig-len-prefixed", action="store_true", help="node built against ed25519 < 1.3 (BZK_WORK_SIG_LEN_PREFIXED)")
     a = ap.parse_args(argv)
     host, port = a.node.rsplit(":", 1)
@@ -474,7 +486,7 @@ def main(argv=None):
             slots.append((bz, sk))
             closers = [sk, bz] + closers   # slots go before the keys they share
     w = Worker(slots[0][0], address, (host, int(port)), slots[0][1], flags=1 if a.sig_len_prefixed else 0, self_check=a.self_check,
-               extra_slots=slots[1:])
+               extra_slots=slots[1:], defer=a.defer)
     try:
         w.register()
         w.run_forever(a.poll, a.rounds)

@@ -262,3 +262,28 @@ def test_native_worker_over_several_devices(bzk):
         assert node.solved == {k: ALICE for k in blobs}
     finally:
         node.close()
+
+
+def test_workers_with_deferred_witness_values(bzk):
+    """--defer: both workers synthesize with BZK_SYNTH_DEFER and prove through bzk_groth16_prove_r1cs - all three kinds of work of a block,
+    every proof checked with the work's own key before posting and accepted by the mock node's ORACLE pairing check"""
+    seed = "native-dev"
+    keys = W.DevSetup(bzk, {k: W.dev_toxic(seed, k) for k in range(3)})
+    vks = [keys.keys(k, 3, 3, 1)[1] for k in range(3)]
+    blobs = _block_of_works(vks)
+    node = MockNode(blobs)
+    try:
+        alice = W.Worker(bzk, ALICE, ("127.0.0.1", node.port), keys, self_check=True, defer=True)
+        assert alice.run_once() == len(blobs)
+        assert alice.stats["unsat"] == 0 and alice.stats["self_check_failed"] == 0 and node.solved == {k: ALICE for k in blobs}
+    finally:
+        node.close()
+    node = MockNode(blobs)
+    try:
+        st, err = _native(["--node", f"127.0.0.1:{node.port}", "--address", ALICE.hex(), "--dev-toxic", seed, "--slots-per-device", "2", "--defer",
+                           "--self-check", "--rounds", "1", "--poll", "0.05"])
+        assert st["proved"] == len(blobs) and st["accepted"] == len(blobs) and st["self_check_failed"] == 0 and st["errors"] == 0, (st, err)
+        assert node.solved == {k: ALICE for k in blobs}
+    finally:
+        node.close()
+        keys.close()
