@@ -265,19 +265,31 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, 
                 int32_t* s = &sel[(size_t)o.out * 4];
                 s[0] = o.in[0]; s[1] = o.in[1]; s[2] = o.in[2]; s[3] = o.t;
             }
-        BZK_HIP(ctx, hipMalloc((void**)&dp.v, std::max<size_t>(1, P.v_ops.size()) * sizeof(wf::Op)));
-        BZK_HIP(ctx, hipMalloc((void**)&dp.f, std::max<size_t>(1, P.f_ops.size()) * sizeof(wf::Op)));
-        BZK_HIP(ctx, hipMalloc((void**)&dp.sel, sel.size() * sizeof(int32_t)));
-        BZK_HIP(ctx, hipMemcpyAsync(dp.v, P.v_ops.data(), P.v_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipMemcpyAsync(dp.f, P.f_ops.data(), P.f_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipMemcpyAsync(dp.sel, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         const Schedule sch = make_schedule(P);
         dp.n_stages = sch.n_stages;
-        BZK_HIP(ctx, hipMalloc((void**)&dp.segs, std::max<size_t>(1, sch.segs.size()) * sizeof(Seg)));
-        BZK_HIP(ctx, hipMalloc((void**)&dp.idx, sch.idx.size() * sizeof(uint32_t)));
-        BZK_HIP(ctx, hipMemcpyAsync(dp.segs, sch.segs.data(), sch.segs.size() * sizeof(Seg), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipMemcpyAsync(dp.idx, sch.idx.data(), sch.idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `sel` and `sch` are locals
+        auto upload = [&]() -> int32_t {
+            BZK_HIP(ctx, hipMalloc((void**)&dp.v, std::max<size_t>(1, P.v_ops.size()) * sizeof(wf::Op)));
+            BZK_HIP(ctx, hipMalloc((void**)&dp.f, std::max<size_t>(1, P.f_ops.size()) * sizeof(wf::Op)));
+            BZK_HIP(ctx, hipMalloc((void**)&dp.sel, sel.size() * sizeof(int32_t)));
+            BZK_HIP(ctx, hipMalloc((void**)&dp.segs, std::max<size_t>(1, sch.segs.size()) * sizeof(Seg)));
+            BZK_HIP(ctx, hipMalloc((void**)&dp.idx, sch.idx.size() * sizeof(uint32_t)));
+            BZK_HIP(ctx, hipMemcpyAsync(dp.v, P.v_ops.data(), P.v_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipMemcpyAsync(dp.f, P.f_ops.data(), P.f_ops.size() * sizeof(wf::Op), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipMemcpyAsync(dp.sel, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipMemcpyAsync(dp.segs, sch.segs.data(), sch.segs.size() * sizeof(Seg), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipMemcpyAsync(dp.idx, sch.idx.data(), sch.idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            return BZK_OK;
+        };
+        const int32_t up = upload();
+        // `sel` and `sch` are locals: no copy out of them may be in flight when this frame goes, whether the upload succeeded or not
+        const hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (up != BZK_OK || se != hipSuccess) {
+            (void)hipGetLastError();
+            for (void* q : {(void*)dp.v, (void*)dp.f, (void*)dp.sel, (void*)dp.segs, (void*)dp.idx})
+                if (q) (void)hipFree(q);
+            if (up == BZK_OK) ctx->last_error = std::string("witfill: program upload: ") + hipGetErrorString(se);
+            return up != BZK_OK ? up : BZK_E_DEVICE;
+        }
         it = S->progs.emplace(&P, dp).first;
     }
     const size_t n_tx = dd.n_tx;
