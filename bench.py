@@ -848,15 +848,23 @@ def production_block_section(ctx, with_1024tx: bool = False):
         sec["gpu_crs_setup_s"] = round(time.perf_counter() - t0, 2)
         del csr
         r.free()
-        tm, tw, tp, tv, ok = [], [], [], [], True
+        import resource as _rs
+
+        def _cpu():
+            ru = _rs.getrusage(_rs.RUSAGE_SELF)
+            return ru.ru_utime + ru.ru_stime
+
+        tm, tw, tp, tv, ok, twc = [], [], [], [], True, []
         for k in range(3):
             push()
             t0 = time.perf_counter()
             blob = w.make_work(kind, vks, 1, log4_batches=tuple(lb)).encode()
             t1 = time.perf_counter()
+            c1 = _cpu()
             dec = L.MpnWork.decode(blob)
             rk = dec.synthesize(prover)
             t2 = time.perf_counter()
+            twc.append(_cpu() - c1)
             assert rk.satisfied and rk.accepted == n_slots
             z = rk.raw("z")
             proof = ctx.groth16_prove(ph, z, rk.raw("az"), rk.raw("bz"), rk.raw("cz"), _fr_blind(5000 + 2 * k), _fr_blind(5001 + 2 * k))
@@ -865,23 +873,28 @@ def production_block_section(ctx, with_1024tx: bool = False):
             t4 = time.perf_counter()
             tm.append(t1 - t0); tw.append(t2 - t1); tp.append(t3 - t2); tv.append((t4 - t3) / 2)   # two verifications (accept, refuse)
             rk.free()
-        sec.update(make_work_s=round(min(tm), 4), wire_bytes=len(blob), decode_and_witness_s=round(min(tw), 4), prove_s=round(min(tp), 4),
+        # decode_and_witness_cpu_s: user + system seconds of the process around decode + synthesize (all generator threads) - the WORKER side's host cost per work
+        sec.update(make_work_s=round(min(tm), 4), wire_bytes=len(blob), decode_and_witness_s=round(min(tw), 4), decode_and_witness_cpu_s=round(min(twc), 4),
+                   prove_s=round(min(tp), 4),
                    prove_s_all=[round(x, 4) for x in tp], verified=bool(ok), verify_ms_host=round(min(tv) * 1e3, 2),
                    tx_per_s_prove_only=round(n_slots / min(tp), 1))
         if True:
             # the same work with the hash-dependent witness values left to the device: at 64 / 256 transitions the deferred-value program has that
             # many workgroups to run, and the host generator is what a production block waits for longest after the proof itself
-            twd, tpd, okd = [], [], True
+            twd, tpd, okd, twdc = [], [], True, []
             for k in range(2):
                 t1 = time.perf_counter()
+                c1 = _cpu()
                 rd = L.MpnWork.decode(blob).synthesize(prover, defer=True)
                 t2 = time.perf_counter()
+                twdc.append(_cpu() - c1)
                 pd = ctx.groth16_prove_r1cs(ph, rd, _fr_blind(6000 + 2 * k), _fr_blind(6001 + 2 * k))
                 t3 = time.perf_counter()
                 okd = okd and rd.defer_info()["deferred"] == 1 and L.groth16_verify(vkb, bytes(rd.raw("z")[32:32 * 6]), pd)
                 twd.append(t2 - t1); tpd.append(t3 - t2)
                 rd.free()
-            sec["deferred"] = {"decode_and_witness_s": round(min(twd), 4), "prove_s": round(min(tpd), 4), "verified": bool(okd)}
+            sec["deferred"] = {"decode_and_witness_s": round(min(twd), 4), "decode_and_witness_cpu_s": round(min(twdc), 4), "prove_s": round(min(tpd), 4),
+                               "verified": bool(okd)}
         if b4 <= 4:
             total += min(tp)
         ctx.params_free(ph)
