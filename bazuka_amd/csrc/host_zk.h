@@ -65,6 +65,12 @@ struct ZkScalar {
     }
 };
 
+// Worker threads the host generator starts when the caller does not say: the CPUs this process may actually USE - the visible ones capped by the
+// container's CPU quota (cgroup v2 cpu.max / v1 cfs quota).  The GPU pool's boxes show 256 CPUs under a 16-CPU quota: one thread per visible CPU
+// there means 256 threads time-slicing 16 cores for a 256-transition witness (round 5, run 22: the deferred generator's bodies are short enough
+// for that overhead to show in the CPU seconds).  Read once.
+int host_default_threads();  // host_zk.hip
+
 // ---- Poseidon on the host (same parameters as the device kernel, src/zk/poseidon/mod.rs:24-84)
 struct PoseidonHostParams {
     int t, rf, rp;

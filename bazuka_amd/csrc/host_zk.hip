@@ -5,7 +5,11 @@
 #include "host_zk.h"
 
 #include <atomic>
+#include <cmath>
+#include <fstream>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bzk_poseidon_opt.h"
@@ -203,6 +207,30 @@ std::mutex g_mds_mu;
 hfr::MdsTable g_mds_tab[18];
 std::atomic<bool> g_mds_ready[18];
 }  // namespace
+
+int host_default_threads() {
+    static const int n = [] {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        double quota = 0;
+        {
+            std::ifstream f("/sys/fs/cgroup/cpu.max");
+            std::string q;
+            double per = 0;
+            if (f >> q >> per) {
+                if (q != "max" && per > 0) quota = atof(q.c_str()) / per;
+            } else {
+                std::ifstream a("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), b("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+                double qq = 0;
+                if ((a >> qq) && (b >> per) && qq > 0 && per > 0) quota = qq / per;
+            }
+        }
+        if (const char* e = getenv("BZK_HOST_THREADS"))  // explicit override (A/B; hosts whose quota is not visible in the cgroup files)
+            if (atoi(e) > 0) return atoi(e);
+        if (quota > 0) return (int)std::max(1.0, std::min((double)hw, std::ceil(quota)));
+        return (int)hw;
+    }();
+    return n;
+}
 
 // poseidon_host_params takes a lock on every call (poseidon.hip); the witness generator asks once per hash from several threads
 PoseidonHostParams poseidon_host_params_cached(int t) {

@@ -91,7 +91,7 @@ struct bzk_mpn {
     std::vector<WithdrawTx> withdraw_queue;
     uint64_t height = 0;
     ZkScalar contract_id = ZkScalar::from_u64(0x4D504E);  // ContractId::Custom of the MPN contract (payments of synthetic txs)
-    int threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    int threads = host_default_threads();  // the CPUs this process may use (visible ones capped by the cgroup quota); bzk_mpn_set_threads overrides
     bzk_ctx* dev = nullptr;  // bzk_mpn_set_device: the witness builders hash their Merkle updates in batches on this context
     bool defer = false;      // bzk_mpn_set_defer: witness-only Update instances leave the hash-dependent values to the device (host_r1cs.h DeferProgram)
     std::string dev_error;
@@ -1486,7 +1486,7 @@ static void finish_r1cs(bzk_r1cs* r) {
         uint8_t* dst = r->z_bytes.data() + 32 * n_in;
         const uint8_t* src = (const uint8_t*)cs.aux.data();
         const size_t bytes = n_aux * 32;
-        const size_t nt = bytes < ((size_t)64 << 20) ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+        const size_t nt = bytes < ((size_t)64 << 20) ? 1 : std::min<size_t>(8, (size_t)host_default_threads());
         if (nt <= 1) {
             if (bytes) memcpy(dst, src, bytes);
         } else {
@@ -2146,7 +2146,7 @@ int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* h, const uint8_t prover_pub[
         const MpnWork& w = h->w;
         const int L = w.config.log4_tree, T = w.config.log4_token_tree, B = w.log4_batch();
         const size_t cap = (size_t)1 << (2 * B);
-        const int nt = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+        const int nt = threads > 0 ? threads : host_default_threads();
         const ZkScalar commitment = mpn_work_commitment(prover_pub, w.reward);
         const bool rec = record_matrices == 1, defer = record_matrices == BZK_SYNTH_DEFER;  // 0: witness only
         std::unique_ptr<bzk_r1cs> r(new bzk_r1cs(rec));

@@ -488,7 +488,7 @@ uint32_t witfill_run_host(const DeferData& dd, const wf::Arrays& A) {
             if (f) flags.fetch_or(f);
         }
     };
-    const size_t nt = std::min<size_t>(dd.n_tx, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    const size_t nt = std::min<size_t>(dd.n_tx, (size_t)std::min(8, host_default_threads()));
     std::vector<std::thread> th;
     for (size_t i = 1; i < nt; ++i) th.emplace_back(worker);
     worker();
