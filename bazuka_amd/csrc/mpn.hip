@@ -1557,6 +1557,7 @@ int32_t bzk_mpn_set_device(bzk_mpn* w, bzk_ctx* ctx) {
     return BZK_OK;
 }
 
+int32_t bzk_host_default_threads(void) { return host_default_threads(); }
 int32_t bzk_mpn_set_threads(bzk_mpn* w, int32_t n) {
     if (!w || n < 1) return BZK_E_ARG;
     w->threads = n;

@@ -87,6 +87,7 @@ SIGNATURES = {
     "bzk_mpn_destroy": (None, [_vp]),
     "bzk_mpn_set_height": (_i32, [_vp, _u64]),
     "bzk_mpn_set_threads": (_i32, [_vp, _i32]),
+    "bzk_host_default_threads": (_i32, []),
     "bzk_mpn_set_device": (_i32, [_vp, _vp]),
     "bzk_mpn_add_account": (_i32, [_vp, _u64, _vp, _u32, _vp, _u64, _vp]),
     "bzk_mpn_add_key": (_i32, [_vp, _u64, _vp, _u32]),
@@ -1056,6 +1057,11 @@ def bellman_params_encode(vk870: bytes, ic: bytes, h: bytes, l: bytes, a: bytes,
     buf = C.create_string_buffer(n.value)
     _st(lib.bzk_bellman_params_encode(*args, buf, n.value, None), "bellman_params_encode")
     return buf.raw
+
+
+def host_default_threads() -> int:
+    """the host generator's default thread count (visible CPUs capped by the cgroup CPU quota; BZK_HOST_THREADS overrides)"""
+    return int(load_library().bzk_host_default_threads())
 
 
 def groth16_verify(vk_bincode: bytes, inputs: bytes, proof387: bytes) -> bool:

@@ -341,7 +341,10 @@ typedef struct bzk_r1cs bzk_r1cs; /* a synthesized circuit instance: assignment 
 int32_t bzk_mpn_create(uint32_t log4_tree, uint32_t log4_token_tree, bzk_mpn** out);
 void bzk_mpn_destroy(bzk_mpn* w);
 int32_t bzk_mpn_set_height(bzk_mpn* w, uint64_t height);
-int32_t bzk_mpn_set_threads(bzk_mpn* w, int32_t n); /* worker threads of the witness generator (default: all cores) */
+int32_t bzk_mpn_set_threads(bzk_mpn* w, int32_t n); /* worker threads of the witness generator (default: bzk_host_default_threads) */
+/* the host generator's default thread count: the visible CPUs capped by the container's CPU quota (cgroup v2 cpu.max / v1 cfs quota);
+ * BZK_HOST_THREADS=n overrides.  Read once per process. */
+int32_t bzk_host_default_threads(void);
 /* SURVEY 8f-3 ("replacing the per-tx KV walk in prepare_works", src/mpn/mod.rs:353-414): with a context set, the builders below and
  * bzk_mpn_make_work decide a batch from account DATA first and then re-hash its Merkle paths LEVEL BY LEVEL on the device - one
  * batched Poseidon launch per tree level over all transactions of the batch (~L + T + 2 launches instead of ~50 sequential host

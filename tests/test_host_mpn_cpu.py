@@ -262,3 +262,25 @@ def test_host_state_root_equals_state_manager_restatement():
             pub = w.add_account(idx, b"acct%d" % i, F(7 + i), 500 + i)
             py.set_account(idx, [0, 0, U(pub[:32]), U(pub[32:])], {0: (7 + i, 500 + i)})
             assert w.root() == F(py.root())
+
+
+def test_default_generator_threads_follow_the_cpu_quota_and_the_override():
+    """bzk_host_default_threads: the visible CPUs capped by the container's CPU quota (what the pool's boxes need: 256 visible, 16 allowed); BZK_HOST_THREADS
+    overrides; read once per process, hence the child processes"""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); from bazuka_amd import lib as L; print(L.host_default_threads())" % ROOT
+    base = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()[-1])
+    assert 1 <= base <= (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    if quota:
+        assert base <= max(1, int(quota + 0.999))
+    env = dict(os.environ, BZK_HOST_THREADS="3")
+    assert int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout.split()[-1]) == 3
