@@ -210,6 +210,7 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, 
 uint32_t witfill_flags(bzk_ctx* ctx);                                                // ... and is read here once that stream has been synchronised
 uint32_t witfill_run_host(const DeferData& dd, const wf::Arrays& A);
 void witfill_quiesce(bzk_ctx* ctx);
+void witfill_schedule_info(const DeferProgram& P, uint64_t info[6]);  // the one-launch schedule of a program, checked on the host
 
 class ConstraintSystem {
    public:

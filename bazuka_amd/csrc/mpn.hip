@@ -1921,6 +1921,15 @@ int32_t bzk_r1cs_defer_info(const bzk_r1cs* r, uint64_t info[10]) {
     info[5] = dd.prog->n_levels; info[6] = dd.prog->hole_aux; info[7] = dd.prog->hole_con; info[8] = dd.filled ? 1 : 0; info[9] = dd.flags;
     return BZK_OK;
 }
+// the schedule the one-launch device kernel would run for this instance's program, checked on the host: info = {stages, segments, hash ops covered,
+// fill ops covered, largest segment, violations (must be 0)}
+int32_t bzk_r1cs_defer_schedule_info(const bzk_r1cs* r, uint64_t info[6]) {
+    if (!r || !info) return BZK_E_ARG;
+    for (int i = 0; i < 6; ++i) info[i] = 0;
+    if (!r->defer) return BZK_OK;
+    witfill_schedule_info(*r->defer->prog, info);
+    return BZK_OK;
+}
 // completes the host arrays with the same ops the device runs (CPU consumers of bzk_r1cs_data; the CPU suite)
 int32_t bzk_r1cs_fill_host(bzk_r1cs* r) {
     if (!r) return BZK_E_ARG;

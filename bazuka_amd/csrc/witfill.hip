@@ -391,6 +391,39 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, 
     return BZK_OK;
 }
 
+// What the one-launch kernel will be handed for `P` (host-side check, no device needed): info = {stages, segments, V_HASH ops covered, F ops covered,
+// largest segment, violations}.  A violation: an op covered twice or not at all, a segment of more than 64 ops or of mixed kind / width, a hash segment in a
+// stage other than its level's, an F segment before the last stage.
+void witfill_schedule_info(const DeferProgram& P, uint64_t info[6]) {
+    const Schedule S = make_schedule(P);
+    std::vector<uint8_t> seen_v(P.v_ops.size(), 0), seen_f(P.f_ops.size(), 0);
+    uint64_t bad = 0, largest = 0, nv = 0, nf = 0;
+    for (uint32_t st = 0; st < S.n_stages; ++st)
+        for (int w = 0; w < WF_WAVES; ++w)
+            for (uint32_t k = S.idx[st * WF_WAVES + w]; k < S.idx[st * WF_WAVES + w + 1]; ++k) {
+                const Seg& g = S.segs[k];
+                largest = std::max<uint64_t>(largest, g.count);
+                if (g.count == 0 || g.count > 64) ++bad;
+                const bool is_v = g.kind == wf::V_HASH;
+                const std::vector<wf::Op>& ops = is_v ? P.v_ops : P.f_ops;
+                std::vector<uint8_t>& seen = is_v ? seen_v : seen_f;
+                if ((size_t)g.start + g.count > ops.size()) { ++bad; continue; }
+                for (uint32_t i = 0; i < g.count; ++i) {
+                    const wf::Op& o = ops[g.start + i];
+                    if (o.kind != g.kind || (o.kind == wf::V_HASH || o.kind == wf::F_POSEIDON ? o.t != g.t : false)) ++bad;
+                    if (is_v && o.level != st + 1) ++bad;
+                    if (!is_v && st + 1 != S.n_stages) ++bad;
+                    if (seen[g.start + i]++) ++bad;
+                    (is_v ? nv : nf) += 1;
+                }
+            }
+    for (size_t i = 0; i < P.v_ops.size(); ++i)
+        if (P.v_ops[i].kind == wf::V_HASH && !seen_v[i]) ++bad;  // (selections are resolved where they are read: no segment of their own)
+    for (size_t i = 0; i < P.f_ops.size(); ++i)
+        if (!seen_f[i]) ++bad;
+    info[0] = S.n_stages; info[1] = S.segs.size(); info[2] = nv; info[3] = nf; info[4] = largest; info[5] = bad;
+}
+
 void witfill_free(bzk_ctx* ctx) {  // bzk_ctx_destroy
     CtxState* S = (CtxState*)ctx->wf_state;
     if (!S) return;

@@ -118,6 +118,7 @@ SIGNATURES = {
     "bzk_r1cs_info": (_i32, [_vp, C.POINTER(_u64)]),
     "bzk_r1cs_defer_info": (_i32, [_vp, C.POINTER(_u64)]),
     "bzk_r1cs_fill_host": (_i32, [_vp]),
+    "bzk_r1cs_defer_schedule_info": (_i32, [_vp, C.POINTER(_u64)]),
     "bzk_mpn_set_defer": (_i32, [_vp, _i32]),
     "bzk_r1cs_data": (_vp, [_vp, _i32, C.POINTER(_u64)]),
     "bzk_r1cs_free": (None, [_vp]),
@@ -840,6 +841,12 @@ class R1cs:
         info = (_u64 * 10)()
         _st(self.lib.bzk_r1cs_defer_info(self.h, info), "r1cs_defer_info")
         return dict(zip(self.DEFER_FIELDS, [int(x) for x in info]))
+
+    def defer_schedule_info(self) -> dict:
+        """the one-launch device schedule of this instance's deferred-value program, checked on the host (bzk_r1cs_defer_schedule_info)"""
+        info = (_u64 * 6)()
+        _st(self.lib.bzk_r1cs_defer_schedule_info(self.h, info), "r1cs_defer_schedule_info")
+        return dict(zip(("stages", "segments", "hash_ops", "fill_ops", "largest_segment", "violations"), [int(x) for x in info]))
 
     def fill_host(self) -> dict:
         """runs the instance's deferred-value program on the CPU (same ops as the device): the views are complete afterwards"""

@@ -405,6 +405,9 @@ void bzk_r1cs_free(bzk_r1cs* r);
 int32_t bzk_mpn_set_defer(bzk_mpn* w, int32_t on);
 int32_t bzk_r1cs_defer_info(const bzk_r1cs* r, uint64_t info[10]);
 int32_t bzk_r1cs_fill_host(bzk_r1cs* r);
+/* the schedule of the instance's program for the one-launch device kernel, checked on the host (no device needed): stages, segments, hash ops
+ * covered, fill ops covered, largest segment (<= 64), violations (0: every op exactly once, in a stage its operands are ready for) */
+int32_t bzk_r1cs_defer_schedule_info(const bzk_r1cs* r, uint64_t info[6]);
 /* bzk_groth16_prove over an instance of the host generator (z / A.z / B.z / C.z are the instance's own pinned arrays), completing deferred
  * witness values on the device first.  BZK_E_UNSAT: a deferred constraint does not hold or a transition's computed state differs from the
  * witness builder's prediction (synthesize again without deferral for the exact first unsatisfied row). */

@@ -36,6 +36,10 @@ def test_deferred_instance_plus_host_fill_equals_the_independent_restatement(nam
     assert holes == 4, "nothing was deferred?"
     for k in ("a_density", "b_density"):   # densities are a property of the circuit, not of the values (witness-only mode: empty maps)
         assert hashlib.sha256(r.view(k)).hexdigest() == hashlib.sha256(dec.synthesize(S.PROVER, threads=threads).view(k)).hexdigest()
+    # what the one-launch device kernel would be handed for this program: every hash op in the stage of its level, every fill op in the last stage, each once
+    sch = r.defer_schedule_info()
+    assert sch["violations"] == 0 and sch["stages"] == d["n_levels"] + 1 and 1 <= sch["largest_segment"] <= 64, sch
+    assert sch["hash_ops"] + sch["fill_ops"] <= d["n_ops"] and sch["fill_ops"] > 0 and sch["hash_ops"] > 0, (sch, d)
     d = r.fill_host()
     assert d["filled"] == 1 and d["flags"] == 0
     for k in ("z", "az", "bz", "cz"):
