@@ -21,6 +21,7 @@ namespace bzk {
 namespace wf {
 
 enum : uint8_t { V_HASH = 1, V_SEL = 2, F_POSEIDON = 3, F_MUX = 4, F_ASSERT_EQ_IF = 5, F_ENFORCE_EQ = 6, F_CHECK_EQ = 7 };
+constexpr int MAX_SEL_CHAIN = 8;  // links operand() follows on the device; DeferProgram::finalize measures a program's, witfill_run_dev refuses deeper ones
 enum : uint32_t { FLAG_UNSATISFIED = 1u, FLAG_CHAIN = 2u };  // a deferred constraint does not hold / a computed state differs from the builder's prediction
 
 // operand: >= 0 a register, < 0 ~index into the transition's input record
@@ -55,7 +56,7 @@ struct TxView {       // where transition `tx` lives
 
 BZK_HD Fr operand(const TxView& v, int32_t o) {
     if (v.sel) {
-        for (int it = 0; it < 8 && o >= 0; ++it) {
+        for (int it = 0; it < MAX_SEL_CHAIN && o >= 0; ++it) {
             const int32_t* s = v.sel + 4 * (size_t)o;
             if (s[3] < 0) break;
             const bool bit = !v.inputs[~s[0]].is_zero();

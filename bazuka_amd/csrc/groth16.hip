@@ -515,6 +515,25 @@ int32_t bzk_staged_wait(bzk_staged* st) {
     if (hipEventSynchronize(st->ready) != hipSuccess) return BZK_E_DEVICE;
     return *st->flags_host ? BZK_E_UNSAT : BZK_OK;
 }
+// read-back of a staged array (0 z, 1 A.z, 2 B.z, 3 C.z) after the staging work - uploads and, if the instance had one, the deferred-value program on
+// the DEVICE - has finished: what the device fill produced, for consumers that pin it on fixtures of the complete arrays (tests/test_gpu_defer.py) or
+// want the complete witness back on the host without running the program there.  *size_out = the array's size in bytes; at most `cap` bytes are copied.
+// The flags of the program are not judged here (bzk_staged_wait does that): a violated instance can still be inspected.
+int32_t bzk_staged_read(const bzk_staged* st, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out) {
+    if (!st || which < 0 || which > 3 || (cap && !out)) return BZK_E_ARG;
+    (void)hipSetDevice(st->owner->device);
+    const uint64_t size = (which == 0 ? st->n_vars : st->n_rows) * 32;
+    if (size_out) *size_out = size;
+    if (hipEventSynchronize(st->ready) != hipSuccess) return BZK_E_DEVICE;
+    const uint64_t nbytes = cap < size ? cap : size;
+    if (!nbytes) return BZK_OK;
+    const void* src = which == 0 ? st->z() : st->ev(which - 1);
+    if (hipMemcpy(out, src, nbytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return BZK_E_DEVICE;
+    }
+    return BZK_OK;
+}
 // hands the buffers back to the staging context (callable from any thread, once no prove call is using them)
 void bzk_staged_free(bzk_staged* st) {
     if (!st) return;

@@ -137,13 +137,29 @@ struct DeferProgram {
     std::vector<DeferGroup> v_groups, f_groups;
     std::vector<std::pair<uint32_t, uint32_t>> con_holes;
     uint32_t n_levels = 0;
+    uint32_t max_sel_chain = 0;         // finalize(): selections naming selections, longest chain (device limit: wf::MAX_SEL_CHAIN)
     size_t hole_aux = 0, hole_con = 0;  // slots per transition left to the device
     void finalize() {
         v_ops.clear(); f_ops.clear();
         for (const wf::Op& o : ops) (o.kind == wf::V_HASH || o.kind == wf::V_SEL ? v_ops : f_ops).push_back(o);
+        // selections keep their EMISSION order inside a level (no key on Is / Not): the host executor runs them in list order, and a selection may read the
+        // register of an earlier selection of the same level; hashes of a level only read lower levels, so their order is free
         std::stable_sort(v_ops.begin(), v_ops.end(), [](const wf::Op& a, const wf::Op& b) {
-            return std::make_tuple(a.level, a.kind, a.t) < std::make_tuple(b.level, b.kind, b.t);
+            return std::make_tuple(a.level, a.kind, a.kind == wf::V_SEL ? (uint8_t)0 : a.t) < std::make_tuple(b.level, b.kind, b.kind == wf::V_SEL ? (uint8_t)0 : b.t);
         });
+        // longest chain of selections naming selections: the device resolves them where they are read, through at most wf::MAX_SEL_CHAIN links
+        {
+            std::vector<uint32_t> depth(std::max<uint32_t>(1, n_regs), 0);
+            max_sel_chain = 0;
+            for (const wf::Op& o : v_ops)
+                if (o.kind == wf::V_SEL && o.out >= 0 && (size_t)o.out < depth.size()) {
+                    uint32_t d = 0;
+                    for (int k = 1; k <= 2; ++k)
+                        if (o.in[k] >= 0 && (size_t)o.in[k] < depth.size()) d = std::max(d, depth[(size_t)o.in[k]]);
+                    depth[(size_t)o.out] = d + 1;
+                    max_sel_chain = std::max(max_sel_chain, d + 1);
+                }
+        }
         std::stable_sort(f_ops.begin(), f_ops.end(), [](const wf::Op& a, const wf::Op& b) { return std::make_tuple(a.kind, a.t) < std::make_tuple(b.kind, b.t); });
         auto cut = [](const std::vector<wf::Op>& v, std::vector<DeferGroup>& g, bool by_level) {
             g.clear();

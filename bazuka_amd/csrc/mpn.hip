@@ -2152,6 +2152,8 @@ int32_t bzk_mpn_work_synthesize(const bzk_mpn_work* h, const uint8_t prover_pub[
                                 int32_t record_matrices, bzk_r1cs** out) {
     if (!h || !prover_pub || !out) return BZK_E_ARG;
     *out = nullptr;
+    // 0 witness only, 1 with the CSR matrices, BZK_SYNTH_DEFER witness only with deferred values: anything else is a caller's mistake, not "non-zero = matrices"
+    if (record_matrices != 0 && record_matrices != 1 && record_matrices != (int32_t)BZK_SYNTH_DEFER) return BZK_E_ARG;
     try {
         const MpnWork& w = h->w;
         const int L = w.config.log4_tree, T = w.config.log4_token_tree, B = w.log4_batch();

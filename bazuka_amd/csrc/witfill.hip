@@ -245,6 +245,10 @@ uint32_t witfill_flags(bzk_ctx* ctx) {  // after the stream of the last witfill_
 int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, uint32_t* flags_dst) {
     const DeferProgram& P = *dd.prog;
     if (!dd.n_tx || P.ops.empty()) return BZK_OK;
+    if (P.max_sel_chain > (uint32_t)wf::MAX_SEL_CHAIN) {  // operand() would stop in the middle of the chain and read a register nobody wrote
+        ctx->last_error = "witfill: a chain of " + std::to_string(P.max_sel_chain) + " selections exceeds the device executor's limit";
+        return BZK_E_INTERNAL;
+    }
     // (a context is driven by one host thread at a time - the library's rule for every entry point - so its state needs no lock)
     if (!ctx->wf_state) ctx->wf_state = new CtxState();
     CtxState* S = (CtxState*)ctx->wf_state;
@@ -421,6 +425,7 @@ void witfill_schedule_info(const DeferProgram& P, uint64_t info[6]) {
         if (P.v_ops[i].kind == wf::V_HASH && !seen_v[i]) ++bad;  // (selections are resolved where they are read: no segment of their own)
     for (size_t i = 0; i < P.f_ops.size(); ++i)
         if (!seen_f[i]) ++bad;
+    if (P.max_sel_chain > (uint32_t)wf::MAX_SEL_CHAIN) ++bad;  // deeper than the device resolves where an operand is read
     info[0] = S.n_stages; info[1] = S.segs.size(); info[2] = nv; info[3] = nf; info[4] = largest; info[5] = bad;
 }
 

@@ -439,9 +439,17 @@ uint64_t run_once(const Options& o, std::vector<Slot>& slots, Stats& st) {
                 random_scalar(r);
                 random_scalar(sb);
                 Bytes proof(387);
-                if (o.defer)  // completes a deferred instance on the device first; a complete one goes through unchanged
-                    ck(bzk_groth16_prove_r1cs(s.ctx, ph, it.r1cs.get(), r, sb, proof.data()), "bzk_groth16_prove_r1cs", s.ctx);
-                else
+                if (o.defer) {  // completes a deferred instance on the device first; a complete one goes through unchanged
+                    const int32_t pst = bzk_groth16_prove_r1cs(s.ctx, ph, it.r1cs.get(), r, sb, proof.data());
+                    if (pst == BZK_E_UNSAT) {  // a violated DEFERRED row: only the device-side fill sees it - the same outcome as info[6] != 0 above
+                        std::lock_guard<std::mutex> g(st.m);
+                        st.synth_s += it.synth_s;
+                        st.prove_s += secs(t1, clk::now());
+                        ++st.unsat;
+                        continue;
+                    }
+                    ck(pst, "bzk_groth16_prove_r1cs", s.ctx);
+                } else
                     ck(bzk_groth16_prove(s.ctx, ph, &a, r, sb, proof.data()), "bzk_groth16_prove", s.ctx);
                 const bool ok = !o.self_check || bzk_mpn_work_verify(it.work->w.get(), o.address, proof.data()) == 1;
                 std::lock_guard<std::mutex> g(st.m);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "bzk_r1cs_stage": (_i32, [_vp, _vp, C.POINTER(_vp)]),
     "bzk_staged_wait": (_i32, [_vp]),
     "bzk_staged_free": (None, [_vp]),
+    "bzk_staged_read": (_i32, [_vp, _i32, _vp, _u64, C.POINTER(_u64)]),
     "bzk_groth16_prove_staged": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "bzk_bellman_params_info": (_i32, [_vp, _u64, C.POINTER(_u64)]),
     "bzk_bellman_params_decode": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
@@ -216,7 +217,14 @@ class WorkConfig(C.Structure):  # bzk_mpn_work_config
 
 
 class BzkError(RuntimeError):
-    pass
+    """status: the C ABI's int32 (BZK_E_*; None where the failure is the binding's own)"""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+BZK_E_UNSAT = -4
 
 
 def load_library():
@@ -282,7 +290,7 @@ class Bzk:
 
     def _ck(self, st: int, what: str):
         if st != 0:
-            raise BzkError(f"{what}: {self.lib.bzk_strerror(st).decode()} [{self.lib.bzk_last_error(self.h).decode()}]")
+            raise BzkError(f"{what}: {self.lib.bzk_strerror(st).decode()} [{self.lib.bzk_last_error(self.h).decode()}]", st)
 
     def sync(self):
         self._ck(self.lib.bzk_sync(self.h), "sync")
@@ -640,6 +648,14 @@ class Bzk:
 
     def staged_free(self, staged):
         self.lib.bzk_staged_free(staged)
+
+    def staged_read(self, staged, which: int) -> bytes:
+        """one staged array (0 z, 1 az, 2 bz, 3 cz) as the DEVICE left it after the uploads and the deferred-value program"""
+        n = _u64()
+        self._ck(self.lib.bzk_staged_read(staged, which, None, 0, C.byref(n)), "staged_read")
+        buf = (C.c_uint8 * n.value)()
+        self._ck(self.lib.bzk_staged_read(staged, which, buf, n.value, None), "staged_read")
+        return bytes(buf)
 
     def groth16_prove_staged(self, ph, staged, r: bytes, s: bytes) -> bytes:
         out = C.create_string_buffer(387)
@@ -1032,7 +1048,7 @@ class MpnWork:
         return buf.raw[: n.value]
 
     def synthesize(self, prover_pub: bytes, fee_token: bytes | None = None, threads: int = 0, record_matrices=False, defer=False) -> R1cs:
-        """defer: BZK_SYNTH_DEFER - an Update work's hash-dependent values are left to the device (Bzk.groth16_prove_r1cs) / R1cs.fill_host"""
+        """defer: BZK_SYNTH_DEFER - a work's hash-dependent values (all three kinds: update, deposit, withdraw) are left to the device (Bzk.groth16_prove_r1cs) / R1cs.fill_host"""
         h = C.c_void_p()
         _st(self.lib.bzk_mpn_work_synthesize(self.h, _ptr(prover_pub), _ptr(fee_token), threads, 2 if defer else int(record_matrices), C.byref(h)),
             "work_synthesize")

@@ -298,7 +298,17 @@ class Worker:
         ph = params_for(work)
         r, s = L.host_scalar_new(self.rng(64)), L.host_scalar_new(self.rng(64))  # bellman: `E::Fr::random(rng)` twice
         if self.defer:
-            proof = bzk.groth16_prove_r1cs(ph, r1cs, r, s)   # the deferred instance is completed on the device first
+            try:
+                proof = bzk.groth16_prove_r1cs(ph, r1cs, r, s)   # the deferred instance is completed on the device first
+            except L.BzkError as e:
+                # a violated DEFERRED row is only seen by the device-side fill: the same outcome as the host scan's `not satisfied` above
+                if e.status != L.BZK_E_UNSAT:
+                    raise
+                with self._lock:
+                    self.stats["synth_s"] += synth_s
+                    self.stats["prove_s"] += time.perf_counter() - t1
+                    self.stats["unsat"] += 1
+                return None
         else:
             proof = bzk.groth16_prove(ph, r1cs.raw("z"), r1cs.raw("az"), r1cs.raw("bz"), r1cs.raw("cz"), r, s)
         ok = (not self.self_check) or work.verify(self.address, proof)   # MpnWork::verify: the node's own acceptance test

@@ -423,6 +423,10 @@ typedef struct bzk_staged bzk_staged;
 int32_t bzk_r1cs_stage(bzk_ctx* ctx, const bzk_r1cs* r, bzk_staged** out);
 int32_t bzk_staged_wait(bzk_staged* staged);
 void bzk_staged_free(bzk_staged* staged);
+/* read-back of one staged array (which: 0 z, 1 A.z, 2 B.z, 3 C.z) once the staging work has finished - i.e. what the DEVICE-side fill produced; *size_out = the
+ * array's size, at most `cap` bytes are copied.  The counterpart of bzk_r1cs_fill_host + bzk_r1cs_data for the device executor: byte-identical to a synthesis
+ * without deferral (what bellman's `ProvingAssignment` holds after `Circuit::synthesize`, src/mpn/circuits/update_circuit.rs:49-494). */
+int32_t bzk_staged_read(const bzk_staged* staged, int32_t which, uint8_t* out, uint64_t cap, uint64_t* size_out);
 int32_t bzk_groth16_prove_staged(bzk_ctx* ctx, bzk_params* params, const bzk_staged* staged, const uint8_t r_blind[32], const uint8_t s_blind[32],
                                  uint8_t proof_out[387]);
 /* CPU mirrors of `ZkHasher::hash`, `hash_to_scalar`'s SHA3 and `JubJub::{generate_keys, sign, verify}` */

@@ -244,7 +244,7 @@ impl GpuPoseidonHasher {
 }
 
 /// `ZkStateModel::compress` through the shared context (drop-in for `model.compress::<PoseidonHasher>(&data)`)
-pub fn compress(model: &ZkStateModel, data: &ZkDataPairs) -> Result<ZkCompressedState, StateManagerError> {
+pub fn compress(model: &ZkStateModel, data: &ZkDataPairs) -> Result<ZkCompressedState, DeviceStateError> {
     shared_gpu().lock().unwrap().compress(model, data)
 }
 
@@ -359,6 +359,61 @@ pub fn groth16_prove_witness(params: &ProvingParams, witness: &Witness, r: ZkSca
     let mut buf = [0u8; 387];
     check(params.gpu.0, unsafe {
         sys::bzk_groth16_prove_r1cs(params.gpu.0, params.params, witness.0, &r as *const _ as *const u8, &s as *const _ as *const u8, buf.as_mut_ptr())
+    })?;
+    Ok(bincode::deserialize(&buf)?)
+}
+
+/// An instance's assignment resident in HBM (`bzk_r1cs_stage`): the uploads and - for a deferred instance - the device-side fill run on a context of the
+/// witness PRODUCER's, so that the prover slot only copies device to device.  The `Witness` it was staged from is kept alive inside (its pinned host arrays are
+/// read by the staging stream until `wait` or a prove call has returned); the handle goes back to the staging context's pool on drop.
+pub struct Staged<'g> {
+    h: *mut sys::bzk_staged,
+    _gpu: &'g Gpu,
+    _witness: Witness,
+}
+unsafe impl Send for Staged<'_> {}
+
+impl Gpu {
+    /// `bzk_r1cs_stage` on THIS context's stream (a producer's context, not a prover slot's); returns at once
+    pub fn stage(&self, witness: Witness) -> Result<Staged<'_>, GpuError> {
+        let mut h = ptr::null_mut();
+        check(self.0, unsafe { sys::bzk_r1cs_stage(self.0, witness.0, &mut h) })?;
+        Ok(Staged { h, _gpu: self, _witness: witness })
+    }
+}
+
+impl Staged<'_> {
+    /// blocks until the staging work has finished; `BZK_E_UNSAT` (a deferred constraint does not hold, or a transition's computed state differs from the
+    /// builder's prediction) arrives as `GpuError::Status`, never as a panic
+    pub fn wait(&self) -> Result<(), GpuError> {
+        check(ptr::null_mut(), unsafe { sys::bzk_staged_wait(self.h) })
+    }
+    /// one complete array as the device left it (0 z, 1 A.z, 2 B.z, 3 C.z): what `ProvingAssignment` holds after `Circuit::synthesize`
+    pub fn read(&self, which: i32) -> Result<Vec<ZkScalar>, GpuError> {
+        let mut bytes = 0u64;
+        check(ptr::null_mut(), unsafe { sys::bzk_staged_read(self.h, which, ptr::null_mut(), 0, &mut bytes) })?;
+        let mut out = vec![ZkScalar::default(); (bytes / 32) as usize];
+        check(ptr::null_mut(), unsafe { sys::bzk_staged_read(self.h, which, out.as_mut_ptr() as *mut u8, bytes, ptr::null_mut()) })?;
+        Ok(out)
+    }
+}
+
+impl Drop for Staged<'_> {
+    fn drop(&mut self) {
+        // the staging stream may still be reading the witness's host arrays: wait before they (and the handle) go
+        unsafe {
+            let _ = sys::bzk_staged_wait(self.h);
+            sys::bzk_staged_free(self.h)
+        }
+    }
+}
+
+/// `groth16_prove` over a staged instance (any context of the same device as the one it was staged on): waits for the staging work in stream order
+/// and copies device to device; same proof bytes as `groth16_prove` / `groth16_prove_witness`
+pub fn groth16_prove_staged(params: &ProvingParams, staged: &Staged<'_>, r: ZkScalar, s: ZkScalar) -> Result<Groth16Proof, GpuError> {
+    let mut buf = [0u8; 387];
+    check(params.gpu.0, unsafe {
+        sys::bzk_groth16_prove_staged(params.gpu.0, params.params, staged.h, &r as *const _ as *const u8, &s as *const _ as *const u8, buf.as_mut_ptr())
     })?;
     Ok(bincode::deserialize(&buf)?)
 }

@@ -56,6 +56,19 @@ def test_production_shape_proof_equals_oracle_and_verifies(name, bzk, co):
         op["n_a"], op["n_b"] = sum(op["a_density"]), sum(op["b_density"])
         want = co.groth16_prove(op, bytes(z), bytes(az), bytes(bz), bytes(cz), rs[:32], rs[32:], nthreads=co.ncpu())
         assert proof == want
+        # the same work with its hash-dependent values DEFERRED (what `bzk-worker --defer` proves in production): device fill inside the
+        # prove call, and staged on a producer's context, against the ORACLE's bytes
+        from bazuka_amd import Bzk
+        d = dec.synthesize(S.PROVER, defer=True)
+        assert d.defer_info()["deferred"] == 1
+        assert bzk.groth16_prove_r1cs(ph, d, rs[:32], rs[32:]) == want
+        stager = Bzk(bzk.device)
+        h = stager.r1cs_stage(d)
+        assert bzk.groth16_prove_staged(ph, h, rs[:32], rs[32:]) == want
+        assert d.defer_info()["filled"] == 0
+        stager.staged_free(h)
+        stager.close()
+        d.free()
     bzk.params_free(ph)
     r.free()
 

@@ -129,7 +129,7 @@ def generate() -> str:
     o.append("use std::os::raw::{c_char, c_void};")
     o.append("")
     for k, v in consts:
-        ty = "i32" if k.startswith("BZK_E_") or k == "BZK_OK" else ("usize" if k.endswith("_BYTES") else "u32")
+        ty = "i32" if k.startswith("BZK_E_") or k == "BZK_OK" or k.startswith("BZK_REFUSE_") else ("usize" if k.endswith("_BYTES") else "u32")
         o.append(f"pub const {k}: {ty} = {v};")
     o.append("")
     for n in opaque:
