@@ -71,6 +71,11 @@ struct bzk_ctx {
     // (evaluations staged + seven transforms).  Created on first use.
     hipStream_t hprio = nullptr;
     hipEvent_t ev_h = nullptr;
+    // round 6: the SATURATING kernels of an MSM (accumulation, folds, bucket reduction) on a lowest-priority side stream, so that the short kernels of
+    // OTHER streams' MSMs (digits, sorts, boundaries - the chain that gates their next accumulation) are not starved beside them (msm_impl.cuh HeavyScope)
+    hipStream_t heavy = nullptr;
+    hipEvent_t ev_heavy_in = nullptr, ev_heavy_out = nullptr;
+    bool heavy_tried = false;
     void* wf_state = nullptr;  // witfill.hip: device copies of the deferred-witness programs, dense Poseidon constants, scratch (witfill_free)
     // bzk_r1cs_stage: staged assignments handed back by bzk_staged_free (possibly from another thread: the prover's), kept for the next call
     std::mutex staged_mu;

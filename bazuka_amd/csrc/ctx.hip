@@ -259,6 +259,12 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
         (void)hipStreamDestroy(ctx->hprio);
     }
     if (ctx->ev_h) (void)hipEventDestroy(ctx->ev_h);
+    if (ctx->heavy) {
+        (void)hipStreamSynchronize(ctx->heavy);
+        (void)hipStreamDestroy(ctx->heavy);
+    }
+    if (ctx->ev_heavy_in) (void)hipEventDestroy(ctx->ev_heavy_in);
+    if (ctx->ev_heavy_out) (void)hipEventDestroy(ctx->ev_heavy_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

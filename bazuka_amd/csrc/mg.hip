@@ -38,22 +38,21 @@
 #include <thread>
 
 #include "bzk_internal.h"
+#include "mg_exchange.h"
 
 struct bzk_mg_params;
 
 namespace {
 
-constexpr int MG_MAX_W = 64;          // windows of a call (c >= 4 -> W <= 64)
-constexpr size_t MG_SLOT_G2 = 384;    // bytes of one standard-limb XYZZ window sum (G2; G1 = 192)
-// every rank's block of an exchange ends in this record, so that a rank whose local stage failed still TAKES PART and every rank
-// returns an error - instead of the peers blocking in ncclAllGather / spinning on the shared-memory barrier, or (worse) combining
-// the stale sums of an earlier call
-struct MgHdr {
-    uint64_t seq;
-    int32_t status, c_bits;
-};
+// the window partition, the exchange record and the shared-memory transport live in mg_exchange.h (no HIP in there: the CPU suite runs that very code
+// with the device stage replaced by oracle window sums, tests/host/mgx_check.cpp)
+using bzk::mgx::slots_per_rank;
+using bzk::mgx::window_range;
+constexpr int MG_MAX_W = bzk::mgx::MAX_W;
+constexpr size_t MG_SLOT_G2 = bzk::mgx::SLOT_G2;
+typedef bzk::mgx::Hdr MgHdr;
 constexpr size_t MG_HDR = sizeof(MgHdr);
-static_assert(MG_HDR == 16, "exchange record");
+static_assert(BZK_MG_UID_BYTES == bzk::mgx::UID_BYTES, "group id");
 
 struct RcclApi {
     void* lib = nullptr;
@@ -96,10 +95,6 @@ struct Worker {
     int32_t status = BZK_OK;
 };
 
-struct ShmHeader {
-    std::atomic<uint64_t> arrive[64];
-};
-
 }  // namespace
 
 struct bzk_mg {
@@ -118,10 +113,9 @@ struct bzk_mg {
     uint8_t* h_win = nullptr;          // pinned: world x MG_MAX_W slots
     std::vector<ncclComm_t> comms;
     // multi-process HOST exchange
-    ShmHeader* shm = nullptr;
-    size_t shm_bytes = 0;
+    bzk::mgx::ShmExchange shmx;
+    bool shm_open_ = false;
     uint64_t seq = 0;
-    std::string shm_name;
     // bzk_mg_stats: where a window-sharded call's time goes on THIS rank (local device 0), cumulative since creation / the last reset
     struct Stats {
         uint64_t calls = 0;
@@ -209,12 +203,6 @@ int32_t run_all(bzk_mg* mg, const std::function<int32_t(int)>& fn) {
     return st;
 }
 
-void window_range(int W, int rank, int world, int* lo, int* hi) {
-    *lo = (int)((int64_t)W * rank / world);
-    *hi = (int)((int64_t)W * (rank + 1) / world);
-}
-int slots_per_rank(int W, int world) { return (W + world - 1) / world; }
-
 int32_t mg_alloc_buffers(bzk_mg* mg) {
     const size_t slot_all = (size_t)mg->world * (MG_MAX_W * MG_SLOT_G2 + MG_HDR);
     mg->d_send.assign(mg->n_local, nullptr);
@@ -231,44 +219,15 @@ int32_t mg_alloc_buffers(bzk_mg* mg) {
 }
 
 int32_t mg_open_shm(bzk_mg* mg, const uint8_t uid[BZK_MG_UID_BYTES]) {
-    char name[64];
-    static const char* hx = "0123456789abcdef";
-    int o = snprintf(name, sizeof name, "/bzk_mg_");
-    // the id may be an RCCL unique id whose leading bytes are a magic / address: mix all 128 bytes into the name
-    uint64_t h[2] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full};
-    for (int i = 0; i < BZK_MG_UID_BYTES; ++i) {
-        h[i & 1] = (h[i & 1] ^ uid[i]) * 0x100000001B3ull;
-        h[(i + 1) & 1] ^= h[i & 1] >> 29;
-    }
-    for (int k = 0; k < 2; ++k)
-        for (int b = 0; b < 16; ++b) name[o++] = hx[(h[k] >> (4 * b)) & 15];
-    name[o] = 0;
-    mg->shm_name = name;
-    mg->shm_bytes = sizeof(ShmHeader) + 2 * (size_t)mg->world * (MG_MAX_W * MG_SLOT_G2 + MG_HDR);
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) return mg_fail(mg, BZK_E_DEVICE, std::string("shm_open ") + name);
-    if (ftruncate(fd, (off_t)mg->shm_bytes) != 0) { close(fd); return mg_fail(mg, BZK_E_DEVICE, "ftruncate shm"); }
-    void* p = mmap(nullptr, mg->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) return mg_fail(mg, BZK_E_DEVICE, "mmap shm");
-    mg->shm = (ShmHeader*)p;
+    std::string err;
+    if (!mg->shmx.open(uid, mg->world, mg->rank0, err)) return mg_fail(mg, BZK_E_DEVICE, err);
+    mg->shm_open_ = true;
     return BZK_OK;
 }
 
 int32_t shm_barrier(bzk_mg* mg, uint64_t seq) {
-    static const double limit_s = [] { const char* e = getenv("BZK_MG_TIMEOUT_S"); return e ? atof(e) : 120.0; }();
-    mg->shm->arrive[mg->rank0].store(seq, std::memory_order_release);
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < mg->world; ++r) {
-        uint32_t spins = 0;
-        while (mg->shm->arrive[r].load(std::memory_order_acquire) < seq) {
-            if (++spins > 2000) {
-                sched_yield();
-                if ((spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
-                    return mg_fail(mg, BZK_E_DEVICE, "bzk_mg: rank " + std::to_string(r) + " did not reach the exchange (timeout)");
-            }
-        }
-    }
+    std::string err;
+    if (!mg->shmx.barrier(seq, err)) return mg_fail(mg, BZK_E_DEVICE, err);
     return BZK_OK;
 }
 
@@ -331,7 +290,7 @@ static int32_t mg_finish_create_impl(bzk_mg* mg, uint32_t exchange, const uint8_
     } else if (mg->multi_process) {
         BZK_TRY(mg_open_shm(mg, uid));
         BZK_TRY(shm_barrier(mg, ++mg->seq));  // everybody has mapped the segment ...
-        if (mg->rank0 == 0) (void)shm_unlink(mg->shm_name.c_str());  // ... so its name can go: nothing is left behind whatever happens later
+        if (mg->rank0 == 0) mg->shmx.unlink_name();  // ... so its name can go: nothing is left behind whatever happens later
     }
     mg->exchange = exchange;
     if (mg->n_local > 1) {
@@ -461,8 +420,8 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
         for (int r = 0; r < mg->world; ++r) {
             MgHdr h;
             memcpy(&h, mg->h_win + (size_t)r * (blk + MG_HDR) + blk, MG_HDR);
-            if (h.seq != seq || h.status != BZK_OK)
-                return mg_fail(mg, BZK_E_DEVICE, "bzk_mg: rank " + std::to_string(r) + (h.seq != seq ? " is at another call of the group" : " failed its local stage (status " + std::to_string(h.status) + ")"));
+            const std::string why = bzk::mgx::judge(h, seq, r, false);
+            if (!why.empty()) return mg_fail(mg, BZK_E_DEVICE, why);
             if (r) memmove(mg->h_win + (size_t)r * blk, mg->h_win + (size_t)r * (blk + MG_HDR), blk);
         }
     }
@@ -479,42 +438,16 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
         for (int v : cs)
             if (v && v != c_bits) { st = mg_fail(mg, BZK_E_INTERNAL, "window size disagrees with msm_window_bits"); break; }
     if (shm) {
-        // shared-memory all-gather: [record | own sums] into slot [parity][rank], sequence-numbered arrival.  A rank that failed
+        // shared-memory all-gather (mg_exchange.h): [record | own sums] into slot [parity][rank], sequence-numbered arrival.  A rank that failed
         // locally still arrives - with its status in the record - so every rank of the group returns an error for this call
-        uint8_t* data = (uint8_t*)(mg->shm + 1);
-        const size_t rank_bytes = (size_t)MG_MAX_W * MG_SLOT_G2 + MG_HDR;
-        uint8_t* mine = data + ((seq & 1) * mg->world + mg->rank0) * rank_bytes;
-        int lo, hi;
-        window_range(W, mg->rank0, mg->world, &lo, &hi);
-        const MgHdr h0{seq, st, cs[0]};
-        memcpy(mine, &h0, MG_HDR);
-        if (st == BZK_OK) memcpy(mine + MG_HDR, mg->h_win + (size_t)mg->rank0 * blk, (size_t)(hi - lo) * sz);
-        const auto tw0 = std::chrono::steady_clock::now();
-        const int32_t bst = shm_barrier(mg, seq);
-        mg->stats.peer_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+        std::string err;
+        const int32_t gst = mg->shmx.all_gather(seq, st, cs[0], mg->h_win + (size_t)mg->rank0 * blk, W, sz, blk, mg->h_win, &mg->stats.peer_wait_ms, err);
         if (st != BZK_OK) return st;
-        BZK_TRY(bst);
-        for (int r = 0; r < mg->world; ++r) {
-            if (r == mg->rank0) continue;
-            const uint8_t* theirs = data + ((seq & 1) * mg->world + r) * rank_bytes;
-            MgHdr h;
-            memcpy(&h, theirs, MG_HDR);
-            // arrive[r] >= seq let us through; the record says whether what lies in the slot belongs to THIS call and is a result
-            if (h.seq != seq || h.status != BZK_OK)
-                return mg_fail(mg, BZK_E_DEVICE, "bzk_mg: rank " + std::to_string(r) + (h.seq != seq ? " is at another call of the group (stale slot)" : " failed its local stage (status " + std::to_string(h.status) + ")"));
-            window_range(W, r, mg->world, &lo, &hi);
-            memcpy(mg->h_win + (size_t)r * blk, theirs + MG_HDR, (size_t)(hi - lo) * sz);
-        }
+        if (gst != BZK_OK) return mg_fail(mg, gst, err);
     }
     // compact the per-rank slots into window order and combine
     std::vector<uint8_t> S((size_t)W * sz);
-    if (n) {
-        for (int r = 0; r < mg->world; ++r) {
-            int lo, hi;
-            window_range(W, r, mg->world, &lo, &hi);
-            memcpy(S.data() + (size_t)lo * sz, mg->h_win + (size_t)r * blk, (size_t)(hi - lo) * sz);
-        }
-    }
+    if (n) bzk::mgx::compact_to_window_order(mg->h_win, W, mg->world, sz, blk, S.data());
     const auto tc0 = std::chrono::steady_clock::now();
     const int32_t hst = horner(S.data(), n ? W : 0, c_bits, 0, out);
     mg->stats.combine_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
@@ -625,7 +558,7 @@ void bzk_mg_destroy(bzk_mg* mg) {
     for (auto& e : mg->ev)
         if (e) (void)hipEventDestroy(e);
     if (mg->h_win) (void)hipHostFree(mg->h_win);
-    if (mg->shm) munmap(mg->shm, mg->shm_bytes);
+    if (mg->shm_open_) mg->shmx.close();
     delete mg;
 }
 

@@ -377,6 +377,9 @@ __global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restr
 // top window concentrates n points on a handful of buckets - is spread over many lanes instead of
 // serialising on one.  Multi-task buckets write per-task partial sums, folded by msm_fold_kernel.
 // ------------------------------------------------------------------------------------------------
+// every array the accumulation kernels gather bases from ends in this many spare bytes: the G2 pair kernel's direct-to-LDS loads read 16-byte pieces, the
+// last of which reaches 8 bytes past a lane's 56-byte component (msm_accumulate_g2pair_kernel); workspace arrays are followed by other workspace arrays
+static constexpr size_t MSM_GATHER_PAD = 256;
 static constexpr uint32_t MSM_SEG_MAX = 256;  // longest serial run of mixed adds one lane executes
 
 // buckets arrive ordered by min(count, 65535) (two 8-bit radix passes instead of four over the full count width: buckets
@@ -392,6 +395,9 @@ static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* _
     ntask[i] = c <= seg ? 1u : (c + seg - 1) / seg;  // empty buckets keep one task (writes the identity)
 }
 
+#ifndef BZK_MSM_HEAVY_PRIO_DEFAULT
+#define BZK_MSM_HEAVY_PRIO_DEFAULT false  // round 6 A/B: see HeavyScope
+#endif
 #ifndef BZK_MSM_PREFETCH
 #define BZK_MSM_PREFETCH 1  // 0: gather each base at the top of its own addition (A/B builds)
 #endif
@@ -469,6 +475,12 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
 #ifndef BZK_G2_PAIR_OCC
 #define BZK_G2_PAIR_OCC 2
 #endif
+#ifndef BZK_G2_PAIR_LDS
+#define BZK_G2_PAIR_LDS 1  // the next base through LDS by direct loads (round 6); 0: through registers (BZK_G2_PAIR_PRE picks where the request sits)
+#endif
+#ifndef BZK_G2_PAIR_PRE
+#define BZK_G2_PAIR_PRE 0  // 0: the next base requested at the top of the addition (round 5; A/B builds)
+#endif
 struct alignas(8) U128a8 {
     uint32_t x, y, z, w;
 };
@@ -530,18 +542,82 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_g2pair_kernel(const v
     const uint32_t s = start[g] + k * q;
     const uint32_t len = k * q >= cnt ? 0u : (cnt - k * q < q ? cnt - k * q : q);
     g2p::Pt acc = g2p::identity();
+#if BZK_G2_PAIR_LDS && defined(__HIP_DEVICE_COMPILE__)
+    // Round 6: the NEXT base travels global memory -> LDS by direct loads (global_load_lds_dwordx4: no destination registers, nothing to
+    // park) while the current addition runs, and is read from LDS at the top of the next iteration.  A lane's half of a base is 2 x 56 bytes (x | y component):
+    // four 16-byte pieces each, the last one reading 8 bytes past the component (inside the point for x; the arrays this kernel gathers from - resident sets,
+    // tables, the workspace - end in a 16-byte pad for the y of the last point).  The destination of such a load is wave-uniform base + lane x 16: one 1 KiB slab per piece.
+    __shared__ __attribute__((aligned(16))) char stage[2][9][1024];  // per wave: 8 slabs of base pieces + one of index words (256 B used)
+    char* const slab = &stage[threadIdx.x >> 6][0][0];
+    const uint32_t lane16 = (threadIdx.x & 63u) * 16u, lane4 = (threadIdx.x & 63u) * 4u;
+    auto request = [&](uint32_t idx) {
+        const uint32_t m = idx >> ibits, b = idx & imask;
+        const char* p = (b >= n_split ? (const char*)bases2 + (size_t)(m * stride2 + (b - n_split)) * sizeof(G2A28)
+                                      : (const char*)bases + (size_t)(m * stride1 + b) * sizeof(G2A28)) + comp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 16 * k), (__attribute__((address_space(3))) void*)(slab + 1024 * k), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 112 + 16 * k),
+                                             (__attribute__((address_space(3))) void*)(slab + 1024 * (4 + k)), 16, 0, 0);
+        }
+    };
+    // the index word of the entry after next travels the same way: a register holding it would be live across the whole addition (the compiler spilled it
+    // and waited for the gather in order to do so)
+    auto request_word = [&](const uint32_t* w) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w, (__attribute__((address_space(3))) void*)(slab + 8192), 4, 0, 0);
+    };
+    auto collect = [&](uint32_t& word) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the direct loads of this wave have landed (they count as vector-memory operations)
+        __asm__ volatile("" ::: "memory");
+        g2p::Aff a;
+        const U128* q = (const U128*)(slab + lane16);
+        const U128 x0 = q[0], x1 = q[64], x2 = q[128], x3 = q[192], y0 = q[256], y1 = q[320], y2 = q[384], y3 = q[448];
+        word = *(const uint32_t*)(slab + 8192 + lane4);
+        a.x.l[0] = x0.x; a.x.l[1] = x0.y; a.x.l[2] = x0.z; a.x.l[3] = x0.w; a.x.l[4] = x1.x; a.x.l[5] = x1.y; a.x.l[6] = x1.z; a.x.l[7] = x1.w;
+        a.x.l[8] = x2.x; a.x.l[9] = x2.y; a.x.l[10] = x2.z; a.x.l[11] = x2.w; a.x.l[12] = x3.x; a.x.l[13] = x3.y;
+        a.y.l[0] = y0.x; a.y.l[1] = y0.y; a.y.l[2] = y0.z; a.y.l[3] = y0.w; a.y.l[4] = y1.x; a.y.l[5] = y1.y; a.y.l[6] = y1.z; a.y.l[7] = y1.w;
+        a.y.l[8] = y2.x; a.y.l[9] = y2.y; a.y.l[10] = y2.z; a.y.l[11] = y2.w; a.y.l[12] = y3.x; a.y.l[13] = y3.y;
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slabs are free again: the next requests may overwrite them
+        return a;
+    };
+    if (len) {
+        const uint32_t v0 = vals[s];
+        bool neg = (v0 >> 31) != 0;
+        request(v0 & vmask);
+        request_word(vals + s + (1 < len ? 1u : 0u));
+        for (uint32_t j = 0; j < len; ++j) {
+            uint32_t vn;
+            const g2p::Aff p = collect(vn);  // base j and the index word of entry j + 1 (past the end of the run: the last entry again - no branch around loads)
+            request(vn & vmask);
+            request_word(vals + s + (j + 2 < len ? j + 2 : len - 1));
+            g2p::add_mixed(acc, p, neg);  // both requests land under this addition; nothing of them is held in registers
+            neg = (vn >> 31) != 0;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // nothing of this wave may still be writing LDS when the workgroup's slot is handed on
+        acc.X = fp28::reduce(acc.X);
+    }
+#else
     if (len) {
         uint32_t v = vals[s];
         g2p::Aff p = ld(v & vmask);
         for (uint32_t j = 0; j < len; ++j) {
             const uint32_t vn = vals[s + (j + 1 < len ? j + 1 : j)];
+#if BZK_G2_PAIR_PRE
+            // requested behind the last product that still needs every register (round 6): with the request at the top of the addition the 28 registers of
+            // `pn` were parked in scratch on EVERY addition (8 scratch stores behind an s_waitcnt vmcnt(0): 3.76 GB of writes per 2^20-point launch, and the
+            // gather waited for instead of flying - VERDICT r5 weak 5); the four-product tail of the formula (980 multiply-adds) covers the gather
+            g2p::Aff pn;
+            g2p::add_mixed(acc, p, (v >> 31) != 0, [&]() { pn = ld(vn & vmask); });
+#else
             const g2p::Aff pn = ld(vn & vmask);  // requested now, first read by the next iteration
             g2p::add_mixed(acc, p, (v >> 31) != 0);
+#endif
             p = pn;
             v = vn;
         }
         acc.X = fp28::reduce(acc.X);  // < 3 p: the discipline of the one-lane consumers (folds, bucket reduction)
     }
+#endif
     char* dst = (char*)(cnt <= seg ? &buckets[g] : &partial[t]) + comp;
     g2p_store56(dst, acc.X);
     g2p_store56(dst + 112, acc.Y);
@@ -1167,6 +1243,63 @@ __global__ void __launch_bounds__(64) dedup_affine_kernel(const typename C::Pt* 
     }
 }
 
+// ---- the saturating part of an MSM on a LOWEST-priority stream (round 6) ----------------------------------------------------------------
+// What the kernel trace of two MSMs in flight shows (profiles/r06_run1_two_msms_timeline.txt): beside another stream's accumulation - two
+// long-lived, issue-saturating waves per SIMD - the short kernels of an MSM's front chain (digits 0.04 ms alone, the sort passes, boundaries)
+// take 1.3 + 0.8 + 0.8 ms: younger waves get the VALU slots the older ones leave.  The chain gates this MSM's own accumulation, so the two
+// MSMs end up taking turns (3.4 ms each instead of 3.8) instead of overlapping.  With the accumulation, the folds and the bucket reduction on
+// a stream of the device's LOWEST priority, everything else - of every stream of the process - outranks them.
+// env BZK_MSM_HEAVY_PRIO=0 | 1 (A/B).
+static bool msm_heavy_prio_on() {
+    static const bool on = [] { const char* e = getenv("BZK_MSM_HEAVY_PRIO"); return e ? atoi(e) != 0 : BZK_MSM_HEAVY_PRIO_DEFAULT; }();
+    return on;
+}
+struct HeavyScope {
+    bzk_ctx* ctx;
+    hipStream_t home = nullptr;
+    bool in = false;
+    explicit HeavyScope(bzk_ctx* c) : ctx(c) {}
+    HeavyScope(const HeavyScope&) = delete;
+    void enter() {
+        if (in || !msm_heavy_prio_on()) return;
+        if (!ctx->heavy && !ctx->heavy_tried) {
+            ctx->heavy_tried = true;
+            int least = 0, greatest = 0;
+            hipStream_t s = nullptr;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess ||
+                hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                if (s) (void)hipStreamDestroy(s);
+                if (a) (void)hipEventDestroy(a);
+                if (b) (void)hipEventDestroy(b);
+            } else {
+                ctx->heavy = s; ctx->ev_heavy_in = a; ctx->ev_heavy_out = b;
+            }
+        }
+        if (!ctx->heavy) return;  // no side stream: everything stays on the context's stream
+        if (hipEventRecord(ctx->ev_heavy_in, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->heavy, ctx->ev_heavy_in, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        home = ctx->stream;
+        ctx->stream = ctx->heavy;  // BZK_LAUNCH / ProfScope work on ctx->stream
+        in = true;
+    }
+    void leave() {
+        if (!in) return;
+        in = false;
+        const hipError_t e = hipEventRecord(ctx->ev_heavy_out, ctx->heavy);
+        ctx->stream = home;
+        // the home stream continues behind the side stream's work (on failure: a host-side wait keeps the order)
+        if (e != hipSuccess || hipStreamWaitEvent(home, ctx->ev_heavy_out, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(ctx->heavy);
+        }
+    }
+    ~HeavyScope() { leave(); }
+};
+
 // bucket phase shared by the windows and by the group sums: boundaries of each key's run in the sorted pair list,
 // buckets in population order, task table, task-based accumulation, folds.  Result: buckets[key] for key < nb.
 template <class Pt>
@@ -1178,7 +1311,7 @@ template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
                                  uint32_t seg, const BucketArrays<typename C::Pt>& A, typename C::Pt* buckets, void* tmp_buf, size_t tmp,
                                  bool group_sums = false, uint32_t wiv_half = 0, const void* bases2 = nullptr, uint32_t n_split = 0xffffffffu,
-                                 uint32_t ibits = 31, uint32_t stride1 = 0, uint32_t stride2 = 0) {
+                                 uint32_t ibits = 31, uint32_t stride1 = 0, uint32_t stride2 = 0, HeavyScope* heavy = nullptr) {
     // start[] and count[] are taken from the workspace back to back: one fill covers both
     if ((const char*)A.count > (const char*)A.start && (size_t)((const char*)A.count - (const char*)A.start) <= (size_t)nb * 4 + 256) {
         BZK_HIP(ctx, hipMemsetAsync(A.start, 0, (size_t)((const char*)A.count - (const char*)A.start) + (size_t)nb * 4, ctx->stream));
@@ -1212,6 +1345,7 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
         if (e != hipSuccess) { ctx->last_error = std::string("exclusive_scan: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
     }
     const uint32_t t_max = (uint32_t)((uint64_t)nb + len / seg + 1);
+    if (heavy) heavy->enter();  // accumulation + folds (+ the caller's bucket reduction) on the lowest-priority stream; the caller leaves the scope
     // G1: 2 waves/SIMD: forcing 3 or 4 (__launch_bounds__) spills 68 / 223 VGPRs and measured 13 % / 80 % slower.
     // G2: 1 wave/SIMD (512 registers: 8 spilled instead of 402 at 2 waves), see msm_policy.cuh
     auto k_acc = msm_accumulate_kernel<C, C::ACC_OCC>;
@@ -1612,7 +1746,10 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                    n, 0xffffffffu, key2, scal2, rep, gof);
         if (M) {
             aux.join();
-            BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true, 0u, sums_aff, n_split));
+            {
+                HeavyScope hs(ctx);  // left (joined) before dedup_affine: the batched inversion is a latency chain, not a saturating grid
+                BZK_TRY(bucket_accumulate<C>(ctx, bases, key2, didx_s, n, M, seg_dd, BA, buckets, tmp_buf, tmp, true, 0u, sums_aff, n_split, 31, 0, 0, &hs));
+            }
             static const uint32_t K = [] {  // sums per lane of the batched inversion (env BZK_DEDUP_K for A/B runs)
                 const char* e = getenv("BZK_DEDUP_K");
                 const int v = e ? atoi(e) : 8;
@@ -1656,8 +1793,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
         }
         aux.join();
+        HeavyScope heavy(ctx);  // accumulation, folds, bucket reduction; left before the window sums (latency-bound trees of a few workgroups)
         BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, wiv ? half : 0u, sums_aff, n_split,
-                                     (uint32_t)ibits, E > 1 ? (uint32_t)prep->n : 0u, E > 1 ? m_max : 0u));
+                                     (uint32_t)ibits, E > 1 ? (uint32_t)prep->n : 0u, E > 1 ? m_max : 0u, &heavy));
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         bool tails_done = false;
@@ -1676,6 +1814,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                     BZK_LAUNCH(ctx, "msm_reduce", msm_reduce_g2pair_kernel<0>, grid2(n_chunks), dim3(64), 0, (const Pt*)buckets, half, ch, n_chunks, chunk_out, per_win,
                                0u, (Pt*)nullptr, 0u);
                 }
+                heavy.leave();
                 constexpr int WTP = C::WSUM_THREADS;
                 const uint32_t groups_p = (per_win_out + WTP - 1) / WTP;
                 StdPt* const win_dst_p = wout ? (StdPt*)wout->d_win + ((table && !folded) ? 0 : wb - w_begin) : win_out;
@@ -1708,6 +1847,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             BZK_LAUNCH(ctx, "msm_reduce", k_red, dim3((n_chunks + 63) / 64), dim3(64), 0, buckets, half, ch, n_chunks, chunk_out, per_win, 0u,
                        (Pt*)nullptr, 0u);
         }
+        heavy.leave();
         constexpr int WT = C::WSUM_THREADS;
         const uint32_t groups = (per_win_out + WT - 1) / WT;
         auto k_wp = msm_window_partial_kernel<C, WT>;
@@ -1799,7 +1939,7 @@ static int32_t msm_table_build(bzk_ctx* ctx, const void* bases_raw, uint64_t n, 
     MsmTable* t = new (std::nothrow) MsmTable();
     if (!t) return BZK_E_ALLOC;
     t->n = n; t->c = c; t->w_total = w_total; t->levels = levels; t->wpl = wpl;
-    hipError_t e = hipMalloc(&t->data, (size_t)levels * n * sizeof(typename C::DevAff));
+    hipError_t e = hipMalloc(&t->data, (size_t)levels * n * sizeof(typename C::DevAff) + MSM_GATHER_PAD);
     if (e != hipSuccess) {
         ctx->last_error = std::string("table alloc: ") + hipGetErrorString(e);
         (void)hipGetLastError();
@@ -1853,11 +1993,11 @@ static int32_t msm_bases_load(bzk_ctx* ctx, const void* bases_raw, uint64_t n, M
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
         if ((size_t)b->endo * n * sizeof(typename C::DevAff) + ((size_t)8 << 30) > free_b) b->endo = 1;
     }
-    hipError_t e = hipMalloc(&b->data, (size_t)b->endo * n * sizeof(typename C::DevAff));
+    hipError_t e = hipMalloc(&b->data, (size_t)b->endo * n * sizeof(typename C::DevAff) + MSM_GATHER_PAD);
     if (e != hipSuccess && b->endo > 1) {
         (void)hipGetLastError();
         b->endo = 1;
-        e = hipMalloc(&b->data, (size_t)n * sizeof(typename C::DevAff));
+        e = hipMalloc(&b->data, (size_t)n * sizeof(typename C::DevAff) + MSM_GATHER_PAD);
     }
     if (e != hipSuccess) {
         ctx->last_error = std::string("bases alloc: ") + hipGetErrorString(e);

@@ -80,3 +80,25 @@ def test_g2_pair_tails_do_not_spill(table):
     for k in ("msm_fold_g2pair_kernel<0>", "msm_fold_small_g2pair_kernel<0>", "msm_reduce_g2pair_kernel<0>", "msm_window_partial_g2pair_kernel<128>",
               "msm_window_sum_g2pair_kernel<128>"):
         assert row(table, "msm_g2", k)["spill"] <= 2, k
+
+
+@pytest.mark.parametrize("obj,kernel", [("msm_g1", "msm_accumulate_kernel"), ("msm_g2", "msm_accumulate_g2pair")])
+def test_no_value_is_parked_in_scratch_per_addition(obj, kernel):
+    """the G2 pair kernel of round 5 parked the prefetched base - 28 registers - in scratch on EVERY addition (8 scratch stores
+    behind an s_waitcnt vmcnt(0) inside the loop: 3.77 GB of writes per 2^20-point launch).  One pass of the widest loop of either accumulation
+    kernel = one point addition: no scratch store may be in it, and the few reloads of loop-invariant values stay few."""
+    c = kr.loop_instruction_counts(obj, kernel)
+    assert c.get("v_mad_u64_u32", 0) >= 3500, c           # it IS the addition loop
+    stores = sum(v for k, v in c.items() if k.startswith("scratch_store"))
+    loads = sum(v for k, v in c.items() if k.startswith("scratch_load"))
+    assert stores == 0, {k: v for k, v in c.items() if k.startswith("scratch")}
+    assert loads <= 12, {k: v for k, v in c.items() if k.startswith("scratch")}
+
+
+def test_g2_pair_accumulation_stages_the_next_base_through_lds(table):
+    """round 6: the next base (and the index word after next) travel global memory -> LDS by direct loads while the current addition runs"""
+    c = kr.loop_instruction_counts("msm_g2", "msm_accumulate_g2pair")
+    assert c.get("global_load_lds_dwordx4", 0) == 8 and c.get("global_load_lds_dword", 0) == 1, c
+    assert sum(v for k, v in c.items() if k.startswith("global_load_dword")) == 0, c      # nothing of the gather lands in registers
+    r = row(table, "msm_g2", "msm_accumulate_g2pair_kernel<2>")
+    assert r["waves"] >= 2 and r["lds"] <= 20 * 1024 and r["scratch"] <= 64, r

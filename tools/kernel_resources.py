@@ -76,6 +76,49 @@ def instruction_counts(obj, symbol_substring):
     return counts
 
 
+def loop_instruction_counts(obj, symbol_substring):
+    """{mnemonic: count} over the LARGEST LOOP (the widest backward branch) of the first function of code object `obj` whose mangled name contains the
+    substring - for the accumulation kernels: one pass = one point addition.  What must not be in there: scratch stores (a value parked per addition)."""
+    tmp = tempfile.mkdtemp()
+    try:
+        path = extract_device_objects(tmp)[obj]
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    body, inside, name = [], False, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            if inside:
+                break
+            inside = symbol_substring in m.group(1)
+            name = m.group(1)
+            continue
+        if inside:
+            a = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+            t = line.split()
+            if a and t and not t[0].startswith("//"):
+                body.append((int(a.group(1), 16), t[0], line))
+    if not body:
+        return {}
+    base = body[0][0]
+    best = None
+    for addr, mn, line in body:
+        if mn.startswith(("s_cbranch", "s_branch")):
+            m = re.search(r"<" + re.escape(name) + r"\+0x([0-9a-f]+)>", line)
+            if m:
+                tgt = base + int(m.group(1), 16)
+                if tgt < addr and (best is None or addr - tgt > best[1] - best[0]):
+                    best = (tgt, addr)
+    if best is None:
+        return {}
+    counts = {}
+    for addr, mn, _ in body:
+        if best[0] <= addr <= best[1]:
+            counts[mn] = counts.get(mn, 0) + 1
+    return counts
+
+
 def functions_clobbering_return_address():
     """[(object, mangled name)] of every NON-kernel device function that takes s[30:31] - its own return address - as the scratch pair of a
     long-branch expansion (`s_getpc_b64 s[30:31]`).  Round 5, run 4: the compiler did that in a 137 KB no-inline function whose early exits jump

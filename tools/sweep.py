@@ -256,6 +256,17 @@ if __name__ == "__main__":
         for ch in ("2", "4", "8"):
             run("g2res", 20, {"BZK_MSM_PAIR_L2_CH": ch, "BZK_MSM_ENDO_G2": "1", "THROUGHPUT": "1"})
         run("g2", 18); run("g2", 16); run("g2", 22)
+    if what in ("r6g2lds",):  # round 6, run 2: the G2 pair accumulation with the next base through LDS (direct loads) against the round-5 form (through registers, parked in scratch), alternating libraries
+        libs = (os.path.join(ROOT, "bazuka_amd", "libbzk.so.g2reg"), os.path.join(ROOT, "bazuka_amd", "libbzk.so"))
+        for rep in range(2):
+            for lib in libs:
+                tag = {"BZK_LIBBZK": lib}
+                print("# lib", os.path.basename(lib), flush=True)
+                run("g2", 20, tag)
+                run("g2res", 20, dict(tag, BZK_MSM_ENDO_G2="1", THROUGHPUT="1"))
+        for lib in libs:
+            print("# lib", os.path.basename(lib), flush=True)
+            run("g2", 18, {"BZK_LIBBZK": lib}); run("g2", 22, {"BZK_LIBBZK": lib})
     if what in ("r5g2",):  # round 5, run 4: one-lane G2 / pair accumulation with one-lane tails / pairs everywhere, same box, alternating (the container of runs 2 - 3 was lost)
         cfgs = ({"BZK_G2_PAIR": "0"}, {"BZK_G2_PAIR": "1", "BZK_G2_PAIR_TAILS": "0"}, {"BZK_G2_PAIR": "1", "BZK_G2_PAIR_TAILS": "1"})
         for rep in range(2):
