@@ -996,6 +996,124 @@ __global__ void __launch_bounds__(THREADS) msm_reduce_l2_quad_kernel(const G1X28
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// 6b. (round 6) bucket reduction WITHOUT scalar multiplications, G1.  The weight of bucket b is b + 1 = 1 + sum_k 2^k bit_k(b), so
+//        sum_b (b + 1) B_b  =  S_tot + sum_k 2^k S_k,      S_k = sum of the buckets whose index has bit k set,  S_tot = sum of all buckets
+//     and with b = L h + l (L = 2^lbits columns, H = 2^hbits rows) every S_k is a sum of ROW sums R_h = sum_l B[h][l] (k >= lbits) or of COLUMN sums
+//     C_l = sum_h B[h][l] (k < lbits), S_tot the sum of all column sums.  Two launches:
+//        msm_rowcol_quad_kernel   the row sums and the column sums: 2 general additions per bucket (the chunked running sum of section 6 spends 4.2: 60 % of
+//                                 it is the chunk offset's 15-bit double-and-add), chains of 7 + log2(lanes per row) links instead of 41
+//        msm_bitsum_quad_kernel   per (bucket set, bit): a tree over the <= 512 row / column sums with that bit set -> the c terms of the set
+//     and the weights 2^k cost nothing: the host's Horner over the windows doubles its accumulator c times per window anyway - the terms join it at
+//     their bit positions (msm_horner_terms_host: the same c W doublings, c W additions instead of W).  No window-sum kernels.
+//     Same-box A/B and the issue budget of a proof before / after: profiles/r06_run4...
+// ------------------------------------------------------------------------------------------------
+// trees over SEGMENTS of `seg` (a power of two) consecutive points of sh[0 .. THREADS): result of segment g in sh[g * seg]
+template <int THREADS>
+__device__ __forceinline__ void g1_quad_tree_seg(G1X28* sh, int seg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int quad = (int)(threadIdx.x >> 2), n_quads = THREADS / 4, n_seg = THREADS / seg;
+    for (int s = seg / 2; s > 0; s >>= 1) {
+        const int n_adds = n_seg * s;
+        for (int q = quad; q < n_adds; q += n_quads) {
+            const int g = q / s, i = q % s;
+            const G1X28 r = g1_add_quad(sh[g * seg + i], sh[g * seg + i + s]);
+            if ((threadIdx.x & 3u) == 0) sh[g * seg + i] = r;
+        }
+        __syncthreads();
+    }
+#endif
+}
+struct RowColPlan {  // host-side shape of one bucket set of `half` = L H buckets
+    uint32_t lbits, hbits, leaf_r, leaf_c, seg_r, seg_c, wgs_r, wgs_c;
+};
+static RowColPlan msm_rowcol_plan(int c_minus_1, uint32_t threads) {
+    RowColPlan P;
+    P.lbits = (uint32_t)(c_minus_1 + 1) / 2;
+    P.hbits = (uint32_t)c_minus_1 - P.lbits;
+    const uint32_t L = 1u << P.lbits, H = 1u << P.hbits;
+    P.leaf_r = std::max<uint32_t>(std::min<uint32_t>(8, L), L / threads);  // buckets one lane sums serially
+    P.leaf_c = std::max<uint32_t>(std::min<uint32_t>(8, H), H / threads);
+    P.seg_r = L / P.leaf_r;                                                 // lanes per row / per column (tree width)
+    P.seg_c = H / P.leaf_c;
+    P.wgs_r = (H + threads / P.seg_r - 1) / (threads / P.seg_r);
+    P.wgs_c = (L + threads / P.seg_c - 1) / (threads / P.seg_c);
+    return P;
+}
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, 2) msm_rowcol_quad_kernel(const G1X28* __restrict__ buckets, uint32_t half, RowColPlan P, G1X28* __restrict__ rows,
+                                                                  G1X28* __restrict__ cols) {
+    __shared__ G1X28 sh[THREADS];
+    const uint32_t L = 1u << P.lbits, H = 1u << P.hbits, per_set = P.wgs_r + P.wgs_c;
+    const uint32_t set = blockIdx.x / per_set;
+    uint32_t local = blockIdx.x % per_set;
+    const G1X28* b = buckets + (size_t)set * half;
+    const bool col_pass = local >= P.wgs_r;
+    uint32_t seg, first, stride, leaf, slot, out_idx;
+    bool valid;
+    if (!col_pass) {
+        seg = P.seg_r;
+        const uint32_t row = local * (THREADS / seg) + threadIdx.x / seg, part = threadIdx.x % seg;
+        valid = row < H;
+        first = row * L + part * P.leaf_r;
+        stride = 1;
+        leaf = P.leaf_r;
+        slot = threadIdx.x;
+        out_idx = row;
+    } else {
+        local -= P.wgs_r;
+        seg = P.seg_c;
+        const uint32_t cpw = THREADS / seg;  // columns per workgroup; the column index is the fastest lane index: neighbours read neighbouring buckets
+        const uint32_t col = local * cpw + threadIdx.x % cpw, part = threadIdx.x / cpw;
+        valid = col < L;
+        first = part * P.leaf_c * L + col;
+        stride = L;
+        leaf = P.leaf_c;
+        slot = (threadIdx.x % cpw) * seg + part;
+        out_idx = col;
+    }
+    G1X28 acc = g1x28::identity();
+    if (valid) {
+        acc = b[first];
+        for (uint32_t j = 1; j < leaf; ++j) {
+            const G1X28 q = b[first + j * stride];
+            g1x28::add_full(acc, q);
+        }
+    }
+    sh[slot] = acc;
+    __syncthreads();
+    g1_quad_tree_seg<THREADS>(sh, (int)seg);
+    if (valid && slot % seg == 0) (col_pass ? cols : rows)[(size_t)set * (col_pass ? L : H) + out_idx] = sh[slot];
+}
+// term t of a set: t < lbits: column sums with bit t of l set; lbits <= t < lbits + hbits: row sums with bit (t - lbits) of h set; t = lbits + hbits
+// (= c - 1): every column sum.  Output: standard-limb XYZZ for the host, terms[set * c + t]
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) msm_bitsum_quad_kernel(const G1X28* __restrict__ rows, const G1X28* __restrict__ cols, RowColPlan P,
+                                                                  XyzzT<FpOps>* __restrict__ terms) {
+    __shared__ G1X28 sh[THREADS];
+    const uint32_t c_terms = P.lbits + P.hbits + 1;
+    const uint32_t set = blockIdx.x / c_terms, t = blockIdx.x % c_terms;
+    const bool total = t == c_terms - 1, from_cols = total || t < P.lbits;
+    const uint32_t n_src = 1u << (from_cols ? P.lbits : P.hbits), bit = total ? 0u : (from_cols ? t : t - P.lbits);
+    const G1X28* src = (from_cols ? cols : rows) + (size_t)set * n_src;
+    const uint32_t n_leaves = total ? n_src : n_src / 2;
+    auto leaf_index = [&](uint32_t j) { return total ? j : ((((j >> bit) << 1) | 1u) << bit) | (j & ((1u << bit) - 1u)); };
+    G1X28 acc = g1x28::identity();
+    if (threadIdx.x < n_leaves) {
+        acc = src[leaf_index(threadIdx.x)];
+        for (uint32_t j = threadIdx.x + THREADS; j < n_leaves; j += THREADS) {
+            const G1X28 q = src[leaf_index(j)];
+            g1x28::add_full(acc, q);
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    int active = 1;
+    while (active < THREADS && (uint32_t)active < n_leaves) active <<= 1;
+    g1_quad_tree<THREADS>(sh, active);
+    if (threadIdx.x == 0) terms[(size_t)set * c_terms + t] = g1x28::to_std(sh[0]);
+}
+
 template <class C, int THREADS>
 __global__ void __launch_bounds__(THREADS) msm_window_partial_kernel(const typename C::Pt* __restrict__ chunk_out, uint32_t per_win,
                                                                      uint32_t groups, typename C::Pt* __restrict__ partial_out) {
@@ -1487,6 +1605,25 @@ static XyzzT<F> msm_horner_host(const XyzzT<F>* S, int count, int c, int w0) {
     return from_host_fast<F>(acc);
 }
 
+// Horner over the TERMS of the multiplication-free reduction (section 6b): window k (k < count) contributes T[k * c + t] at bit position
+// c (w0 + k) + t for t < c - 1 and its last term - the plain sum of the set - at position c (w0 + k).  The same c (count + w0) doublings as
+// msm_horner_host, count * c additions.  step: bits between consecutive bucket sets (c; c * wpl never occurs here: folded tables keep the old path)
+template <class F>
+static XyzzT<F> msm_horner_terms_host(const XyzzT<F>* T, int count, int c, int w0) {
+    typedef typename HostFast<F>::Ops H;
+    XyzzT<H> acc = xyzz_identity<H>();
+    for (int k = count - 1; k >= 0; --k) {
+        const XyzzT<F>* t = T + (size_t)k * c;
+        for (int bit = c - 1; bit >= 0; --bit) {
+            acc = xyzz_dbl<H>(acc);
+            if (bit < c - 1) xyzz_add<H>(acc, to_host_fast<F>(t[bit]));
+            if (bit == 0) xyzz_add<H>(acc, to_host_fast<F>(t[c - 1]));
+        }
+    }
+    for (int d = 0; d < c * w0; ++d) acc = xyzz_dbl<H>(acc);
+    return from_host_fast<F>(acc);
+}
+
 template <class C>
 static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
                        int w_end, XyzzT<typename C::HostF>& result, const MsmTable* table = nullptr, const MsmBases* prep = nullptr,
@@ -1559,6 +1696,12 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const uint32_t ch2 = std::min<uint32_t>(pair_tails ? pair_l2_ch : quad_l2 ? quad_l2_ch : 8u, per_win);
     const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && ((flags & BZK_F_THROUGHPUT) || pair_tails)));
     const uint32_t per_win_out = two_level ? per_win + per_win / ch2 : per_win;  // chunk results per window handed to the window sums
+    // round 6: the multiplication-free reduction (section 6b: row / column sums, bit sums, the weights in the host's Horner) - G1, whole results only (a
+    // caller that wants WINDOW sums on the device - the device groups - keeps the chunked running sum).  env BZK_MSM_BITSUM=0: the old path (A/B)
+    static const bool bitsum_on = [] { const char* e = getenv("BZK_MSM_BITSUM"); return e ? atoi(e) != 0 : true; }();
+    const bool bitsum = bitsum_on && !C::PARK_REDUCE && !wout && !folded && c >= 11 && c <= 21;
+    const RowColPlan rc_plan = msm_rowcol_plan(c - 1, 256);
+    const size_t rc_per_set = ((size_t)1 << rc_plan.lbits) + ((size_t)1 << rc_plan.hbits);
     if (wout) { wout->c = c; wout->w_total = w_total; wout->w_begin = w_begin; wout->w_end = w_end; wout->single = table && !folded; }
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
@@ -1621,13 +1764,15 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     if (two_level) total += ws_pad((size_t)group * per_win * sizeof(Pt));
     total += ws_pad(((size_t)group * (per_win_out / C::WSUM_THREADS + 1)) * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(StdPt));
+    const size_t n_sets_max = (table && !folded) ? 1 : (size_t)group;
+    if (bitsum) total += ws_pad(n_sets_max * rc_per_set * sizeof(Pt)) + ws_pad(n_sets_max * (size_t)c * sizeof(StdPt));
     if (C::CONVERT_BASES && !table) total += ws_pad((size_t)((prep ? 0 : n) + (size_t)m_max * E) * sizeof(typename C::DevAff));
     if (dedup) {
         total += 11 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
     }
     total += ws_pad(tmp) + 8192;
     BZK_TRY(ws_reserve(ctx, total));
-    BZK_TRY(pinned_reserve(ctx, (size_t)w_total * sizeof(StdPt) + 64));
+    BZK_TRY(pinned_reserve(ctx, std::max<size_t>((size_t)w_total, bitsum ? n_sets_max * (size_t)c : 0) * sizeof(StdPt) + 64));
     WsCursor cur(ctx->ws);
     uint32_t* keys = cur.take<uint32_t>(len_max);
     uint32_t* vals = cur.take<uint32_t>(len_max);
@@ -1647,6 +1792,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     Pt* chunk_tot = two_level ? cur.take<Pt>((size_t)group * per_win) : nullptr;
     Pt* wpart = cur.take<Pt>((size_t)group * (per_win_out / C::WSUM_THREADS + 1));
     StdPt* win_out = cur.take<StdPt>(w_total);
+    Pt* rc_buf = bitsum ? cur.take<Pt>(n_sets_max * rc_per_set) : nullptr;           // row sums of every set, then the column sums
+    StdPt* terms_out = bitsum ? cur.take<StdPt>(n_sets_max * (size_t)c) : nullptr;
     const void* bases = table ? table->data : bases_raw;
     typename C::DevAff* conv = nullptr;
     typename C::DevAff* sums_aff = nullptr;  // de-duplication group sums in affine form: base indices n .. n + m_max
@@ -1772,7 +1919,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;
     const bool wiv = !wiv_off && !table && group <= 16 && (uint64_t)n + m_max < ((uint64_t)1 << 27);
-    std::vector<StdPt> wsum((size_t)(w_end - w_begin));
+    std::vector<StdPt> wsum((size_t)(w_end - w_begin) * (bitsum ? (size_t)c : 1));  // window sums, or (section 6b) the c terms of every bucket set
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
         const uint64_t len = (uint64_t)wc * n_eff * (folded ? (uint64_t)levels : (uint64_t)E);
@@ -1796,6 +1943,25 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         HeavyScope heavy(ctx);  // accumulation, folds, bucket reduction; left before the window sums (latency-bound trees of a few workgroups)
         BZK_TRY(bucket_accumulate<C>(ctx, bases, keys_s, vals_s, len, nb, seg, BA, buckets, tmp_buf, tmp, false, wiv ? half : 0u, sums_aff, n_split,
                                      (uint32_t)ibits, E > 1 ? (uint32_t)prep->n : 0u, E > 1 ? m_max : 0u, &heavy));
+        if constexpr (!C::PARK_REDUCE) {
+            if (bitsum) {
+                G1X28* const rows = (G1X28*)rc_buf;
+                G1X28* const cols = rows + ((size_t)n_red_win << rc_plan.hbits);
+                BZK_LAUNCH(ctx, "msm_rowcol", (msm_rowcol_quad_kernel<256>), dim3((unsigned)n_red_win * (rc_plan.wgs_r + rc_plan.wgs_c)), dim3(256), 0,
+                           (const G1X28*)buckets, half, rc_plan, rows, cols);
+                heavy.leave();
+                BZK_LAUNCH(ctx, "msm_bitsum", (msm_bitsum_quad_kernel<256>), dim3((unsigned)n_red_win * (unsigned)c), dim3(256), 0, (const G1X28*)rows,
+                           (const G1X28*)cols, rc_plan, (XyzzT<FpOps>*)terms_out);
+                BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, terms_out, (size_t)n_red_win * c * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
+                BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (table && !folded) {  // one bucket set fed by every level of the table: its c terms are the whole result
+                    result = msm_horner_terms_host<F>((const StdPt*)ctx->pinned, 1, c, 0);
+                    return BZK_OK;
+                }
+                memcpy(&wsum[(size_t)(wb - w_begin) * c], ctx->pinned, (size_t)wc * c * sizeof(StdPt));
+                continue;
+            }
+        }
         auto k_red = msm_reduce_kernel<C>;
         const uint32_t n_chunks = (uint32_t)n_red_win * per_win;
         bool tails_done = false;
@@ -1884,7 +2050,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     }
     if (wout) return BZK_OK;
     // Horner over the window sums (host): result = 2^(c*w_begin) * sum_k 2^(c k) S_{w_begin+k}
-    result = msm_horner_host<F>(wsum.data(), (int)wsum.size(), c, w_begin);
+    result = bitsum ? msm_horner_terms_host<F>(wsum.data(), w_end - w_begin, c, w_begin) : msm_horner_host<F>(wsum.data(), (int)wsum.size(), c, w_begin);
     return BZK_OK;
 }
 

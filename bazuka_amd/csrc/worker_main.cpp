@@ -523,6 +523,9 @@ int usage(const char* why) {
 }  // namespace
 
 int main(int argc, char** argv) {
+    // 16 hardware queues for the slots' streams instead of HIP's default 4 (read by the runtime at its first call; a value set by the operator wins):
+    // bazuka_amd/__init__.py has the measurement
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     Options o;
     bool have_node = false, have_addr = false;
     for (int i = 1; i < argc; ++i) {

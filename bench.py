@@ -34,6 +34,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the process's first HIP call (torch initialises the runtime): see bazuka_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 LOG_N = 20
 # micro-benchmarked peak of the library's own Fp product (chains of dependent calls, all CUs busy):
@@ -1110,36 +1112,39 @@ def main():
     # sums, read-back, ~1.4 ms) overlaps the accumulation of the other.  `value` above stays the one-at-a-time rate.
     overlapped = None
     if world == 1 and not args.no_overlap:
+        # Informational (N = 1): the same MSM issued from 2 and 4 host threads, each on a context of its own (stream + workspace), over the SAME resident
+        # base set - what a prover with independent MSMs in flight sees (round 5 measured this over RAW bases, i.e. with a conversion per call: +1.8 %; the
+        # resident-set figure is the comparable one).  `value` above stays the one-at-a-time rate.
         import threading
-        ctxs = [Bzk(local_rank) for _ in range(2)]
-        outs = [None, None]
-
-        def run(i, k):
-            for _ in range(k):
-                outs[i] = ctxs[i].msm_g1_dev(bases, scalars, n)
-
-        for i in range(2):
-            run(i, max(1, args.warmup))
+        ctxs = [Bzk(local_rank) for _ in range(4)]
+        for c in ctxs:
+            for _ in range(max(1, args.warmup)):
+                assert c.msm_bases_run_dev(rbases, scalars, n) == result
         torch.cuda.synchronize()
-        raw_ms = []  # the per-call pipeline on RAW bases (conversion inside the call), one at a time, for the record
-        for _ in range(5):
-            t0 = time.perf_counter()
-            ctxs[0].msm_g1_dev(bases, scalars, n)
-            raw_ms.append((time.perf_counter() - t0) * 1e3)
-        per = (args.steps + 1) // 2
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=run, args=(i, per)) for i in range(2)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        assert outs[0] == result and outs[1] == result, "overlapped MSMs differ from the one-at-a-time result"
-        overlapped = {"value": round(n * 2 * per / dt / 1e6, 3), "unit": "Mpt/s", "msms": 2 * per,
-                      "ms_per_msm": round(dt * 1e3 / (2 * per), 4),
-                      "how": "two independent MSMs in flight (2 contexts / streams / host threads, raw bases); informational, not `value`",
-                      "one_at_a_time_raw_bases_ms": round(min(raw_ms), 4)}
+        overlapped = {"how": "K independent MSMs in flight (K contexts / streams / host threads over one resident base set); informational, not `value`",
+                      "unit": "Mpt/s"}
+        for k_in in (2, 4):
+            outs = [None] * k_in
+            per = (args.steps + k_in - 1) // k_in
+
+            def run(i):
+                for _ in range(per):
+                    outs[i] = ctxs[i].msm_bases_run_dev(rbases, scalars, n)
+
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                th = [threading.Thread(target=run, args=(i,)) for i in range(k_in)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            assert all(o == result for o in outs), "overlapped MSMs differ from the one-at-a-time result"
+            overlapped[f"in_flight_{k_in}"] = {"value": round(n * k_in * per / best / 1e6, 3), "msms": k_in * per, "ms_per_msm": round(best * 1e3 / (k_in * per), 4)}
+        overlapped["value"] = overlapped["in_flight_2"]["value"]
         for c in ctxs:
             c.close()
     ms_per_step = elapsed * 1e3 / args.steps

@@ -256,6 +256,14 @@ if __name__ == "__main__":
         for ch in ("2", "4", "8"):
             run("g2res", 20, {"BZK_MSM_PAIR_L2_CH": ch, "BZK_MSM_ENDO_G2": "1", "THROUGHPUT": "1"})
         run("g2", 18); run("g2", 16); run("g2", 22)
+    if what in ("r6bitsum",):  # round 6, run 4: the multiplication-free bucket reduction (row / column sums + bit sums, weights in the host Horner) against the chunked running sum, same box, alternating
+        for rep in range(2):
+            for bs in ("0", "1"):
+                run("g1res", 20, {"BZK_MSM_BITSUM": bs})
+                run("g1res", 20, {"BZK_MSM_BITSUM": bs, "BZK_MSM_ENDO_G1": "1", "THROUGHPUT": "1"})
+                run("g1tab", 20, {"BZK_MSM_BITSUM": bs, "BZK_MSM_TABLE_C": "20"})
+        for bs in ("0", "1"):
+            run("g1", 18, {"BZK_MSM_BITSUM": bs}); run("g1", 16, {"BZK_MSM_BITSUM": bs}); run("g1res", 22, {"BZK_MSM_BITSUM": bs}); run("g1res", 24, {"BZK_MSM_BITSUM": bs})
     if what in ("r6g2lds",):  # round 6, run 2: the G2 pair accumulation with the next base through LDS (direct loads) against the round-5 form (through registers, parked in scratch), alternating libraries
         libs = (os.path.join(ROOT, "bazuka_amd", "libbzk.so.g2reg"), os.path.join(ROOT, "bazuka_amd", "libbzk.so"))
         for rep in range(2):
