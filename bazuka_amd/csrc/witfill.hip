@@ -12,6 +12,7 @@
 #include "bzk_internal.h"
 #include "bzk_poseidon_opt.h"
 #include "bzk_witfill.cuh"
+#include "bzk_poseidon29_coop.cuh"
 #include "host_r1cs.h"
 
 namespace bzk {
@@ -190,6 +191,155 @@ Schedule make_schedule(const DeferProgram& P) {
     return S;
 }
 
+// ---- round 6: the program on COOPERATING lanes.  The one-launch form above spends a lane per hash: a transition's 20 dependency
+// levels are 20 one-lane Poseidon hashes back to back (0.25 - 0.8 ms each) and pass 2 is one lane per dense trace (0.5 - 2 ms) - 15 ms per proof, in a
+// 512-register body with 6.8 KB of scratch that needs a drained CU.  Here:
+//   pass 1  wf_pass1_coop_kernel: a workgroup of two waves per TRANSITION, per level each wave takes segments of <= 8 hashes of one width - EIGHT LANES PER
+//           HASH (bzk_poseidon29_coop.cuh: ~2x shorter chain), a workgroup barrier between levels; an Update transition has at most 8 hashes per level,
+//           i.e. one wave-step per level
+//   pass 2  wf_trace_all_kernel: eight lanes per dense trace (lane j holds state element j and writes its own S-box / idle-lane slots), all traces of all
+//           transitions and widths in ONE launch; the small ops stay on wf_small_kernel (a lane per op and transition)
+// No body above 256 registers, no scratch: the waves fit beside the accumulation's.  Same values: the slots are written by the same formulas as
+// wf::f_poseidon (bzk_witfill.cuh), which the CPU suite pins on the independent restatement's fixtures.
+constexpr int WFC_WAVES = 2;
+struct CSeg {
+    uint32_t start;  // first op (index into v_ops)
+    uint8_t count;   // <= 8
+    uint8_t t;
+    uint16_t pad;
+};
+__global__ void __launch_bounds__(64 * WFC_WAVES) wf_pass1_coop_kernel(const wf::Op* __restrict__ v_ops, const CSeg* __restrict__ segs, const uint32_t* __restrict__ idx,
+                                                                      uint32_t n_levels, uint32_t n_tx, const Fr* __restrict__ inputs, uint32_t n_inputs,
+                                                                      Fr* __restrict__ regs, const int32_t* __restrict__ sel, DevTables tab) {
+    const uint32_t tx = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, grp = lane >> 3, j = lane & 7u;
+    const wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, 0, 0, sel};
+    for (uint32_t level = 0; level < n_levels; ++level) {
+        for (uint32_t s = idx[level * WFC_WAVES + wave]; s < idx[level * WFC_WAVES + wave + 1]; ++s) {
+            const CSeg sg = segs[s];
+            const bool live = grp < sg.count;
+            const wf::Op& op = v_ops[sg.start + (live ? grp : sg.count - 1u)];  // idle groups mirror the last hash: every group stays convergent for the shuffles
+            const uint32_t t = sg.t, jj = j < t ? j : t - 1u;
+            const Fr mine = jj >= 1u ? wf::operand(v, op.in[jj - 1u]) : Fr::zero();
+            Fr h;
+            switch (t) {  // wave-uniform
+                case 3: h = poseidon29_coop_val<3>(mine, tab.sparse[3], tab.rf[3], tab.rp[3]); break;
+                case 5: h = poseidon29_coop_val<5>(mine, tab.sparse[5], tab.rf[5], tab.rp[5]); break;
+                case 6: h = poseidon29_coop_val<6>(mine, tab.sparse[6], tab.rf[6], tab.rp[6]); break;
+                default: h = poseidon29_coop_val<8>(mine, tab.sparse[8], tab.rf[8], tab.rp[8]); break;
+            }
+            if (live && j == 1u) v.regs[(size_t)op.out * v.reg_stride] = h;
+        }
+        __threadfence_block();  // a level's registers (global memory) are read by the other wave of this workgroup next
+        __syncthreads();
+    }
+}
+// the dense trace of one Poseidon gadget instance on eight lanes: wf::f_poseidon's slots, lane j writing what belongs to state element j
+struct TraceArgs {  // everything but the per-width part
+    uint32_t n_tx, n_inputs;
+    const Fr* inputs;
+    Fr* regs;
+    const int32_t* sel;
+    wf::Arrays A;
+    size_t base_aux, stride_aux, base_con, stride_con;
+};
+template <int T>
+static __device__ __forceinline__ void trace_coop(const wf::Op* __restrict__ ops, uint32_t count, uint32_t block, const TraceArgs& a, const Fr29* __restrict__ dense, int rf, int rp) {
+    const uint32_t n_tx = a.n_tx, n_inputs = a.n_inputs;
+    const Fr* const inputs = a.inputs;
+    Fr* const regs = a.regs;
+    const int32_t* const sel = a.sel;
+    const wf::Arrays A = a.A;
+    const size_t base_aux = a.base_aux, stride_aux = a.stride_aux, base_con = a.base_con, stride_con = a.stride_con;
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 7u, g0 = lane & ~7u;
+    const uint64_t total = (uint64_t)count * n_tx;
+    uint64_t g = (uint64_t)block * 32 + (threadIdx.x >> 3);
+    const bool live = g < total;
+    if (!live) g = total - 1;  // whole groups stay convergent for the shuffles
+    const uint32_t tx = (uint32_t)(g % n_tx);
+    const wf::TxView v{inputs + (size_t)tx * n_inputs, regs + tx, n_tx, base_aux + tx * stride_aux, base_con + tx * stride_con, sel};
+    const wf::Op& op = ops[g / n_tx];
+    const uint32_t jj = j < (uint32_t)T ? j : (uint32_t)T - 1u;
+    Fr29 e = jj >= 1u ? fr29::to29(wf::operand(v, op.in[jj - 1u])) : fr29::zero();
+    if (j == 0) e = fr29::zero();
+    const Fr one = wf::fr_one_mont();
+    const Fr29* mds = dense + (size_t)(rf + rp) * T;
+    const bool mine = live && j < (uint32_t)T;
+    size_t off = 0;  // slot offset of the round inside the gadget's window (the same for variables and constraints)
+#pragma unroll 1
+    for (int rnd = 0; rnd < rf + rp; ++rnd) {
+        e = fr29::norm(fr29::add(e, dense[(size_t)rnd * T + jj]));  // k <= 3
+        const bool full = rnd < rf / 2 || rnd >= rf / 2 + rp;
+        // every lane runs the S-box (one instruction stream); in a partial round only lane 0's is the gadget's
+        const Fr29 x2 = fr29::sqr(e), x4 = fr29::sqr(x2), x5 = fr29::mul(e, x4);
+        const bool sbox_lane = full ? mine : (live && j == 0);
+        if (sbox_lane) {
+            const size_t a = v.aux_base + op.aux_off + off + (full ? 3u * j : 0u), c = v.con_base + op.con_off + off + (full ? 3u * j : 0u);
+            const Fr X = fr29::from29(e), X2 = fr29::from29(x2), X4 = fr29::from29(x4), X5 = fr29::from29(x5);
+            A.z_aux[a] = X2; A.z_aux[a + 1] = X4; A.z_aux[a + 2] = X5;
+            A.az[c] = X;  A.bz[c] = X;  A.cz[c] = X2;
+            A.az[c + 1] = X2; A.bz[c + 1] = X2; A.cz[c + 1] = X4;
+            A.az[c + 2] = X;  A.bz[c + 2] = X4; A.cz[c + 2] = X5;
+        } else if (!full && mine) {  // Number::compress of an idle lane: v * 1 = v
+            const size_t a = v.aux_base + op.aux_off + off + 3u + (j - 1u), c = v.con_base + op.con_off + off + 3u + (j - 1u);
+            const Fr V = fr29::from29(e);
+            A.z_aux[a] = V;
+            A.az[c] = V; A.bz[c] = one; A.cz[c] = V;
+        }
+        if (full || j == 0) e = x5;
+        off += full ? 3u * T : 3u + (T - 1u);
+        Fr29 st[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) st[k] = shfl29(e, (int)g0 + k);
+        e = p29::row_dot<T>(mds + (size_t)jj * T, st);
+    }
+}
+// all dense traces of a program in ONE launch: the blocks of the four widths side by side (a block is of one width: no divergence), so that a proof waits
+// for the longest trace once instead of for four launches one behind the other (run 5 of round 6: 0.58 - 0.72 ms each)
+struct TraceWidths {
+    const wf::Op* ops[4];   // widths 3, 5, 6, 8
+    uint32_t count[4];
+    uint32_t first_block[5];
+};
+__global__ void __launch_bounds__(256) wf_trace_all_kernel(TraceWidths W, TraceArgs a, DevTables tab) {
+    const uint32_t b = blockIdx.x;
+    if (b < W.first_block[1]) trace_coop<3>(W.ops[0], W.count[0], b - W.first_block[0], a, tab.dense[3], tab.rf[3], tab.rp[3]);
+    else if (b < W.first_block[2]) trace_coop<5>(W.ops[1], W.count[1], b - W.first_block[1], a, tab.dense[5], tab.rf[5], tab.rp[5]);
+    else if (b < W.first_block[3]) trace_coop<6>(W.ops[2], W.count[2], b - W.first_block[2], a, tab.dense[6], tab.rf[6], tab.rp[6]);
+    else trace_coop<8>(W.ops[3], W.count[3], b - W.first_block[3], a, tab.dense[8], tab.rf[8], tab.rp[8]);
+}
+
+// pass-1 schedule of the cooperative form: per level and wave a run of segments (<= 8 hashes of one width = one wave-step), most expensive first
+struct CoopSchedule {
+    std::vector<CSeg> segs;
+    std::vector<uint32_t> idx;  // n_levels * WFC_WAVES + 1
+};
+CoopSchedule make_coop_schedule(const DeferProgram& P) {
+    auto cost = [](uint8_t t) { return t <= 3 ? 0.25 : t <= 5 ? 0.41 : t <= 6 ? 0.56 : 0.8; };
+    CoopSchedule S;
+    S.idx.push_back(0);
+    for (uint32_t lvl = 1; lvl <= P.n_levels; ++lvl) {
+        std::vector<CSeg> c;
+        for (const DeferGroup& g : P.v_groups)
+            if (g.kind == wf::V_HASH && g.level == lvl)
+                for (uint32_t o = 0; o < g.count; o += 8) c.push_back({g.start + o, (uint8_t)std::min<uint32_t>(8, g.count - o), g.t, 0});
+        std::stable_sort(c.begin(), c.end(), [&](const CSeg& a, const CSeg& b) { return cost(a.t) > cost(b.t); });
+        std::vector<CSeg> per_wave[WFC_WAVES];
+        double load[WFC_WAVES] = {};
+        for (const CSeg& x : c) {
+            int w = 0;
+            for (int i = 1; i < WFC_WAVES; ++i)
+                if (load[i] < load[w]) w = i;
+            per_wave[w].push_back(x);
+            load[w] += cost(x.t);
+        }
+        for (int w = 0; w < WFC_WAVES; ++w) {
+            S.segs.insert(S.segs.end(), per_wave[w].begin(), per_wave[w].end());
+            S.idx.push_back((uint32_t)S.segs.size());
+        }
+    }
+    return S;
+}
+
 // per (context, program): the ops in device memory; per context: the constant tables and the grow-only scratch (registers + inputs)
 struct CtxState {
     struct DevProg {
@@ -198,6 +348,8 @@ struct CtxState {
         Seg* segs = nullptr;                // the one-launch schedule (make_schedule)
         uint32_t* idx = nullptr;
         uint32_t n_stages = 0;
+        CSeg* csegs = nullptr;              // pass 1 of the cooperative form (make_coop_schedule)
+        uint32_t* cidx = nullptr;
     };
     std::map<const DeferProgram*, DevProg> progs;
     DevTables tab;
@@ -270,6 +422,7 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, 
                 s[0] = o.in[0]; s[1] = o.in[1]; s[2] = o.in[2]; s[3] = o.t;
             }
         const Schedule sch = make_schedule(P);
+        const CoopSchedule csch = make_coop_schedule(P);
         dp.n_stages = sch.n_stages;
         auto upload = [&]() -> int32_t {
             BZK_HIP(ctx, hipMalloc((void**)&dp.v, std::max<size_t>(1, P.v_ops.size()) * sizeof(wf::Op)));
@@ -282,14 +435,18 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, 
             BZK_HIP(ctx, hipMemcpyAsync(dp.sel, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
             BZK_HIP(ctx, hipMemcpyAsync(dp.segs, sch.segs.data(), sch.segs.size() * sizeof(Seg), hipMemcpyHostToDevice, ctx->stream));
             BZK_HIP(ctx, hipMemcpyAsync(dp.idx, sch.idx.data(), sch.idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipMalloc((void**)&dp.csegs, std::max<size_t>(1, csch.segs.size()) * sizeof(CSeg)));
+            BZK_HIP(ctx, hipMalloc((void**)&dp.cidx, csch.idx.size() * sizeof(uint32_t)));
+            BZK_HIP(ctx, hipMemcpyAsync(dp.csegs, csch.segs.data(), csch.segs.size() * sizeof(CSeg), hipMemcpyHostToDevice, ctx->stream));
+            BZK_HIP(ctx, hipMemcpyAsync(dp.cidx, csch.idx.data(), csch.idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             return BZK_OK;
         };
         const int32_t up = upload();
-        // `sel` and `sch` are locals: no copy out of them may be in flight when this frame goes, whether the upload succeeded or not
+        // `sel`, `sch` and `csch` are locals: no copy out of them may be in flight when this frame goes, whether the upload succeeded or not
         const hipError_t se = hipStreamSynchronize(ctx->stream);
         if (up != BZK_OK || se != hipSuccess) {
             (void)hipGetLastError();
-            for (void* q : {(void*)dp.v, (void*)dp.f, (void*)dp.sel, (void*)dp.segs, (void*)dp.idx})
+            for (void* q : {(void*)dp.v, (void*)dp.f, (void*)dp.sel, (void*)dp.segs, (void*)dp.idx, (void*)dp.csegs, (void*)dp.cidx})
                 if (q) (void)hipFree(q);
             if (up == BZK_OK) ctx->last_error = std::string("witfill: program upload: ") + hipGetErrorString(se);
             return up != BZK_OK ? up : BZK_E_DEVICE;
@@ -315,7 +472,10 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, 
     BZK_HIP(ctx, hipMemcpyAsync(d_in, dd.inputs.data(), n_tx * (size_t)P.n_inputs * 32, hipMemcpyHostToDevice, ctx->stream));
     // BZK_WF_MODE=levels: one launch per (level, width) group instead of the one-launch form (A/B); BZK_WF_PRIO=1: on a highest-priority side stream
     // (measured worse under load with the launch-per-level form: 35 vs 50 proofs/s at 8 slots, profiles/r05_run7...; default off)
-    static const bool one_launch = [] { const char* e = getenv("BZK_WF_MODE"); return !(e && strcmp(e, "levels") == 0); }();
+    // BZK_WF_MODE: coop (default since round 6: eight lanes per hash, pass 1 as one launch with a workgroup per transition, pass 2 one launch per kind and width) |
+    // one (round 5: the whole program of a transition in one launch, a lane per hash) | levels (a launch per (level, width) group)
+    static const int wf_mode = [] { const char* e = getenv("BZK_WF_MODE"); return !e || strcmp(e, "coop") == 0 ? 2 : strcmp(e, "levels") == 0 ? 0 : 1; }();
+    const bool one_launch = wf_mode == 1;
     static const bool want_prio = [] { const char* e = getenv("BZK_WF_PRIO"); return e && atoi(e) != 0; }();
     if (want_prio && !S->prio_tried) {
         S->prio_tried = true;
@@ -355,6 +515,45 @@ int32_t witfill_run_dev(bzk_ctx* ctx, const DeferData& dd, const wf::Arrays& A, 
         return BZK_OK;
     }
     auto blocks = [&](uint32_t count, uint32_t bs) { return dim3((unsigned)(((uint64_t)count * ntx + bs - 1) / bs)); };
+    if (wf_mode == 2) {
+        for (int t = 0; t < 9; ++t)
+            if (t != 3 && t != 5 && t != 6 && t != 8 && S->tab.dense[t]) { ctx->last_error = "witfill: no device form for Poseidon width " + std::to_string(t); return BZK_E_INTERNAL; }
+        if (P.n_levels)
+            BZK_LAUNCH(ctx, "wf_pass1", wf_pass1_coop_kernel, dim3(ntx), dim3(64 * WFC_WAVES), 0, (const wf::Op*)it->second.v, (const CSeg*)it->second.csegs,
+                       (const uint32_t*)it->second.cidx, P.n_levels, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, S->tab);
+        TraceWidths W{};
+        const int width_of[4] = {3, 5, 6, 8};
+        for (const DeferGroup& g : P.f_groups) {
+            const wf::Op* o = it->second.f + g.start;
+            if (g.kind != wf::F_POSEIDON) {
+                BZK_LAUNCH(ctx, "wf_small", wf_small_kernel, blocks(g.count, 256), dim3(256), 0, o, g.count, ntx, (const Fr*)d_in, P.n_inputs, d_regs, dsel, A, dd.base_aux,
+                           dd.stride_aux, dd.base_con, dd.stride_con, flags_dev);
+                continue;
+            }
+            for (int k = 0; k < 4; ++k)
+                if (width_of[k] == g.t) {
+                    if (W.count[k]) { ctx->last_error = "witfill: two trace groups of one width"; return BZK_E_INTERNAL; }  // finalize() sorts the F ops by (kind, width)
+                    W.ops[k] = o;
+                    W.count[k] = g.count;
+                }
+        }
+        uint32_t nblk = 0;
+        for (int k = 0; k < 4; ++k) {
+            W.first_block[k] = nblk;
+            nblk += (uint32_t)(((uint64_t)W.count[k] * ntx + 31) / 32);
+        }
+        W.first_block[4] = nblk;
+        if (nblk) {
+            const TraceArgs ta{ntx, P.n_inputs, (const Fr*)d_in, d_regs, dsel, A, dd.base_aux, dd.stride_aux, dd.base_con, dd.stride_con};
+            BZK_LAUNCH(ctx, "wf_trace", wf_trace_all_kernel, dim3(nblk), dim3(256), 0, W, ta, S->tab);
+        }
+        BZK_HIP(ctx, hipMemcpyAsync(flags_out, flags_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (S->prio) {
+            BZK_HIP(ctx, hipEventRecord(S->ev_out, S->prio));
+            BZK_HIP(ctx, hipStreamWaitEvent(home, S->ev_out, 0));
+        }
+        return BZK_OK;
+    }
     // pass 1
     for (const DeferGroup& g : P.v_groups) {
         const wf::Op* o = it->second.v + g.start;
@@ -426,6 +625,11 @@ void witfill_schedule_info(const DeferProgram& P, uint64_t info[6]) {
     for (size_t i = 0; i < P.f_ops.size(); ++i)
         if (!seen_f[i]) ++bad;
     if (P.max_sel_chain > (uint32_t)wf::MAX_SEL_CHAIN) ++bad;  // deeper than the device resolves where an operand is read
+    if (env_on("BZK_WF_DUMP")) {  // the shape of the program on stderr: ops per (kind, width, level) - what a device schedule has to work with
+        for (const DeferGroup& g : P.v_groups) fprintf(stderr, "[bzk] wf program: V kind %u width %u level %u: %u ops\n", g.kind, g.t, g.level, g.count);
+        for (const DeferGroup& g : P.f_groups) fprintf(stderr, "[bzk] wf program: F kind %u width %u: %u ops\n", g.kind, g.t, g.count);
+        fprintf(stderr, "[bzk] wf program: %u registers, %u inputs, %u levels, longest selection chain %u\n", P.n_regs, P.n_inputs, P.n_levels, P.max_sel_chain);
+    }
     info[0] = S.n_stages; info[1] = S.segs.size(); info[2] = nv; info[3] = nf; info[4] = largest; info[5] = bad;
 }
 
@@ -438,6 +642,8 @@ void witfill_free(bzk_ctx* ctx) {  // bzk_ctx_destroy
         (void)hipFree(kv.second.sel);
         (void)hipFree(kv.second.segs);
         (void)hipFree(kv.second.idx);
+        (void)hipFree(kv.second.csegs);
+        (void)hipFree(kv.second.cidx);
     }
     for (void* p : S->dense_dev)
         if (p) (void)hipFree(p);
