@@ -262,10 +262,13 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     # generator skips the Poseidon gadget's variables, the Merkle muxes and the root checks (82 % of a transition's constraints) and the prover runs the
     # instance's program on the GPU before anything reads the arrays.  Same proof bytes (tests/test_gpu_defer.py).  BZK_BENCH_DEFER=1: the live producers
     # below use it too (A/B; the default is the plain generator: see DESIGN.md section 3.5 for the measured trade)
-    defer = os.environ.get("BZK_BENCH_DEFER", "0") != "0"
+    # Default since round 6: ON when several ranks share the host (N > 1: the producers are bound by the host's CPU quota and a deferred witness costs 0.035 - 0.040
+    # instead of 0.051 - 0.063 CPU-s), OFF for one rank (the GPU is the bound there and the program is 5.6 ms of extra device work per proof: 69.3 - 70.3 against
+    # 71.5 - 72.4 proofs/s, profiles/r06_run6...)
+    defer = os.environ.get("BZK_BENCH_DEFER", "1" if world > 1 else "0") != "0"
     # BZK_BENCH_STAGE=1 (with or without deferral): each producer owns a context and STAGES its instances - the 116 MB upload and the deferred-value
     # program run on the producer's stream (bzk_r1cs_stage), the prover slots copy device to device (bzk_groth16_prove_staged)
-    stage = os.environ.get("BZK_BENCH_STAGE", "0") != "0"
+    stage = os.environ.get("BZK_BENCH_STAGE", "1" if world > 1 else "0") != "0"
     w.set_defer(True)
     twd, tpd, tcd = [], [], []
     for k in range(n_proofs):
@@ -1323,7 +1326,7 @@ def main():
                     "quota_feeds_proofs_per_s": round(q_now / (sum(per_proof) / len(per_proof)), 1) if ok and q_now else None,
                     "live_over_ring": round(live_total / ring_total, 3) if live_total and ring_total else None,
                     "reading": "live_over_ring < 1 with quota_feeds_proofs_per_s < proofs_per_sec: the ranks' witness producers are bound by the host's CPU quota, "
-                               "not by the GPUs (deferred witness values - BZK_BENCH_DEFER=1 - lower witness_cpu_s)"}
+                               "not by the GPUs (the N > 1 default - deferred witness values staged by the producers, BZK_BENCH_DEFER / _STAGE - already lowers witness_cpu_s)"}
                 out["proofs"]["proofs_per_sec_is"] = ("sum over the ranks of proofs_per_s_ring: every rank proves a ring of pre-synthesised 16-tx witnesses "
                                                      "(upload + proof, own r, s per proof); the ranks' LIVE witness producers share one host CPU quota "
                                                      f"({cpu_quota()} CPUs for {world} ranks) and are reported beside it (live_producers_total)")

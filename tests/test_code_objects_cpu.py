@@ -102,3 +102,13 @@ def test_g2_pair_accumulation_stages_the_next_base_through_lds(table):
     assert sum(v for k, v in c.items() if k.startswith("global_load_dword")) == 0, c      # nothing of the gather lands in registers
     r = row(table, "msm_g2", "msm_accumulate_g2pair_kernel<2>")
     assert r["waves"] >= 2 and r["lds"] <= 20 * 1024 and r["scratch"] <= 64, r
+
+
+def test_witness_fill_kernels_fit_beside_other_work(table):
+    """round 5's one-launch fill (wf_tx_kernel) is a 512-register body with 6.8 KB of scratch per lane that needs a drained CU.  The
+    cooperative form of round 6 (eight lanes per hash): no scratch, no body that takes a whole SIMD's register file."""
+    for k in ("wf_pass1_coop_kernel", "wf_trace_all_kernel"):
+        r = row(table, "witfill", k)
+        assert r["scratch"] == 0 and r["spill"] == 0, r
+        assert r["vgpr"] <= 304, r      # a SIMD that one accumulation wave has left (512 - 176) takes it
+    assert row(table, "witfill", "wf_small_kernel")["vgpr"] <= 64
