@@ -175,7 +175,7 @@ def _pmc_traffic(log_n):
     return None, f"stale: no profiles/*pmc_traffic*.json carries source stamp {stamp} (re-run tools/runs/pmc passes)"
 
 
-OTHER_KERNEL_SOURCES = ("ntt.hip", "poseidon.hip", "bzk_fr29.cuh", "bzk_poseidon29.cuh", "msm_impl.cuh", "msm_policy.cuh", "msm_g2.hip", "bzk_fp28.cuh",
+OTHER_KERNEL_SOURCES = ("ntt.hip", "poseidon.hip", "bzk_fr29.cuh", "bzk_poseidon29.cuh", "bzk_poseidon29_coop.cuh", "msm_impl.cuh", "msm_policy.cuh", "msm_g2.hip", "bzk_fp28.cuh",
                         "bzk_g2pair.cuh", "msm_g2pair_tails.cuh")
 
 
