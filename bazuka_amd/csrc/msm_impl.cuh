@@ -313,7 +313,10 @@ static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* _
     const uint32_t c = endx_count[g] - start[g];
     endx_count[g] = c;
     iota[g] = g;
-    ckey[g] = c < 65535u ? c : 65535u;  // 16-bit sort key of the population order (true counts are gathered through the order)
+    // 8-bit sort key of the population order (round 6; 16 bits = two radix passes until then): a bucket of more than MSM_SEG_MAX = 254 entries is cut into
+    // equal tasks of <= seg whatever its size, so the mutual order of such buckets does not matter - only that they all come before the single-task ones,
+    // which the clamp at 255 > seg guarantees (the true counts are gathered through the order)
+    ckey[g] = c < 255u ? c : 255u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,11 +383,10 @@ __global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restr
 // every array the accumulation kernels gather bases from ends in this many spare bytes: the G2 pair kernel's direct-to-LDS loads read 16-byte pieces, the
 // last of which reaches 8 bytes past a lane's 56-byte component (msm_accumulate_g2pair_kernel); workspace arrays are followed by other workspace arrays
 static constexpr size_t MSM_GATHER_PAD = 256;
-static constexpr uint32_t MSM_SEG_MAX = 256;  // longest serial run of mixed adds one lane executes
+static constexpr uint32_t MSM_SEG_MAX = 254;  // longest serial run of mixed adds one lane executes (< 255: see msm_count_kernel's sort key)
 
-// buckets arrive ordered by min(count, 65535) (two 8-bit radix passes instead of four over the full count width: buckets
-// beyond 65535 entries are cut into tasks of <= 256 anyway, their mutual order does not matter); the true counts are
-// gathered through the order here
+// buckets arrive ordered by min(count, 255) (ONE 8-bit radix pass: buckets beyond 254 entries are cut into tasks of <= 254 anyway, their
+// mutual order does not matter); the true counts are gathered through the order here
 static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order,
                                                                uint32_t nb, uint32_t seg, uint32_t* __restrict__ count_sorted,
                                                                uint32_t* __restrict__ ntask) {
@@ -673,31 +675,36 @@ __global__ void __launch_bounds__(64) msm_fold_small_kernel(const uint32_t* __re
 // heavily populated buckets: one 64-lane workgroup per bucket: lanes stride over the partial sums, LDS tree
 template <class C>
 __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ order,
-                                                      const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ ntask, uint32_t nb,
+                                                      const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ ntask, uint32_t nb, uint32_t n_big,
                                                       uint32_t seg, const typename C::Pt* __restrict__ partial,
                                                       typename C::Pt* __restrict__ buckets) {
     typedef typename C::Pt Pt;
     __shared__ Pt sh[64];
-    const uint32_t i = blockIdx.x;
-    if (i >= nb) return;
-    const uint32_t cnt = count_sorted[i];
-    if (cnt <= seg) return;  // wave-uniform: whole workgroup leaves
-    const uint32_t nt = (cnt + seg - 1) / seg;
-    if (nt <= msm_fold_threshold(tbase, ntask, nb)) return;
-    const Pt* src = partial + tbase[i];
-    Pt acc = threadIdx.x < nt ? src[threadIdx.x] : C::identity();
-    for (uint32_t j = threadIdx.x + 64; j < nt; j += 64) add_from<C>(acc, &src[j]);
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 32; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            Pt a = sh[threadIdx.x];
-            add_from<C>(a, &sh[threadIdx.x + s]);
-            sh[threadIdx.x] = a;
-        }
+    // round 6: a bounded grid walks the sorted positions and STOPS at the first single-task bucket (the order is by population, largest first: every later
+    // position is single-task too) - for uniform scalars that is position 0, and the launch costs a few microseconds instead of one exiting workgroup per
+    // position that could in principle hold a multi-task bucket (63 k of them at 2^20 points: 0.03 ms)
+    const uint32_t thr = msm_fold_threshold(tbase, ntask, nb);
+    for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
+        const uint32_t cnt = count_sorted[i];
+        if (cnt <= seg) break;  // workgroup-uniform
+        const uint32_t nt = (cnt + seg - 1) / seg;
+        if (nt <= thr) continue;  // msm_fold_small_kernel's
+        const Pt* src = partial + tbase[i];
+        Pt acc = threadIdx.x < nt ? src[threadIdx.x] : C::identity();
+        for (uint32_t j = threadIdx.x + 64; j < nt; j += 64) add_from<C>(acc, &src[j]);
+        sh[threadIdx.x] = acc;
         __syncthreads();
+        for (int s = 32; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                Pt a = sh[threadIdx.x];
+                add_from<C>(a, &sh[threadIdx.x + s]);
+                sh[threadIdx.x] = a;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) buckets[order[i]] = sh[0];
+        __syncthreads();  // sh[] is free again
     }
-    if (threadIdx.x == 0) buckets[order[i]] = sh[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1086,14 +1093,14 @@ __global__ void __launch_bounds__(THREADS, 2) msm_rowcol_quad_kernel(const G1X28
     if (valid && slot % seg == 0) (col_pass ? cols : rows)[(size_t)set * (col_pass ? L : H) + out_idx] = sh[slot];
 }
 // term t of a set: t < lbits: column sums with bit t of l set; lbits <= t < lbits + hbits: row sums with bit (t - lbits) of h set; t = lbits + hbits
-// (= c - 1): every column sum.  Output: standard-limb XYZZ for the host, terms[set * c + t]
+// (= c - 1): every row sum.  Output: standard-limb XYZZ for the host, terms[set * c + t]
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) msm_bitsum_quad_kernel(const G1X28* __restrict__ rows, const G1X28* __restrict__ cols, RowColPlan P,
                                                                   XyzzT<FpOps>* __restrict__ terms) {
     __shared__ G1X28 sh[THREADS];
     const uint32_t c_terms = P.lbits + P.hbits + 1;
     const uint32_t set = blockIdx.x / c_terms, t = blockIdx.x % c_terms;
-    const bool total = t == c_terms - 1, from_cols = total || t < P.lbits;
+    const bool total = t == c_terms - 1, from_cols = !total && t < P.lbits;  // the plain sum of the set over its ROW sums: H <= L of them (one tree level less)
     const uint32_t n_src = 1u << (from_cols ? P.lbits : P.hbits), bit = total ? 0u : (from_cols ? t : t - P.lbits);
     const G1X28* src = (from_cols ? cols : rows) + (size_t)set * n_src;
     const uint32_t n_leaves = total ? n_src : n_src / 2;
@@ -1451,8 +1458,8 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
         ProfScope ps(ctx, "msm_sort_buckets");
         size_t t = tmp;
         hipError_t e = msm_tuned_sort()
-                           ? rocprim::radix_sort_pairs_desc<SortCfg32>(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 16, ctx->stream)
-                           : rocprim::radix_sort_pairs_desc(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 16, ctx->stream);
+                           ? rocprim::radix_sort_pairs_desc<SortCfg32>(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 8, ctx->stream)
+                           : rocprim::radix_sort_pairs_desc(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 8, ctx->stream);
         if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
     }
     BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.order, nb, seg, A.count_s, A.ntask);
@@ -1511,7 +1518,7 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
             return BZK_OK;
         }
     }
-    BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(n_big), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, seg, A.partial, buckets);
+    BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(std::min<uint32_t>(n_big, 2048u)), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_big, seg, A.partial, buckets);
     BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_pos, seg,
                A.partial, buckets);
     return BZK_OK;
@@ -1749,7 +1756,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         return (uint32_t)std::max<uint64_t>(32, len_ / (target - nb_));
     };
     if (!table || folded) seg = std::min(seg, enough_tasks(seg, len_max, nb_max));
-    static const uint32_t seg_override = [] { const char* e = getenv("BZK_MSM_SEG"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 8 && v <= 256 ? v : 0); }();
+    static const uint32_t seg_override = [] { const char* e = getenv("BZK_MSM_SEG"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 8 && v <= (int)MSM_SEG_MAX ? v : 0); }();
     if (seg_override) seg = seg_override;  // A/B runs
     const uint32_t seg_dd = 8;  // group sums are latency-bound (a 7 k-member group of bits is one bucket): short serial runs
     // capacity of the per-task partial sums: sized for the shortest run length any later adjustment can pick (32; 64 for tables)

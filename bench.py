@@ -1232,7 +1232,10 @@ def main():
             proofs = {"error": repr(e)}
         if world > 1:
             mine = torch.tensor([float(proofs.get("proofs_per_s_ring", float("nan"))), float(proofs.get("proofs_per_s_pipelined", float("nan"))),
-                                 float(proofs.get("witness_cpu_s", float("nan"))), float(proofs.get("prover_host_cpu_s_per_proof", float("nan")))],
+                                 # what a witness costs THIS rank's live producers: the deferred generator's figure where they use it (the N > 1 default)
+                                 float((proofs.get("deferred") or {}).get("witness_cpu_s", float("nan")) if (proofs.get("deferred") or {}).get("live_producers_use_it")
+                                       else proofs.get("witness_cpu_s", float("nan"))),
+                                 float(proofs.get("prover_host_cpu_s_per_proof", float("nan")))],
                                 dtype=torch.float64, device="cpu" if dry else dev)
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
