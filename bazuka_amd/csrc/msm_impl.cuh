@@ -1092,33 +1092,57 @@ __global__ void __launch_bounds__(THREADS, 2) msm_rowcol_quad_kernel(const G1X28
     g1_quad_tree_seg<THREADS>(sh, (int)seg);
     if (valid && slot % seg == 0) (col_pass ? cols : rows)[(size_t)set * (col_pass ? L : H) + out_idx] = sh[slot];
 }
-// term t of a set: t < lbits: column sums with bit t of l set; lbits <= t < lbits + hbits: row sums with bit (t - lbits) of h set; t = lbits + hbits
-// (= c - 1): every row sum.  Output: standard-limb XYZZ for the host, terms[set * c + t]
+// Terms of a set.  Bit k of the bucket index contributes S_k = (k < lbits: the column sums with bit k of l set; else: the row sums with bit k - lbits of h
+// set); two ADJACENT bits share a workgroup of 2 x THREADS lanes (THREADS = 128: the two trees' 2 x 128 points are the 56 KiB of LDS a workgroup may declare) - each half runs the tree of one bit, then one quad forms D_j = S_2j + 2 S_(2j+1) (a
+// doubling and an addition: ~12 us) - so the host's Horner adds half as many points (an XYZZ addition costs a host core 0.5 us: 272 of them were 0.14 of
+// the step's 3.5 ms).  Terms of a set, standard-limb XYZZ at terms[set * n_terms + t]:  t < n_pairs: D_t (bit position 2 t);  t = n_pairs: the plain sum
+// of the set (every row sum; position 0).  n_pairs = ceil((c - 1) / 2).
+__host__ __device__ inline uint32_t msm_bitsum_pairs(const RowColPlan& P) { return (P.lbits + P.hbits + 1u) / 2u; }
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS) msm_bitsum_quad_kernel(const G1X28* __restrict__ rows, const G1X28* __restrict__ cols, RowColPlan P,
-                                                                  XyzzT<FpOps>* __restrict__ terms) {
-    __shared__ G1X28 sh[THREADS];
-    const uint32_t c_terms = P.lbits + P.hbits + 1;
-    const uint32_t set = blockIdx.x / c_terms, t = blockIdx.x % c_terms;
-    const bool total = t == c_terms - 1, from_cols = !total && t < P.lbits;  // the plain sum of the set over its ROW sums: H <= L of them (one tree level less)
-    const uint32_t n_src = 1u << (from_cols ? P.lbits : P.hbits), bit = total ? 0u : (from_cols ? t : t - P.lbits);
+__global__ void __launch_bounds__(2 * THREADS) msm_bitsum_quad_kernel(const G1X28* __restrict__ rows, const G1X28* __restrict__ cols, RowColPlan P,
+                                                                      XyzzT<FpOps>* __restrict__ terms) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ G1X28 sh[2 * THREADS];
+    const uint32_t n_bits = P.lbits + P.hbits, n_pairs = msm_bitsum_pairs(P), n_terms = n_pairs + 1u;
+    const uint32_t set = blockIdx.x / n_terms, t = blockIdx.x % n_terms;
+    const uint32_t half = threadIdx.x / THREADS, tid = threadIdx.x % THREADS;  // half 0: bit 2 t (or the plain sum), half 1: bit 2 t + 1
+    const bool total = t == n_pairs;
+    const uint32_t k = 2u * t + half;
+    const bool have = total ? half == 0 : k < n_bits;  // an odd bit count leaves the last pair's upper half empty
+    const bool from_cols = !total && k < P.lbits;
+    const uint32_t n_src = 1u << (from_cols ? P.lbits : P.hbits), bit = total ? 0u : (from_cols ? k : k - P.lbits);
     const G1X28* src = (from_cols ? cols : rows) + (size_t)set * n_src;
-    const uint32_t n_leaves = total ? n_src : n_src / 2;
+    const uint32_t n_leaves = !have ? 0u : (total ? n_src : n_src / 2);
     auto leaf_index = [&](uint32_t j) { return total ? j : ((((j >> bit) << 1) | 1u) << bit) | (j & ((1u << bit) - 1u)); };
     G1X28 acc = g1x28::identity();
-    if (threadIdx.x < n_leaves) {
-        acc = src[leaf_index(threadIdx.x)];
-        for (uint32_t j = threadIdx.x + THREADS; j < n_leaves; j += THREADS) {
+    if (tid < n_leaves) {
+        acc = src[leaf_index(tid)];
+        for (uint32_t j = tid + THREADS; j < n_leaves; j += THREADS) {
             const G1X28 q = src[leaf_index(j)];
             g1x28::add_full(acc, q);
         }
     }
-    sh[threadIdx.x] = acc;
+    G1X28* const my = sh + half * THREADS;
+    my[tid] = acc;
     __syncthreads();
-    int active = 1;
-    while (active < THREADS && (uint32_t)active < n_leaves) active <<= 1;
-    g1_quad_tree<THREADS>(sh, active);
-    if (threadIdx.x == 0) terms[(size_t)set * c_terms + t] = g1x28::to_std(sh[0]);
+    // both halves walk the same number of levels (the barriers are the workgroup's); a half whose tree is narrower idles through the wide levels
+    const uint32_t widest = 1u << (P.lbits > P.hbits ? P.lbits : P.hbits);
+    int levels_from = 1;
+    while (levels_from < THREADS && (uint32_t)levels_from < widest) levels_from <<= 1;
+    const int quad = (int)(tid >> 2), n_quads = THREADS / 4;
+    for (int s = levels_from / 2; s > 0; s >>= 1) {  // (slots beyond a half's leaves hold identities: their additions return at once)
+        for (int p = quad; p < s; p += n_quads) {
+            const G1X28 r = g1_add_quad(my[p], my[p + s]);
+            if ((tid & 3u) == 0) my[p] = r;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {  // one quad: D = S_lo + 2 S_hi
+        G1X28 r = sh[0];
+        if (!total && 2u * t + 1u < n_bits) r = g1_add_quad(r, g1_dbl_quad(sh[THREADS]));
+        if (threadIdx.x == 0) terms[(size_t)set * n_terms + t] = g1x28::to_std(r);
+    }
+#endif
 }
 
 template <class C, int THREADS>
@@ -1612,19 +1636,20 @@ static XyzzT<F> msm_horner_host(const XyzzT<F>* S, int count, int c, int w0) {
     return from_host_fast<F>(acc);
 }
 
-// Horner over the TERMS of the multiplication-free reduction (section 6b): window k (k < count) contributes T[k * c + t] at bit position
-// c (w0 + k) + t for t < c - 1 and its last term - the plain sum of the set - at position c (w0 + k).  The same c (count + w0) doublings as
-// msm_horner_host, count * c additions.  step: bits between consecutive bucket sets (c; c * wpl never occurs here: folded tables keep the old path)
+// Horner over the TERMS of the multiplication-free reduction (section 6b): bucket set k (k < count) contributes its n_pairs digit terms D_j = S_2j + 2 S_(2j+1)
+// at bit positions c (w0 + k) + 2 j and its last term - the plain sum of the set - at position c (w0 + k).  The same c (count + w0) doublings as
+// msm_horner_host, count * (n_pairs + 1) additions.
 template <class F>
 static XyzzT<F> msm_horner_terms_host(const XyzzT<F>* T, int count, int c, int w0) {
     typedef typename HostFast<F>::Ops H;
+    const int n_pairs = c / 2, n_terms = n_pairs + 1;  // ceil((c - 1) / 2)
     XyzzT<H> acc = xyzz_identity<H>();
     for (int k = count - 1; k >= 0; --k) {
-        const XyzzT<F>* t = T + (size_t)k * c;
+        const XyzzT<F>* t = T + (size_t)k * n_terms;
         for (int bit = c - 1; bit >= 0; --bit) {
             acc = xyzz_dbl<H>(acc);
-            if (bit < c - 1) xyzz_add<H>(acc, to_host_fast<F>(t[bit]));
-            if (bit == 0) xyzz_add<H>(acc, to_host_fast<F>(t[c - 1]));
+            if ((bit & 1) == 0 && bit / 2 < n_pairs) xyzz_add<H>(acc, to_host_fast<F>(t[bit / 2]));
+            if (bit == 0) xyzz_add<H>(acc, to_host_fast<F>(t[n_pairs]));
         }
     }
     for (int d = 0; d < c * w0; ++d) acc = xyzz_dbl<H>(acc);
@@ -1772,14 +1797,15 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     total += ws_pad(((size_t)group * (per_win_out / C::WSUM_THREADS + 1)) * sizeof(Pt));
     total += ws_pad((size_t)w_total * sizeof(StdPt));
     const size_t n_sets_max = (table && !folded) ? 1 : (size_t)group;
-    if (bitsum) total += ws_pad(n_sets_max * rc_per_set * sizeof(Pt)) + ws_pad(n_sets_max * (size_t)c * sizeof(StdPt));
+    const size_t n_terms = (size_t)c / 2 + 1;  // per bucket set: ceil((c - 1) / 2) digit terms + the plain sum (msm_bitsum_quad_kernel)
+    if (bitsum) total += ws_pad(n_sets_max * rc_per_set * sizeof(Pt)) + ws_pad(n_sets_max * n_terms * sizeof(StdPt));
     if (C::CONVERT_BASES && !table) total += ws_pad((size_t)((prep ? 0 : n) + (size_t)m_max * E) * sizeof(typename C::DevAff));
     if (dedup) {
         total += 11 * ws_pad(n * 4) + ws_pad(n * 32) + ws_pad((size_t)m_max * sizeof(typename C::Fld));
     }
     total += ws_pad(tmp) + 8192;
     BZK_TRY(ws_reserve(ctx, total));
-    BZK_TRY(pinned_reserve(ctx, std::max<size_t>((size_t)w_total, bitsum ? n_sets_max * (size_t)c : 0) * sizeof(StdPt) + 64));
+    BZK_TRY(pinned_reserve(ctx, std::max<size_t>((size_t)w_total, bitsum ? n_sets_max * n_terms : 0) * sizeof(StdPt) + 64));
     WsCursor cur(ctx->ws);
     uint32_t* keys = cur.take<uint32_t>(len_max);
     uint32_t* vals = cur.take<uint32_t>(len_max);
@@ -1800,7 +1826,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     Pt* wpart = cur.take<Pt>((size_t)group * (per_win_out / C::WSUM_THREADS + 1));
     StdPt* win_out = cur.take<StdPt>(w_total);
     Pt* rc_buf = bitsum ? cur.take<Pt>(n_sets_max * rc_per_set) : nullptr;           // row sums of every set, then the column sums
-    StdPt* terms_out = bitsum ? cur.take<StdPt>(n_sets_max * (size_t)c) : nullptr;
+    StdPt* terms_out = bitsum ? cur.take<StdPt>(n_sets_max * n_terms) : nullptr;
     const void* bases = table ? table->data : bases_raw;
     typename C::DevAff* conv = nullptr;
     typename C::DevAff* sums_aff = nullptr;  // de-duplication group sums in affine form: base indices n .. n + m_max
@@ -1926,7 +1952,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
 
     const int mont = (flags & BZK_F_CANONICAL) ? 0 : 1;
     const bool wiv = !wiv_off && !table && group <= 16 && (uint64_t)n + m_max < ((uint64_t)1 << 27);
-    std::vector<StdPt> wsum((size_t)(w_end - w_begin) * (bitsum ? (size_t)c : 1));  // window sums, or (section 6b) the c terms of every bucket set
+    std::vector<StdPt> wsum((size_t)(w_end - w_begin) * (bitsum ? n_terms : 1));  // window sums, or (section 6b) the terms of every bucket set
     for (int wb = w_begin; wb < w_end; wb += group) {
         const int wc = std::min(group, w_end - wb);
         const uint64_t len = (uint64_t)wc * n_eff * (folded ? (uint64_t)levels : (uint64_t)E);
@@ -1957,15 +1983,15 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                 BZK_LAUNCH(ctx, "msm_rowcol", (msm_rowcol_quad_kernel<256>), dim3((unsigned)n_red_win * (rc_plan.wgs_r + rc_plan.wgs_c)), dim3(256), 0,
                            (const G1X28*)buckets, half, rc_plan, rows, cols);
                 heavy.leave();
-                BZK_LAUNCH(ctx, "msm_bitsum", (msm_bitsum_quad_kernel<256>), dim3((unsigned)n_red_win * (unsigned)c), dim3(256), 0, (const G1X28*)rows,
+                BZK_LAUNCH(ctx, "msm_bitsum", (msm_bitsum_quad_kernel<128>), dim3((unsigned)n_red_win * (unsigned)n_terms), dim3(256), 0, (const G1X28*)rows,
                            (const G1X28*)cols, rc_plan, (XyzzT<FpOps>*)terms_out);
-                BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, terms_out, (size_t)n_red_win * c * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
+                BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, terms_out, (size_t)n_red_win * n_terms * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
                 BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (table && !folded) {  // one bucket set fed by every level of the table: its c terms are the whole result
                     result = msm_horner_terms_host<F>((const StdPt*)ctx->pinned, 1, c, 0);
                     return BZK_OK;
                 }
-                memcpy(&wsum[(size_t)(wb - w_begin) * c], ctx->pinned, (size_t)wc * c * sizeof(StdPt));
+                memcpy(&wsum[(size_t)(wb - w_begin) * n_terms], ctx->pinned, (size_t)wc * n_terms * sizeof(StdPt));
                 continue;
             }
         }

@@ -53,6 +53,21 @@ def test_status_strings():
     assert lib.bzk_abi_version() == 1
 
 
+def test_staging_entries_refuse_bad_arguments_without_touching_a_device():
+    """argument checks of the round-5 / 6 staging entries (no GPU needed: they return before any device call); synthesize refuses a record_matrices
+    value outside {0, 1, BZK_SYNTH_DEFER}"""
+    import ctypes as C
+    from bazuka_amd import load_library
+    lib = load_library()
+    n = C.c_uint64(7)
+    assert lib.bzk_staged_read(None, 0, None, 0, C.byref(n)) == -1 and n.value == 7     # BZK_E_ARG, nothing written
+    assert lib.bzk_staged_wait(None) == -1
+    lib.bzk_staged_free(None)                                                           # a no-op
+    assert lib.bzk_r1cs_stage(None, None, None) == -1
+    out = C.c_void_p()
+    assert lib.bzk_mpn_work_synthesize(None, None, None, 0, 3, C.byref(out)) == -1
+
+
 def test_host_g1_sum_matches_oracle(co):
     """bzk_g1_sum / bzk_g2_sum are host-side (no GPU): fold packed points like the multi-GPU combine."""
     from bazuka_amd import load_library

@@ -2,8 +2,8 @@
 
     sum_b (b + 1) B_b  =  S_tot + sum_k 2^k S_k,    S_k = sum of the buckets whose index has bit k set
 
-with b = L h + l: S_k from COLUMN sums (k < log2 L) or ROW sums (k >= log2 L), the weights applied by the host's Horner at bit positions
-(msm_horner_terms_host).  This file restates the kernels' index maps (msm_rowcol_plan, the lane -> bucket maps of msm_rowcol_quad_kernel, leaf_index of
+with b = L h + l: S_k from COLUMN sums (k < log2 L) or ROW sums (k >= log2 L); adjacent bits are combined on the device (D_j = S_2j + 2 S_(2j+1)) and the
+remaining weights applied by the host's Horner at bit positions 2 j (msm_horner_terms_host).  This file restates the kernels' index maps (msm_rowcol_plan, the lane -> bucket maps of msm_rowcol_quad_kernel, leaf_index of
 msm_bitsum_quad_kernel, the term positions of the Horner) in Python over the group Z - a MODEL of the device code, kept beside it so that the identity and
 the maps are checked on the GPU-less box for every window size the path takes (c = 11 .. 16 and the static table's c = 20); the device code itself is pinned
 by the GPU parity tests (every MSM result of tests/test_gpu_msm.py, test_gpu_fullsize.py, test_gpu_endo.py goes through it).
@@ -60,34 +60,42 @@ def rowcol(b, P):
 
 
 def bitsums(rows, cols, P):
-    """msm_bitsum_quad_kernel: term t of a set"""
-    c_terms = P["lbits"] + P["hbits"] + 1
-    out = []
-    for t in range(c_terms):
-        total = t == c_terms - 1
-        from_cols = not total and t < P["lbits"]
+    """msm_bitsum_quad_kernel: term t < n_pairs of a set is D_t = S_2t + 2 S_(2t+1) (two adjacent bits, one workgroup half each); term n_pairs is the plain sum"""
+    n_bits = P["lbits"] + P["hbits"]
+    n_pairs = (n_bits + 1) // 2
+
+    def bit_sum(k):
+        from_cols = k < P["lbits"]
         n_src = 1 << (P["lbits"] if from_cols else P["hbits"])
-        bit = 0 if total else (t if from_cols else t - P["lbits"])
+        bit = k if from_cols else k - P["lbits"]
         src = cols if from_cols else rows
-        n_leaves = n_src if total else n_src // 2
-        leaf_index = (lambda j: j) if total else (lambda j: ((((j >> bit) << 1) | 1) << bit) | (j & ((1 << bit) - 1)))
-        idx = [leaf_index(j) for j in range(n_leaves)]
-        assert len(set(idx)) == n_leaves and all(total or (i >> bit) & 1 for i in idx) and max(idx) < n_src
-        out.append(sum(src[i] for i in idx))
+        idx = [((((j >> bit) << 1) | 1) << bit) | (j & ((1 << bit) - 1)) for j in range(n_src // 2)]
+        assert len(set(idx)) == n_src // 2 and all((i >> bit) & 1 for i in idx) and max(idx) < n_src
+        return sum(src[i] for i in idx)
+
+    out = []
+    for t in range(n_pairs):
+        d = bit_sum(2 * t)
+        if 2 * t + 1 < n_bits:          # an odd bit count leaves the last pair's upper half empty
+            d += 2 * bit_sum(2 * t + 1)
+        out.append(d)
+    out.append(sum(rows))               # the plain sum over the ROW sums
     return out
 
 
 def horner_terms(terms, count, c, w0):
     """msm_horner_terms_host"""
+    n_pairs = c // 2
+    n_terms = n_pairs + 1
     acc = 0
     for k in range(count - 1, -1, -1):
-        t = terms[k * c:(k + 1) * c]
+        t = terms[k * n_terms:(k + 1) * n_terms]
         for bit in range(c - 1, -1, -1):
             acc *= 2
-            if bit < c - 1:
-                acc += t[bit]
+            if bit % 2 == 0 and bit // 2 < n_pairs:
+                acc += t[bit // 2]
             if bit == 0:
-                acc += t[c - 1]
+                acc += t[n_pairs]
     return acc << (c * w0)
 
 
@@ -105,7 +113,7 @@ def test_row_column_bit_sums_and_the_horner_positions_give_the_weighted_bucket_s
         assert sum(rows) == sum(cols) == sum(b)
         terms += bitsums(rows, cols, P)
         want += sum((i + 1) * x for i, x in enumerate(b)) << (c * (w + w0))
-    assert len(terms) == W * c
+    assert len(terms) == W * (c // 2 + 1)
     assert horner_terms(terms, W, c, w0) == want
 
 

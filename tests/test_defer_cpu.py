@@ -102,3 +102,17 @@ def test_a_wrong_sibling_is_reported_by_the_fill_not_by_the_host_scan():
         if flags:
             return
     pytest.skip("no single-byte mutation in the sampled range produced a decodable work with a deferred violation")
+
+
+def test_record_matrices_outside_its_three_values_is_refused():
+    """2 became BZK_SYNTH_DEFER in round 5, so `non-zero = matrices` no longer holds - any other value is a caller's mistake, not a silent
+    witness-only instance"""
+    import ctypes as C
+    dec = L.MpnWork.decode(S.make_work("update_3_3_1"))
+    for bad in (3, -1, 7):
+        h = C.c_void_p()
+        assert dec.lib.bzk_mpn_work_synthesize(dec.h, S.PROVER, None, 1, bad, C.byref(h)) == -1 and not h.value
+    for ok in (0, 1, 2):
+        h = C.c_void_p()
+        assert dec.lib.bzk_mpn_work_synthesize(dec.h, S.PROVER, None, 1, ok, C.byref(h)) == 0 and h.value
+        L.R1cs(h).free()
