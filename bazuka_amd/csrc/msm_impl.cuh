@@ -1983,6 +1983,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                 BZK_LAUNCH(ctx, "msm_rowcol", (msm_rowcol_quad_kernel<256>), dim3((unsigned)n_red_win * (rc_plan.wgs_r + rc_plan.wgs_c)), dim3(256), 0,
                            (const G1X28*)buckets, half, rc_plan, rows, cols);
                 heavy.leave();
+                // halves of 128 lanes: with 256-lane halves (112 KiB of static LDS - the runtime takes it) a workgroup saves a tree level and loses more to its
+                // eight waves sharing a CU: 0.166 - 0.170 against 0.150 - 0.153 ms, same box, alternating (profiles/r06_run11_bitsum_wide_negative.txt)
                 BZK_LAUNCH(ctx, "msm_bitsum", (msm_bitsum_quad_kernel<128>), dim3((unsigned)n_red_win * (unsigned)n_terms), dim3(256), 0, (const G1X28*)rows,
                            (const G1X28*)cols, rc_plan, (XyzzT<FpOps>*)terms_out);
                 BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, terms_out, (size_t)n_red_win * n_terms * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
