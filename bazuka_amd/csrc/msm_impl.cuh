@@ -307,16 +307,18 @@ static __global__ void __launch_bounds__(256) msm_offsets_wiv_kernel(const uint3
 
 // count[g] = end[g] - start[g] (in place over `endx`), iota[g] = g
 static __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* __restrict__ start, uint32_t* __restrict__ endx_count,
-                                                        uint32_t* __restrict__ iota, uint32_t* __restrict__ ckey, uint32_t nb) {
+                                                        uint32_t* __restrict__ iota, uint32_t* __restrict__ ckey, uint32_t nb, uint32_t clamp) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nb) return;
     const uint32_t c = endx_count[g] - start[g];
     endx_count[g] = c;
     iota[g] = g;
-    // 8-bit sort key of the population order (round 6; 16 bits = two radix passes until then): a bucket of more than MSM_SEG_MAX = 254 entries is cut into
-    // equal tasks of <= seg whatever its size, so the mutual order of such buckets does not matter - only that they all come before the single-task ones,
-    // which the clamp at 255 > seg guarantees (the true counts are gathered through the order)
-    ckey[g] = c < 255u ? c : 255u;
+    // sort key of the population order, clamped (the true counts are gathered through the order).  clamp = 255 (ONE 8-bit radix pass) for calls whose mean
+    // population is small - the 2^20-point headline: 32 per bucket -: a bucket of more than MSM_SEG_MAX = 254 entries is cut into equal tasks of <= seg whatever
+    // its size, and the clamp keeps all such buckets before the single-task ones.  clamp = 65535 (two passes) where buckets are full (2^22 points and up): there
+    // the order among the multi-task buckets decides whether the lanes of a wave walk runs of equal length - with 8-bit keys every bucket of a 2^24-point call
+    // tied at 255 and the accumulation ran 21 % longer (39.8 -> 48.3 ms: runs of 256 beside runs of 171; round 6, runs 9 / 12)
+    ckey[g] = c < clamp ? c : clamp;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,8 +387,8 @@ __global__ void __launch_bounds__(64) msm_table_build_kernel(const void* __restr
 static constexpr size_t MSM_GATHER_PAD = 256;
 static constexpr uint32_t MSM_SEG_MAX = 254;  // longest serial run of mixed adds one lane executes (< 255: see msm_count_kernel's sort key)
 
-// buckets arrive ordered by min(count, 255) (ONE 8-bit radix pass: buckets beyond 254 entries are cut into tasks of <= 254 anyway, their
-// mutual order does not matter); the true counts are gathered through the order here
+// buckets arrive ordered by their clamped count (msm_count_kernel: 255 for sparsely, 65535 for densely populated calls); the true counts are
+// gathered through the order here
 static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order,
                                                                uint32_t nb, uint32_t seg, uint32_t* __restrict__ count_sorted,
                                                                uint32_t* __restrict__ ntask) {
@@ -1477,13 +1479,17 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     }
     // counts, identity permutation and the clamped population keys in one pass: A.ntask holds the keys until msm_ntask overwrites it,
     // A.tbase receives the (unused) sorted keys
-    BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, A.ntask, nb);
+    // one radix pass over 8-bit keys while the mean population is small, two over 16-bit keys otherwise (msm_count_kernel)
+    const bool small_pop = len / nb <= 64;
+    const uint32_t pop_clamp = small_pop ? 255u : 65535u;
+    const int pop_bits = small_pop ? 8 : 16;
+    BZK_LAUNCH(ctx, "msm_count", msm_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.start, A.count, A.iota, A.ntask, nb, pop_clamp);
     {
         ProfScope ps(ctx, "msm_sort_buckets");
         size_t t = tmp;
         hipError_t e = msm_tuned_sort()
-                           ? rocprim::radix_sort_pairs_desc<SortCfg32>(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 8, ctx->stream)
-                           : rocprim::radix_sort_pairs_desc(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, 8, ctx->stream);
+                           ? rocprim::radix_sort_pairs_desc<SortCfg32>(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, pop_bits, ctx->stream)
+                           : rocprim::radix_sort_pairs_desc(tmp_buf, t, A.ntask, A.tbase, A.iota, A.order, (size_t)nb, 0, pop_bits, ctx->stream);
         if (e != hipSuccess) { ctx->last_error = std::string("radix_sort_pairs_desc: ") + hipGetErrorString(e); return BZK_E_DEVICE; }
     }
     BZK_LAUNCH(ctx, "msm_ntask", msm_ntask_kernel, dim3((nb + 255) / 256), dim3(256), 0, A.count, A.order, nb, seg, A.count_s, A.ntask);
