@@ -130,12 +130,14 @@ int32_t ntt_run(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inverse, int c
 int32_t ntt_h_chain(bzk_ctx* ctx, void* a, void* b, void* c, uint32_t log_m);              // ntt.hip: the h polynomial's 7 transforms, fused
 // msm_g1.hip / msm_g2.hip: windows [w_begin, w_end) (w_end < 0: all) of an MSM over a resident base set (or raw bases when `bases` is
 // null); the window sums stay in DEVICE memory at d_win as standard-limb XYZZ points (G1 192 B, G2 384 B each), in stream order,
-// nothing is read back.  info = {c, w_total, w_begin, w_end}.  *_horner_packed: host Horner sum_k 2^(c (w0 + k)) S[k] -> packed point
+// nothing is read back.  info = {c, w_total, w_begin, w_end, terms per bucket set (0: window sums; G1 since round 6: msm_g1_window_terms)}.  *_horner_packed: host Horner sum_k 2^(c (w0 + k)) S[k] -> packed point
 int32_t msm_g1_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
-                           int w_begin, int w_end, void* d_win, int32_t info[4]);
+                           int w_begin, int w_end, void* d_win, int32_t info[5]);
 int32_t msm_g2_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
-                           int w_begin, int w_end, void* d_win, int32_t info[4]);
+                           int w_begin, int w_end, void* d_win, int32_t info[5]);
 int msm_window_bits(uint64_t n);
+int msm_g1_window_terms(uint64_t n);  // 0: a window-range G1 call leaves window sums at d_win; k > 0: the k terms of every bucket set (info[4] of the call agrees)
+int32_t g1_horner_terms_packed(const void* T, int count, int c, int w0, uint8_t* out);
 int32_t g1_horner_packed(const void* S, int count, int c, int w0, uint8_t* out);
 int32_t g2_horner_packed(const void* S, int count, int c, int w0, uint8_t* out);
 static inline size_t ws_pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }

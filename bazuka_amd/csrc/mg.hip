@@ -50,6 +50,7 @@ using bzk::mgx::slots_per_rank;
 using bzk::mgx::window_range;
 constexpr int MG_MAX_W = bzk::mgx::MAX_W;
 constexpr size_t MG_SLOT_G2 = bzk::mgx::SLOT_G2;
+constexpr size_t MG_SLOT_MAX = bzk::mgx::SLOT_MAX;  // per window: a G2 window sum, or the <= 11 terms of a G1 bucket set (round 6)
 typedef bzk::mgx::Hdr MgHdr;
 constexpr size_t MG_HDR = sizeof(MgHdr);
 static_assert(BZK_MG_UID_BYTES == bzk::mgx::UID_BYTES, "group id");
@@ -204,14 +205,14 @@ int32_t run_all(bzk_mg* mg, const std::function<int32_t(int)>& fn) {
 }
 
 int32_t mg_alloc_buffers(bzk_mg* mg) {
-    const size_t slot_all = (size_t)mg->world * (MG_MAX_W * MG_SLOT_G2 + MG_HDR);
+    const size_t slot_all = (size_t)mg->world * (MG_MAX_W * MG_SLOT_MAX + MG_HDR);
     mg->d_send.assign(mg->n_local, nullptr);
     mg->d_all.assign(mg->n_local, nullptr);
     mg->d_stage.assign(mg->n_local, nullptr);
     mg->d_stage_bytes.assign(mg->n_local, 0);
     for (int i = 0; i < mg->n_local; ++i) {
         if (hipSetDevice(mg->devices[i]) != hipSuccess) return mg_fail(mg, BZK_E_DEVICE, "hipSetDevice");
-        if (hipMalloc(&mg->d_send[i], (size_t)MG_MAX_W * MG_SLOT_G2 + MG_HDR) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "exchange buffer");
+        if (hipMalloc(&mg->d_send[i], (size_t)MG_MAX_W * MG_SLOT_MAX + MG_HDR) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "exchange buffer");
         if (hipMalloc(&mg->d_all[i], slot_all) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "exchange buffer");
     }
     if (hipHostMalloc((void**)&mg->h_win, slot_all, hipHostMallocPortable) != hipSuccess) return mg_fail(mg, BZK_E_ALLOC, "pinned exchange buffer");
@@ -331,9 +332,14 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
     if (!mg || !B || !out || (n && !scalars_dev && !scalars_host)) return BZK_E_ARG;
     if (B->g2 != g2 || n > B->n || (int)B->per_dev.size() != mg->n_local) return BZK_E_ARG;
     std::lock_guard<std::mutex> call(mg->call_mutex);
-    const size_t sz = g2 ? MG_SLOT_G2 : MG_SLOT_G2 / 2;
+    // what a rank leaves per window: a window sum (G2: 384 bytes), or - G1 since round 6 - the TERMS of the window's bucket set (msm_impl.cuh section 6b:
+    // c / 2 + 1 points of 192 bytes; a function of n and the environment alone, so every rank sizes its block alike): the ranks' chunked running sums with
+    // their 41-link chains (0.6 + 0.2 ms per rank whatever the group's size) are gone from the window-sharded G1 MSM as they are from the single-GPU one
+    const int n_terms = g2 ? 0 : bzk::msm_g1_window_terms(n ? n : 1);
+    const size_t sz = g2 ? MG_SLOT_G2 : (size_t)(n_terms ? n_terms : 1) * (MG_SLOT_G2 / 2);
+    if (sz > MG_SLOT_MAX) return mg_fail(mg, BZK_E_INTERNAL, "terms per window");
     auto windows = g2 ? bzk::msm_g2_windows_dev : bzk::msm_g1_windows_dev;
-    auto horner = g2 ? bzk::g2_horner_packed : bzk::g1_horner_packed;
+    auto horner = g2 ? bzk::g2_horner_packed : (n_terms ? bzk::g1_horner_terms_packed : bzk::g1_horner_packed);
     // the window count is a function of n alone (bzk_msm_window_count): every rank derives the same partition without talking
     const int W = (int)bzk_msm_window_count(n ? n : 1);
     if (W > MG_MAX_W) return mg_fail(mg, BZK_E_INTERNAL, "window count");
@@ -365,11 +371,12 @@ int32_t mg_msm(bzk_mg* mg, const bzk_mg_bases* B, int g2, const void* const* sca
 #endif
             const void* sc = scalars_dev ? scalars_dev[i] : nullptr;
             if (!scalars_dev && n) BZK_TRY(stage_scalars(mg, i, scalars_host, n, &sc));
-            int32_t info[4] = {0, 0, 0, 0};
+            int32_t info[5] = {0, 0, 0, 0, 0};
             // a rank without windows (world > W) still takes part in the exchange
             if (hi > lo && n) {
                 BZK_TRY(windows(c, B->per_dev[i], nullptr, sc, n, flags, lo, hi, mg->d_send[i], info));
                 if (info[1] != W) { c->last_error = "bzk_mg: window count disagrees with bzk_msm_window_count"; return BZK_E_INTERNAL; }
+                if (info[4] != n_terms) { c->last_error = "bzk_mg: terms per window disagree with msm_g1_window_terms"; return BZK_E_INTERNAL; }
                 cs[i] = info[0];
             }
             return BZK_OK;

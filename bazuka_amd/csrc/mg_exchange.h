@@ -23,6 +23,9 @@ namespace mgx {
 
 constexpr int MAX_W = 64;          // windows of a call (c >= 4 -> W <= 64)
 constexpr size_t SLOT_G2 = 384;    // bytes of one standard-limb XYZZ window sum (G2; G1 = 192)
+// bytes a rank may publish per window: G2 one window sum; G1 since round 6 the TERMS of the window's bucket set (multiplication-free reduction, msm_impl.cuh
+// section 6b: c / 2 + 1 <= 11 points of 192 bytes) - the ranks stop before any per-window combination and the host's Horner takes the terms at their bit positions
+constexpr size_t SLOT_MAX = 11 * 192;
 constexpr int MAX_WORLD = 64;
 constexpr int UID_BYTES = 128;
 
@@ -61,13 +64,13 @@ struct ShmHeader {
 };
 
 // single node by contract: a segment named after the group id, double-buffered (parity of the call's sequence number), one slot per rank and parity:
-// [Hdr | the rank's window sums]
+// [Hdr | the rank's window sums or terms]
 struct ShmExchange {
     ShmHeader* shm = nullptr;
     size_t bytes = 0;
     int world = 0, rank = 0;
     std::string name;
-    static constexpr size_t RANK_BYTES = (size_t)MAX_W * SLOT_G2 + sizeof(Hdr);
+    static constexpr size_t RANK_BYTES = (size_t)MAX_W * SLOT_MAX + sizeof(Hdr);
 
     static std::string name_of(const uint8_t uid[UID_BYTES]) {
         char nm[64];

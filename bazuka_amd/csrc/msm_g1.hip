@@ -106,9 +106,13 @@ int32_t bzk_msm_bases_info(const bzk_msm_bases* bases, uint64_t* n, int32_t* for
 // hooks for mg.hip / groth16.hip (not part of the C ABI)
 namespace bzk {
 int32_t msm_g1_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
-                           int w_begin, int w_end, void* d_win, int32_t info[4]) {
+                           int w_begin, int w_end, void* d_win, int32_t info[5]) {
     return msm_windows_dev<G1Fast>(ctx, (const MsmBases*)bases, bases_raw, scalars, n, flags, w_begin, w_end, d_win, info);
 }
+// what a window-range call over n points leaves per bucket set at d_win: 0 = one window sum, k > 0 = the k terms of the multiplication-free reduction
+// (msm_impl.cuh section 6b) - a function of n and the process's environment alone, so every rank of a device group sizes its exchange alike
+int msm_g1_window_terms(uint64_t n) { return msm_terms_per_set<G1Fast>(msm_window_bits(n)); }
+int32_t g1_horner_terms_packed(const void* T, int count, int c, int w0, uint8_t* out) { return horner_terms_packed<FpOps>(T, count, c, w0, out); }
 int msm_window_bits(uint64_t n) {  // the window size behind bzk_msm_window_count(n): what a call that names a window range runs with
     int c = msm_pick_c(n ? n : 1);
     if (const char* e = getenv("BZK_MSM_C")) {

@@ -71,7 +71,7 @@ int32_t bzk_msm_g2_bases_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, c
 // hooks for mg.hip / groth16.hip (not part of the C ABI)
 namespace bzk {
 int32_t msm_g2_windows_dev(bzk_ctx* ctx, const bzk_msm_bases* bases, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
-                           int w_begin, int w_end, void* d_win, int32_t info[4]) {
+                           int w_begin, int w_end, void* d_win, int32_t info[5]) {
     return msm_windows_dev<G2Fast>(ctx, (const MsmBases*)bases, bases_raw, scalars, n, flags, w_begin, w_end, d_win, info);
 }
 int32_t g2_horner_packed(const void* S, int count, int c, int w0, uint8_t* out) { return horner_packed<Fp2Ops>(S, count, c, w0, out); }

@@ -1626,7 +1626,18 @@ struct MsmWinOut {
     void* d_win = nullptr;
     int c = 0, w_total = 0, w_begin = 0, w_end = 0;  // filled in by msm_run
     bool single = false;                             // full static table: d_win[0] is the result itself
+    // round 6: 0 = d_win holds one window SUM per bucket set; n > 0 = it holds the n TERMS of every bucket set (multiplication-free reduction, section 6b:
+    // the caller combines them with msm_horner_terms_host) - msm_terms_per_set<C>(c) says which before the call, so that ranks size their exchange alike
+    int terms_per_set = 0;
 };
+// does the multiplication-free reduction (section 6b) serve this curve at window size c?  G1 with 11 <= c <= 21; env BZK_MSM_BITSUM=0: never (A/B)
+template <class C>
+static bool msm_bitsum_applies(int c) {
+    static const bool on = [] { const char* e = getenv("BZK_MSM_BITSUM"); return e ? atoi(e) != 0 : true; }();
+    return on && !C::PARK_REDUCE && c >= 11 && c <= 21;
+}
+template <class C>
+static int msm_terms_per_set(int c) { return msm_bitsum_applies<C>(c) ? c / 2 + 1 : 0; }
 
 // Horner over window sums on the host: result = sum_k 2^(c (w0 + k)) S[k].  c * (count + w0) doublings that nothing can overlap
 // with - they run on the 6 x 64-bit host field of host_fp64.h (round 3: 0.63 -> 0.45 us per doubling, same values).
@@ -1734,13 +1745,12 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     const uint32_t ch2 = std::min<uint32_t>(pair_tails ? pair_l2_ch : quad_l2 ? quad_l2_ch : 8u, per_win);
     const bool two_level = per_win >= 64 && (ctx->msm_reduce2 > 0 || (ctx->msm_reduce2 == 0 && ((flags & BZK_F_THROUGHPUT) || pair_tails)));
     const uint32_t per_win_out = two_level ? per_win + per_win / ch2 : per_win;  // chunk results per window handed to the window sums
-    // round 6: the multiplication-free reduction (section 6b: row / column sums, bit sums, the weights in the host's Horner) - G1, whole results only (a
-    // caller that wants WINDOW sums on the device - the device groups - keeps the chunked running sum).  env BZK_MSM_BITSUM=0: the old path (A/B)
-    static const bool bitsum_on = [] { const char* e = getenv("BZK_MSM_BITSUM"); return e ? atoi(e) != 0 : true; }();
-    const bool bitsum = bitsum_on && !C::PARK_REDUCE && !wout && !folded && c >= 11 && c <= 21;
+    // round 6: the multiplication-free reduction (section 6b: row / column sums, bit sums, the weights in the host's Horner) - G1.  env BZK_MSM_BITSUM=0: the old path (A/B)
+    // (a caller that leaves its results on the device - a rank of a device group - receives the TERMS of its bucket sets instead of window sums: MsmWinOut)
+    const bool bitsum = msm_bitsum_applies<C>(c) && !folded;
     const RowColPlan rc_plan = msm_rowcol_plan(c - 1, 256);
     const size_t rc_per_set = ((size_t)1 << rc_plan.lbits) + ((size_t)1 << rc_plan.hbits);
-    if (wout) { wout->c = c; wout->w_total = w_total; wout->w_begin = w_begin; wout->w_end = w_end; wout->single = table && !folded; }
+    if (wout) { wout->c = c; wout->w_total = w_total; wout->w_begin = w_begin; wout->w_end = w_end; wout->single = table && !folded; wout->terms_per_set = bitsum ? c / 2 + 1 : 0; }
 
     // windows are processed in groups so that one group's pair list stays below 2^30 entries
     int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w_end - w_begin), ((uint64_t)1 << 30) / n));
@@ -1920,8 +1930,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
             // reading the caller's bases and writing the workspace: wait for it before the caller may touch either
             aux.join();
             BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (wout) {  // the window sums of an all-zero scalar vector: identities
-                std::vector<StdPt> ids((size_t)(wout->single ? 1 : w_end - w_begin), xyzz_identity<F>());
+            if (wout) {  // the window sums (or terms) of an all-zero scalar vector: identities
+                std::vector<StdPt> ids((size_t)(wout->single ? 1 : w_end - w_begin) * (size_t)std::max(1, wout->terms_per_set), xyzz_identity<F>());
                 BZK_HIP(ctx, hipMemcpy(wout->d_win, ids.data(), ids.size() * sizeof(StdPt), hipMemcpyHostToDevice));
             }
             return BZK_OK;
@@ -1991,8 +2001,13 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
                 heavy.leave();
                 // halves of 128 lanes: with 256-lane halves (112 KiB of static LDS - the runtime takes it) a workgroup saves a tree level and loses more to its
                 // eight waves sharing a CU: 0.166 - 0.170 against 0.150 - 0.153 ms, same box, alternating (profiles/r06_run11_bitsum_wide_negative.txt)
+                StdPt* const terms_dst = wout ? (StdPt*)wout->d_win + ((table && !folded) ? 0 : (size_t)(wb - w_begin) * n_terms) : terms_out;
                 BZK_LAUNCH(ctx, "msm_bitsum", (msm_bitsum_quad_kernel<128>), dim3((unsigned)n_red_win * (unsigned)n_terms), dim3(256), 0, (const G1X28*)rows,
-                           (const G1X28*)cols, rc_plan, (XyzzT<FpOps>*)terms_out);
+                           (const G1X28*)cols, rc_plan, (XyzzT<FpOps>*)terms_dst);
+                if (wout) {  // the terms stay on the device, in stream order; the caller reads them back (or exchanges them) and combines
+                    if (table && !folded) return BZK_OK;
+                    continue;
+                }
                 BZK_HIP(ctx, hipMemcpyAsync(ctx->pinned, terms_out, (size_t)n_red_win * n_terms * sizeof(StdPt), hipMemcpyDeviceToHost, ctx->stream));
                 BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (table && !folded) {  // one bucket set fed by every level of the table: its c terms are the whole result
@@ -2255,7 +2270,7 @@ static int32_t msm_bases_entry(bzk_ctx* ctx, const MsmBases* b, const void* scal
 // DEVICE memory at d_win (standard-limb XYZZ, sizeof = 4 field elements), nothing read back.  w_end < 0: every window.
 template <class C>
 static int32_t msm_windows_dev(bzk_ctx* ctx, const MsmBases* b, const void* bases_raw, const void* scalars, uint64_t n, uint32_t flags,
-                               int w_begin, int w_end, void* d_win, int32_t info[4]) {
+                               int w_begin, int w_end, void* d_win, int32_t info[5]) {
     typedef typename C::HostF F;
     if (!ctx || (!b && !bases_raw) || !d_win || (n && !scalars)) return BZK_E_ARG;
     if (b && b->device != ctx->device) return BZK_E_ARG;
@@ -2264,13 +2279,21 @@ static int32_t msm_windows_dev(bzk_ctx* ctx, const MsmBases* b, const void* base
     MsmWinOut wo;
     wo.d_win = d_win;
     BZK_TRY(msm_run<C>(ctx, bases_raw, scalars, n, flags, w_begin, w_end, r, nullptr, b, &wo));
-    if (info) { info[0] = wo.c; info[1] = wo.w_total; info[2] = wo.w_begin; info[3] = wo.w_end; }
+    if (info) { info[0] = wo.c; info[1] = wo.w_total; info[2] = wo.w_begin; info[3] = wo.w_end; info[4] = wo.terms_per_set; }
     return BZK_OK;
 }
 template <class F>
 static int32_t horner_packed(const void* S, int count, int c, int w0, uint8_t* out) {
     if (!out || count < 0 || (count && !S)) return BZK_E_ARG;
     XyzzT<F> r = msm_horner_host<F>((const XyzzT<F>*)S, count, c, w0);
+    PointIO<F>::pack(r, out);
+    return BZK_OK;
+}
+
+template <class F>
+static int32_t horner_terms_packed(const void* T, int count, int c, int w0, uint8_t* out) {
+    if (!out || count < 0 || (count && !T)) return BZK_E_ARG;
+    XyzzT<F> r = msm_horner_terms_host<F>((const XyzzT<F>*)T, count, c, w0);
     PointIO<F>::pack(r, out);
     return BZK_OK;
 }

@@ -1196,8 +1196,9 @@ def main():
         dist.all_gather_object(per_rank, mine_diag)
         out["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "per_rank": per_rank,
                              "launcher_role": "rendezvous, barriers and the 128-byte group id only",
-                             "data_path": (f"libbzk bzk_mg_* (C ABI): transport {mg.exchange}, group of {mg.world}; one all-gather of the "
-                                           f"{W} window sums (192 B each) per MSM, Horner combine on the host") if mg else
+                             "data_path": (f"libbzk bzk_mg_* (C ABI): transport {mg.exchange}, group of {mg.world}; one all-gather per MSM of what the ranks leave per "
+                                           f"window - the 9 terms (192 B each) of the window's bucket set, multiplication-free reduction - for the {W} windows, Horner "
+                                           "combine on the host") if mg else
                                           "torch.distributed all-gather of 97-byte partial sums + bzk_g1_sum (--partition points)"}
     if dry:
         out["dryrun"] = (f"ranks share GPUs (rendezvous over {dry}; window sums exchanged through libbzk's shared-memory transport, RCCL refuses "

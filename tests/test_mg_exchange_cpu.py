@@ -33,22 +33,66 @@ def _build():
 def _lib():
     lib = C.CDLL(_build())
     lib.mgx_rank_run.restype = C.c_int32
-    lib.mgx_rank_run.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p,
+    lib.mgx_rank_run.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p,
                                  C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
+    lib.mgx_window_terms.restype = C.c_int32
+    lib.mgx_window_terms.argtypes = [C.c_uint64]
     lib.mgx_window_bits.restype = C.c_int32
     lib.mgx_window_bits.argtypes = [C.c_uint64]
     return lib
 
 
-def _rank(rank, world, uid, calls, sums, fault_rank, fault_call, q):
+def _rank(rank, world, uid, calls, sums, n_terms, fault_rank, fault_call, q):
     sys.path.insert(0, ROOT)
     os.environ.setdefault("BZK_MG_TIMEOUT_S", "60")
     lib = _lib()
     out = C.create_string_buffer(97 * calls)
     st = (C.c_int32 * calls)()
     err = C.create_string_buffer(256)
-    rc = lib.mgx_rank_run(uid, rank, world, N, calls, sums, fault_rank, fault_call, out, st, err, 256)
+    rc = lib.mgx_rank_run(uid, rank, world, N, calls, sums, n_terms, fault_rank, fault_call, out, st, err, 256)
     q.put((rank, rc, list(st), out.raw, err.value.decode()))
+
+
+def _digits(scalars_canon, c, W):
+    half, rows = 1 << (c - 1), []
+    for k in scalars_canon:
+        carry, row = 0, []
+        for w in range(W):
+            d = ((k >> (c * w)) & ((1 << c) - 1)) + carry
+            if d > half:
+                d, carry = d - (1 << c), 1
+            else:
+                carry = 0
+            row.append(d)
+        assert carry == 0
+        rows.append(row)
+    return rows
+
+
+def _xyzz(pr, p97):
+    one = pr.fp_to_mont_bytes(1)
+    return (p97[:96] + one + one) if p97[96] == 0 else (bytes(48) + one + bytes(96))
+
+
+def _window_terms(co, pr, bases, scalars_canon, c, W):
+    """the c / 2 + 1 TERMS of every window's bucket set (msm_impl.cuh section 6b) from the oracle: with b = |d| - 1 the bucket of a non-zero digit d,
+    D_j = sum_i sign(d_i) (bit_2j(b_i) + 2 bit_(2j+1)(b_i)) P_i  and the plain sum  sum_i sign(d_i) P_i  - MSMs over tiny scalars"""
+    digs = _digits(scalars_canon, c, W)
+    n_pairs, out = c // 2, b""
+    for w in range(W):
+        for t in range(n_pairs + 1):
+            sc = b""
+            for i in range(len(scalars_canon)):
+                d = digs[i][w]
+                if d == 0:
+                    v = 0
+                else:
+                    b = abs(d) - 1
+                    v = 1 if t == n_pairs else ((b >> (2 * t)) & 1) + 2 * ((b >> (2 * t + 1)) & 1)
+                    v = v if d > 0 else -v
+                sc += pr.fr_to_mont_bytes(v % pr.R_MOD)
+            out += _xyzz(pr, co.msm_g1(bases, sc))
+    return out
 
 
 def _window_sums(co, pr, bases, scalars_canon, c, W):
@@ -83,23 +127,26 @@ def calls_data(co, pr):
     lib = _lib()
     c, W = lib.mgx_window_bits(N), L.load_library().bzk_msm_window_count(N)
     assert 4 <= c <= 16 and W == (256 + c - 1) // c
+    assert lib.mgx_window_terms(N) in (0, c // 2 + 1) and lib.mgx_window_terms(1 << 20) == 9      # 2^20 points: c = 16, 8 digit terms + the plain sum
     bases = co.g1_bases(71, 0, N)
-    sums, want = b"", []
+    sums, terms, want = b"", b"", []
+    n_terms = c // 2 + 1
     for call in range(3):
         ks = fr_list(N, 7100 + call)
         if call == 1:
             ks[:4] = [0, 1, pr.R_MOD - 1, (1 << 254) + 12345]      # edge digits: zero scalar, top-window carry
         sums += _window_sums(co, pr, bases, ks, c, W)
+        terms += _window_terms(co, pr, bases, ks, c, W)
         want.append(co.msm_g1(bases, b"".join(pr.fr_to_mont_bytes(k) for k in ks)))
-    assert len(sums) == 3 * W * 192
-    return sums, want
+    assert len(sums) == 3 * W * 192 and len(terms) == 3 * W * n_terms * 192
+    return {0: sums, n_terms: terms}, want, n_terms
 
 
-def _run_group(world, sums, fault_rank=-1, fault_call=0):
+def _run_group(world, sums, n_terms=0, fault_rank=-1, fault_call=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     uid = os.urandom(128)
-    ps = [ctx.Process(target=_rank, args=(r, world, uid, 3, sums, fault_rank, fault_call, q)) for r in range(world)]
+    ps = [ctx.Process(target=_rank, args=(r, world, uid, 3, sums, n_terms, fault_rank, fault_call, q)) for r in range(world)]
     for p in ps:
         p.start()
     got = sorted(q.get(timeout=180) for _ in ps)
@@ -109,18 +156,21 @@ def _run_group(world, sums, fault_rank=-1, fault_call=0):
     return got
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_ranks_as_processes_gather_and_combine_to_the_oracles_bytes(calls_data, world):
-    sums, want = calls_data
-    for rank, rc, st, out, err in _run_group(world, sums):
+@pytest.mark.parametrize("world,terms", [(2, False), (3, False), (4, False), (2, True), (3, True), (4, True)])
+def test_ranks_as_processes_gather_and_combine_to_the_oracles_bytes(calls_data, world, terms):
+    """terms = False: one window sum per window (G2's exchange, G1's with BZK_MSM_BITSUM=0); True: the terms of every window's bucket set - what the ranks of a
+    G1 group exchange since round 6 (1.7 KB per window at c = 16 instead of 192 bytes: the per-rank bucket reduction chain is gone)"""
+    data, want, n_terms = calls_data
+    sums, nt = (data[n_terms], n_terms) if terms else (data[0], 0)
+    for rank, rc, st, out, err in _run_group(world, sums, nt):
         assert rc == 0 and st == [0, 0, 0], (rank, rc, st, err)
         for k in range(3):
             assert out[97 * k:97 * k + 97] == want[k], (rank, k)
 
 
 def test_a_failed_rank_fails_that_call_on_every_rank_and_only_that_call(calls_data):
-    sums, want = calls_data
-    for rank, rc, st, out, err in _run_group(4, sums, fault_rank=2, fault_call=2):
+    data, want, n_terms = calls_data
+    for rank, rc, st, out, err in _run_group(4, data[n_terms], n_terms, fault_rank=2, fault_call=2):
         assert rc == 0, (rank, err)
         assert st[0] == 0 and st[2] == 0 and st[1] != 0, (rank, st)
         assert out[:97] == want[0] and out[194:291] == want[2], rank      # the calls around it: right, and not the failed call's leftovers
