@@ -268,7 +268,9 @@ def full_prove_section(ctx, n_proofs: int = 4, n_prod: int = 4, prod_threads: in
     defer = os.environ.get("BZK_BENCH_DEFER", "1" if world > 1 else "0") != "0"
     # BZK_BENCH_STAGE=1 (with or without deferral): each producer owns a context and STAGES its instances - the 116 MB upload and the deferred-value
     # program run on the producer's stream (bzk_r1cs_stage), the prover slots copy device to device (bzk_groth16_prove_staged)
-    stage = os.environ.get("BZK_BENCH_STAGE", "1" if world > 1 else "0") != "0"
+    # default ON since round 6 for every N: staging alone (plain instances) is + 1 - 2 % pipelined on one GPU - the 116 MB upload leaves the prover slot's
+    # stream (73.8 / 75.6 -> 75.3 / 76.4 proofs/s, same box, alternating: profiles/r06_run16_staged_plain_producers.txt)
+    stage = os.environ.get("BZK_BENCH_STAGE", "1") != "0"
     w.set_defer(True)
     twd, tpd, tcd = [], [], []
     for k in range(n_proofs):
