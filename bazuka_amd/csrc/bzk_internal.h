@@ -60,6 +60,19 @@ struct bzk_ctx {
     // should overlap on the device - the five MSMs of a Groth16 proof.  Created on first use, owned by the parent.
     std::vector<bzk_ctx*> lanes;
     std::vector<struct bzk_lane_thread*> lane_threads;  // one persistent host thread per lane (ctx.hip: lane_post / lane_wait)
+    // round 6 (run 18): child contexts of ONE stand-alone MSM call whose windows run as several ranges in flight (msm_impl.cuh msm_run_split): the
+    // front chain of one range hides under the accumulation of another, the tails of one under the accumulation of the next.  Own stream + workspace
+    // each, created on first use, owned by the parent; `is_part` marks such a child (it never splits again).  split_terms: device staging of the terms
+    // the ranges leave (W x terms per set x 192 B), split_ev: the fork event recorded on the parent's stream
+    // msm_split: ranges per call (0 = the library default, 1 = off), msm_split_min_log: smallest log2(n) that splits, msm_split_prio: children at the highest
+    // stream priority - read from env BZK_MSM_SPLIT / BZK_MSM_SPLIT_MIN_LOG / BZK_MSM_SPLIT_PRIO when the context is created (tests and A/B runs)
+    std::vector<bzk_ctx*> parts;
+    int msm_split = 0, msm_split_min_log = 0, msm_split_prio = -1;
+    int msm_split_cuts[4] = {0, 0, 0, 0};  // env BZK_MSM_SPLIT_CUTS="a,b[,c[,d]]": windows per range, highest range first (A/B runs; used when they add up to W)
+    bool is_part = false, split_active = false;
+    void* split_terms = nullptr;
+    size_t split_terms_bytes = 0;
+    hipEvent_t split_ev = nullptr;
     bool no_coop = false;  // env BZK_NO_COOP=1: never use the cooperative (8 lanes per node) Poseidon kernel (A/B runs)
     bool timing = false;  // env BZK_TIMING=1: host-side phase timings of bzk_groth16_prove on stderr
     hipEvent_t ev_z = nullptr;  // "assignment staged" event of bzk_groth16_prove: created on first use, destroyed with the ctx
@@ -76,6 +89,7 @@ struct bzk_ctx {
     hipStream_t heavy = nullptr;
     hipEvent_t ev_heavy_in = nullptr, ev_heavy_out = nullptr;
     bool heavy_tried = false;
+    bool heavy_force = false;  // a later window range of a split call (msm_run_split, priority mode 2): HeavyScope applies whatever BZK_MSM_HEAVY_PRIO says
     void* wf_state = nullptr;  // witfill.hip: device copies of the deferred-witness programs, dense Poseidon constants, scratch (witfill_free)
     // bzk_r1cs_stage: staged assignments handed back by bzk_staged_free (possibly from another thread: the prover's), kept for the next call
     std::mutex staged_mu;
@@ -106,6 +120,7 @@ namespace bzk {
 
 int32_t ws_reserve(bzk_ctx* ctx, size_t bytes);           // ensures ctx->ws has >= bytes
 bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i);                // i-th child context (nullptr on failure)
+bzk_ctx* ctx_part(bzk_ctx* ctx, size_t i, bool high_prio); // i-th window-range child of a split MSM call (nullptr on failure)
 int32_t pinned_reserve(bzk_ctx* ctx, size_t bytes);
 // runs `job` on the persistent host thread of lane i (created on first use, bound to the ctx's device); lane_wait blocks until that
 // job has returned.  One job per lane at a time.

@@ -37,10 +37,17 @@ extern "C" int32_t bzk_ctx_trim(bzk_ctx* ctx, uint64_t* released) {
     if (!ctx) return BZK_E_ARG;
     if (released) *released = 0;
     (void)hipSetDevice(ctx->device);
+    uint64_t kids = 0;
+    for (bzk_ctx* c : ctx->parts) {  // the window-range children of split MSM calls hold workspaces of their own
+        uint64_t r = 0;
+        BZK_TRY(bzk_ctx_trim(c, &r));
+        kids += r;
+    }
+    if (released) *released = kids;
     if (!ctx->ws) return BZK_OK;
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     BZK_HIP(ctx, hipFree(ctx->ws));
-    if (released) *released = ctx->ws_bytes;
+    if (released) *released = kids + ctx->ws_bytes;
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     return BZK_OK;
@@ -83,6 +90,39 @@ bzk_ctx* ctx_lane(bzk_ctx* ctx, size_t i) {
         ctx->lanes.push_back(c);
     }
     bzk_ctx* c = ctx->lanes[i];
+    c->prof = ctx->prof;
+    c->prof_only = ctx->prof_only;
+    c->debug = ctx->debug;
+    c->timing = ctx->timing;
+    c->msm_c_override = ctx->msm_c_override;
+    c->msm_chunk_override = ctx->msm_chunk_override;
+    c->msm_reduce2 = ctx->msm_reduce2;
+    c->msm_no_endo = ctx->msm_no_endo;
+    return c;
+}
+
+// window-range children of a split MSM call (bzk_ctx::parts): own non-blocking stream (highest priority on request: the front chain of a later
+// range - digits, sorts, boundaries - then outranks the accumulation it runs beside), own workspace and pinned staging
+bzk_ctx* ctx_part(bzk_ctx* ctx, size_t i, bool high_prio) {
+    while (ctx->parts.size() <= i) {
+        bzk_ctx* c = nullptr;
+        hipStream_t s = nullptr;
+        if (high_prio) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                s = nullptr;
+            }
+        }
+        if (bzk_ctx_create(ctx->device, s, &c) != BZK_OK) {
+            if (s) (void)hipStreamDestroy(s);
+            return nullptr;
+        }
+        if (s) c->own_stream = true;
+        c->is_part = true;
+        ctx->parts.push_back(c);
+    }
+    bzk_ctx* c = ctx->parts[i];
     c->prof = ctx->prof;
     c->prof_only = ctx->prof_only;
     c->debug = ctx->debug;
@@ -209,6 +249,17 @@ int32_t bzk_ctx_create(int32_t device_id, void* stream, bzk_ctx** out) {
     if (const char* e = getenv("BZK_MSM_CHUNK")) ctx->msm_chunk_override = atoi(e);
     if (const char* e = getenv("BZK_MSM_REDUCE2")) ctx->msm_reduce2 = atoi(e);
     if (const char* e = getenv("BZK_MSM_NO_ENDO")) ctx->msm_no_endo = atoi(e) != 0;
+    if (const char* e = getenv("BZK_MSM_SPLIT")) ctx->msm_split = atoi(e);
+    if (const char* e = getenv("BZK_MSM_SPLIT_MIN_LOG")) ctx->msm_split_min_log = atoi(e);
+    if (const char* e = getenv("BZK_MSM_SPLIT_PRIO")) ctx->msm_split_prio = atoi(e);
+    if (const char* e = getenv("BZK_MSM_SPLIT_CUTS")) {
+        int k = 0;
+        for (const char* q = e; *q && k < 4; ++k) {
+            ctx->msm_split_cuts[k] = atoi(q);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
     if (const char* e = getenv("BZK_DEBUG")) ctx->debug = atoi(e) != 0;
     if (const char* e = getenv("BZK_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char* e = getenv("BZK_NO_COOP")) ctx->no_coop = atoi(e) != 0;
@@ -231,6 +282,9 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
         delete t;
     }
     for (bzk_ctx* c : ctx->lanes) bzk_ctx_destroy(c);
+    for (bzk_ctx* c : ctx->parts) bzk_ctx_destroy(c);
+    if (ctx->split_terms) (void)hipFree(ctx->split_terms);
+    if (ctx->split_ev) (void)hipEventDestroy(ctx->split_ev);
     for (auto& r : ctx->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -322,6 +376,7 @@ int32_t bzk_prof_filter(bzk_ctx* ctx, const char* substr) {
     if (!ctx) return BZK_E_ARG;
     ctx->prof_only = substr ? substr : "";
     for (bzk_ctx* c : ctx->lanes) c->prof_only = ctx->prof_only;
+    for (bzk_ctx* c : ctx->parts) c->prof_only = ctx->prof_only;
     return BZK_OK;
 }
 
@@ -329,6 +384,7 @@ int32_t bzk_prof_reset(bzk_ctx* ctx) {
     if (!ctx) return BZK_E_ARG;
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (bzk_ctx* c : ctx->lanes) BZK_TRY(bzk_prof_reset(c));
+    for (bzk_ctx* c : ctx->parts) BZK_TRY(bzk_prof_reset(c));
     for (auto& r : ctx->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -342,7 +398,9 @@ int32_t bzk_prof_query(bzk_ctx* ctx, const char* name, uint64_t* launches, doubl
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t n = 0;
     double tot = 0;
-    for (bzk_ctx* c : ctx->lanes) {  // kernels launched on the lanes count towards the parent's totals
+    std::vector<bzk_ctx*> kids(ctx->lanes);
+    kids.insert(kids.end(), ctx->parts.begin(), ctx->parts.end());
+    for (bzk_ctx* c : kids) {  // kernels launched on the lanes / window-range children count towards the parent's totals
         uint64_t ln = 0;
         double lt = 0;
         BZK_TRY(bzk_prof_query(c, name, &ln, &lt));
@@ -367,6 +425,8 @@ int32_t bzk_prof_dump(bzk_ctx* ctx, char* buf, uint64_t cap) {
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::map<std::string, std::pair<uint64_t, double>> agg;
     std::vector<bzk_ctx*> all(ctx->lanes);
+    for (bzk_ctx* l : ctx->lanes) all.insert(all.end(), l->parts.begin(), l->parts.end());
+    all.insert(all.end(), ctx->parts.begin(), ctx->parts.end());
     all.push_back(ctx);
     for (bzk_ctx* c : all) {
         (void)hipStreamSynchronize(c->stream);

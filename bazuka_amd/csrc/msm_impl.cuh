@@ -399,6 +399,12 @@ static __global__ void __launch_bounds__(256) msm_ntask_kernel(const uint32_t* _
     ntask[i] = c <= seg ? 1u : (c + seg - 1) / seg;  // empty buckets keep one task (writes the identity)
 }
 
+#ifndef BZK_MSM_SPLIT_DEFAULT
+#define BZK_MSM_SPLIT_DEFAULT 2       // window ranges in flight of one stand-alone G1 call (msm_run_split)
+#endif
+#ifndef BZK_MSM_SPLIT_PRIO_DEFAULT
+#define BZK_MSM_SPLIT_PRIO_DEFAULT 0  // the later ranges' streams at the highest priority
+#endif
 #ifndef BZK_MSM_HEAVY_PRIO_DEFAULT
 #define BZK_MSM_HEAVY_PRIO_DEFAULT false  // round 6 A/B: see HeavyScope
 #endif
@@ -674,11 +680,56 @@ __global__ void __launch_bounds__(64) msm_fold_small_kernel(const uint32_t* __re
     buckets[order[i]] = acc;
 }
 
-// heavily populated buckets: one 64-lane workgroup per bucket: lanes stride over the partial sums, LDS tree
+// GIANT buckets (round 6, run 22): a bucket of more than MSM_FOLD_WIDE_FROM tasks would be folded by ONE workgroup below - its 64 lanes each walk nt / 64
+// general additions in a row.  Where the top window of a call is degenerate (c = 15: 17 x 15 = 255 bits, so window 17 only holds the carries of the signed
+// recoding - 45 % of all uniform scalars land in ITS bucket 0: 236 k entries = 5 700 tasks at 2^19 points) that one chain was 1.6 ms of a 4.1 ms call
+// (profiles/r06_run21_mid_size_task_cut.txt); skewed scalar vectors (one value repeated) have such a bucket in every window.  One level more: any workgroup of a
+// fixed grid folds a CHUNK of 64 partial sums of a giant bucket (one load + a 6-level tree) into `wide`, and the workgroup fold below then meets nt / 64 chunk
+// sums instead of nt partial sums: a chain of ~15 general additions whatever the population.  The order ties every bucket beyond the clamp of its sort key
+// (msm_count_kernel), so giants are looked for among the first MSM_FOLD_WIDE_POS sorted positions only - any beyond keep the one-level fold (correct, slower).
+// break-even: nt / 64 + 6 general additions in a row (one level) against 7 + nt / 4096 + 7 (two levels) at nt = 512; at 2^16 points (nt ~ 256) the extra level lost 0.11 ms (run 23)
+static constexpr uint32_t MSM_FOLD_WIDE_FROM = 640, MSM_FOLD_WIDE_POS = 64, MSM_FOLD_WIDE_GRID = 512;
+__device__ __forceinline__ uint32_t msm_fold_wide_slot(const uint32_t* __restrict__ tbase, uint32_t i) { return tbase[i] / 64 + i; }  // disjoint ranges: tbase grows by nt
+template <class C>
+__global__ void __launch_bounds__(64) msm_fold_wide_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ tbase, uint32_t nb,
+                                                           uint32_t seg, const typename C::Pt* __restrict__ partial, typename C::Pt* __restrict__ wide) {
+    typedef typename C::Pt Pt;
+    __shared__ Pt sh[64];
+    const uint32_t n_pos = nb < MSM_FOLD_WIDE_POS ? nb : MSM_FOLD_WIDE_POS;
+    uint32_t before = 0;  // chunks of the giants at earlier positions: the chunks of ALL giants are dealt round-robin over the grid (eight giants of 16 chunks each -
+                          // the top window at c = 14 - are one round of 128 workgroups, not eight rounds of the same 16: run 22, 0.91 ms -> one tree)
+    for (uint32_t i = 0; i < n_pos; ++i) {
+        const uint32_t cnt = count_sorted[i];
+        const uint32_t nt = cnt <= seg ? 1u : (cnt + seg - 1) / seg;
+        if (nt <= MSM_FOLD_WIDE_FROM) continue;  // workgroup-uniform
+        const uint32_t chunks = (nt + 63) / 64;
+        const Pt* src = partial + tbase[i];
+        Pt* dst = wide + msm_fold_wide_slot(tbase, i);
+        const uint32_t first = (blockIdx.x + gridDim.x - before % gridDim.x) % gridDim.x;
+        before += chunks;
+        for (uint32_t ch = first; ch < chunks; ch += gridDim.x) {
+            const uint32_t j = ch * 64 + threadIdx.x;
+            sh[threadIdx.x] = j < nt ? src[j] : C::identity();
+            __syncthreads();
+            for (int s = 32; s > 0; s >>= 1) {
+                if ((int)threadIdx.x < s) {
+                    Pt a = sh[threadIdx.x];
+                    add_from<C>(a, &sh[threadIdx.x + s]);
+                    sh[threadIdx.x] = a;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) dst[ch] = sh[0];
+            __syncthreads();  // sh[] is free again
+        }
+    }
+}
+
+// heavily populated buckets: one 64-lane workgroup per bucket: lanes stride over the partial sums (a giant bucket's chunk sums: above), LDS tree
 template <class C>
 __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ order,
                                                       const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ ntask, uint32_t nb, uint32_t n_big,
-                                                      uint32_t seg, const typename C::Pt* __restrict__ partial,
+                                                      uint32_t seg, const typename C::Pt* __restrict__ partial, const typename C::Pt* __restrict__ wide,
                                                       typename C::Pt* __restrict__ buckets) {
     typedef typename C::Pt Pt;
     __shared__ Pt sh[64];
@@ -689,9 +740,13 @@ __global__ void __launch_bounds__(64) msm_fold_kernel(const uint32_t* __restrict
     for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
         const uint32_t cnt = count_sorted[i];
         if (cnt <= seg) break;  // workgroup-uniform
-        const uint32_t nt = (cnt + seg - 1) / seg;
+        uint32_t nt = (cnt + seg - 1) / seg;
         if (nt <= thr) continue;  // msm_fold_small_kernel's
         const Pt* src = partial + tbase[i];
+        if (wide && i < MSM_FOLD_WIDE_POS && nt > MSM_FOLD_WIDE_FROM) {  // msm_fold_wide_kernel left one sum per chunk of 64
+            src = wide + msm_fold_wide_slot(tbase, i);
+            nt = (nt + 63) / 64;
+        }
         Pt acc = threadIdx.x < nt ? src[threadIdx.x] : C::identity();
         for (uint32_t j = threadIdx.x + 64; j < nt; j += 64) add_from<C>(acc, &src[j]);
         sh[threadIdx.x] = acc;
@@ -1412,7 +1467,7 @@ struct HeavyScope {
     explicit HeavyScope(bzk_ctx* c) : ctx(c) {}
     HeavyScope(const HeavyScope&) = delete;
     void enter() {
-        if (in || !msm_heavy_prio_on()) return;
+        if (in || !(msm_heavy_prio_on() || ctx->heavy_force)) return;
         if (!ctx->heavy && !ctx->heavy_tried) {
             ctx->heavy_tried = true;
             int least = 0, greatest = 0;
@@ -1457,6 +1512,7 @@ template <class Pt>
 struct BucketArrays {
     uint32_t *start, *count, *count_s, *iota, *order, *ntask, *tbase;
     Pt* partial;
+    Pt* wide = nullptr;  // chunk sums of giant buckets (msm_fold_wide_kernel): msm_fold_wide_cap(capacity of `partial`) points, or null = one-level fold
 };
 template <class C>
 static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t* keys_s, const uint32_t* vals_s, uint64_t len, uint32_t nb,
@@ -1548,7 +1604,14 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
             return BZK_OK;
         }
     }
-    BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(std::min<uint32_t>(n_big, 2048u)), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_big, seg, A.partial, buckets);
+    static const bool wide_off = env_on("BZK_MSM_NO_WIDE_FOLD");  // A/B runs
+    const typename C::Pt* const wide = wide_off ? nullptr : A.wide;
+    // a giant bucket holds more than MSM_FOLD_WIDE_FROM tasks of `seg` entries: none can exist in a shorter pair list
+    if (wide && len > (uint64_t)seg * MSM_FOLD_WIDE_FROM) {
+        auto k_wide = msm_fold_wide_kernel<C>;
+        BZK_LAUNCH(ctx, "msm_fold_wide", k_wide, dim3(MSM_FOLD_WIDE_GRID), dim3(64), 0, A.count_s, A.tbase, nb, seg, A.partial, A.wide);
+    }
+    BZK_LAUNCH(ctx, "msm_fold", k_fold, dim3(std::min<uint32_t>(n_big, 2048u)), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_big, seg, A.partial, wide, buckets);
     BZK_LAUNCH(ctx, "msm_fold_small", k_fold_small, dim3((n_pos + 63) / 64), dim3(64), 0, A.count_s, A.order, A.tbase, A.ntask, nb, n_pos, seg,
                A.partial, buckets);
     return BZK_OK;
@@ -1792,7 +1855,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     auto enough_tasks = [&](uint32_t sg, uint64_t len_, uint32_t nb_) {
         // endomorphism form: E x fewer, E x fuller buckets - two tasks per resident lane are enough (cutting every other bucket of a
         // 262 144-bucket call in two bought partial sums and folds, not balance: r04 run 3)
-        const uint64_t target = (E > 1 ? 2ull : 4ull) * 131072;
+        // a window range of a split call (msm_run_split) runs beside the other ranges' kernels: it need not fill the device alone, and every cut costs a fold
+        const uint64_t target = (E > 1 || ctx->is_part || ctx->split_active ? 2ull : 4ull) * 131072;
         if (nb_ >= target || len_ / sg + nb_ >= target) return sg;
         return (uint32_t)std::max<uint64_t>(32, len_ / (target - nb_));
     };
@@ -1807,6 +1871,8 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     total += 4 * ws_pad(len_max * 4);                 // keys, vals, keys_sorted, vals_sorted
     total += 7 * ws_pad((size_t)nb_alloc * 4);        // start, count, count_sorted, iota, order, ntask, tbase
     total += ws_pad((size_t)t_cap * sizeof(Pt));      // per-task partial sums (multi-task buckets only)
+    const size_t wide_cap = (size_t)t_cap / 32 + 2 * MSM_FOLD_WIDE_POS + 2;  // slot(i) + chunks(i) <= t / 64 + i + t / 64 + 1 (msm_fold_wide_slot)
+    total += ws_pad(wide_cap * sizeof(Pt));
     total += ws_pad((size_t)nb_alloc * sizeof(Pt));   // buckets
     total += ws_pad((size_t)group * per_win_out * sizeof(Pt));
     if (two_level) total += ws_pad((size_t)group * per_win * sizeof(Pt));
@@ -1836,6 +1902,7 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     BA.ntask = cur.take<uint32_t>(nb_alloc);
     BA.tbase = cur.take<uint32_t>(nb_alloc);
     BA.partial = cur.take<Pt>(t_cap);
+    BA.wide = cur.take<Pt>(wide_cap);
     Pt* buckets = cur.take<Pt>(nb_alloc);
     Pt* chunk_out = cur.take<Pt>((size_t)group * per_win_out);
     Pt* chunk_tot = two_level ? cur.take<Pt>((size_t)group * per_win) : nullptr;
@@ -2110,6 +2177,129 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
     return BZK_OK;
 }
 
+// ---- one stand-alone MSM as several window RANGES in flight (round 6, run 18) ------------------------------------------------------------------
+// A stand-alone call is a chain: digits, sorts, boundaries (0.5 ms at 2^20 points, latency / HBM-bound small grids), the accumulation (2.3 ms, saturating),
+// row / column sums + bit sums (0.5 ms, mostly idle lanes), read-back + host Horner (0.15 ms, device idle): a third of the call leaves the multiplier idle.
+// Two INDEPENDENT calls in flight hide those phases under each other's accumulation (bench two_msms_in_flight: 1.15 - 1.18 x).  The same holds WITHIN a call:
+// its windows are independent until the Horner.  So the call runs as P ranges of windows, highest first, each with its own stream + workspace (range 0 on the
+// call's own context, the others on bzk_ctx::parts children): the front chain of range k + 1 runs beside the accumulation of range k, the reduction of range k
+// beside the accumulation of range k + 1, and the host's Horner consumes the ranges in the order they finish (highest windows first - Horner's own order).
+// Every range leaves the TERMS of its bucket sets (multiplication-free reduction, section 6b), so this form exists where that reduction does (G1, 11 <= c <= 21),
+// for whole-MSM calls over a resident base set that are not flagged BZK_F_THROUGHPUT (those overlap with other calls already) or BZK_F_DEDUP.
+// Same result bytes: the same window terms enter the same Horner.  env (read when a context is created) BZK_MSM_SPLIT = 1 (off) | 2 | 3 | 4,
+// BZK_MSM_SPLIT_MIN_LOG (default 18), BZK_MSM_SPLIT_PRIO = 1: the children's streams at the highest priority (A/B).
+template <class C>
+static int msm_split_parts(const bzk_ctx* ctx, uint64_t n, uint32_t flags, const MsmBases* prep) {
+    // measured (profiles/r06_run20..23): two ranges gain 13 - 16 % at 2^18 and 2^19 points, nothing (+- 1 %) from 2^20 up - there the ranges' accumulations
+    // saturate the device either way and what overlaps is paid for in stretched neighbours -, and lose 15 % at 2^17: by default [2^18, 2^20) points
+    const bool explicit_range = ctx->msm_split_min_log >= 10 && ctx->msm_split_min_log <= 30;
+    const int min_log = explicit_range ? ctx->msm_split_min_log : 18;
+    if (!explicit_range && ctx->msm_split <= 0 && ctx->msm_split_cuts[0] <= 0 && n >= ((uint64_t)1 << 20)) return 1;
+    int parts = ctx->msm_split > 0 ? std::min(ctx->msm_split, 4) : BZK_MSM_SPLIT_DEFAULT;
+    if (ctx->msm_split_cuts[0] > 0) {  // explicit window counts per range
+        parts = 0;
+        while (parts < 4 && ctx->msm_split_cuts[parts] > 0) ++parts;
+    }
+    if (parts < 2 || C::PARK_REDUCE || !prep || ctx->is_part || (flags & (BZK_F_THROUGHPUT | BZK_F_DEDUP)) || n < ((uint64_t)1 << min_log) || n > prep->n) return 1;
+    if (msm_endo_mode<C>() == 1 && prep->endo > 1 && !ctx->msm_no_endo) return 1;  // that call takes the endomorphism form: shared bucket sets, no window ranges
+    const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n);
+    if (!msm_bitsum_applies<C>(c)) return 1;
+    const int W = msm_windows_for(c);
+    if ((uint64_t)W * n >= ((uint64_t)1 << 30)) return 1;  // the ranges of such a call are window groups already (msm_run)
+    return std::min(parts, W / 2);
+}
+// continues a Horner over terms (msm_horner_terms_host without its trailing doublings): acc <- acc 2^(c count) + sum_k 2^(c k) (terms of set k)
+template <class F>
+static void msm_horner_terms_continue(XyzzT<typename HostFast<F>::Ops>& acc, const XyzzT<F>* T, int count, int c) {
+    typedef typename HostFast<F>::Ops H;
+    const int n_pairs = c / 2, n_terms = n_pairs + 1;
+    for (int k = count - 1; k >= 0; --k) {
+        const XyzzT<F>* t = T + (size_t)k * n_terms;
+        for (int bit = c - 1; bit >= 0; --bit) {
+            acc = xyzz_dbl<H>(acc);
+            if ((bit & 1) == 0 && bit / 2 < n_pairs) xyzz_add<H>(acc, to_host_fast<F>(t[bit / 2]));
+            if (bit == 0) xyzz_add<H>(acc, to_host_fast<F>(t[n_pairs]));
+        }
+    }
+}
+template <class C>
+static int32_t msm_run_split(bzk_ctx* ctx, const void* scalars, uint64_t n, uint32_t flags, XyzzT<typename C::HostF>& result, const MsmBases* prep, int parts) {
+    typedef typename C::HostF F;
+    typedef XyzzT<F> StdPt;
+    typedef typename HostFast<F>::Ops H;
+    // priority mode (fixed when the first child is created): 0 = every range at the call's priority; 1 = the later ranges' streams at the highest priority;
+    // 2 = as 1, and their SATURATING kernels (accumulation, folds, row / column sums: HeavyScope) at the lowest - the front chain of range k + 1 outranks the
+    // accumulation of range k, which outranks the accumulation of range k + 1, which the tails of range k outrank: the ranges finish in issue order
+    const int prio_mode = ctx->msm_split_prio >= 0 ? ctx->msm_split_prio : BZK_MSM_SPLIT_PRIO_DEFAULT;
+    const bool kids_high = prio_mode != 0;
+    const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n);
+    const int W = msm_windows_for(c), n_terms = msm_terms_per_set<C>(c);
+    bzk_ctx* pc[4] = {ctx, nullptr, nullptr, nullptr};
+    for (int p = 1; p < parts; ++p) {
+        if (!(pc[p] = ctx_part(ctx, (size_t)p - 1, kids_high))) { ctx->last_error = "msm split: child context"; return BZK_E_DEVICE; }
+        pc[p]->heavy_force = prio_mode == 2;
+    }
+    const size_t bytes_all = (size_t)W * n_terms * sizeof(StdPt);
+    if (ctx->split_terms_bytes < bytes_all) {
+        if (ctx->split_terms) {
+            BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            BZK_HIP(ctx, hipFree(ctx->split_terms));
+            ctx->split_terms = nullptr;
+            ctx->split_terms_bytes = 0;
+        }
+        if (hipMalloc(&ctx->split_terms, bytes_all) != hipSuccess) { (void)hipGetLastError(); ctx->last_error = "msm split: terms buffer"; return BZK_E_ALLOC; }
+        ctx->split_terms_bytes = bytes_all;
+    }
+    if (!ctx->split_ev) BZK_HIP(ctx, hipEventCreateWithFlags(&ctx->split_ev, hipEventDisableTiming));
+    BZK_TRY(pinned_reserve(ctx, bytes_all + 64));  // msm_run asks for no more than this on the call's own context: the staging is not re-allocated under a copy
+    // range p = windows [lo[p], lo[p - 1]), highest windows first
+    int lo[5];
+    lo[0] = W;
+    for (int p = 1; p <= parts; ++p) lo[p] = (int)((int64_t)W * (parts - p) / parts);
+    {
+        int sum = 0, k = 0;
+        while (k < 4 && ctx->msm_split_cuts[k] > 0) sum += ctx->msm_split_cuts[k++];
+        if (k == parts && sum == W)
+            for (int p = 1; p <= parts; ++p) lo[p] = lo[p - 1] - ctx->msm_split_cuts[p - 1];
+    }
+    // the children start behind whatever the caller's stream holds at this point (the scalars may be its work)
+    BZK_HIP(ctx, hipEventRecord(ctx->split_ev, ctx->stream));
+    for (int p = 1; p < parts; ++p) BZK_HIP(ctx, hipStreamWaitEvent(pc[p]->stream, ctx->split_ev, 0));
+    int32_t st = BZK_OK;
+    int issued = 0;
+    ctx->split_active = true;  // range 0 runs on the call's own context: its msm_run sees the same task-count target as the children's
+    struct Off { bzk_ctx* c; ~Off() { c->split_active = false; } } off{ctx};
+    for (int p = 0; p < parts && st == BZK_OK; ++p) {
+        const int wb = lo[p + 1], we = lo[p];
+        MsmWinOut wo;
+        wo.d_win = (StdPt*)ctx->split_terms + (size_t)wb * n_terms;
+        XyzzT<F> unused;
+        st = msm_run<C>(pc[p], nullptr, scalars, n, flags, wb, we, unused, nullptr, prep, &wo);
+        issued = p + 1;
+        if (st == BZK_OK && (wo.terms_per_set != n_terms || wo.c != c || wo.w_total != W)) { st = BZK_E_INTERNAL; pc[p]->last_error = "msm split: window plan differs"; }
+        if (st == BZK_OK && hipMemcpyAsync((StdPt*)ctx->pinned + (size_t)wb * n_terms, wo.d_win, (size_t)(we - wb) * n_terms * sizeof(StdPt), hipMemcpyDeviceToHost,
+                                           pc[p]->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            st = BZK_E_DEVICE;
+            pc[p]->last_error = "msm split: read-back";
+        }
+        if (st != BZK_OK && pc[p] != ctx) ctx->last_error = pc[p]->last_error;
+    }
+    // the host consumes the ranges in issue order (= Horner's order); after a failure it still waits for everything issued - the ranges read the caller's
+    // scalars and write the shared staging
+    XyzzT<H> acc = xyzz_identity<H>();
+    for (int p = 0; p < issued; ++p) {
+        if (hipStreamSynchronize(pc[p]->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (st == BZK_OK) { st = BZK_E_DEVICE; ctx->last_error = "msm split: range failed on the device"; }
+        }
+        if (st == BZK_OK) msm_horner_terms_continue<F>(acc, (const StdPt*)ctx->pinned + (size_t)lo[p + 1] * n_terms, lo[p] - lo[p + 1], c);
+    }
+    if (st != BZK_OK) return st;
+    result = from_host_fast<F>(acc);
+    return BZK_OK;
+}
+
 template <class C>
 static int32_t msm_entry_dev(bzk_ctx* ctx, const void* bases, const void* scalars, uint64_t n, uint32_t flags, int w_begin,
                              int w_end, uint8_t* out) {
@@ -2262,7 +2452,12 @@ static int32_t msm_bases_entry(bzk_ctx* ctx, const MsmBases* b, const void* scal
     if (b->device != ctx->device) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     XyzzT<F> r;
-    BZK_TRY(msm_run<C>(ctx, nullptr, scalars, n, flags, w_begin, w_end, r, nullptr, b));
+    const int parts = (w_begin == 0 && w_end < 0) ? msm_split_parts<C>(ctx, n, flags, b) : 1;
+    if (parts > 1) {
+        BZK_TRY(msm_run_split<C>(ctx, scalars, n, flags, r, b, parts));
+    } else {
+        BZK_TRY(msm_run<C>(ctx, nullptr, scalars, n, flags, w_begin, w_end, r, nullptr, b));
+    }
     PointIO<F>::pack(r, out);
     return BZK_OK;
 }

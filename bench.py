@@ -1248,15 +1248,21 @@ def main():
     if rank == 0:
         if acc_n:
             per_launch_ms = acc_ms / acc_n
-            alg_bytes = 128.0 * n_rank  # 96 B affine base + 32 B scalar per (point, scalar) pair of this rank's launch
+            # since round 6 run 18 a stand-alone call runs its windows as several ranges in flight (msm_run_split): `launches_per_step` accumulation
+            # launches per MSM, each over ALL points but only its share of the windows - a launch is credited that share of the MSM's algorithmic bytes
+            # (and of its additions below); the launches of one step overlap each other's front chains and reductions, so a launch's own duration
+            # includes the issue slots it gave away
+            launches_per_step = max(1, round(acc_n / args.steps))
+            alg_bytes = 128.0 * n_rank / launches_per_step  # 96 B affine base + 32 B scalar per (point, scalar) pair of this rank's MSM
             achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                                "traffic": _pmc_traffic(args.log_n)[0], "traffic_source": _pmc_traffic(args.log_n)[1],
-                               "avg_launch_ms": round(per_launch_ms, 4),
+                               "avg_launch_ms": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
+                               "accumulate_ms_per_step": round(acc_ms / args.steps, 4),
                                "note": "integer-ALU bound (381-bit Montgomery carry chains); HBM fraction is "
                                        "structurally ~1e-3, see DESIGN.md"}
-            pairs = n_rank * (w1 - w0)  # one mixed add per (point, window) pair (zero digits skipped: ~2^-16 of them)
+            pairs = n_rank * (w1 - w0) / launches_per_step  # one mixed add per (point, window) pair (zero digits skipped: ~2^-16 of them)
             gmul = pairs * MULS_PER_MIXED_ADD / (per_launch_ms * 1e-3) / 1e9
             out["roofline"]["alu"] = {"achieved": round(gmul, 2), "peak": FP_MUL_PEAK_G, "unit": "G Fp-mul/s",
                                       "frac": round(gmul / FP_MUL_PEAK_G, 4),

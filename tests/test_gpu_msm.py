@@ -395,6 +395,57 @@ def test_msm_g1_2p26_vs_oracle_and_8way_window_shards(bzk, co):
     _large_g1_msm_vs_oracle(bzk, co, 26, 11, 8)
 
 
+# ---- one stand-alone call as several window ranges in flight (msm_impl.cuh msm_run_split)
+
+def _ctx_with_env(env):
+    """a context of its own created under `env` (the split knobs are read when a context is created)"""
+    from bazuka_amd import Bzk
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return Bzk(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("n", [1 << 16, (1 << 16) + 4321, 1 << 18])
+def test_msm_g1_split_ranges_vs_oracle(bzk, co, n):
+    """a resident-set G1 call run as 1 / 2 / 3 / 4 window ranges in flight (children at normal and at the highest stream priority) returns the
+    oracle's bytes, as does the raw-base call (never split); back-to-back calls on one context re-use the children"""
+    bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    bzk.g1_synth_bases_dev(77, 0, n, bases)
+    sc = _uniform_scalars_dev(n, 9000 + n % 1000)
+    want = co.msm_g1_np(bases.cpu().numpy(), sc.cpu().numpy(), nthreads=co.ncpu())
+    assert bzk.msm_g1_dev(bases, sc, n) == want
+    for parts, prio in ((1, 0), (2, 0), (2, 1), (3, 0), (4, 1)):
+        ctx = _ctx_with_env({"BZK_MSM_SPLIT": str(parts), "BZK_MSM_SPLIT_PRIO": str(prio), "BZK_MSM_SPLIT_MIN_LOG": "12"})
+        try:
+            h = ctx.msm_bases_load_dev(bases, n)
+            try:
+                for _ in range(3):
+                    assert ctx.msm_bases_run_dev(h, sc, n) == want, (parts, prio)
+                # per-kernel events of a split call land on the children and are reported with the parent's
+                ctx.prof_enable(True); ctx.prof_reset()
+                assert ctx.msm_bases_run_dev(h, sc, n) == want
+                launches = ctx.prof_dump().get("msm_accumulate", (0, 0.0))[0]
+                ctx.prof_enable(False)
+                assert launches == parts, (parts, launches)
+                # fewer scalars than the set holds, zero scalars, and the flagged forms (never split) on the same context
+                m = n - 1000
+                assert ctx.msm_bases_run_dev(h, sc[:32 * m], m) == co.msm_g1_np(bases[:96 * m].cpu().numpy(), sc[:32 * m].cpu().numpy(), nthreads=co.ncpu())
+                z = torch.zeros(n * 32, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+                assert ctx.msm_bases_run_dev(h, z, n) == bzk.msm_g1_dev(bases, z, n)
+                assert ctx.msm_bases_run_dev(h, sc, n, throughput=True) == want
+            finally:
+                ctx.msm_bases_free(h)
+        finally:
+            ctx.close()
+
+
 # ---- every window size, not only the ones the size-based pick happens to choose for the test sizes
 
 @pytest.mark.parametrize("c", [5, 9, 11, 13, 14, 15, 17])

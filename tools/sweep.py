@@ -43,11 +43,19 @@ def child(mode, log_n):
         (ctx.g2_synth_bases_dev if g2 else ctx.g1_synth_bases_dev)(1, 0, n, bases); sc = rand_fr(n)
         hb = ctx.msm_bases_load_dev(bases, n, g2=g2)
         thr = os.environ.get("THROUGHPUT", "0") == "1"
-        ms = timeit(lambda: ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr), reps=3)
+        ms = timeit(lambda: ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr), reps=int(os.environ.get("SWEEP_REPS", "3")))
+        k_mean = int(os.environ.get("SWEEP_MEAN_OVER", "0"))  # back-to-back calls, as bench.py times its steps
+        mean_ms = None
+        if k_mean:
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(k_mean):
+                ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr)
+            torch.cuda.synchronize(); mean_ms = round((time.perf_counter() - t) * 1e3 / k_mean, 4)
         res = ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr)
         same = res == (ctx.msm_g2_dev if g2 else ctx.msm_g1_dev)(bases, sc, n)
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.04}
         print(json.dumps({"mode": mode, "log_n": log_n, "endo_g1": os.environ.get("BZK_MSM_ENDO_G1"), "endo_g2": os.environ.get("BZK_MSM_ENDO_G2"), "throughput": thr,
+                          "seg": os.environ.get("BZK_MSM_SEG"), "no_wide": os.environ.get("BZK_MSM_NO_WIDE_FOLD"), "split": os.environ.get("BZK_MSM_SPLIT"), "cuts": os.environ.get("BZK_MSM_SPLIT_CUTS"), "split_prio": os.environ.get("BZK_MSM_SPLIT_PRIO"), "mean_ms": mean_ms,
                           "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 2), "same_as_raw": same, "digest": hashlib.sha256(bytes(res)).hexdigest()[:16], "prof": prof}))
         ctx.msm_bases_free(hb)
     elif mode == "g1tab":
@@ -127,6 +135,49 @@ if __name__ == "__main__":
         for ps in ("1", "0"):
             run("g2", 20, {"BZK_MSM_PSORT": ps})
         run("g1win", 23)
+    if what in ("r6split",):  # round 6 run 18: one stand-alone G1 call as 1 / 2 / 3 / 4 window ranges in flight (msm_run_split), children at normal / highest priority
+        for rep in (0, 1):  # alternating
+            for lg in (20, 22, 18, 24):
+                for sp, pr in (("1", "0"), ("2", "0"), ("2", "1"), ("3", "0"), ("3", "1"), ("4", "0"), ("4", "1")):
+                    if lg != 20 and sp in ("3",):
+                        continue
+                    run("g1res", lg, {"BZK_MSM_SPLIT": sp, "BZK_MSM_SPLIT_PRIO": pr, "SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20" if lg <= 22 else "5",
+                                      "BZK_MSM_SPLIT_MIN_LOG": "16"})
+    if what in ("r6split2",):  # run 19: unequal ranges (short first range = short exposed head, short last range = short exposed tail), 2 tasks per lane in a range
+        for rep in (0, 1):
+            for lg in (20, 22):
+                for cuts in ("", "8,8", "4,12", "12,4", "4,8,4", "2,12,2", "2,10,4", "4,10,2", "2,6,6,2", "6,10", "10,6"):
+                    env = {"SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20", "BZK_MSM_SPLIT_MIN_LOG": "16"}
+                    env.update({"BZK_MSM_SPLIT_CUTS": cuts} if cuts else {"BZK_MSM_SPLIT": "1"})
+                    run("g1res", lg, env)
+            for cuts in ("", "9,9", "4,10,4", "6,12", "12,6"):  # 2^18: c = 15?, W = 18 (cuts that do not add up to W fall back to equal ranges)
+                env = {"SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20", "BZK_MSM_SPLIT_MIN_LOG": "16"}
+                env.update({"BZK_MSM_SPLIT_CUTS": cuts} if cuts else {"BZK_MSM_SPLIT": "1"})
+                run("g1res", 18, env)
+    if what in ("r6split3",):  # run 20: priority modes (0 none, 1 later ranges high, 2 later ranges high with their saturating kernels lowest)
+        for rep in (0, 1):
+            for lg, cutss in ((20, ("8,8", "6,10", "10,6", "4,12")), (22, ("8,8", "6,10")), (18, ("9,9",)), (19, ("8,8",)), (17, ("9,9",)), (16, ("10,10",)), (24, ("8,8",))):
+                base = {"SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20" if lg <= 22 else "5", "BZK_MSM_SPLIT_MIN_LOG": "16"}
+                run("g1res", lg, dict(base, BZK_MSM_SPLIT="1"))
+                for cuts in cutss:
+                    for pr in ("0", "1", "2"):
+                        if pr == "1" and cuts != cutss[0]:
+                            continue
+                        run("g1res", lg, dict(base, BZK_MSM_SPLIT_CUTS=cuts, BZK_MSM_SPLIT_PRIO=pr))
+    if what in ("r6seg",):  # run 21: the task cut of mid-size calls (enough_tasks): run length forced against the default
+        for rep in (0, 1):
+            for lg in (19, 18, 17, 16):
+                for seg in ("", "32", "48", "64", "128", "254"):
+                    env = {"SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20", "BZK_MSM_SPLIT": "1"}
+                    if seg:
+                        env["BZK_MSM_SEG"] = seg
+                    run("g1res", lg, env)
+    if what in ("r6wide",):  # run 22: two-level fold of giant buckets (msm_fold_wide_kernel) against the one-level fold, unsplit and as two ranges
+        for rep in (0, 1):
+            for lg in (19, 18, 17, 16, 20, 21):
+                for wide_off in ("1", "0"):
+                    for sp in ("1", "2"):
+                        run("g1res", lg, {"SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20", "BZK_MSM_SPLIT": sp, "BZK_MSM_SPLIT_MIN_LOG": "16", "BZK_MSM_NO_WIDE_FOLD": wide_off})
     if what in ("occ",):
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
