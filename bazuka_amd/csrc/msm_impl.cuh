@@ -450,6 +450,64 @@ __global__ void __launch_bounds__(128, OCC) msm_accumulate_kernel(const void* __
     const uint32_t s = start[g] + k * q;
     const uint32_t len = k * q >= cnt ? 0u : (cnt - k * q < q ? cnt - k * q : q);  // empty bucket: writes the identity
     typename C::Pt acc = C::identity();
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (C::ACC_LDS) {
+        // Round 6, run 24: the NEXT base travels global memory -> LDS by direct loads (global_load_lds_dwordx4: no destination registers) from the TOP of the current
+        // addition and is read from LDS at the top of the next one - the G2 pair kernel's way (below).  Requested into registers it could only be asked for under the
+        // fused-Y tail of the formula (28 registers are not free any earlier): ~2.5 us of cover - enough for a base set that sits in the Infinity Cache (the
+        // 2^20-point resident set: 117 MB), not for gathers that go to HBM (a 13-level static table is 1.5 GB: its accumulation ran 1.6 x longer per addition).
+        // A base is 112 B = 7 pieces of 16 B; a piece's destination is wave-uniform + lane x 16: seven 1 KiB slabs per wave and one of index words.
+        __shared__ __attribute__((aligned(16))) char stage[2][8][1024];
+        char* const slab = &stage[threadIdx.x >> 6][0][0];
+        const uint32_t lane16 = (threadIdx.x & 63u) * 16u, lane4 = (threadIdx.x & 63u) * 4u;
+        auto request = [&](uint32_t idx) {
+            const uint32_t m = idx >> ibits, b = idx & imask;
+            const char* p = b >= n_split ? (const char*)bases2 + (size_t)(m * stride2 + (b - n_split)) * sizeof(typename C::DevAff)
+                                         : (const char*)bases + (size_t)(m * stride1 + b) * sizeof(typename C::DevAff);
+#pragma unroll
+            for (int k2 = 0; k2 < 7; ++k2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 16 * k2), (__attribute__((address_space(3))) void*)(slab + 1024 * k2), 16, 0, 0);
+        };
+        auto request_word = [&](const uint32_t* w) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w, (__attribute__((address_space(3))) void*)(slab + 7168), 4, 0, 0);
+        };
+        auto collect = [&](uint32_t& word) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the direct loads of this wave have landed
+            __asm__ volatile("" ::: "memory");
+            const U128* q2 = (const U128*)(slab + lane16);
+            U128 v[7];
+#pragma unroll
+            for (int k2 = 0; k2 < 7; ++k2) v[k2] = q2[64 * k2];
+            word = *(const uint32_t*)(slab + 7168 + lane4);
+            typename C::DevAff a;
+            uint32_t* dst = a.x.l;  // x.l[0..13] then y.l[0..13] are contiguous (2 x 56 B)
+#pragma unroll
+            for (int k2 = 0; k2 < 7; ++k2) {
+                dst[4 * k2] = v[k2].x; dst[4 * k2 + 1] = v[k2].y; dst[4 * k2 + 2] = v[k2].z; dst[4 * k2 + 3] = v[k2].w;
+            }
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slabs are free again: the next requests may overwrite them
+            return a;
+        };
+        if (len) {
+            const uint32_t v0 = vals[s];
+            bool neg = (v0 >> 31) != 0;
+            request(v0 & vmask);
+            request_word(vals + s + (1 < len ? 1u : 0u));
+            for (uint32_t j = 0; j < len; ++j) {
+                uint32_t vn;
+                const typename C::DevAff p = collect(vn);  // base j and the index word of entry j + 1 (past the end of the run: the last entry again - no branch around loads)
+                request(vn & vmask);
+                request_word(vals + s + (j + 2 < len ? j + 2 : len - 1));
+                C::add_mixed_pre(acc, p, neg, []() {});
+                neg = (vn >> 31) != 0;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // nothing of this wave may still be writing LDS when the workgroup's slot is handed on
+        }
+        if (cnt <= seg) buckets[g] = acc;
+        else partial[t] = acc;
+        return;
+    }
+#endif
 #if BZK_MSM_PREFETCH
     if (len) {
         // software pipelining of the gathers: the next base is requested inside the current addition, after its last product CALL

@@ -34,6 +34,10 @@ struct G1Fast {
 #define BZK_G1_ACC_OCC 2  // waves per SIMD the accumulate kernel is compiled for (A/B builds)
 #endif
     static constexpr int ACC_OCC = BZK_G1_ACC_OCC;
+#ifndef BZK_G1_ACC_LDS
+#define BZK_G1_ACC_LDS 1  // the accumulation's next base global memory -> LDS by direct loads, requested at the TOP of the current addition (msm_accumulate_kernel); 0: into registers under the fused-Y tail
+#endif
+    static constexpr bool ACC_LDS = BZK_G1_ACC_LDS != 0;
     // endomorphism form (bzk_endo.cuh): scalars split into ENDO signed sub-scalars of ENDO_BITS bits over the images X^(2 m) P
     static constexpr int ENDO = 2, ENDO_BITS = 128;
     static constexpr int ENDO_DEFAULT = 2;
@@ -116,6 +120,7 @@ struct G2Fast {
     // the accumulation on PAIRS of lanes (bzk_g2pair.cuh): half a point per lane, two waves per SIMD, every product inlined.
     // env BZK_G2_PAIR=0 keeps the one-lane kernel (same-box A/B; both are compiled in)
     static constexpr bool PAIR_ACC = true;
+    static constexpr bool ACC_LDS = false;  // (the one-lane G2 accumulation, kept for A/B, gathers into registers)
     typedef Fp2Ops HostF;
     typedef G2X28 Pt;
     typedef G2A28 DevAff;

@@ -30,7 +30,9 @@ def row(table, obj, kernel):
 def test_g1_accumulate_keeps_two_waves_and_no_scratch(table):
     r = row(table, "msm_g1", "msm_accumulate_kernel<G1Fast, 2>")
     assert r["vgpr"] <= 256 and r["waves"] >= 2
-    assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0
+    # round 6 run 24: the next base is staged through LDS by direct loads - 7 slabs of base pieces + 1 of index words per wave, two waves per workgroup;
+    # four workgroups per CU (two waves per SIMD) take 64 of its 160 KiB
+    assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 16384
 
 
 def test_g1_accumulate_has_its_products_inlined():
@@ -102,6 +104,14 @@ def test_g2_pair_accumulation_stages_the_next_base_through_lds(table):
     assert sum(v for k, v in c.items() if k.startswith("global_load_dword")) == 0, c      # nothing of the gather lands in registers
     r = row(table, "msm_g2", "msm_accumulate_g2pair_kernel<2>")
     assert r["waves"] >= 2 and r["lds"] <= 20 * 1024 and r["scratch"] <= 64, r
+
+
+def test_g1_accumulation_stages_the_next_base_through_lds():
+    """round 6 run 24: the G1 accumulation requests the next base (7 x 16 B) and the index word after next as direct loads to LDS at the top of the
+    addition - nothing of the gather is held in registers across the products"""
+    c = kr.loop_instruction_counts("msm_g1", "msm_accumulate_kernel")
+    assert c.get("global_load_lds_dwordx4", 0) == 7 and c.get("global_load_lds_dword", 0) == 1, c
+    assert sum(v for k, v in c.items() if k.startswith("global_load_dword")) == 0, c
 
 
 def test_witness_fill_kernels_fit_beside_other_work(table):

@@ -55,7 +55,7 @@ def child(mode, log_n):
         same = res == (ctx.msm_g2_dev if g2 else ctx.msm_g1_dev)(bases, sc, n)
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.04}
         print(json.dumps({"mode": mode, "log_n": log_n, "endo_g1": os.environ.get("BZK_MSM_ENDO_G1"), "endo_g2": os.environ.get("BZK_MSM_ENDO_G2"), "throughput": thr,
-                          "seg": os.environ.get("BZK_MSM_SEG"), "no_wide": os.environ.get("BZK_MSM_NO_WIDE_FOLD"), "split": os.environ.get("BZK_MSM_SPLIT"), "cuts": os.environ.get("BZK_MSM_SPLIT_CUTS"), "split_prio": os.environ.get("BZK_MSM_SPLIT_PRIO"), "mean_ms": mean_ms,
+                          "lib": os.path.basename(os.environ.get("BZK_LIBBZK", "")), "seg": os.environ.get("BZK_MSM_SEG"), "no_wide": os.environ.get("BZK_MSM_NO_WIDE_FOLD"), "split": os.environ.get("BZK_MSM_SPLIT"), "cuts": os.environ.get("BZK_MSM_SPLIT_CUTS"), "split_prio": os.environ.get("BZK_MSM_SPLIT_PRIO"), "mean_ms": mean_ms,
                           "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 2), "same_as_raw": same, "digest": hashlib.sha256(bytes(res)).hexdigest()[:16], "prof": prof}))
         ctx.msm_bases_free(hb)
     elif mode == "g1tab":
@@ -178,6 +178,15 @@ if __name__ == "__main__":
                 for wide_off in ("1", "0"):
                     for sp in ("1", "2"):
                         run("g1res", lg, {"SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20", "BZK_MSM_SPLIT": sp, "BZK_MSM_SPLIT_MIN_LOG": "16", "BZK_MSM_NO_WIDE_FOLD": wide_off})
+    if what in ("r6acclds",):  # run 24: the G1 accumulation's next base through LDS by direct loads (requested at the top of the addition) vs into registers under the tail
+        alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bazuka_amd", "libbzk.so.acclds0")
+        for rep in (0, 1):
+            for lib in (alt, ""):
+                env = {"BZK_LIBBZK": lib} if lib else {}
+                for lg in (20, 22, 24, 18):
+                    run("g1res", lg, dict(env, SWEEP_REPS="8", SWEEP_MEAN_OVER="20" if lg <= 22 else "5"))
+                run("g1tab", 20, env)
+                run("g1res", 20, dict(env, THROUGHPUT="1", SWEEP_REPS="8"))
     if what in ("occ",):
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
