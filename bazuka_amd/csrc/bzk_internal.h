@@ -72,6 +72,8 @@ struct bzk_ctx {
     bool is_part = false, split_active = false;
     void* split_terms = nullptr;
     size_t split_terms_bytes = 0;
+    void* split_conv = nullptr;  // internal form of the raw bases of a split call (msm_entry_dev), grow-only; released by bzk_ctx_trim
+    size_t split_conv_bytes = 0;
     hipEvent_t split_ev = nullptr;
     bool no_coop = false;  // env BZK_NO_COOP=1: never use the cooperative (8 lanes per node) Poseidon kernel (A/B runs)
     bool timing = false;  // env BZK_TIMING=1: host-side phase timings of bzk_groth16_prove on stderr

@@ -43,6 +43,13 @@ extern "C" int32_t bzk_ctx_trim(bzk_ctx* ctx, uint64_t* released) {
         BZK_TRY(bzk_ctx_trim(c, &r));
         kids += r;
     }
+    if (ctx->split_conv) {
+        BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BZK_HIP(ctx, hipFree(ctx->split_conv));
+        kids += ctx->split_conv_bytes;
+        ctx->split_conv = nullptr;
+        ctx->split_conv_bytes = 0;
+    }
     if (released) *released = kids;
     if (!ctx->ws) return BZK_OK;
     BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -284,6 +291,7 @@ void bzk_ctx_destroy(bzk_ctx* ctx) {
     for (bzk_ctx* c : ctx->lanes) bzk_ctx_destroy(c);
     for (bzk_ctx* c : ctx->parts) bzk_ctx_destroy(c);
     if (ctx->split_terms) (void)hipFree(ctx->split_terms);
+    if (ctx->split_conv) (void)hipFree(ctx->split_conv);
     if (ctx->split_ev) (void)hipEventDestroy(ctx->split_ev);
     for (auto& r : ctx->recs) {
         (void)hipEventDestroy(r.a);

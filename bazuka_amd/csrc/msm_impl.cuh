@@ -2258,8 +2258,9 @@ static int msm_split_parts(const bzk_ctx* ctx, uint64_t n, uint32_t flags, const
         parts = 0;
         while (parts < 4 && ctx->msm_split_cuts[parts] > 0) ++parts;
     }
-    if (parts < 2 || C::PARK_REDUCE || !prep || ctx->is_part || (flags & (BZK_F_THROUGHPUT | BZK_F_DEDUP)) || n < ((uint64_t)1 << min_log) || n > prep->n) return 1;
-    if (msm_endo_mode<C>() == 1 && prep->endo > 1 && !ctx->msm_no_endo) return 1;  // that call takes the endomorphism form: shared bucket sets, no window ranges
+    // prep == nullptr: a call over raw bases (msm_entry_dev converts them once for all ranges)
+    if (parts < 2 || C::PARK_REDUCE || ctx->is_part || (flags & (BZK_F_THROUGHPUT | BZK_F_DEDUP)) || n < ((uint64_t)1 << min_log) || (prep && n > prep->n)) return 1;
+    if (prep && msm_endo_mode<C>() == 1 && prep->endo > 1 && !ctx->msm_no_endo) return 1;  // that call takes the endomorphism form: shared bucket sets, no window ranges
     const int c = ctx->msm_c_override >= 2 && ctx->msm_c_override <= 20 ? ctx->msm_c_override : msm_pick_c(n);
     if (!msm_bitsum_applies<C>(c)) return 1;
     const int W = msm_windows_for(c);
@@ -2365,7 +2366,29 @@ static int32_t msm_entry_dev(bzk_ctx* ctx, const void* bases, const void* scalar
     if (!ctx || !out || (n && (!bases || !scalars))) return BZK_E_ARG;
     (void)hipSetDevice(ctx->device);
     XyzzT<F> r;
-    BZK_TRY(msm_run<C>(ctx, bases, scalars, n, flags, w_begin, w_end, r));  // w_end < 0: all windows of the c msm_run picks
+    const int parts = (w_begin == 0 && w_end < 0 && n) ? msm_split_parts<C>(ctx, n, flags, nullptr) : 1;
+    if (parts > 1) {
+        // window ranges in flight (msm_run_split) over raw bases: converted ONCE, on the call's stream, into a buffer of the context's that every range gathers from
+        const size_t need = (size_t)n * sizeof(typename C::DevAff) + MSM_GATHER_PAD;
+        if (ctx->split_conv_bytes < need) {
+            if (ctx->split_conv) {
+                BZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                BZK_HIP(ctx, hipFree(ctx->split_conv));
+                ctx->split_conv = nullptr;
+                ctx->split_conv_bytes = 0;
+            }
+            if (hipMalloc(&ctx->split_conv, need + (need >> 3)) != hipSuccess) { (void)hipGetLastError(); ctx->last_error = "msm split: base buffer"; return BZK_E_ALLOC; }
+            ctx->split_conv_bytes = need + (need >> 3);
+        }
+        BZK_TRY(msm_convert_launch<C>(ctx, bases, n, (typename C::DevAff*)ctx->split_conv));
+        MsmBases tmp;
+        tmp.data = ctx->split_conv;
+        tmp.n = n;
+        tmp.device = ctx->device;
+        BZK_TRY(msm_run_split<C>(ctx, scalars, n, flags, r, &tmp, parts));
+    } else {
+        BZK_TRY(msm_run<C>(ctx, bases, scalars, n, flags, w_begin, w_end, r));  // w_end < 0: all windows of the c msm_run picks
+    }
     PointIO<F>::pack(r, out);
     return BZK_OK;
 }

@@ -784,6 +784,22 @@ def other_configs_section(ctx, dev):
                                        "kernel_ms": kernels(lambda: ctx.msm_table_run_dev(tab, sc, n))}
     ctx.msm_table_free(tab)
     del gb, sc
+    # mid-size stand-alone calls (round 6, runs 21 - 23): below 0.66 M points the window is narrower than 16 bits and the top window of the signed recoding is
+    # degenerate - at 2^19 points (c = 15) its bucket 0 receives 45 % of all scalars.  Such giant buckets are folded in two levels (msm_fold_wide_kernel) and the
+    # call runs as two window ranges in flight (msm_run_split): 4.1 ms -> 2.25 ms at 2^19 points, 2.07 -> 1.73 ms at 2^18 (profiles/r06_run22_23_giant_bucket_fold.txt)
+    for lg in (19, 18):
+        n = 1 << lg
+        gb = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+        ctx.g1_synth_bases_dev(SEED, 0, n, gb)
+        sc = rand_fr(n, 1900 + lg)
+        hb = ctx.msm_bases_load_dev(gb, n)
+        ms = timeit(lambda: ctx.msm_bases_run_dev(hb, sc, n), reps=5)
+        same = ctx.msm_bases_run_dev(hb, sc, n) == ctx.msm_g1_dev(gb, sc, n)
+        out[f"msm_g1_2p{lg}"] = {"what": f"2^{lg}-point G1 MSM over a resident base set ({ctx.msm_window_count(n)} windows; two window ranges in flight, giant buckets folded in two levels)",
+                                 "ms": round(ms, 3), "Mpt_per_s": round(n / ms / 1e3, 2), "same_bytes_as_per_call_pipeline": same,
+                                 "kernel_ms": kernels(lambda: ctx.msm_bases_run_dev(hb, sc, n))}
+        ctx.msm_bases_free(hb)
+        del gb, sc
     # the same per-call pipeline at 2^24 points (bases 1.9 GB in internal form: beyond the Infinity Cache; 32 entries per bucket -> 512):
     # where the fixed cost of the bucket reduction and the window sums is 3 % of the call instead of 23 %
     n = 1 << 24

@@ -415,7 +415,7 @@ def _ctx_with_env(env):
 @pytest.mark.parametrize("n", [1 << 16, (1 << 16) + 4321, 1 << 18])
 def test_msm_g1_split_ranges_vs_oracle(bzk, co, n):
     """a resident-set G1 call run as 1 / 2 / 3 / 4 window ranges in flight (children at normal and at the highest stream priority) returns the
-    oracle's bytes, as does the raw-base call (never split); back-to-back calls on one context re-use the children"""
+    oracle's bytes, as does the raw-base call (its bases converted once for all ranges); back-to-back calls on one context re-use the children"""
     bases = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
     bzk.g1_synth_bases_dev(77, 0, n, bases)
     sc = _uniform_scalars_dev(n, 9000 + n % 1000)
@@ -440,6 +440,9 @@ def test_msm_g1_split_ranges_vs_oracle(bzk, co, n):
                 z = torch.zeros(n * 32, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
                 assert ctx.msm_bases_run_dev(h, z, n) == bzk.msm_g1_dev(bases, z, n)
                 assert ctx.msm_bases_run_dev(h, sc, n, throughput=True) == want
+                # the raw-base entry in the same number of ranges, twice (the converted bases live in a buffer of the context's), then on a shorter prefix
+                assert ctx.msm_g1_dev(bases, sc, n) == want and ctx.msm_g1_dev(bases, sc, n) == want
+                assert ctx.msm_g1_dev(bases[:96 * m], sc[:32 * m], m) == ctx.msm_bases_run_dev(h, sc[:32 * m], m)
             finally:
                 ctx.msm_bases_free(h)
         finally:
