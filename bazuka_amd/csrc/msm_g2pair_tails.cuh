@@ -83,22 +83,68 @@ __global__ void __launch_bounds__(64) msm_fold_small_g2pair_kernel(const uint32_
     g2p_st_pt(&buckets[order[i]], comp, acc);
 }
 
-// ---- heavily populated buckets: one workgroup of 64 PAIRS per bucket: pairs stride over the partial sums, then a tree through LDS
+// ---- GIANT buckets (round 6, run 27; msm_impl.cuh msm_fold_wide_kernel is the one-lane twin): a bucket of more than `wide_from` tasks - the carry-only top
+// window of a recoding narrower than 16 bits holds 45 % of all uniform scalars in ONE bucket - is cut into chunks of 64 partial sums; any workgroup of a fixed
+// grid folds a chunk (one load + a 6-level tree of 64 pairs) into `wide`, the chunks of all giants among the first `wide_pos` sorted positions dealt round-robin;
+// the workgroup fold below then meets nt / 64 chunk sums.  At 2^19 points the one-level fold was 2.66 ms of a 9.5 ms G2 call (90 pair additions in a row per pair).
+__device__ __forceinline__ uint32_t g2p_fold_wide_slot(const uint32_t* __restrict__ tbase, uint32_t i) { return tbase[i] / 64 + i; }
+template <int UNIT = 0>
+__global__ void __launch_bounds__(128) msm_fold_wide_g2pair_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ tbase, uint32_t nb,
+                                                                   uint32_t seg, uint32_t wide_from, uint32_t wide_pos, const G2X28* __restrict__ partial,
+                                                                   G2X28* __restrict__ wide) {
+    __shared__ G2X28 sh[64];
+    const uint32_t pr = threadIdx.x >> 1, comp = (threadIdx.x & 1u) * 56u;
+    const uint32_t n_pos = nb < wide_pos ? nb : wide_pos;
+    uint32_t before = 0;
+    for (uint32_t i = 0; i < n_pos; ++i) {
+        const uint32_t cnt = count_sorted[i];
+        const uint32_t nt = cnt <= seg ? 1u : (cnt + seg - 1) / seg;
+        if (nt <= wide_from) continue;  // workgroup-uniform
+        const uint32_t chunks = (nt + 63) / 64;
+        const G2X28* src = partial + tbase[i];
+        G2X28* dst = wide + g2p_fold_wide_slot(tbase, i);
+        const uint32_t first = (blockIdx.x + gridDim.x - before % gridDim.x) % gridDim.x;
+        before += chunks;
+        for (uint32_t ch = first; ch < chunks; ch += gridDim.x) {
+            const uint32_t j = ch * 64 + pr;
+            g2p_st_pt(&sh[pr], comp, j < nt ? g2p_ld_pt(&src[j], comp) : g2p::identity());
+            __syncthreads();
+            for (uint32_t s = 32; s > 0; s >>= 1) {
+                if (pr < s) {
+                    g2p::Pt a = g2p_ld_pt(&sh[pr], comp);
+                    const g2p::Pt q = g2p_ld_pt(&sh[pr + s], comp);
+                    g2p_add_ni(&a, &q);
+                    g2p_st_pt(&sh[pr], comp, a);
+                }
+                __syncthreads();
+            }
+            if (pr == 0) g2p_st_pt(&dst[ch], comp, g2p_ld_pt(&sh[0], comp));
+            __syncthreads();  // sh[] is free again
+        }
+    }
+}
+
+// ---- heavily populated buckets: one workgroup of 64 PAIRS per bucket: pairs stride over the partial sums (a giant's chunk sums: above), then a tree through LDS
 template <int UNIT = 0>
 __global__ void __launch_bounds__(128) msm_fold_g2pair_kernel(const uint32_t* __restrict__ count_sorted, const uint32_t* __restrict__ order,
                                                               const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ ntask, uint32_t nb,
                                                               uint32_t seg, uint32_t bulk_from, uint32_t thr_small, uint32_t thr_bulk,
-                                                              const G2X28* __restrict__ partial, G2X28* __restrict__ buckets) {
+                                                              const G2X28* __restrict__ partial, G2X28* __restrict__ buckets,
+                                                              const G2X28* __restrict__ wide, uint32_t wide_from, uint32_t wide_pos) {
     __shared__ G2X28 sh[64];
     const uint32_t i = blockIdx.x;
     if (i >= nb) return;
     const uint32_t cnt = count_sorted[i];
     if (cnt <= seg) return;  // uniform: the whole workgroup leaves
-    const uint32_t nt = (cnt + seg - 1) / seg;
+    uint32_t nt = (cnt + seg - 1) / seg;
     const uint32_t extra = tbase[nb - 1] + ntask[nb - 1] - nb;
     if (nt <= (extra >= bulk_from ? thr_bulk : thr_small)) return;
     const uint32_t pr = threadIdx.x >> 1, comp = (threadIdx.x & 1u) * 56u;
     const G2X28* src = partial + tbase[i];
+    if (wide && i < wide_pos && nt > wide_from) {  // msm_fold_wide_g2pair_kernel left one sum per chunk of 64
+        src = wide + g2p_fold_wide_slot(tbase, i);
+        nt = (nt + 63) / 64;
+    }
     g2p::Pt acc = pr < nt ? g2p_ld_pt(&src[pr], comp) : g2p::identity();
     for (uint32_t j = pr + 64; j < nt; j += 64) {
         const g2p::Pt q = g2p_ld_pt(&src[j], comp);

@@ -1655,8 +1655,13 @@ static int32_t bucket_accumulate(bzk_ctx* ctx, const void* bases, const uint32_t
     const uint32_t n_big = (uint32_t)std::min<uint64_t>(nb, len / ((uint64_t)seg * (surely_bulk ? MSM_FOLD_SMALL_BULK : MSM_FOLD_SMALL)) + 1);
     if constexpr (C::PAIR_ACC) {
         if (msm_g2_pair_tails_on()) {
+            static const bool wide_off_p = env_on("BZK_MSM_NO_WIDE_FOLD");  // A/B runs
+            const G2X28* const wide_p = wide_off_p ? nullptr : (const G2X28*)A.wide;
+            if (wide_p && len > (uint64_t)seg * MSM_FOLD_WIDE_FROM)  // a giant bucket holds more than MSM_FOLD_WIDE_FROM tasks of `seg` entries
+                BZK_LAUNCH(ctx, "msm_fold_wide", msm_fold_wide_g2pair_kernel<0>, dim3(MSM_FOLD_WIDE_GRID), dim3(128), 0, A.count_s, A.tbase, nb, seg, MSM_FOLD_WIDE_FROM,
+                           MSM_FOLD_WIDE_POS, (const G2X28*)A.partial, (G2X28*)A.wide);
             BZK_LAUNCH(ctx, "msm_fold", msm_fold_g2pair_kernel<0>, dim3(n_big), dim3(128), 0, A.count_s, A.order, A.tbase, A.ntask, nb, seg, MSM_FOLD_BULK_FROM,
-                       MSM_FOLD_SMALL, MSM_FOLD_SMALL_BULK, A.partial, buckets);
+                       MSM_FOLD_SMALL, MSM_FOLD_SMALL_BULK, A.partial, buckets, wide_p, MSM_FOLD_WIDE_FROM, MSM_FOLD_WIDE_POS);
             BZK_LAUNCH(ctx, "msm_fold_small", msm_fold_small_g2pair_kernel<0>, dim3((unsigned)((2ull * n_pos + 63) / 64)), dim3(64), 0, A.count_s, A.order, A.tbase,
                        A.ntask, nb, n_pos, seg, MSM_FOLD_BULK_FROM, MSM_FOLD_SMALL, MSM_FOLD_SMALL_BULK, A.partial, buckets);
             return BZK_OK;

@@ -144,6 +144,26 @@ def test_msm_g2_2p16_vs_oracle(bzk, co):
     assert bzk.msm_g2_dev(bases, to_dev(scb), n) == co.msm_g2(dev_bytes(bases), scb, nthreads=co.ncpu())
 
 
+@pytest.mark.parametrize("g2", [False, True])
+def test_msm_giant_buckets_two_level_fold_vs_oracle(bzk, co, g2):
+    """buckets of more than 640 tasks take the two-level fold (msm_fold_wide_kernel / msm_fold_wide_g2pair_kernel): one scalar repeated for every point (ONE
+    giant bucket per window, 40 000 entries = 1 250 tasks of 32), three values (several giants per window, dealt round-robin over the grid), and a vector in which
+    the giants share their windows with ordinary buckets - all equal to the oracle's bytes"""
+    n = 40000
+    bases = torch.empty(n * (192 if g2 else 96), dtype=torch.uint8, device="cuda")
+    (bzk.g2_synth_bases_dev if g2 else bzk.g1_synth_bases_dev)(91, 0, n, bases)
+    hb = dev_bytes(bases)
+    run = bzk.msm_g2_dev if g2 else bzk.msm_g1_dev
+    want = co.msm_g2 if g2 else co.msm_g1
+    vals = [0x1F3A5C7E9B2D4F60718293A4B5C6D7E8F9012345678, 0x2B1, 0x7FFF0001FFFE0003FFFC0007]
+    mixed = fr_list(n, 31)
+    for i in range(0, n, 3):
+        mixed[i] = vals[0]
+    for scalars in ([vals[0]] * n, [vals[i % 3] for i in range(n)], mixed):
+        scb = fr_bytes(scalars)
+        assert run(bases, to_dev(scb), n) == want(hb, scb, nthreads=co.ncpu())
+
+
 def test_msm_g1_static_table_matches_plain_and_oracle(bzk, co):
     """static-base tables (bzk_msm_g1_table_*): same bytes as the per-call pipeline and the oracle; prefix use
     (fewer scalars than table entries) and window-range shards"""
