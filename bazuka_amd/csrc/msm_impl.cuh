@@ -1154,8 +1154,10 @@ static RowColPlan msm_rowcol_plan(int c_minus_1, uint32_t threads) {
     P.lbits = (uint32_t)(c_minus_1 + 1) / 2;
     P.hbits = (uint32_t)c_minus_1 - P.lbits;
     const uint32_t L = 1u << P.lbits, H = 1u << P.hbits;
-    P.leaf_r = std::max<uint32_t>(std::min<uint32_t>(8, L), L / threads);  // buckets one lane sums serially
-    P.leaf_c = std::max<uint32_t>(std::min<uint32_t>(8, H), H / threads);
+    // buckets one lane sums serially before the trees (env BZK_MSM_RC_LEAF = 2 | 4 | 8 | 16 for A/B runs; run 30: 4 and 16 against 8)
+    static const uint32_t leaf_want = [] { const char* e = getenv("BZK_MSM_RC_LEAF"); const int v = e ? atoi(e) : 8; return (uint32_t)((v == 2 || v == 4 || v == 8 || v == 16) ? v : 8); }();
+    P.leaf_r = std::max<uint32_t>(std::min<uint32_t>(leaf_want, L), L / threads);
+    P.leaf_c = std::max<uint32_t>(std::min<uint32_t>(leaf_want, H), H / threads);
     P.seg_r = L / P.leaf_r;                                                 // lanes per row / per column (tree width)
     P.seg_c = H / P.leaf_c;
     P.wgs_r = (H + threads / P.seg_r - 1) / (threads / P.seg_r);

@@ -73,7 +73,9 @@ int32_t bzk_dev_alloc(bzk_ctx* ctx, uint64_t bytes, void** dptr);
 int32_t bzk_dev_free(bzk_ctx* ctx, void* dptr);
 /* The call workspace of a ctx is grow-only (one slab, re-used by every call: no allocation on the hot path).  After a one-off large
  * call - a 2^26-point MSM leaves ~24 GB behind - bzk_ctx_trim waits for the stream and hands the slab back to the device; the next
- * call allocates what it needs.  *released (may be NULL) = bytes freed. */
+ * call allocates what it needs.  *released (may be NULL) = bytes freed.  (A context whose stand-alone G1 MSM calls run as two window ranges in
+ * flight - 2^18 <= n < 2^20 points, DESIGN 3.2d - owns a child context with a workspace of its own and a buffer for converted raw bases: both are
+ * released as well.) */
 int32_t bzk_ctx_trim(bzk_ctx* ctx, uint64_t* released);
 int32_t bzk_h2d(bzk_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int32_t bzk_d2h(bzk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);

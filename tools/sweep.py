@@ -55,7 +55,7 @@ def child(mode, log_n):
         same = res == (ctx.msm_g2_dev if g2 else ctx.msm_g1_dev)(bases, sc, n)
         ctx.prof_enable(True); ctx.prof_reset(); ctx.msm_bases_run_dev(hb, sc, n, g2=g2, throughput=thr); prof = {k: round(v[1], 3) for k, v in ctx.prof_dump().items() if v[1] > 0.04}
         print(json.dumps({"mode": mode, "log_n": log_n, "endo_g1": os.environ.get("BZK_MSM_ENDO_G1"), "endo_g2": os.environ.get("BZK_MSM_ENDO_G2"), "throughput": thr,
-                          "lib": os.path.basename(os.environ.get("BZK_LIBBZK", "")), "seg": os.environ.get("BZK_MSM_SEG"), "no_wide": os.environ.get("BZK_MSM_NO_WIDE_FOLD"), "split": os.environ.get("BZK_MSM_SPLIT"), "cuts": os.environ.get("BZK_MSM_SPLIT_CUTS"), "split_prio": os.environ.get("BZK_MSM_SPLIT_PRIO"), "mean_ms": mean_ms,
+                          "lib": os.path.basename(os.environ.get("BZK_LIBBZK", "")), "seg": os.environ.get("BZK_MSM_SEG"), "rc_leaf": os.environ.get("BZK_MSM_RC_LEAF"), "no_wide": os.environ.get("BZK_MSM_NO_WIDE_FOLD"), "split": os.environ.get("BZK_MSM_SPLIT"), "cuts": os.environ.get("BZK_MSM_SPLIT_CUTS"), "split_prio": os.environ.get("BZK_MSM_SPLIT_PRIO"), "mean_ms": mean_ms,
                           "ms": round(ms, 3), "Mpt/s": round(n / ms / 1e3, 2), "same_as_raw": same, "digest": hashlib.sha256(bytes(res)).hexdigest()[:16], "prof": prof}))
         ctx.msm_bases_free(hb)
     elif mode == "g1tab":
@@ -187,6 +187,11 @@ if __name__ == "__main__":
                     run("g1res", lg, dict(env, SWEEP_REPS="8", SWEEP_MEAN_OVER="20" if lg <= 22 else "5"))
                 run("g1tab", 20, env)
                 run("g1res", 20, dict(env, THROUGHPUT="1", SWEEP_REPS="8"))
+    if what in ("r6rcleaf",):  # run 30: buckets per lane of the row / column sums' serial phase
+        for rep in (0, 1):
+            for lf in ("8", "4", "16", "2"):
+                for lg in (20, 22):
+                    run("g1res", lg, {"SWEEP_REPS": "8", "SWEEP_MEAN_OVER": "20", "BZK_MSM_RC_LEAF": lf})
     if what in ("occ",):
         for occ in (2, 3, 4):
             run("g1", 20, {"BZK_MSM_ACC_OCC": str(occ)})
