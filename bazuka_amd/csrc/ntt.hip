@@ -170,6 +170,8 @@ struct NttPass {
     const Fr29P* tw_r;    // w_R^j * 2^261, j < R/2
     const Fr29P* tlo;     // COL: w_N'^j * 2^261, j < 1024
     const Fr29P* thi;     // COL: w_N'^(1024 j) * 2^261
+    const Fr29P* tone;    // COL (round 6, run 31): w_N'^j * 2^261 for EVERY j < N' where N' <= 2^17 (the second boundary of a three-pass plan), or null: one load
+                          // from a cache-resident table (<= 6 MB) instead of lo * hi - one of the transform's 15.5 products per element
     const Fr29P* pre;     // FIRST_MUL: g^i * 2^266 by input index (forward coset transform) or null (constant 2^266)
     const Fr29P* post;    // final pass: a multiplier per OUTPUT index ((g^-k / n) 2^256, or (g^k / n) 2^261 for the fused inverse -> coset hand-over) or null
     const Fr29P* post_c;  // final pass: one element (see NttTables::post_one)
@@ -322,8 +324,13 @@ __global__ void __launch_bounds__(256, OCC) ntt_pass_kernel(NttPass a) {
         Fr29 v = lds_ld(tile, t);
         if (!a.final_pass) {
             const uint64_t e = (inner0 + c) * ka;
-            Fr29 w = ld29(a.tlo[e & 1023]);
-            if (e >> 10) w = fr29::mul(w, ld29(a.thi[e >> 10]));
+            Fr29 w;
+            if (a.tone) {  // workgroup-uniform
+                w = ld29(a.tone[e]);
+            } else {
+                w = ld29(a.tlo[e & 1023]);
+                if (e >> 10) w = fr29::mul(w, ld29(a.thi[e >> 10]));
+            }
             const Fr29 o = fr29::mul(v, w);  // k 2, normalised: below 2^256
             if (a.ip32) ((Fr*)a.dst)[base + (uint64_t)ka * a.S + c] = fr29::repack_to32(o);
             else ((Fr29P*)a.dst)[base + (uint64_t)ka * a.S + c] = st29(o);
@@ -349,6 +356,7 @@ struct NttTables {
     Fr29P* tw_r[2][3] = {};   // [inverse][pass]: w_R^j
     Fr29P* tlo[2][2] = {};    // [inverse][col pass]
     Fr29P* thi[2][2] = {};
+    Fr29P* tone[2][2] = {};   // [inverse][col pass]: the single-level table of a boundary with N' <= 2^17 (else null)
     // per-index multiplier tables (n x 48 B each), built on first use:
     Fr29P* pre_g = nullptr;        // g^j * 2^266          first load of a stand-alone forward coset transform
     Fr29P* post_ginv = nullptr;    // (g^-j / n) * 2^256   final store of an inverse coset transform (input carried as x 2^261)
@@ -424,6 +432,8 @@ static int32_t ntt_tables(bzk_ctx* ctx, int log_n, NttTables** out) {
             const Fr base = k == 0 ? dirs[d] : host_pow_u64(dirs[d], (uint64_t)1 << T->b[0]);
             BZK_TRY(build_table29(ctx, base, 1024, c5, &T->tlo[d][k]));
             BZK_TRY(build_table29(ctx, host_pow_u64(base, 1024), (np + 1023) / 1024, c5, &T->thi[d][k]));
+            static const bool tone_off = env_on("BZK_NTT_NO_TONE");  // A/B runs
+            if (!tone_off && k > 0 && np <= ((uint64_t)1 << 17)) BZK_TRY(build_table29(ctx, base, np, c5, &T->tone[d][k]));
         }
     }
     {
@@ -550,6 +560,7 @@ static int32_t ntt_run_ex(bzk_ctx* ctx, void* data_dev, uint32_t log_n, int inve
             a.S = S;
             a.tlo = T->tlo[d][k];
             a.thi = T->thi[d][k];
+            a.tone = T->tone[d][k];
             lanes = S;
         } else {
             a.R1 = T->nb >= 2 ? 1u << T->b[0] : 1u;
@@ -601,6 +612,7 @@ void ntt_free_tables(bzk_ctx* ctx) {
             for (int k = 0; k < 2; ++k) {
                 if (T->tlo[d][k]) (void)hipFree(T->tlo[d][k]);
                 if (T->thi[d][k]) (void)hipFree(T->thi[d][k]);
+                if (T->tone[d][k]) (void)hipFree(T->tone[d][k]);
             }
         }
         if (T->pre_g) (void)hipFree(T->pre_g);
