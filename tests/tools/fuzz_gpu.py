@@ -1,7 +1,7 @@
 """Differential fuzzing of the C ABI against the CPU oracle on random shapes (run on a GPU box):
 MSM G1/G2 (plain, de-duplicated, window partitions, witness-like / degenerate scalar mixes, repeated and negated bases),
 NTT (all four modes, every log size up to 14), Poseidon batches (every arity), 4-ary trees, tree updates, the general state seam one-shot and
-device-resident (random models under random deltas).
+device-resident (random models under random deltas), stand-alone calls as window ranges in flight over giant-bucket scalar mixes (round 6).
 usage: python tests/tools/fuzz_gpu.py [seconds=60] [seed=1]"""
 import json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,9 +42,55 @@ def main(seconds=60, seed=1):
     counts = {}
     t_end = time.time() + seconds
     while time.time() < t_end:
-        kind = rnd.choice(("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows", "table", "window_size",
-                           "bases", "mg", "h_chain", "state", "state_dev"))
+        kinds = ("msm_g1", "msm_g1", "msm_g2", "ntt", "poseidon", "tree", "windows", "table", "window_size",
+                 "bases", "mg", "h_chain", "state", "state_dev", "ranges")
+        if os.environ.get("FUZZ_KINDS"):  # e.g. FUZZ_KINDS=ranges,msm_g2 for a soak of chosen paths
+            kinds = tuple(k for k in kinds if k in os.environ["FUZZ_KINDS"].split(",")) or kinds
+        kind = rnd.choice(kinds)
         counts[kind] = counts.get(kind, 0) + 1
+        if kind == "ranges":
+            # round 6: one stand-alone call as 1 - 4 window ranges in flight (msm_run_split; a context of its own created under the knobs), resident set and
+            # raw bases, over scalar mixes that put GIANT buckets (more than 640 tasks: the two-level fold, msm_fold_wide_kernel and its G2 pair twin) into some
+            # or all windows
+            import torch
+            g2 = rnd.random() < 0.3
+            n = rnd.choice((3000, 9000, 22000, 30000, 47000)) if not g2 else rnd.choice((3000, 22000, 30000))
+            bases = (co.g2_bases if g2 else co.g1_bases)(rnd.randrange(1 << 30), 0, n, nthreads=nt)
+            mode = rnd.randrange(4)
+            if mode == 0:
+                sc = scalars(rnd, n)
+            else:
+                vals = fr_list(rnd.choice((1, 2, 3, 7)), rnd.randrange(1 << 30))
+                scl = fr_list(n, rnd.randrange(1 << 30)) if mode == 3 else [None] * n
+                for i in range(n):
+                    if scl[i] is None or i % 2 == 0:
+                        scl[i] = vals[i % len(vals)]
+                sc = fr_bytes(scl)
+            want = (co.msm_g2 if g2 else co.msm_g1)(bases, sc, nthreads=nt)
+            env = {"BZK_MSM_SPLIT": str(rnd.randrange(1, 5)), "BZK_MSM_SPLIT_PRIO": str(rnd.randrange(3)), "BZK_MSM_SPLIT_MIN_LOG": "10"}
+            if rnd.random() < 0.2:
+                env["BZK_MSM_SPLIT_CUTS"] = rnd.choice(("2,3", "5,1", "1,1,1", "4,4,4,4"))  # used when they add up to the window count, else equal ranges
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                c2 = Bzk(0)
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            try:
+                db = torch.frombuffer(bytearray(bases), dtype=torch.uint8).cuda(); ds = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+                torch.cuda.synchronize()
+                hb = c2.msm_bases_load_dev(db, n, g2=g2)
+                for _ in range(2):
+                    assert c2.msm_bases_run_dev(hb, ds, n, g2=g2) == want, (kind, "resident", n, g2, mode, env)
+                assert (c2.msm_g2_dev if g2 else c2.msm_g1_dev)(db, ds, n) == want, (kind, "raw", n, g2, mode, env)
+                m = rnd.randrange(1, n + 1)
+                assert c2.msm_bases_run_dev(hb, ds, m, g2=g2) == (co.msm_g2 if g2 else co.msm_g1)(bases[:m * (192 if g2 else 96)], sc[:32 * m], nthreads=nt), \
+                    (kind, "prefix", n, m, g2, mode, env)
+                c2.msm_bases_free(hb)
+            finally:
+                c2.close()
+            continue
         if kind in ("bases", "mg"):  # round 3: resident base sets, device groups (several contexts on this one GPU)
             import torch
             from bazuka_amd import Mg
