@@ -1923,6 +1923,9 @@ static int32_t msm_run(bzk_ctx* ctx, const void* bases_raw, const void* scalars,
         // a window range of a split call (msm_run_split) runs beside the other ranges' kernels: it need not fill the device alone, and every cut costs a fold
         const uint64_t target = (E > 1 || ctx->is_part || ctx->split_active ? 2ull : 4ull) * 131072;
         if (nb_ >= target || len_ / sg + nb_ >= target) return sg;
+        // run 34: two tasks per lane of FULL buckets need no cut - a rank of 2 (8 of 16 windows over 2^21 points: 262 144 buckets of 64 entries) ran 3.72 - 3.77 ms with
+        // its fuller half of the buckets cut in two (and folded) against 3.45 - 3.51 ms uncut; thinner buckets (c = 15 calls: 32 entries) keep the cut
+        if (nb_ >= 2ull * 131072 && len_ / nb_ >= 48) return sg;
         return (uint32_t)std::max<uint64_t>(32, len_ / (target - nb_));
     };
     if (!table || folded) seg = std::min(seg, enough_tasks(seg, len_max, nb_max));
