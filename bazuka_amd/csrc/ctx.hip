@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -154,6 +156,7 @@ struct bzk_lane_thread {
 namespace bzk {
 
 static void lane_thread_main(bzk_lane_thread* t, int device) {
+    (void)pthread_setname_np(pthread_self(), "bzk-lane");  // per-thread CPU accounting by name (tools/host_cpu_probe.py reads /proc/self/task/*/comm)
     (void)hipSetDevice(device);
     std::unique_lock<std::mutex> lk(t->m);
     for (;;) {

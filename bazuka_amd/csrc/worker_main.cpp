@@ -526,6 +526,10 @@ int main(int argc, char** argv) {
     // 16 hardware queues for the slots' streams instead of HIP's default 4 (read by the runtime at its first call; a value set by the operator wins):
     // bazuka_amd/__init__.py has the measurement
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // launches through the runtime's per-stream worker threads instead of from the calling threads (round 6, runs 37 - 39): the prover side's host CPU per proof
+    // 0.0174 -> 0.0065 CPU-s (the runtime's helper threads no longer spend 0.009 s of system time per proof), four slots + 4 % proofs/s under a CPU quota
+    // (profiles/r06_run37_39_host_cpu_of_the_prover.txt); read by the runtime when it initialises, an operator's own setting wins
+    setenv("AMD_DIRECT_DISPATCH", "0", 0);
     Options o;
     bool have_node = false, have_addr = false;
     for (int i = 1; i < argc; ++i) {

@@ -480,6 +480,11 @@ def main(argv=None):
     quota = cpu_quota()
     if quota is not None and quota < len(devices) * a.slots_per_device * 5 + (os.cpu_count() or 1) // 2:
         os.environ.setdefault("BZK_SYNC_BLOCKING", "1")
+    # A proving service hands its launches to the HIP runtime's per-stream worker threads (AMD_DIRECT_DISPATCH=0, read when the runtime initialises: before the
+    # first context): the prover side then costs the host 0.0065 - 0.0084 CPU-s per proof instead of 0.0174 - 0.0202 (with direct dispatch the runtime's helper
+    # threads spend 0.009 s of system time per proof) and four slots prove 4 % more per second under a CPU quota; a lone latency-bound call is 2 % slower that way,
+    # which is why the library does not decide this for its callers (profiles/r06_run37_39_host_cpu_of_the_prover.txt).  An operator's own setting wins.
+    os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
 
     def key_source(bzk):
         return BellmanKeys(bzk, dict(enumerate(a.params))) if a.params else DevSetup(bzk, {k: toxic(k) for k in range(3)})
