@@ -1015,7 +1015,7 @@ def main():
             cenv = dict(os.environ, AMD_DIRECT_DISPATCH=os.environ.get("BZK_BENCH_PROOFS_DISPATCH", "0"))
             cmd = [sys.executable, os.path.abspath(__file__), "--proofs-child", os.environ.get("LOCAL_RANK", "0"), "--gpus", str(args.gpus)] + \
                   (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
-            cp = subprocess.run(cmd, env=cenv, capture_output=True, text=True, timeout=1500)
+            cp = subprocess.run(cmd, env=cenv, capture_output=True, text=True, timeout=600)  # ~75 s when all is well; after that the section runs in this process
             for line in reversed(cp.stdout.splitlines()):
                 if line.startswith("BZK_PROOFS_JSON "):
                     early_proofs = json.loads(line[len("BZK_PROOFS_JSON "):])
