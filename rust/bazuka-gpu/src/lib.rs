@@ -14,6 +14,12 @@
 //!   * `prove_work`             - an `MpnWork` (src/mpn/mod.rs:263-270) -> the `ZkProof` that `MpnWork::verify` (:281-295) accepts
 //!   * `DeviceGroup`            - 1..8 GPUs of a node: window-sharded MSM + a proof pool (no torch, no Python)
 //!
+//! Process-level runtime settings a PROVING host should make before its first call into libbzk (they are read when the HIP runtime initialises; the
+//! library cannot make them for a process that already did): `GPU_MAX_HW_QUEUES=16` (a prover keeps 4 slots x 4 streams busy) and
+//! `AMD_DIRECT_DISPATCH=0` (launches through the runtime's worker threads: the prover side costs the host 0.0084 instead of 0.0202 CPU-s per proof,
+//! four slots prove 4 % more per second under a CPU quota; a caller of lone MSMs keeps the default - 2 % faster for it).  `std::env::set_var` at
+//! the top of `main`, as bazuka_amd/csrc/worker_main.cpp does with `setenv`; INTEGRATION.md, environment table.
+//!
 //! Layout assumptions (already relied upon by the reference's own `transmute`s, src/zk/groth16/mod.rs:7-17): `ZkScalar` is
 //! `[u64; 4]` little-endian Montgomery limbs; bincode 1.3 with default options; `Groth16Proof` = 97 + 193 + 97 bytes under bincode.
 use bazuka::core::Address;
